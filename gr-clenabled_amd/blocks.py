@@ -1,0 +1,359 @@
+"""Host-side mirror of the gr::clenabled block API for the hot path.
+
+Constructor arguments are the reference's ``make(...)`` arguments, in the same
+positional order GRC passes them (include/clenabled/*.h, grc/*.block.yml), and
+``work()/general_work()`` keep the ``noutput_items`` contract.  Everything is a
+thin call into the C ABI (include/mi355_clenabled.h); there is no Python or CPU
+compute path here.
+
+Two flavours of each work call:
+  work(noutput_items, input_items, output_items)         numpy (host) buffers,
+      the GNU Radio contract: blocking, H2D / kernel / D2H inside the call
+  work_device(noutput_items, input_items, output_items)  torch CUDA tensors,
+      enqueue-only on torch's current stream (device-resident chaining / bench)
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, lib
+
+# include/clenabled/GRCLBase.h:57-70, clMathOpTypes.h:11-20
+DTYPE_COMPLEX, DTYPE_FLOAT, DTYPE_INT, DTYPE_SHORT, DTYPE_BYTE, DTYPE_PACKEDXY = 1, 2, 3, 4, 5, 6
+OCLTYPE_GPU, OCLTYPE_ACCELERATOR, OCLTYPE_CPU, OCLTYPE_ANY = 1, 2, 3, 4
+OCLDEVICESELECTOR_FIRST, OCLDEVICESELECTOR_SPECIFIC = 1, 2
+MATHOP_MULTIPLY, MATHOP_ADD, MATHOP_SUBTRACT, MATHOP_COMPLEX_CONJUGATE, MATHOP_MULTIPLY_CONJUGATE = 1, 2, 3, 4, 5
+MATHOP_EMPTY, MATHOP_EMPTY_W_COPY = 255, 254
+CLFFT_FORWARD, CLFFT_BACKWARD = -1, 1
+CLXCORR_TRIANGULAR_ORDER, CLXCORR_FULL_MATRIX = 1, 2
+
+_NP_OF = {DTYPE_COMPLEX: np.complex64, DTYPE_FLOAT: np.float32, DTYPE_INT: np.int32}
+
+
+def _host(a, dtype=None, writable=False):
+    if not isinstance(a, np.ndarray) or not a.flags["C_CONTIGUOUS"] or (dtype is not None and a.dtype != dtype):
+        if writable:
+            raise TypeError("output buffers must be C-contiguous numpy arrays of dtype %s" % dtype)
+        a = np.ascontiguousarray(a, dtype=dtype)
+    return a
+
+
+def _hp(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def _dp(t):
+    if not t.is_cuda or not t.is_contiguous():
+        raise TypeError("device path needs contiguous CUDA tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+def _torch_stream(device):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _Block:
+    """Owns one mi355 context, like every reference block owns one cl::Context
+    (lib/GRCLBase.cpp:115-144)."""
+
+    def __init__(self, openCLPlatformType, devSelector, platformId, devId, setDebug):
+        self._L = lib()
+        self._ctx = C.c_void_p()
+        self._h = C.c_void_p()
+        check(self._L.mi355_ctx_create(int(openCLPlatformType), int(devSelector), int(platformId), int(devId),
+                                       1 if setDebug else 0, C.byref(self._ctx)), "mi355_ctx_create")
+        self.device = self._L.mi355_ctx_device(self._ctx)
+
+    _destroy = None
+
+    def stop(self):
+        if getattr(self, "_h", None) and self._h.value and self._destroy:
+            getattr(self._L, self._destroy)(self._h)
+            self._h = C.c_void_p()
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._L.mi355_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+        return True
+
+    def __del__(self):
+        try:
+            self.stop()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(self._L.mi355_ctx_synchronize(self._ctx), "mi355_ctx_synchronize")
+
+
+class clMathOp(_Block):
+    """clMathOp::make(idataType, openCLPlatformType, devSelector, platformId, devId,
+    operatorType, setDebug=0)  -- include/clenabled/clMathOp.h:42"""
+    _destroy = "mi355_mathop_destroy"
+
+    def __init__(self, idataType, openCLPlatformType, devSelector, platformId, devId, operatorType, setDebug=0):
+        super().__init__(openCLPlatformType, devSelector, platformId, devId, setDebug)
+        self.dtype = idataType
+        check(self._L.mi355_mathop_create(self._ctx, int(idataType), int(operatorType), 0, C.byref(self._h)),
+              "mi355_mathop_create")
+
+    def work(self, noutput_items, input_items, output_items):
+        dt = _NP_OF[self.dtype]
+        a, b = _host(input_items[0], dt), _host(input_items[1], dt)
+        c = _host(output_items[0], dt, writable=True)
+        check(self._L.mi355_mathop_work(self._h, noutput_items, _hp(a), _hp(b), _hp(c)), "mi355_mathop_work")
+        return noutput_items
+
+    testOpenCL = work  # lib/clMathOp_impl.cc:354-359
+
+    def work_device(self, noutput_items, input_items, output_items):
+        check(self._L.mi355_mathop_work_dev(self._h, noutput_items, _dp(input_items[0]), _dp(input_items[1]),
+                                            _dp(output_items[0]), _torch_stream(self.device)), "mi355_mathop_work_dev")
+        return noutput_items
+
+
+class clMathConst(_Block):
+    """clMathConst::make(idataType, openCLPlatformType, devSelector, platformId, devId,
+    fValue, operatorType, setDebug=0)  -- include/clenabled/clMathConst.h:51"""
+    _destroy = "mi355_mathconst_destroy"
+
+    def __init__(self, idataType, openCLPlatformType, devSelector, platformId, devId, fValue, operatorType, setDebug=0):
+        super().__init__(openCLPlatformType, devSelector, platformId, devId, setDebug)
+        self.dtype = idataType
+        check(self._L.mi355_mathconst_create(self._ctx, int(idataType), int(operatorType), float(fValue), 0,
+                                             C.byref(self._h)), "mi355_mathconst_create")
+
+    def k(self):
+        v = C.c_float()
+        check(self._L.mi355_mathconst_get_k(self._h, C.byref(v)), "mi355_mathconst_get_k")
+        return v.value
+
+    def set_k(self, newValue):
+        check(self._L.mi355_mathconst_set_k(self._h, float(newValue)), "mi355_mathconst_set_k")
+
+    def work(self, noutput_items, input_items, output_items):
+        dt = _NP_OF[self.dtype]
+        a = _host(input_items[0], dt)
+        c = _host(output_items[0], dt, writable=True)
+        check(self._L.mi355_mathconst_work(self._h, noutput_items, _hp(a), _hp(c)), "mi355_mathconst_work")
+        return noutput_items
+
+    testOpenCL = work
+
+    def work_device(self, noutput_items, input_items, output_items):
+        check(self._L.mi355_mathconst_work_dev(self._h, noutput_items, _dp(input_items[0]), _dp(output_items[0]),
+                                               _torch_stream(self.device)), "mi355_mathconst_work_dev")
+        return noutput_items
+
+
+class clFFT(_Block):
+    """clFFT::make(fftSize, clFFTDir, window, idataType, openCLPlatformType, devSelector,
+    platformId, devId, setDebug=0, num_streams=1, shift=False) -- the positional
+    order of lib/clFFT_impl.cc:34-36, which is what GRC emits
+    (grc/clenabled_clFFT.block.yml:84-89); the header's parameter names differ
+    (SURVEY App. B-1).  noutput_items counts VECTORS of fftSize items."""
+    _destroy = "mi355_fft_destroy"
+
+    def __init__(self, fftSize, clFFTDir, window, idataType, openCLPlatformType, devSelector, platformId, devId,
+                 setDebug=0, num_streams=1, shift=False):
+        window = np.ascontiguousarray(window if window is not None else [], dtype=np.float32)
+        if not (window.size == 0 or window.size == fftSize):
+            # lib/clFFT_impl.cc:74-76
+            raise RuntimeError("OpenCL FFT: window not the same length as fft_size")
+        super().__init__(openCLPlatformType, devSelector, platformId, devId, setDebug)
+        self.fft_size, self.dtype, self.num_streams = int(fftSize), idataType, int(num_streams)
+        check(self._L.mi355_fft_create(self._ctx, int(fftSize), int(clFFTDir), _hp(window) if window.size else None,
+                                       int(window.size), int(idataType), int(num_streams), 1 if shift else 0,
+                                       C.byref(self._h)), "mi355_fft_create")
+
+    def work(self, noutput_items, input_items, output_items):
+        dt = _NP_OF[self.dtype]
+        ins = [_host(x, dt) for x in input_items[:self.num_streams]]
+        outs = [_host(x, np.complex64, writable=True) for x in output_items[:self.num_streams]]
+        pi = (C.c_void_p * len(ins))(*[x.ctypes.data for x in ins])
+        po = (C.c_void_p * len(outs))(*[x.ctypes.data for x in outs])
+        check(self._L.mi355_fft_work(self._h, noutput_items, pi, po), "mi355_fft_work")
+        return noutput_items
+
+    def testOpenCL(self, noutput_items, input_items, output_items):
+        # the reference's test hook counts SAMPLES (lib/clFFT_impl.cc:520-524)
+        return self.work(noutput_items // self.fft_size, input_items, output_items) * self.fft_size
+
+    def work_device(self, noutput_items, input_items, output_items):
+        st = _torch_stream(self.device)
+        for x, y in zip(input_items[:self.num_streams], output_items[:self.num_streams]):
+            check(self._L.mi355_fft_work_dev(self._h, noutput_items, _dp(x), _dp(y), st), "mi355_fft_work_dev")
+        return noutput_items
+
+
+class _FilterBase(_Block):
+    _destroy = "mi355_filter_destroy"
+
+    def _create(self, decimation, taps, complex_taps, use_time):
+        self._complex = complex_taps
+        self.decimation = int(decimation)
+        t = np.ascontiguousarray(taps, dtype=np.complex64 if complex_taps else np.float32)
+        check(self._L.mi355_filter_create(self._ctx, int(decimation), _hp(t), int(t.size), 1 if complex_taps else 0,
+                                          1 if use_time else 0, C.byref(self._h)), "mi355_filter_create")
+
+    def taps(self):
+        n = self._L.mi355_filter_ntaps(self._h)
+        out = np.empty(n, np.complex64 if self._complex else np.float32)
+        check(min(self._L.mi355_filter_get_taps(self._h, _hp(out), n), 0), "mi355_filter_get_taps")
+        return out
+
+    def ntaps(self):
+        return self._L.mi355_filter_ntaps(self._h)
+
+    def set_taps2(self, taps):
+        t = np.ascontiguousarray(taps, dtype=np.complex64 if self._complex else np.float32)
+        check(self._L.mi355_filter_set_taps(self._h, _hp(t), int(t.size)), "mi355_filter_set_taps")
+
+    set_taps = set_taps2
+
+    def history(self):
+        return self.ntaps()
+
+    def fftsize(self):
+        return self._L.mi355_filter_fftsize(self._h)
+
+    def set_nthreads(self, n):  # lib/clFilter_impl.cc:413-415: only meaningful for the CPU FFTW plan
+        pass
+
+    def work(self, noutput_items, input_items, output_items):
+        """input_items[0] is the history-prefixed buffer: noutput*decim + ntaps-1 items."""
+        x = _host(input_items[0], np.complex64)
+        need = noutput_items * self.decimation + self.ntaps() - 1
+        if x.size < need:
+            raise ValueError("filter work(): need %d input items (history included), got %d" % (need, x.size))
+        y = _host(output_items[0], np.complex64, writable=True)
+        check(self._L.mi355_filter_work(self._h, noutput_items, _hp(x), _hp(y)), "mi355_filter_work")
+        return noutput_items
+
+    def testOpenCL(self, noutput_items, input_items, output_items):
+        return self.work(noutput_items, input_items, output_items)
+
+    def work_device(self, noutput_items, input_items, output_items):
+        check(self._L.mi355_filter_work_dev(self._h, noutput_items, _dp(input_items[0]), _dp(output_items[0]),
+                                            _torch_stream(self.device)), "mi355_filter_work_dev")
+        return noutput_items
+
+
+class clFilter(_FilterBase):
+    """clFilter::make(openclPlatform, devSelector, platformId, devId, decimation, taps,
+    nthreads=1, setDebug=0, use_time=False)  -- include/clenabled/clFilter.h:52-53"""
+
+    def __init__(self, openclPlatform, devSelector, platformId, devId, decimation, taps, nthreads=1, setDebug=0,
+                 use_time=False):
+        super().__init__(openclPlatform, devSelector, platformId, devId, setDebug)
+        self._create(decimation, taps, False, use_time)
+
+
+class clComplexFilter(_FilterBase):
+    """clComplexFilter::make(openclPlatform, devSelector, platformId, devId, decimation,
+    taps, nthreads=1, setDebug=0)  -- include/clenabled/clComplexFilter.h:706
+    The reference only has the time-domain kernel for complex taps; ``use_time``
+    is an additive keyword selecting the fast-convolution kernel instead."""
+
+    def __init__(self, openclPlatform, devSelector, platformId, devId, decimation, taps, nthreads=1, setDebug=0,
+                 use_time=True):
+        super().__init__(openclPlatform, devSelector, platformId, devId, setDebug)
+        self._create(decimation, taps, True, use_time)
+
+
+class clPolyphaseChannelizer(_Block):
+    """clPolyphaseChannelizer::make(openCLPlatformType, devSelector, platformId, devId, taps,
+    buf_items, num_channels, ninputs_per_iter, ch_map, setDebug=0)
+    -- include/clenabled/clPolyphaseChannelizer.h:48-49"""
+    _destroy = "mi355_pfb_destroy"
+
+    def __init__(self, openCLPlatformType, devSelector, platformId, devId, taps, buf_items, num_channels,
+                 ninputs_per_iter, ch_map, setDebug=0):
+        if buf_items % num_channels != 0:
+            # lib/clPolyphaseChannelizer_impl.cc:59-62
+            raise ValueError("buf_items must be a multiple of num_channels")
+        super().__init__(openCLPlatformType, devSelector, platformId, devId, setDebug)
+        t = np.ascontiguousarray(taps, dtype=np.float32)
+        m = np.ascontiguousarray(ch_map, dtype=np.int32)
+        self._ntaps = int(t.size)
+        check(self._L.mi355_pfb_create(self._ctx, _hp(t), int(t.size), int(buf_items), int(num_channels),
+                                       int(ninputs_per_iter), _hp(m), int(m.size), C.byref(self._h)), "mi355_pfb_create")
+
+    def history(self):
+        return self._ntaps
+
+    def noutput(self):
+        return self._L.mi355_pfb_noutput(self._h)
+
+    def ninput(self):
+        return self._L.mi355_pfb_ninput(self._h)
+
+    def general_work(self, noutput_items, ninput_items, input_items, output_items):
+        x = _host(input_items[0], np.complex64)
+        if x.size < self.ninput():
+            raise ValueError("pfb general_work(): need %d input items (history included)" % self.ninput())
+        y = _host(output_items[0], np.complex64, writable=True)
+        check(self._L.mi355_pfb_work(self._h, _hp(x), _hp(y)), "mi355_pfb_work")
+        return self.noutput()
+
+    def work_device(self, input_items, output_items):
+        check(self._L.mi355_pfb_work_dev(self._h, _dp(input_items[0]), _dp(output_items[0]), _torch_stream(self.device)),
+              "mi355_pfb_work_dev")
+        return self.noutput()
+
+
+class clXEngine(_Block):
+    """clXEngine::make(openCLPlatformType, devSelector, platformId, devId, setDebug, data_type,
+    polarization, num_inputs, output_format, first_channel, num_channels, integration,
+    antenna_list, ...)  -- include/clenabled/clXEngine.h:48-52.  Only the
+    correlation path (xcorrelate / frame gather) is implemented; file/PDU output
+    arguments are accepted and ignored."""
+    _destroy = "mi355_xengine_destroy"
+
+    def __init__(self, openCLPlatformType, devSelector, platformId, devId, setDebug, data_type, polarization, num_inputs,
+                 output_format, first_channel, num_channels, integration, antenna_list=(), output_file=False,
+                 file_base="", rollover_size_mb=0, internal_synchronizer=False, sync_timestamp=0, object_name="",
+                 starting_chan_center_freq=0.0, channel_width=0.0, disable_output=False, pipeline_integration=0):
+        if num_inputs < 2:
+            # lib/clXEngine_impl.cc:106-109
+            raise IndexError("Please specify at least 2 inputs to correlate.")
+        super().__init__(openCLPlatformType, devSelector, platformId, devId, setDebug)
+        self.data_type = data_type
+        self.npol = 2 if data_type == DTYPE_PACKEDXY else int(polarization)
+        self.num_inputs, self.num_channels, self.integration = int(num_inputs), int(num_channels), int(integration)
+        self.pipeline_integration = int(pipeline_integration)
+        check(self._L.mi355_xengine_create(self._ctx, int(data_type), self.npol, int(num_inputs), int(num_channels),
+                                           int(integration), C.byref(self._h)), "mi355_xengine_create")
+
+    def get_input_buffer_size(self):  # lib/clXEngine_impl.h:176 (items, not bytes)
+        return self.num_inputs * self.num_channels * self.npol * self.integration
+
+    def input_bytes(self):
+        return self._L.mi355_xengine_input_bytes(self._h)
+
+    def get_output_buffer_size(self):
+        return self._L.mi355_xengine_output_items(self._h)
+
+    def xcorrelate(self, input_matrix, cross_correlation, accumulate=False):
+        """xcorrelate(char*/XComplex* input_matrix, XComplex* cross_correlation)
+        -- lib/clXEngine_impl.h:179-201, followed by the blocking read-back of
+        runThread (lib/clXEngine_impl.cc:1257)."""
+        x = np.ascontiguousarray(input_matrix)
+        if x.nbytes < self.input_bytes():
+            raise ValueError("xcorrelate: input needs %d bytes" % self.input_bytes())
+        y = _host(cross_correlation, np.complex64, writable=True)
+        check(self._L.mi355_xengine_xcorrelate(self._h, _hp(x), _hp(y), 1 if accumulate else 0), "mi355_xengine_xcorrelate")
+        return self.get_output_buffer_size()
+
+    def xcorrelate_device(self, input_matrix, cross_correlation, accumulate=False):
+        check(self._L.mi355_xengine_xcorrelate_dev(self._h, _dp(input_matrix), _dp(cross_correlation),
+                                                   1 if accumulate else 0, _torch_stream(self.device)),
+              "mi355_xengine_xcorrelate_dev")
+        return self.get_output_buffer_size()
+
+    def gather(self, nframes, frame0, input_items, frame_buffer):
+        """Host frame gather of work_processor (lib/clXEngine_impl.cc:987-1061)."""
+        ins = [np.ascontiguousarray(x) for x in input_items]
+        p = (C.c_void_p * len(ins))(*[x.ctypes.data for x in ins])
+        check(self._L.mi355_xengine_gather(self._h, int(nframes), int(frame0), p, _hp(frame_buffer)), "mi355_xengine_gather")
+        return nframes

@@ -1,0 +1,77 @@
+// Internal helpers shared by the HIP translation units behind mi355_clenabled.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "mi355_clenabled.h"
+
+struct mi355_ctx {
+    int device = 0;
+    int debug = 0;
+    hipStream_t stream[2] = {nullptr, nullptr};  // [0] = compute stream handed out by mi355_ctx_stream
+    int num_cus = 0;
+    std::mutex lock;
+};
+
+void mi355_set_error(const char *fmt, ...);
+
+#define MI355_HIP(call)                                                                  \
+    do {                                                                                 \
+        hipError_t e__ = (call);                                                         \
+        if (e__ != hipSuccess) {                                                         \
+            mi355_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+            return MI355_ERR_HIP;                                                        \
+        }                                                                                \
+    } while (0)
+
+#define MI355_REQUIRE(cond, msg)                         \
+    do {                                                 \
+        if (!(cond)) {                                   \
+            mi355_set_error("invalid argument: %s", msg); \
+            return MI355_ERR_INVALID_ARG;                \
+        }                                                \
+    } while (0)
+
+static inline size_t mi355_dtype_size(int dtype)
+{
+    switch (dtype) {
+    case MI355_DTYPE_COMPLEX: return 8;
+    case MI355_DTYPE_FLOAT: return 4;
+    case MI355_DTYPE_INT: return 4;
+    case MI355_DTYPE_SHORT: return 2;
+    case MI355_DTYPE_BYTE: return 2;   // interleaved int8 I,Q (lib/clXEngine_impl.cc:66-68)
+    case MI355_DTYPE_PACKEDXY: return 1;
+    }
+    return 0;
+}
+
+static inline hipStream_t mi355_pick_stream(mi355_ctx *ctx, void *stream)
+{
+    return stream ? (hipStream_t)stream : ctx->stream[0];
+}
+
+// ---------------------------------------------------------------------------
+// Pinned double-buffered staging for the host-pointer work() path.
+// Two slots; slot s runs H2D -> kernel -> D2H on ctx->stream[s], so the copy-in
+// of chunk c+1 overlaps the kernel / copy-out of chunk c (north_star: "pinned
+// double-buffered H2D/D2H overlapping compute on HIP streams").
+// ---------------------------------------------------------------------------
+struct HostPipe {
+    static constexpr int MAXIN = 2;
+    mi355_ctx *ctx = nullptr;
+    size_t cap_in[MAXIN] = {0, 0};
+    size_t cap_out = 0;
+    void *h_in[2][MAXIN] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    void *d_in[2][MAXIN] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    void *h_out[2] = {nullptr, nullptr};
+    void *d_out[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+
+    int init(mi355_ctx *c);
+    int ensure(int nin, const size_t *in_bytes, size_t out_bytes);
+    void release();
+};

@@ -1,0 +1,443 @@
+// clMathOp / clMathConst elementwise family as gfx950 HIP kernels.
+// Reference behaviour: lib/clMathOp_impl.cc:104-238,361-442 and
+// lib/clMathConst_impl.cc:100-225,311-361.
+//
+// HBM-bound streaming kernels: 16 B per lane per access (two gr_complex), four
+// independent accesses in flight per lane, grid capped at 8 blocks per CU and
+// grid-strided.  Algorithmic traffic: 24 B/item (clMathOp, complex),
+// 16 B/item (clMathConst, complex).
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kUnroll = 4;
+
+struct alignas(16) U4 { unsigned x, y, z, w; };
+
+__device__ __forceinline__ float f(unsigned u) { return __uint_as_float(u); }
+__device__ __forceinline__ unsigned u(float v) { return __float_as_uint(v); }
+
+// one 16-byte vector = two complex / four float / four int items
+template <int DT, int OP>
+__device__ __forceinline__ U4 apply2(U4 a, U4 b)
+{
+    U4 r;
+    if constexpr (DT == MI355_DTYPE_INT) {
+        if constexpr (OP == MI355_OP_MULTIPLY) { r.x = a.x * b.x; r.y = a.y * b.y; r.z = a.z * b.z; r.w = a.w * b.w; }
+        else if constexpr (OP == MI355_OP_ADD) { r.x = a.x + b.x; r.y = a.y + b.y; r.z = a.z + b.z; r.w = a.w + b.w; }
+        else { r.x = a.x - b.x; r.y = a.y - b.y; r.z = a.z - b.z; r.w = a.w - b.w; }
+    } else if constexpr (OP == MI355_OP_ADD) {
+        r.x = u(f(a.x) + f(b.x)); r.y = u(f(a.y) + f(b.y)); r.z = u(f(a.z) + f(b.z)); r.w = u(f(a.w) + f(b.w));
+    } else if constexpr (OP == MI355_OP_SUBTRACT) {
+        r.x = u(f(a.x) - f(b.x)); r.y = u(f(a.y) - f(b.y)); r.z = u(f(a.z) - f(b.z)); r.w = u(f(a.w) - f(b.w));
+    } else if constexpr (DT == MI355_DTYPE_FLOAT) {  // multiply
+        r.x = u(f(a.x) * f(b.x)); r.y = u(f(a.y) * f(b.y)); r.z = u(f(a.z) * f(b.z)); r.w = u(f(a.w) * f(b.w));
+    } else {  // complex multiply / multiply-conjugate
+        const float s = (OP == MI355_OP_MULTIPLY_CONJUGATE) ? -1.0f : 1.0f;
+        float ar = f(a.x), ai = f(a.y), br = f(b.x), bi = s * f(b.y);
+        r.x = u(ar * br - ai * bi); r.y = u(ar * bi + ai * br);
+        ar = f(a.z); ai = f(a.w); br = f(b.z); bi = s * f(b.w);
+        r.z = u(ar * br - ai * bi); r.w = u(ar * bi + ai * br);
+    }
+    return r;
+}
+
+template <int DT, int OP>
+__device__ __forceinline__ U4 apply1(U4 a, float k, unsigned ki)
+{
+    U4 r;
+    if constexpr (OP == MI355_OP_EMPTY_W_COPY) {
+        r = a;
+    } else if constexpr (OP == MI355_OP_COMPLEX_CONJUGATE) {
+        r.x = a.x; r.y = u(-1.0f * f(a.y)); r.z = a.z; r.w = u(-1.0f * f(a.w));
+    } else if constexpr (DT == MI355_DTYPE_INT) {
+        if constexpr (OP == MI355_OP_MULTIPLY) { r.x = a.x * ki; r.y = a.y * ki; r.z = a.z * ki; r.w = a.w * ki; }
+        else if constexpr (OP == MI355_OP_ADD) { r.x = a.x + ki; r.y = a.y + ki; r.z = a.z + ki; r.w = a.w + ki; }
+        else { r.x = a.x - ki; r.y = a.y - ki; r.z = a.z - ki; r.w = a.w - ki; }
+    } else {  // float and complex: the real scalar hits every 32-bit lane
+        if constexpr (OP == MI355_OP_MULTIPLY) { r.x = u(f(a.x) * k); r.y = u(f(a.y) * k); r.z = u(f(a.z) * k); r.w = u(f(a.w) * k); }
+        else if constexpr (OP == MI355_OP_ADD) { r.x = u(f(a.x) + k); r.y = u(f(a.y) + k); r.z = u(f(a.z) + k); r.w = u(f(a.w) + k); }
+        else { r.x = u(f(a.x) - k); r.y = u(f(a.y) - k); r.z = u(f(a.z) - k); r.w = u(f(a.w) - k); }
+    }
+    return r;
+}
+
+// nvec 16-byte vectors + ntail trailing 32-bit (float/int) or 64-bit (complex) items
+template <int DT, int OP>
+__global__ __launch_bounds__(kThreads) void k_mathop(const U4 *__restrict__ a, const U4 *__restrict__ b, U4 *__restrict__ c,
+                                                     size_t nvec, int ntail)
+{
+    const size_t stride = (size_t)gridDim.x * kThreads * kUnroll;
+    for (size_t base = (size_t)blockIdx.x * kThreads * kUnroll + threadIdx.x; base < nvec; base += stride) {
+        U4 va[kUnroll], vb[kUnroll];
+#pragma unroll
+        for (int q = 0; q < kUnroll; q++) {
+            size_t i = base + (size_t)q * kThreads;
+            if (i < nvec) { va[q] = a[i]; vb[q] = b[i]; }
+        }
+#pragma unroll
+        for (int q = 0; q < kUnroll; q++) {
+            size_t i = base + (size_t)q * kThreads;
+            if (i < nvec) c[i] = apply2<DT, OP>(va[q], vb[q]);
+        }
+    }
+    if (ntail && blockIdx.x == 0 && threadIdx.x == 0) {
+        // fewer than one vector left: at most 1 complex or 3 scalars
+        const unsigned *ta = (const unsigned *)(a + nvec), *tb = (const unsigned *)(b + nvec);
+        unsigned *tc = (unsigned *)(c + nvec);
+        U4 x = {0, 0, 0, 0}, y = {0, 0, 0, 0};
+        unsigned *px = &x.x, *py = &y.x;
+        for (int j = 0; j < ntail; j++) { px[j] = ta[j]; py[j] = tb[j]; }
+        U4 r = apply2<DT, OP>(x, y);
+        const unsigned *pr = &r.x;
+        for (int j = 0; j < ntail; j++) tc[j] = pr[j];
+    }
+}
+
+template <int DT, int OP>
+__global__ __launch_bounds__(kThreads) void k_mathconst(const U4 *__restrict__ a, U4 *__restrict__ c, size_t nvec, int ntail,
+                                                        float k, unsigned ki)
+{
+    const size_t stride = (size_t)gridDim.x * kThreads * kUnroll;
+    for (size_t base = (size_t)blockIdx.x * kThreads * kUnroll + threadIdx.x; base < nvec; base += stride) {
+        U4 va[kUnroll];
+#pragma unroll
+        for (int q = 0; q < kUnroll; q++) {
+            size_t i = base + (size_t)q * kThreads;
+            if (i < nvec) va[q] = a[i];
+        }
+#pragma unroll
+        for (int q = 0; q < kUnroll; q++) {
+            size_t i = base + (size_t)q * kThreads;
+            if (i < nvec) c[i] = apply1<DT, OP>(va[q], k, ki);
+        }
+    }
+    if (ntail && blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned *ta = (const unsigned *)(a + nvec);
+        unsigned *tc = (unsigned *)(c + nvec);
+        U4 x = {0, 0, 0, 0};
+        unsigned *px = &x.x;
+        for (int j = 0; j < ntail; j++) px[j] = ta[j];
+        U4 r = apply1<DT, OP>(x, k, ki);
+        const unsigned *pr = &r.x;
+        for (int j = 0; j < ntail; j++) tc[j] = pr[j];
+    }
+}
+
+// EMPTY: the reference's "return;" kernel (lib/clMathConst_impl.cc:183-184), kept as a launch-latency probe
+__global__ void k_empty() {}
+
+inline int grid_for(const mi355_ctx *ctx, size_t nvec)
+{
+    size_t per_block = (size_t)kThreads * kUnroll;
+    size_t blocks = (nvec + per_block - 1) / per_block;
+    size_t cap = (size_t)(ctx->num_cus > 0 ? ctx->num_cus : 256) * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+struct mi355_mathop {
+    mi355_ctx *ctx;
+    int dtype, op;
+    size_t isize;
+    HostPipe pipe;
+};
+
+struct mi355_mathconst {
+    mi355_ctx *ctx;
+    int dtype, op;
+    size_t isize;
+    float k;
+    HostPipe pipe;
+    std::mutex klock;
+};
+
+namespace {
+
+template <int DT, int OP>
+int launch2(mi355_ctx *ctx, size_t nitems, size_t isize, const void *a, const void *b, void *c, hipStream_t st)
+{
+    size_t bytes = nitems * isize;
+    size_t nvec = bytes / 16;
+    int ntail = (int)((bytes - nvec * 16) / 4);
+    hipLaunchKernelGGL((k_mathop<DT, OP>), dim3(grid_for(ctx, nvec)), dim3(kThreads), 0, st, (const U4 *)a, (const U4 *)b,
+                       (U4 *)c, nvec, ntail);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+template <int DT, int OP>
+int launch1(mi355_ctx *ctx, size_t nitems, size_t isize, const void *a, void *c, float k, hipStream_t st)
+{
+    size_t bytes = nitems * isize;
+    size_t nvec = bytes / 16;
+    int ntail = (int)((bytes - nvec * 16) / 4);
+    hipLaunchKernelGGL((k_mathconst<DT, OP>), dim3(grid_for(ctx, nvec)), dim3(kThreads), 0, st, (const U4 *)a, (U4 *)c, nvec, ntail,
+                       k, (unsigned)(int)k);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+int dispatch2(mi355_mathop *h, size_t n, const void *a, const void *b, void *c, hipStream_t st)
+{
+#define CASE2(DT, OP) \
+    if (h->dtype == DT && h->op == OP) return launch2<DT, OP>(h->ctx, n, h->isize, a, b, c, st)
+    CASE2(MI355_DTYPE_COMPLEX, MI355_OP_MULTIPLY);
+    CASE2(MI355_DTYPE_COMPLEX, MI355_OP_ADD);
+    CASE2(MI355_DTYPE_COMPLEX, MI355_OP_SUBTRACT);
+    CASE2(MI355_DTYPE_COMPLEX, MI355_OP_MULTIPLY_CONJUGATE);
+    CASE2(MI355_DTYPE_FLOAT, MI355_OP_MULTIPLY);
+    CASE2(MI355_DTYPE_FLOAT, MI355_OP_ADD);
+    CASE2(MI355_DTYPE_FLOAT, MI355_OP_SUBTRACT);
+    CASE2(MI355_DTYPE_INT, MI355_OP_MULTIPLY);
+    CASE2(MI355_DTYPE_INT, MI355_OP_ADD);
+    CASE2(MI355_DTYPE_INT, MI355_OP_SUBTRACT);
+#undef CASE2
+    return MI355_ERR_UNSUPPORTED;
+}
+
+int dispatch1(mi355_mathconst *h, size_t n, const void *a, void *c, float k, hipStream_t st)
+{
+    if (h->op == MI355_OP_EMPTY) {
+        hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, st);
+        MI355_HIP(hipGetLastError());
+        return MI355_OK;
+    }
+#define CASE1(DT, OP) \
+    if (h->dtype == DT && h->op == OP) return launch1<DT, OP>(h->ctx, n, h->isize, a, c, k, st)
+    CASE1(MI355_DTYPE_COMPLEX, MI355_OP_MULTIPLY);
+    CASE1(MI355_DTYPE_COMPLEX, MI355_OP_ADD);
+    CASE1(MI355_DTYPE_COMPLEX, MI355_OP_SUBTRACT);
+    CASE1(MI355_DTYPE_COMPLEX, MI355_OP_COMPLEX_CONJUGATE);
+    CASE1(MI355_DTYPE_COMPLEX, MI355_OP_EMPTY_W_COPY);
+    CASE1(MI355_DTYPE_FLOAT, MI355_OP_MULTIPLY);
+    CASE1(MI355_DTYPE_FLOAT, MI355_OP_ADD);
+    CASE1(MI355_DTYPE_FLOAT, MI355_OP_SUBTRACT);
+    CASE1(MI355_DTYPE_FLOAT, MI355_OP_EMPTY_W_COPY);
+    CASE1(MI355_DTYPE_INT, MI355_OP_MULTIPLY);
+    CASE1(MI355_DTYPE_INT, MI355_OP_ADD);
+    CASE1(MI355_DTYPE_INT, MI355_OP_SUBTRACT);
+    CASE1(MI355_DTYPE_INT, MI355_OP_EMPTY_W_COPY);
+#undef CASE1
+    return MI355_ERR_UNSUPPORTED;
+}
+
+bool valid_op2(int dtype, int op)
+{
+    if (op == MI355_OP_MULTIPLY || op == MI355_OP_ADD || op == MI355_OP_SUBTRACT) return true;
+    return dtype == MI355_DTYPE_COMPLEX && op == MI355_OP_MULTIPLY_CONJUGATE;
+}
+
+bool valid_op1(int dtype, int op)
+{
+    if (op == MI355_OP_MULTIPLY || op == MI355_OP_ADD || op == MI355_OP_SUBTRACT || op == MI355_OP_EMPTY ||
+        op == MI355_OP_EMPTY_W_COPY)
+        return true;
+    return dtype == MI355_DTYPE_COMPLEX && op == MI355_OP_COMPLEX_CONJUGATE;
+}
+
+constexpr size_t kChunkBytes = 8u << 20;  // staging chunk of the host path
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+extern "C" int mi355_mathop_create(mi355_ctx *ctx, int dtype, int op, size_t max_items, mi355_mathop **out)
+{
+    MI355_REQUIRE(ctx && out, "NULL argument");
+    *out = nullptr;
+    MI355_REQUIRE(dtype == MI355_DTYPE_COMPLEX || dtype == MI355_DTYPE_FLOAT || dtype == MI355_DTYPE_INT,
+                  "clMathOp dtype must be complex, float or int");
+    MI355_REQUIRE(valid_op2(dtype, op), "operator not valid for clMathOp with this data type");
+    mi355_mathop *h = new (std::nothrow) mi355_mathop();
+    if (!h) return MI355_ERR_NOMEM;
+    h->ctx = ctx; h->dtype = dtype; h->op = op; h->isize = mi355_dtype_size(dtype);
+    int rc = h->pipe.init(ctx);
+    if (rc == MI355_OK) {
+        size_t want = (max_items ? max_items : 8192) * h->isize;
+        if (want > kChunkBytes) want = kChunkBytes;
+        size_t inb[2] = {want, want};
+        rc = h->pipe.ensure(2, inb, want);
+    }
+    if (rc != MI355_OK) { h->pipe.release(); delete h; return rc; }
+    *out = h;
+    return MI355_OK;
+}
+
+extern "C" int mi355_mathop_destroy(mi355_mathop *h)
+{
+    if (!h) return MI355_OK;
+    h->pipe.release();
+    delete h;
+    return MI355_OK;
+}
+
+extern "C" int mi355_mathop_work_dev(mi355_mathop *h, size_t nitems, const void *a, const void *b, void *c, void *stream)
+{
+    MI355_REQUIRE(h != nullptr, "handle is NULL");
+    if (nitems == 0) return MI355_OK;
+    MI355_REQUIRE(a && b && c, "NULL buffer");
+    MI355_REQUIRE(aligned16(a) && aligned16(b) && aligned16(c), "device buffers must be 16-byte aligned");
+    MI355_HIP(hipSetDevice(h->ctx->device));
+    return dispatch2(h, nitems, a, b, c, mi355_pick_stream(h->ctx, stream));
+}
+
+extern "C" int mi355_mathop_work(mi355_mathop *h, size_t nitems, const void *a, const void *b, void *c)
+{
+    MI355_REQUIRE(h != nullptr, "handle is NULL");
+    if (nitems == 0) return MI355_OK;
+    MI355_REQUIRE(a && b && c, "NULL buffer");
+    std::lock_guard<std::mutex> g(h->ctx->lock);
+    MI355_HIP(hipSetDevice(h->ctx->device));
+    const size_t chunk_items = kChunkBytes / h->isize;
+    size_t first = nitems < chunk_items ? nitems : chunk_items;
+    size_t inb[2] = {first * h->isize, first * h->isize};
+    int rc = h->pipe.ensure(2, inb, first * h->isize);
+    if (rc) return rc;
+    HostPipe &p = h->pipe;
+    const char *pa = (const char *)a, *pb = (const char *)b;
+    char *pc = (char *)c;
+    size_t nchunks = (nitems + chunk_items - 1) / chunk_items;
+    size_t pend_off[2] = {0, 0}, pend_bytes[2] = {0, 0};
+    for (size_t ci = 0; ci < nchunks; ci++) {
+        int s = (int)(ci & 1);
+        hipStream_t st = h->ctx->stream[s];
+        if (pend_bytes[s]) {  // slot busy with chunk ci-2: drain it
+            MI355_HIP(hipEventSynchronize(p.done[s]));
+            memcpy(pc + pend_off[s], p.h_out[s], pend_bytes[s]);
+            pend_bytes[s] = 0;
+        }
+        size_t off_items = ci * chunk_items;
+        size_t n = nitems - off_items < chunk_items ? nitems - off_items : chunk_items;
+        size_t bytes = n * h->isize, off = off_items * h->isize;
+        memcpy(p.h_in[s][0], pa + off, bytes);
+        memcpy(p.h_in[s][1], pb + off, bytes);
+        MI355_HIP(hipMemcpyAsync(p.d_in[s][0], p.h_in[s][0], bytes, hipMemcpyHostToDevice, st));
+        MI355_HIP(hipMemcpyAsync(p.d_in[s][1], p.h_in[s][1], bytes, hipMemcpyHostToDevice, st));
+        rc = dispatch2(h, n, p.d_in[s][0], p.d_in[s][1], p.d_out[s], st);
+        if (rc) return rc;
+        MI355_HIP(hipMemcpyAsync(p.h_out[s], p.d_out[s], bytes, hipMemcpyDeviceToHost, st));
+        MI355_HIP(hipEventRecord(p.done[s], st));
+        pend_off[s] = off; pend_bytes[s] = bytes;
+    }
+    for (int q = 0; q < 2; q++) {
+        int s = (int)((nchunks + q) & 1);  // older slot first
+        if (pend_bytes[s]) {
+            MI355_HIP(hipEventSynchronize(p.done[s]));
+            memcpy(pc + pend_off[s], p.h_out[s], pend_bytes[s]);
+            pend_bytes[s] = 0;
+        }
+    }
+    return MI355_OK;
+}
+
+// ---------------------------------------------------------------------------
+extern "C" int mi355_mathconst_create(mi355_ctx *ctx, int dtype, int op, float k, size_t max_items, mi355_mathconst **out)
+{
+    MI355_REQUIRE(ctx && out, "NULL argument");
+    *out = nullptr;
+    MI355_REQUIRE(dtype == MI355_DTYPE_COMPLEX || dtype == MI355_DTYPE_FLOAT || dtype == MI355_DTYPE_INT,
+                  "clMathConst dtype must be complex, float or int");
+    MI355_REQUIRE(valid_op1(dtype, op), "operator not valid for clMathConst with this data type");
+    mi355_mathconst *h = new (std::nothrow) mi355_mathconst();
+    if (!h) return MI355_ERR_NOMEM;
+    h->ctx = ctx; h->dtype = dtype; h->op = op; h->k = k; h->isize = mi355_dtype_size(dtype);
+    int rc = h->pipe.init(ctx);
+    if (rc == MI355_OK) {
+        size_t want = (max_items ? max_items : 8192) * h->isize;
+        if (want > kChunkBytes) want = kChunkBytes;
+        rc = h->pipe.ensure(1, &want, want);
+    }
+    if (rc != MI355_OK) { h->pipe.release(); delete h; return rc; }
+    *out = h;
+    return MI355_OK;
+}
+
+extern "C" int mi355_mathconst_destroy(mi355_mathconst *h)
+{
+    if (!h) return MI355_OK;
+    h->pipe.release();
+    delete h;
+    return MI355_OK;
+}
+
+extern "C" int mi355_mathconst_set_k(mi355_mathconst *h, float k)
+{
+    MI355_REQUIRE(h != nullptr, "handle is NULL");
+    std::lock_guard<std::mutex> g(h->klock);
+    h->k = k;
+    return MI355_OK;
+}
+
+extern "C" int mi355_mathconst_get_k(const mi355_mathconst *h, float *k)
+{
+    MI355_REQUIRE(h && k, "NULL argument");
+    *k = h->k;
+    return MI355_OK;
+}
+
+extern "C" int mi355_mathconst_work_dev(mi355_mathconst *h, size_t nitems, const void *a, void *c, void *stream)
+{
+    MI355_REQUIRE(h != nullptr, "handle is NULL");
+    if (nitems == 0) return MI355_OK;
+    MI355_REQUIRE(a && c, "NULL buffer");
+    MI355_REQUIRE(aligned16(a) && aligned16(c), "device buffers must be 16-byte aligned");
+    MI355_HIP(hipSetDevice(h->ctx->device));
+    float k;
+    { std::lock_guard<std::mutex> g(h->klock); k = h->k; }
+    return dispatch1(h, nitems, a, c, k, mi355_pick_stream(h->ctx, stream));
+}
+
+extern "C" int mi355_mathconst_work(mi355_mathconst *h, size_t nitems, const void *a, void *c)
+{
+    MI355_REQUIRE(h != nullptr, "handle is NULL");
+    if (nitems == 0) return MI355_OK;
+    MI355_REQUIRE(a && c, "NULL buffer");
+    std::lock_guard<std::mutex> g(h->ctx->lock);
+    MI355_HIP(hipSetDevice(h->ctx->device));
+    float k;
+    { std::lock_guard<std::mutex> gk(h->klock); k = h->k; }
+    const size_t chunk_items = kChunkBytes / h->isize;
+    size_t first = nitems < chunk_items ? nitems : chunk_items;
+    size_t inb = first * h->isize;
+    int rc = h->pipe.ensure(1, &inb, inb);
+    if (rc) return rc;
+    HostPipe &p = h->pipe;
+    const char *pa = (const char *)a;
+    char *pc = (char *)c;
+    size_t nchunks = (nitems + chunk_items - 1) / chunk_items;
+    size_t pend_off[2] = {0, 0}, pend_bytes[2] = {0, 0};
+    for (size_t ci = 0; ci < nchunks; ci++) {
+        int s = (int)(ci & 1);
+        hipStream_t st = h->ctx->stream[s];
+        if (pend_bytes[s]) {
+            MI355_HIP(hipEventSynchronize(p.done[s]));
+            if (h->op != MI355_OP_EMPTY) memcpy(pc + pend_off[s], p.h_out[s], pend_bytes[s]);
+            pend_bytes[s] = 0;
+        }
+        size_t off_items = ci * chunk_items;
+        size_t n = nitems - off_items < chunk_items ? nitems - off_items : chunk_items;
+        size_t bytes = n * h->isize, off = off_items * h->isize;
+        memcpy(p.h_in[s][0], pa + off, bytes);
+        MI355_HIP(hipMemcpyAsync(p.d_in[s][0], p.h_in[s][0], bytes, hipMemcpyHostToDevice, st));
+        rc = dispatch1(h, n, p.d_in[s][0], p.d_out[s], k, st);
+        if (rc) return rc;
+        MI355_HIP(hipMemcpyAsync(p.h_out[s], p.d_out[s], bytes, hipMemcpyDeviceToHost, st));
+        MI355_HIP(hipEventRecord(p.done[s], st));
+        pend_off[s] = off; pend_bytes[s] = bytes;
+    }
+    for (int q = 0; q < 2; q++) {
+        int s = (int)((nchunks + q) & 1);
+        if (pend_bytes[s]) {
+            MI355_HIP(hipEventSynchronize(p.done[s]));
+            if (h->op != MI355_OP_EMPTY) memcpy(pc + pend_off[s], p.h_out[s], pend_bytes[s]);
+            pend_bytes[s] = 0;
+        }
+    }
+    return MI355_OK;
+}

@@ -1,0 +1,202 @@
+// Device runtime behind mi355_clenabled.h: context, streams, errors, staging.
+// Takes the place of the reference's GRCLBase OpenCL shim
+// (include/clenabled/GRCLBase.h:77-141, lib/GRCLBase.cpp:17-474): one context =
+// one HIP device + two streams; errors are status codes, never exit().
+#include <cstdarg>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void mi355_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *mi355_last_error(void) { return g_err; }
+
+extern "C" const char *mi355_version(void) { return "gr-clenabled_amd 0.1 (gfx950)"; }
+
+extern "C" const char *mi355_strerror(int code)
+{
+    switch (code) {
+    case MI355_OK: return "ok";
+    case MI355_ERR_INVALID_ARG: return "invalid argument";
+    case MI355_ERR_NO_DEVICE: return "no gfx950 device";
+    case MI355_ERR_UNSUPPORTED: return "unsupported configuration";
+    case MI355_ERR_HIP: return "HIP runtime error";
+    case MI355_ERR_NOMEM: return "out of memory";
+    case MI355_ERR_STATE: return "invalid handle state";
+    }
+    return "unknown error";
+}
+
+extern "C" int mi355_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        mi355_set_error("hipGetDeviceCount -> %s", hipGetErrorString(e));
+        return MI355_ERR_NO_DEVICE;
+    }
+    return n;
+}
+
+extern "C" int mi355_ctx_create(int ocl_type, int dev_selector, int platform_id, int dev_id, int debug, mi355_ctx **out)
+{
+    MI355_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    if (ocl_type == MI355_OCLTYPE_CPU) {
+        mi355_set_error("OCLTYPE_CPU requested: this library has no CPU path");
+        return MI355_ERR_UNSUPPORTED;
+    }
+    MI355_REQUIRE(ocl_type == MI355_OCLTYPE_GPU || ocl_type == MI355_OCLTYPE_ACCELERATOR || ocl_type == MI355_OCLTYPE_ANY,
+                  "openCLPlatformType must be 1, 2 or 4");
+    MI355_REQUIRE(dev_selector == MI355_DEVSEL_FIRST || dev_selector == MI355_DEVSEL_SPECIFIC, "devSelector must be 1 or 2");
+    int n = mi355_device_count();
+    if (n <= 0) {
+        if (n == 0) mi355_set_error("no HIP device visible");
+        return MI355_ERR_NO_DEVICE;
+    }
+    int dev = 0;
+    if (dev_selector == MI355_DEVSEL_SPECIFIC) {
+        MI355_REQUIRE(platform_id == 0, "platformId must be 0 (single HIP platform)");
+        MI355_REQUIRE(dev_id >= 0 && dev_id < n, "devId out of range");
+        dev = dev_id;
+    }
+    hipDeviceProp_t prop;
+    MI355_HIP(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        mi355_set_error("device %d is %s, this library carries gfx950 code only", dev, prop.gcnArchName);
+        return MI355_ERR_NO_DEVICE;
+    }
+    mi355_ctx *c = new (std::nothrow) mi355_ctx();
+    if (!c) return MI355_ERR_NOMEM;
+    c->device = dev;
+    c->debug = debug;
+    c->num_cus = prop.multiProcessorCount;
+    MI355_HIP(hipSetDevice(dev));
+    for (int i = 0; i < 2; i++) MI355_HIP(hipStreamCreateWithFlags(&c->stream[i], hipStreamNonBlocking));
+    if (debug)
+        fprintf(stderr, "[mi355] context on device %d (%s, %d CUs, %.1f GB)\n", dev, prop.gcnArchName, prop.multiProcessorCount,
+                prop.totalGlobalMem / 1e9);
+    *out = c;
+    return MI355_OK;
+}
+
+extern "C" int mi355_ctx_destroy(mi355_ctx *ctx)
+{
+    if (!ctx) return MI355_OK;
+    (void)hipSetDevice(ctx->device);
+    for (int i = 0; i < 2; i++)
+        if (ctx->stream[i]) {
+            (void)hipStreamSynchronize(ctx->stream[i]);
+            (void)hipStreamDestroy(ctx->stream[i]);
+        }
+    delete ctx;
+    return MI355_OK;
+}
+
+extern "C" int mi355_ctx_device(const mi355_ctx *ctx) { return ctx ? ctx->device : MI355_ERR_INVALID_ARG; }
+
+extern "C" void *mi355_ctx_stream(mi355_ctx *ctx) { return ctx ? (void *)ctx->stream[0] : nullptr; }
+
+extern "C" int mi355_ctx_synchronize(mi355_ctx *ctx)
+{
+    MI355_REQUIRE(ctx != nullptr, "ctx is NULL");
+    MI355_HIP(hipSetDevice(ctx->device));
+    for (int i = 0; i < 2; i++) MI355_HIP(hipStreamSynchronize(ctx->stream[i]));
+    return MI355_OK;
+}
+
+extern "C" int mi355_malloc(mi355_ctx *ctx, size_t bytes, void **dptr)
+{
+    MI355_REQUIRE(ctx && dptr, "NULL argument");
+    MI355_HIP(hipSetDevice(ctx->device));
+    MI355_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+    return MI355_OK;
+}
+
+extern "C" int mi355_free(mi355_ctx *ctx, void *dptr)
+{
+    MI355_REQUIRE(ctx != nullptr, "ctx is NULL");
+    MI355_HIP(hipSetDevice(ctx->device));
+    MI355_HIP(hipFree(dptr));
+    return MI355_OK;
+}
+
+extern "C" int mi355_memcpy_h2d(mi355_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
+{
+    MI355_REQUIRE(ctx != nullptr, "ctx is NULL");
+    MI355_HIP(hipSetDevice(ctx->device));
+    MI355_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream[0]));
+    MI355_HIP(hipStreamSynchronize(ctx->stream[0]));
+    return MI355_OK;
+}
+
+extern "C" int mi355_memcpy_d2h(mi355_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes)
+{
+    MI355_REQUIRE(ctx != nullptr, "ctx is NULL");
+    MI355_HIP(hipSetDevice(ctx->device));
+    MI355_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream[0]));
+    MI355_HIP(hipStreamSynchronize(ctx->stream[0]));
+    return MI355_OK;
+}
+
+// ---------------------------------------------------------------------------
+int HostPipe::init(mi355_ctx *c)
+{
+    ctx = c;
+    MI355_HIP(hipSetDevice(c->device));
+    for (int s = 0; s < 2; s++) MI355_HIP(hipEventCreateWithFlags(&done[s], hipEventDisableTiming));
+    return MI355_OK;
+}
+
+int HostPipe::ensure(int nin, const size_t *in_bytes, size_t out_bytes)
+{
+    MI355_HIP(hipSetDevice(ctx->device));
+    for (int i = 0; i < nin; i++) {
+        if (in_bytes[i] <= cap_in[i]) continue;
+        for (int s = 0; s < 2; s++) {
+            if (h_in[s][i]) MI355_HIP(hipHostFree(h_in[s][i]));
+            if (d_in[s][i]) MI355_HIP(hipFree(d_in[s][i]));
+            h_in[s][i] = d_in[s][i] = nullptr;
+            MI355_HIP(hipHostMalloc(&h_in[s][i], in_bytes[i], hipHostMallocDefault));
+            MI355_HIP(hipMalloc(&d_in[s][i], in_bytes[i]));
+        }
+        cap_in[i] = in_bytes[i];
+    }
+    if (out_bytes > cap_out) {
+        for (int s = 0; s < 2; s++) {
+            if (h_out[s]) MI355_HIP(hipHostFree(h_out[s]));
+            if (d_out[s]) MI355_HIP(hipFree(d_out[s]));
+            h_out[s] = d_out[s] = nullptr;
+            MI355_HIP(hipHostMalloc(&h_out[s], out_bytes, hipHostMallocDefault));
+            MI355_HIP(hipMalloc(&d_out[s], out_bytes));
+        }
+        cap_out = out_bytes;
+    }
+    return MI355_OK;
+}
+
+void HostPipe::release()
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    for (int s = 0; s < 2; s++) {
+        for (int i = 0; i < MAXIN; i++) {
+            if (h_in[s][i]) (void)hipHostFree(h_in[s][i]);
+            if (d_in[s][i]) (void)hipFree(d_in[s][i]);
+            h_in[s][i] = d_in[s][i] = nullptr;
+        }
+        if (h_out[s]) (void)hipHostFree(h_out[s]);
+        if (d_out[s]) (void)hipFree(d_out[s]);
+        h_out[s] = d_out[s] = nullptr;
+        if (done[s]) (void)hipEventDestroy(done[s]);
+        done[s] = nullptr;
+    }
+    cap_in[0] = cap_in[1] = cap_out = 0;
+}

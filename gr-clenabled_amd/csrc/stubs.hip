@@ -1,0 +1,28 @@
+// TEMPORARY: entry points not implemented yet return MI355_ERR_UNSUPPORTED.
+#include "common.h"
+#define STUB(sig) extern "C" int sig { mi355_set_error("not implemented yet"); return MI355_ERR_UNSUPPORTED; }
+STUB(mi355_fft_create(mi355_ctx *, int, int, const float *, int, int, int, int, mi355_fft **))
+STUB(mi355_fft_destroy(mi355_fft *))
+STUB(mi355_fft_work(mi355_fft *, int, const void *const *, void *const *))
+STUB(mi355_fft_work_dev(mi355_fft *, int, const void *, void *, void *))
+STUB(mi355_filter_create(mi355_ctx *, int, const void *, int, int, int, mi355_filter **))
+STUB(mi355_filter_destroy(mi355_filter *))
+STUB(mi355_filter_set_taps(mi355_filter *, const void *, int))
+STUB(mi355_filter_ntaps(const mi355_filter *))
+STUB(mi355_filter_get_taps(const mi355_filter *, void *, int))
+STUB(mi355_filter_fftsize(const mi355_filter *))
+STUB(mi355_filter_work(mi355_filter *, size_t, const void *, void *))
+STUB(mi355_filter_work_dev(mi355_filter *, size_t, const void *, void *, void *))
+STUB(mi355_pfb_create(mi355_ctx *, const float *, int, int, int, int, const int *, int, mi355_pfb **))
+STUB(mi355_pfb_destroy(mi355_pfb *))
+STUB(mi355_pfb_noutput(const mi355_pfb *))
+STUB(mi355_pfb_ninput(const mi355_pfb *))
+STUB(mi355_pfb_work(mi355_pfb *, const void *, void *))
+STUB(mi355_pfb_work_dev(mi355_pfb *, const void *, void *, void *))
+STUB(mi355_xengine_create(mi355_ctx *, int, int, int, int, int, mi355_xengine **))
+STUB(mi355_xengine_destroy(mi355_xengine *))
+extern "C" size_t mi355_xengine_input_bytes(const mi355_xengine *) { return 0; }
+extern "C" size_t mi355_xengine_output_items(const mi355_xengine *) { return 0; }
+STUB(mi355_xengine_xcorrelate(mi355_xengine *, const void *, void *, int))
+STUB(mi355_xengine_xcorrelate_dev(mi355_xengine *, const void *, void *, int, void *))
+STUB(mi355_xengine_gather(const mi355_xengine *, int, int, const void *const *, void *))

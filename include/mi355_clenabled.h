@@ -1,0 +1,209 @@
+/*
+ * mi355_clenabled.h -- C ABI of the MI355X (gfx950) streaming-DSP hot path that
+ * replaces gr-clenabled's OpenCL runtime shim and kernel bodies.
+ *
+ * This is the drop-in boundary: the reference's block implementations
+ * (lib/cl*_impl.cc) inherit GRCLBase (include/clenabled/GRCLBase.h:77-141,
+ * lib/GRCLBase.cpp:17-474) and call cl::CommandQueue / clFFT from work();
+ * a gr-clenabled maintainer binds the entry points below instead (see
+ * INTEGRATION.md for the exact _impl stubs).  Plain C, opaque handles, raw
+ * pointers and sizes only; nothing here throws or calls exit().
+ *
+ * Conventions
+ *   - every function returns MI355_OK (0) or a negative MI355_ERR_* code;
+ *     mi355_last_error() gives the thread's last diagnostic string;
+ *   - gr_complex == { float re, im } interleaved, 8 bytes
+ *     (include/clenabled/clSComplex.h:12-17);
+ *   - `*_work(...)`     take HOST pointers, exactly what GNU Radio hands a
+ *     block's work(); the call stages through pinned double buffers
+ *     (H2D / kernel / D2H overlapped on two HIP streams) and returns when the
+ *     output is complete -- the contract of the reference's blocking
+ *     enqueueReadBuffer (e.g. lib/clMathOp_impl.cc:438);
+ *   - `*_work_dev(...)` take DEVICE pointers plus a hipStream_t (as void*; NULL
+ *     = the handle's own stream) and only enqueue: this is the device-resident
+ *     path chained blocks and the benchmarks use;
+ *   - there is NO CPU fallback: OCLTYPE_CPU (3) is refused with
+ *     MI355_ERR_UNSUPPORTED and every call fails loudly without a gfx950 GPU.
+ */
+#ifndef MI355_CLENABLED_H
+#define MI355_CLENABLED_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_OK               0
+#define MI355_ERR_INVALID_ARG (-1)
+#define MI355_ERR_NO_DEVICE   (-2)
+#define MI355_ERR_UNSUPPORTED (-3)
+#define MI355_ERR_HIP         (-4)
+#define MI355_ERR_NOMEM       (-5)
+#define MI355_ERR_STATE       (-6)
+
+/* data types: include/clenabled/GRCLBase.h:57-62 */
+#define MI355_DTYPE_COMPLEX  1
+#define MI355_DTYPE_FLOAT    2
+#define MI355_DTYPE_INT      3
+#define MI355_DTYPE_SHORT    4
+#define MI355_DTYPE_BYTE     5
+#define MI355_DTYPE_PACKEDXY 6
+/* device selection: include/clenabled/GRCLBase.h:64-70 */
+#define MI355_OCLTYPE_GPU         1
+#define MI355_OCLTYPE_ACCELERATOR 2
+#define MI355_OCLTYPE_CPU         3
+#define MI355_OCLTYPE_ANY         4
+#define MI355_DEVSEL_FIRST    1
+#define MI355_DEVSEL_SPECIFIC 2
+/* operators: include/clenabled/clMathOpTypes.h:11-20 */
+#define MI355_OP_MULTIPLY           1
+#define MI355_OP_ADD                2
+#define MI355_OP_SUBTRACT           3
+#define MI355_OP_COMPLEX_CONJUGATE  4
+#define MI355_OP_MULTIPLY_CONJUGATE 5
+#define MI355_OP_EMPTY_W_COPY     254
+#define MI355_OP_EMPTY            255
+/* FFT direction as GRC passes it (clFFT's enum; lib/clFFT_impl.cc:84-89,
+ * grc/clenabled_clFFT.block.yml:37-41) */
+#define MI355_FFT_FORWARD  (-1)
+#define MI355_FFT_BACKWARD   1
+
+typedef struct mi355_ctx     mi355_ctx;
+typedef struct mi355_mathop  mi355_mathop;
+typedef struct mi355_mathconst mi355_mathconst;
+typedef struct mi355_fft     mi355_fft;
+typedef struct mi355_filter  mi355_filter;
+typedef struct mi355_pfb     mi355_pfb;
+typedef struct mi355_xengine mi355_xengine;
+
+/* ---------------------------------------------------------------------------
+ * Runtime: replaces GRCLBase::InitOpenCL / cleanup (lib/GRCLBase.cpp:17-369,
+ * 423-474) and the ctor arguments (include/clenabled/GRCLBase.h:136-137).
+ * ------------------------------------------------------------------------- */
+const char *mi355_strerror(int code);
+const char *mi355_last_error(void);
+const char *mi355_version(void);
+/* number of gfx950 devices visible, or a negative error */
+int mi355_device_count(void);
+/* ocl_type 1/2/4 -> HIP device; 3 (CPU) -> MI355_ERR_UNSUPPORTED.
+ * dev_selector FIRST -> ordinal 0; SPECIFIC -> ordinal dev_id (platform_id must
+ * be 0: there is one HIP platform). */
+int mi355_ctx_create(int ocl_type, int dev_selector, int platform_id, int dev_id, int debug, mi355_ctx **out);
+int mi355_ctx_destroy(mi355_ctx *ctx);
+int mi355_ctx_device(const mi355_ctx *ctx);
+/* the context's compute stream (hipStream_t) */
+void *mi355_ctx_stream(mi355_ctx *ctx);
+int mi355_ctx_synchronize(mi355_ctx *ctx);
+/* device memory helpers for callers without their own allocator (C++ harness) */
+int mi355_malloc(mi355_ctx *ctx, size_t bytes, void **dptr);
+int mi355_free(mi355_ctx *ctx, void *dptr);
+int mi355_memcpy_h2d(mi355_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int mi355_memcpy_d2h(mi355_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* ---------------------------------------------------------------------------
+ * clMathOp: c = a (op) b.  Replaces clMathOp_impl::processOpenCL
+ * (lib/clMathOp_impl.cc:361-442) and its kernels (:104-238).
+ * dtype COMPLEX/FLOAT/INT; op MULTIPLY/ADD/SUBTRACT (+MULTIPLY_CONJUGATE for
+ * complex).  max_items is a sizing hint (0 -> 8192, :80-84); buffers grow.
+ * ------------------------------------------------------------------------- */
+int mi355_mathop_create(mi355_ctx *ctx, int dtype, int op, size_t max_items, mi355_mathop **out);
+int mi355_mathop_destroy(mi355_mathop *h);
+int mi355_mathop_work(mi355_mathop *h, size_t nitems, const void *a, const void *b, void *c);
+int mi355_mathop_work_dev(mi355_mathop *h, size_t nitems, const void *a, const void *b, void *c, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * clMathConst: c = a (op) k with a REAL scalar k applied to both components of
+ * a complex item.  Replaces clMathConst_impl::processOpenCL
+ * (lib/clMathConst_impl.cc:311-361), kernels (:100-225), k()/set_k()
+ * (lib/clMathConst_impl.h:107-108).  op MULTIPLY/ADD/SUBTRACT,
+ * COMPLEX_CONJUGATE (complex only), EMPTY_W_COPY (copy), EMPTY (no-op launch).
+ * ------------------------------------------------------------------------- */
+int mi355_mathconst_create(mi355_ctx *ctx, int dtype, int op, float k, size_t max_items, mi355_mathconst **out);
+int mi355_mathconst_destroy(mi355_mathconst *h);
+int mi355_mathconst_set_k(mi355_mathconst *h, float k);
+int mi355_mathconst_get_k(const mi355_mathconst *h, float *k);
+int mi355_mathconst_work(mi355_mathconst *h, size_t nitems, const void *a, void *c);
+int mi355_mathconst_work_dev(mi355_mathconst *h, size_t nitems, const void *a, void *c, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * clFFT: per frame Y = [fftshift] FFT_N( x .* window ), unnormalised in both
+ * directions.  Replaces the clFFT plan + MultiplyFloat kernel + host fftshift
+ * of clFFT_impl (ctor lib/clFFT_impl.cc:65-151, processOpenCL :526-634).
+ * fft_size: power of two, 8..16384.  window: NULL/0 or exactly fft_size floats
+ * (:74-76).  dtype COMPLEX or FLOAT (real input, complex output).
+ * `nvec` = number of frames per stream (= noutput_items of work(), :637-654).
+ * ------------------------------------------------------------------------- */
+int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, const float *window, int window_len,
+                     int dtype, int num_streams, int shift, mi355_fft **out);
+int mi355_fft_destroy(mi355_fft *h);
+int mi355_fft_work(mi355_fft *h, int nvec, const void *const *in_streams, void *const *out_streams);
+int mi355_fft_work_dev(mi355_fft *h, int nvec, const void *in, void *out, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * clFilter / clComplexFilter: decimating FIR on a complex stream,
+ *     y[m] = sum_k h[k] * x[m*decimation - k]
+ * Replaces clFilter_impl (ctor lib/clFilter_impl.cc:50-83, filterGPUTimeDomain
+ * :504-589, filterGPUFrequencyDomain :591-681, set_taps2 :441-479) and
+ * clComplexFilter_impl::filterGPU (lib/clComplexFilter_impl.cc:959-1030).
+ * `in` is GNU Radio's history-prefixed buffer (set_history(ntaps), :78):
+ * in[ntaps-1] is x[0]; noutput*decimation + ntaps - 1 samples are read.
+ * use_time = 0 : fused overlap-save fast convolution (FFT -> xH -> IFFT in LDS)
+ * use_time = 1 : direct-form tap dot product
+ * complex_taps = 1 : taps is ntaps gr_complex (clComplexFilter), else floats.
+ * ------------------------------------------------------------------------- */
+int mi355_filter_create(mi355_ctx *ctx, int decimation, const void *taps, int ntaps, int complex_taps,
+                        int use_time, mi355_filter **out);
+int mi355_filter_destroy(mi355_filter *h);
+int mi355_filter_set_taps(mi355_filter *h, const void *taps, int ntaps);
+int mi355_filter_ntaps(const mi355_filter *h);
+int mi355_filter_get_taps(const mi355_filter *h, void *taps_out, int cap);
+/* FFT size the fast-convolution kernel runs (0 in time-domain mode) */
+int mi355_filter_fftsize(const mi355_filter *h);
+int mi355_filter_work(mi355_filter *h, size_t noutput_items, const void *in_with_history, void *out);
+int mi355_filter_work_dev(mi355_filter *h, size_t noutput_items, const void *in_with_history, void *out, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * clPolyphaseChannelizer: M-branch polyphase filterbank + M-point backward DFT
+ * + channel map, one multiplexed output stream.  Replaces
+ * clPolyphaseChannelizer_impl (ctor lib/clPolyphaseChannelizer_impl.cc:47-67,
+ * general_work :83-109, kernels :153-177, clFFT plan :208-225).
+ * One call consumes buf_items inputs and produces nmap*buf_items/ninputs_per_iter
+ * outputs.  `in` is history-prefixed (set_history(ntaps), :63) and must hold
+ * buf_items - ninputs_per_iter + ntaps samples.
+ * ------------------------------------------------------------------------- */
+int mi355_pfb_create(mi355_ctx *ctx, const float *taps, int ntaps, int buf_items, int num_channels,
+                     int ninputs_per_iter, const int *ch_map, int nmap, mi355_pfb **out);
+int mi355_pfb_destroy(mi355_pfb *h);
+int mi355_pfb_noutput(const mi355_pfb *h);
+int mi355_pfb_ninput(const mi355_pfb *h);
+int mi355_pfb_work(mi355_pfb *h, const void *in_with_history, void *out);
+int mi355_pfb_work_dev(mi355_pfb *h, const void *in_with_history, void *out, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * clXEngine: V[f][k][pol2] = sum_t x_s1(t,f) conj(x_s2(t,f)), k = s1(s1+1)/2+s2.
+ * Replaces clXEngine_impl's device side: xcorrelate() overloads
+ * (lib/clXEngine_impl.h:150-201), kernels (lib/clXEngine_impl.cc:605-916),
+ * accumulator zero/"+=" for pipeline integration (:289-292,785-796), and the
+ * host frame gather of work_processor (:987-1061).
+ * data_type COMPLEX (cf32), BYTE (int8 I,Q) or PACKEDXY (4-bit, npol forced 2).
+ * Input layout [t][station][chan][pol]; output matrix_flat_length =
+ * nchan * ninputs(ninputs+1)/2 * npol^2 gr_complex, triangular order.
+ * ------------------------------------------------------------------------- */
+int mi355_xengine_create(mi355_ctx *ctx, int data_type, int npol, int num_inputs, int num_channels,
+                         int integration, mi355_xengine **out);
+int mi355_xengine_destroy(mi355_xengine *h);
+size_t mi355_xengine_input_bytes(const mi355_xengine *h);
+size_t mi355_xengine_output_items(const mi355_xengine *h);
+/* accumulate=0: out = V ; accumulate=1: out += V (pipeline integration) */
+int mi355_xengine_xcorrelate(mi355_xengine *h, const void *in_host, void *out_host, int accumulate);
+int mi355_xengine_xcorrelate_dev(mi355_xengine *h, const void *in_dev, void *out_dev, int accumulate, void *stream);
+/* host gather: copy frames [0,nframes) of each input stream into time slots
+ * frame0.. of a frame buffer laid out as the reference's pinned host buffer */
+int mi355_xengine_gather(const mi355_xengine *h, int nframes, int frame0, const void *const *inputs, void *frame_buffer);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_CLENABLED_H */

@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures in tests/golden/.
+
+Nothing here imports the oracle or the product: expected outputs come from
+(a) known answers the reference's own tests hold, (b) values the survey recorded
+from the reference's own source files, and (c) float64
+numpy evaluation of the mathematical definitions (numpy.fft, np.convolve,
+direct sums).  Run:  python tests/golden/gen_golden.py
+"""
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def crandn(rng, n):
+    return (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+
+
+def firdes_low_pass64(gain, fs, cutoff, tw, atten=53.0):
+    """float64 windowed-sinc (Hamming) low-pass; definition of firdes::low_pass."""
+    nt = int(atten * fs / (22.0 * tw))
+    nt += (nt & 1) == 0
+    M = (nt - 1) // 2
+    n = np.arange(-M, M + 1)
+    w = 0.54 - 0.46 * np.cos(2 * np.pi * np.arange(nt) / (nt - 1))
+    w0 = 2 * np.pi * cutoff / fs
+    with np.errstate(invalid="ignore", divide="ignore"):
+        t = np.where(n == 0, w0 / np.pi, np.sin(n * w0) / (n * np.pi)) * w
+    t = t * (gain / t.sum())
+    return t
+
+
+def main():
+    kat = {
+        "_source": "reference known-answer tests and SURVEY.md section 8(c)",
+        "mathop_multiply": {"a": [1.0, 0.5], "b": [1.0, 0.5], "n": 8192, "expect": [0.75, 1.0],
+                            "ref": "lib/test_clenabled.cc:1596-1600"},
+        "mathconst_multiply": {"a": [1.0, 0.5], "k": 2.0, "expect": [2.0, 1.0], "ref": "lib/test_clenabled.cc:1351-1356"},
+        "fft_tone": {"n": 2048, "peak_bin": 2047, "peak": [0.0, 2048.0], "others_abs_max": 1e-3,
+                     "ref": "lib/clFFT_impl.cc:361-455 (FFTValidationTest input :369-377)"},
+        "firdes_low_pass_65": {"args": [1.0, 10e6, 1e6, 372000.0], "ntaps": 65, "t0": 0.000756795635, "t32": 0.199991778,
+                               "ref": "lib/firdes.cc:92-137 compiled by the survey"},
+        "firdes_low_pass_2047": {"args": [1.0, 64.0, 0.5, 0.0753], "ntaps": 2047, "t0": -1.22261542e-06,
+                                 "t1023": 0.0156404767, "ref": "lib/firdes.cc:92-137 compiled by the survey"},
+        "firdes_low_pass_145": {"args": [1.0, 300e3, 48e3, 5e3], "ntaps": 145,
+                                "ref": "examples/test_flowgraphs/OpenCL_Test-PolyphaseChannelizer.grc:47-75"},
+        "window_blackman_4096": {"i1": 2.01165676e-07, "i2048": 0.999999762, "ref": "lib/window.cc:166-170"},
+        "fft_filter_sizes_65": {"fftsize": 256, "nsamples": 192, "ref": "lib/fft_filter.cc:72-97"},
+    }
+    with open(os.path.join(HERE, "kat.json"), "w") as f:
+        json.dump(kat, f, indent=1)
+
+    rng = np.random.default_rng(20260928)
+
+    # ---- FFT: seeded frames vs float64 numpy.fft -------------------------------
+    fft = {}
+    for n in (8, 64, 1024, 4096):
+        x = crandn(rng, 2 * n)
+        X = np.fft.fft(x.astype(np.complex128).reshape(2, n), axis=1)
+        fft["x%d" % n] = x
+        fft["fwd%d" % n] = X.reshape(-1).astype(np.complex64)
+        fft["inv%d" % n] = (np.fft.ifft(x.astype(np.complex128).reshape(2, n), axis=1) * n).reshape(-1).astype(np.complex64)
+    n = 4096
+    k = np.arange(n)
+    win = (0.42 - 0.5 * np.cos(2 * np.pi * k / (n - 1)) + 0.08 * np.cos(4 * np.pi * k / (n - 1)))
+    fft["blackman4096"] = win.astype(np.float32)
+    xw = fft["x4096"].astype(np.complex128).reshape(2, n) * win.astype(np.float32).astype(np.float64)
+    fft["fwd_win_shift4096"] = np.fft.fftshift(np.fft.fft(xw, axis=1), axes=1).reshape(-1).astype(np.complex64)
+    # reverse + shift (no window): halves swapped on input, unnormalised inverse
+    xs = np.fft.ifftshift(fft["x4096"].astype(np.complex128).reshape(2, n), axes=1)
+    fft["inv_shift4096"] = (np.fft.ifft(xs, axis=1) * n).reshape(-1).astype(np.complex64)
+    # the reference's one-cycle tone (lib/clFFT_impl.cc:369-377, lib/test_clenabled.cc:835-851)
+    t = np.arange(2048)
+    fft["tone2048"] = (np.sin(2 * np.pi * t / 2048) + 1j * np.cos(2 * np.pi * t / 2048)).astype(np.complex64)
+    # real input
+    xr = rng.standard_normal(2 * 1024).astype(np.float32)
+    fft["xr1024"] = xr
+    fft["fwd_real1024"] = np.fft.fft(xr.astype(np.float64).reshape(2, 1024), axis=1).reshape(-1).astype(np.complex64)
+    np.savez_compressed(os.path.join(HERE, "fft_golden.npz"), **fft)
+
+    # ---- filters: float64 convolution -----------------------------------------------
+    flt = {}
+    taps = firdes_low_pass64(1.0, 10e6, 1e6, 372000.0).astype(np.float32)
+    assert taps.size == 65
+    x = crandn(rng, 8 * 192)
+    y = np.convolve(x.astype(np.complex128), taps.astype(np.float64))[: x.size]
+    flt["taps65"], flt["x"], flt["y_d1"] = taps, x, y.astype(np.complex64)
+    flt["y_d2"], flt["y_d3"] = y[::2].astype(np.complex64), y[::3].astype(np.complex64)
+    ctaps = (taps.astype(np.float64) * np.exp(1j * np.pi * np.arange(65) / 8)).astype(np.complex64)
+    yc = np.convolve(x.astype(np.complex128), ctaps.astype(np.complex128))[: x.size]
+    flt["ctaps65"], flt["yc_d1"], flt["yc_d2"] = ctaps, yc.astype(np.complex64), yc[::2].astype(np.complex64)
+    t7 = np.array([0.001 * i for i in range(1, 8)], np.float32)  # taps i/1000, lib/test-clfilter.cc:98-100
+    flt["taps7"], flt["y7_d1"] = t7, np.convolve(x.astype(np.complex128), t7.astype(np.float64))[: x.size].astype(np.complex64)
+    np.savez_compressed(os.path.join(HERE, "filter_golden.npz"), **flt)
+
+    # ---- polyphase channelizer: closed form of SURVEY App. A.4 in float64 ---------------
+    pfb = {}
+
+    def pfb_closed(taps, M, R, buf_items, chmap, xh):
+        K = taps.size
+        nsteps = buf_items // R
+        out = np.zeros((nsteps, len(chmap)), np.complex128)
+        kk = np.arange(K)
+        for i in range(nsteps):
+            seg = xh[i * R + K - 1 - kk].astype(np.complex128) * taps.astype(np.float64)
+            for q, c in enumerate(chmap):
+                out[i, q] = np.sum(seg * np.exp(2j * np.pi * c * (kk + i * (M - R)) / M))
+        return out.reshape(-1).astype(np.complex64)
+
+    # (a) the reference flowgraph case: M=3, oversampled R=2, 145 taps
+    t145 = firdes_low_pass64(1.0, 300e3, 48e3, 5e3).astype(np.float32)
+    assert t145.size == 145
+    M, R, buf = 3, 2, 60
+    xh = crandn(rng, buf - R + t145.size)
+    pfb["a_taps"], pfb["a_x"], pfb["a_cfg"] = t145, xh, np.array([M, R, buf], np.int32)
+    pfb["a_chmap"] = np.array([0, 1, 2], np.int32)
+    pfb["a_y"] = pfb_closed(t145, M, R, buf, [0, 1, 2], xh)
+    # (b) BASELINE config 4 shape: M=64, R=64, 2048 taps (2047 + one zero), partial channel map
+    t2048 = np.concatenate([firdes_low_pass64(1.0, 64.0, 0.5, 0.0753), [0.0]]).astype(np.float32)
+    assert t2048.size == 2048
+    M, R, buf = 64, 64, 64 * 6
+    xh = crandn(rng, buf - R + 2048)
+    pfb["b_taps"], pfb["b_x"], pfb["b_cfg"] = t2048, xh, np.array([M, R, buf], np.int32)
+    pfb["b_chmap"] = np.arange(64, dtype=np.int32)
+    pfb["b_y"] = pfb_closed(t2048, M, R, buf, list(range(64)), xh)
+    # (c) oversampled power-of-two case with a permuted, partial map: M=8, R=4
+    t8 = rng.standard_normal(8 * 5 + 3).astype(np.float32)
+    M, R, buf = 8, 4, 64
+    xh = crandn(rng, buf - R + t8.size)
+    cm = [7, 0, 3, 3, 5]
+    pfb["c_taps"], pfb["c_x"], pfb["c_cfg"] = t8, xh, np.array([M, R, buf], np.int32)
+    pfb["c_chmap"] = np.array(cm, np.int32)
+    pfb["c_y"] = pfb_closed(t8, M, R, buf, cm, xh)
+    np.savez_compressed(os.path.join(HERE, "pfb_golden.npz"), **pfb)
+
+    # ---- X-engine: exact integer sums ---------------------------------------------------
+    xe = {}
+
+    def xeng_exact(x, N, F, npol, T):
+        """x: int array [T][N][F][npol][2] -> float64 complex [F][B][npol*npol] (unscaled integer sums)."""
+        z = x[..., 0].astype(np.float64) + 1j * x[..., 1].astype(np.float64)
+        B = N * (N + 1) // 2
+        out = np.zeros((F, B, npol * npol), np.complex128)
+        for s1 in range(N):
+            for s2 in range(s1 + 1):
+                k = s1 * (s1 + 1) // 2 + s2
+                for p1 in range(npol):
+                    for p2 in range(npol):
+                        out[:, k, p1 * npol + p2] = np.sum(z[:, s1, :, p1] * np.conj(z[:, s2, :, p2]), axis=0)
+        return out
+
+    N, F, T = 4, 8, 16
+    for npol in (1, 2):
+        x = rng.integers(-127, 128, size=(T, N, F, npol, 2), dtype=np.int64).astype(np.int8)
+        s = xeng_exact(x, N, F, npol, T)
+        xe["i8_p%d_x" % npol] = x.reshape(-1)
+        xe["i8_p%d_sum_re" % npol] = s.real.reshape(-1).astype(np.int64)
+        xe["i8_p%d_sum_im" % npol] = s.imag.reshape(-1).astype(np.int64)
+    xe["cfg"] = np.array([N, F, T], np.int32)
+    # complex float path: same definition in float64
+    xc = crandn(rng, T * N * F * 2).reshape(T, N, F, 2)
+    z = xc.astype(np.complex128)
+    B = N * (N + 1) // 2
+    o = np.zeros((F, B, 4), np.complex128)
+    for s1 in range(N):
+        for s2 in range(s1 + 1):
+            k = s1 * (s1 + 1) // 2 + s2
+            for p1 in range(2):
+                for p2 in range(2):
+                    o[:, k, p1 * 2 + p2] = np.sum(z[:, s1, :, p1] * np.conj(z[:, s2, :, p2]), axis=0)
+    xe["cf_p2_x"], xe["cf_p2_y"] = xc.reshape(-1), o.reshape(-1).astype(np.complex64)
+    # packed 4-bit: LUT incl. code 8 -> 0 (lib/clXEngine_impl.cc:833), scale 1/7
+    lut = np.array([0, 1, 2, 3, 4, 5, 6, 7, 0, -7, -6, -5, -4, -3, -2, -1], np.float64)
+    pk = rng.integers(0, 256, size=(T, N, F, 2), dtype=np.int64).astype(np.uint8)
+    pk[0, 0, 0, 0] = 0x88  # force the code-8 case
+    zz = (lut[pk >> 4] + 1j * lut[pk & 15]) / 7.0  # [T][N][F][pol]
+    o = np.zeros((F, B, 4), np.complex128)
+    for s1 in range(N):
+        for s2 in range(s1 + 1):
+            k = s1 * (s1 + 1) // 2 + s2
+            for p1 in range(2):
+                for p2 in range(2):
+                    o[:, k, p1 * 2 + p2] = np.sum(zz[:, s1, :, p1] * np.conj(zz[:, s2, :, p2]), axis=0)
+    xe["p4_x"], xe["p4_y"] = pk.reshape(-1), o.reshape(-1).astype(np.complex64)
+    np.savez_compressed(os.path.join(HERE, "xengine_golden.npz"), **xe)
+
+    tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith((".npz", ".json")))
+    print("golden fixtures written, %.1f KiB" % (tot / 1024))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,62 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mi355_clenabled.h
+declares; argument validation that needs no GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "mi355_clenabled.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi355_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(pkg):
+    L = pkg.lib()
+    names = _declared()
+    assert len(names) >= 45
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, "declared in the header but not exported: %s" % missing
+    # and the Python binding table covers the header exactly
+    assert sorted(L._declared) == names
+
+
+def test_version_and_strerror(pkg):
+    L = pkg.lib()
+    assert b"gfx950" in L.mi355_version()
+    assert L.mi355_strerror(0) == b"ok"
+    assert L.mi355_strerror(-3) == b"unsupported configuration"
+
+
+def test_cpu_device_type_is_refused_not_emulated(pkg):
+    """OCLTYPE_CPU (3) must NOT fall back to a host implementation."""
+    L = pkg.lib()
+    ctx = C.c_void_p()
+    assert L.mi355_ctx_create(3, 1, 0, 0, 0, C.byref(ctx)) == -3
+    assert not ctx.value
+    assert L.mi355_ctx_create(9, 1, 0, 0, 0, C.byref(ctx)) == -1
+    assert L.mi355_ctx_create(1, 7, 0, 0, 0, C.byref(ctx)) == -1
+
+
+def test_block_constructor_errors_mirror_reference(pkg):
+    # lib/clFFT_impl.cc:74-76 -> runtime_error before any device work
+    with pytest.raises(RuntimeError):
+        pkg.clFFT(64, pkg.CLFFT_FORWARD, [1.0] * 63, pkg.DTYPE_COMPLEX, 1, 1, 0, 0)
+    # lib/clPolyphaseChannelizer_impl.cc:59-62 -> invalid_argument
+    with pytest.raises(ValueError):
+        pkg.clPolyphaseChannelizer(1, 1, 0, 0, [1.0] * 8, 10, 4, 4, [0])
+    # lib/clXEngine_impl.cc:106-109 -> out_of_range
+    with pytest.raises(IndexError):
+        pkg.clXEngine(1, 1, 0, 0, False, pkg.DTYPE_BYTE, 1, 1, 1, 0, 16, 16)
+
+
+def test_no_gpu_means_loud_failure(pkg):
+    """Without a device every block constructor raises; nothing silently computes on the CPU."""
+    if pkg.lib().mi355_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.Mi355Error):
+        pkg.clMathOp(pkg.DTYPE_COMPLEX, 1, 1, 0, 0, pkg.MATHOP_MULTIPLY)

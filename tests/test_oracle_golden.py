@@ -1,0 +1,196 @@
+"""CPU: pins the oracle against the reference's known answers, the values the
+survey recorded from the reference's own files, and float64 definitions."""
+import json
+import os
+
+import numpy as np
+
+from conftest import GOLDEN, crandn, golden, relerr
+
+
+def _kat():
+    with open(os.path.join(GOLDEN, "kat.json")) as f:
+        return json.load(f)
+
+
+def test_mathop_known_answers(oracle):
+    k = _kat()["mathop_multiply"]
+    a = np.full(k["n"], complex(*k["a"]), np.complex64)
+    out = oracle.mathop(oracle.DTYPE_COMPLEX, oracle.OP_MULTIPLY, a, a)
+    assert np.all(out == np.complex64(complex(*k["expect"])))
+    k = _kat()["mathconst_multiply"]
+    out = oracle.mathconst(oracle.DTYPE_COMPLEX, oracle.OP_MULTIPLY, k["k"], np.full(64, complex(*k["a"]), np.complex64))
+    assert np.all(out == np.complex64(complex(*k["expect"])))
+
+
+def test_mathop_all_ops_vs_numpy(oracle):
+    rng = np.random.default_rng(1)
+    a, b = crandn(rng, 1001), crandn(rng, 1001)
+    o = oracle
+    assert relerr(o.mathop(1, o.OP_MULTIPLY, a, b), a.astype(np.complex128) * b) < 1e-6
+    assert np.array_equal(o.mathop(1, o.OP_ADD, a, b), a + b)
+    assert np.array_equal(o.mathop(1, o.OP_SUBTRACT, a, b), a - b)
+    assert relerr(o.mathop(1, o.OP_MULTIPLY_CONJUGATE, a, b), a.astype(np.complex128) * np.conj(b)) < 1e-6
+    assert np.array_equal(o.mathconst(1, o.OP_CONJUGATE, 0, a), np.conj(a))
+    # the REAL constant is added to both components (lib/clMathConst_impl.cc:194-197)
+    assert np.array_equal(o.mathconst(1, o.OP_ADD, 2.5, a), (a.real + np.float32(2.5)) + 1j * (a.imag + np.float32(2.5)))
+    ia = rng.integers(-2**31, 2**31, 777, dtype=np.int64).astype(np.int32)
+    ib = rng.integers(-2**31, 2**31, 777, dtype=np.int64).astype(np.int32)
+    assert np.array_equal(o.mathop(3, o.OP_MULTIPLY, ia, ib), (ia.astype(np.int64) * ib).astype(np.int32))  # wraps
+    assert np.array_equal(o.mathop(3, o.OP_ADD, ia, ib), (ia.astype(np.int64) + ib).astype(np.int32))
+    assert np.array_equal(o.mathconst(3, o.OP_MULTIPLY, 3.0, ia), (ia.astype(np.int64) * 3).astype(np.int32))
+    fa, fb = a.real.copy(), b.real.copy()
+    assert np.array_equal(o.mathop(2, o.OP_MULTIPLY, fa, fb), fa * fb)
+
+
+def test_window_and_firdes_recorded_values(oracle):
+    k = _kat()
+    w = oracle.window(oracle.WIN_BLACKMAN, 4096)
+    assert np.float32(w[1]) == np.float32(k["window_blackman_4096"]["i1"])
+    assert np.float32(w[2048]) == np.float32(k["window_blackman_4096"]["i2048"])
+    t = oracle.firdes_low_pass(*k["firdes_low_pass_65"]["args"])
+    assert t.size == 65 and t[0] == np.float32(k["firdes_low_pass_65"]["t0"]) and t[32] == np.float32(k["firdes_low_pass_65"]["t32"])
+    t = oracle.firdes_low_pass(*k["firdes_low_pass_2047"]["args"])
+    assert t.size == 2047 and t[0] == np.float32(k["firdes_low_pass_2047"]["t0"])
+    assert t[1023] == np.float32(k["firdes_low_pass_2047"]["t1023"])
+    assert oracle.firdes_low_pass(*k["firdes_low_pass_145"]["args"]).size == 145
+    g = golden("filter_golden.npz")
+    assert relerr(oracle.firdes_low_pass(1.0, 10e6, 1e6, 372000.0), g["taps65"]) < 1e-6
+    assert relerr(w, golden("fft_golden.npz")["blackman4096"]) < 1e-6
+    # symmetric linear-phase design, unit DC gain
+    t = oracle.firdes_low_pass(1.0, 10e6, 1e6, 372000.0)
+    assert np.allclose(t, t[::-1], atol=1e-7) and abs(float(t.sum()) - 1.0) < 1e-6
+
+
+def test_fft_tone_known_answer(oracle):
+    k = _kat()["fft_tone"]
+    x = golden("fft_golden.npz")["tone2048"]
+    for f64 in (False, True):
+        X = oracle.fft(x, -1, f64=f64)
+        assert abs(X[k["peak_bin"]] - complex(*k["peak"])) < 1e-3
+        assert np.abs(np.delete(X, k["peak_bin"])).max() < k["others_abs_max"]
+
+
+def test_fft_vs_float64(oracle):
+    g = golden("fft_golden.npz")
+    for n in (8, 64, 1024, 4096):
+        x = g["x%d" % n]
+        for v in range(2):
+            fr = x[v * n:(v + 1) * n]
+            assert relerr(oracle.fft(fr, -1), g["fwd%d" % n][v * n:(v + 1) * n]) < 2e-6
+            assert relerr(oracle.fft(fr, +1), g["inv%d" % n][v * n:(v + 1) * n]) < 2e-6
+            assert relerr(oracle.fft(fr, -1, f64=True), g["fwd%d" % n][v * n:(v + 1) * n]) < 2e-7
+
+
+def test_fft_block_window_shift(oracle):
+    g = golden("fft_golden.npz")
+    o = oracle
+    out = o.fft_block(4096, True, g["blackman4096"], True, o.DTYPE_COMPLEX, g["x4096"])
+    assert relerr(out, g["fwd_win_shift4096"]) < 2e-6
+    out = o.fft_block(4096, False, None, True, o.DTYPE_COMPLEX, g["x4096"])
+    assert relerr(out, g["inv_shift4096"]) < 2e-6
+    out = o.fft_block(1024, True, None, False, o.DTYPE_FLOAT, g["xr1024"])
+    assert relerr(out, g["fwd_real1024"]) < 2e-6
+    assert o.fft_block(4096, True, None, False, o.DTYPE_COMPLEX, g["x4096"]).size == 8192
+    try:
+        o.fft(np.zeros(12, np.complex64))
+        assert False, "non power of two must be refused"
+    except ValueError:
+        pass
+
+
+def test_fft_filter_sizes_and_outputs(oracle):
+    k = _kat()["fft_filter_sizes_65"]
+    g = golden("filter_golden.npz")
+    f = oracle.FFTFilter(1, g["taps65"])
+    assert (f.fftsize, f.nsamples) == (k["fftsize"], k["nsamples"])
+    # tap spectrum pre-scaled by 1/fftsize (lib/fft_filter.cc:52-57)
+    H = np.fft.fft(np.concatenate([g["taps65"].astype(np.float64), np.zeros(256 - 65)])) / 256
+    assert relerr(f.xformed_taps(), H) < 1e-6
+    x = g["x"]
+    assert relerr(f.filter(x.size, x), g["y_d1"]) < 2e-6
+    for d in (2, 3):
+        f = oracle.FFTFilter(d, g["taps65"])
+        y = f.filter(x.size // d, x)
+        ref = g["y_d%d" % d]
+        m = min(y.size, ref.size)
+        assert m >= x.size // d and relerr(y[:m], ref[:m]) < 2e-6
+
+
+def test_fir_vs_fft_filter_and_golden(oracle):
+    g = golden("filter_golden.npz")
+    x, t = g["x"], g["taps65"]
+    xh = np.concatenate([np.zeros(t.size - 1, np.complex64), x])
+    y = oracle.fir_ccf(t, xh, x.size)
+    assert relerr(y, g["y_d1"]) < 2e-6
+    assert relerr(y, oracle.FFTFilter(1, t).filter(x.size, x)) < 2e-6  # the two mirrors agree to ~2e-7
+    assert relerr(oracle.fir_ccf(t, xh, x.size // 2, 2), g["y_d2"]) < 2e-6
+    assert relerr(oracle.fir_ccf(t, xh, x.size // 3, 3), g["y_d3"]) < 2e-6
+    assert relerr(oracle.fir_ccc(g["ctaps65"], xh, x.size), g["yc_d1"]) < 2e-6
+    assert relerr(oracle.fir_ccc(g["ctaps65"], xh, x.size // 2, 2), g["yc_d2"]) < 2e-6
+    xh7 = np.concatenate([np.zeros(6, np.complex64), x])
+    assert relerr(oracle.fir_ccf(g["taps7"], xh7, x.size), g["y7_d1"]) < 2e-6
+
+
+def test_pfb_vs_closed_form(oracle):
+    g = golden("pfb_golden.npz")
+    for c in "abc":
+        M, R, buf = (int(v) for v in g[c + "_cfg"])
+        for f64, tol in ((True, 1e-6), (False, 1e-5)):
+            y = oracle.pfb(g[c + "_taps"], buf, M, R, g[c + "_chmap"], g[c + "_x"], f64=f64)
+            assert y.size == g[c + "_y"].size
+            assert relerr(y, g[c + "_y"]) < tol, (c, f64)
+    try:
+        oracle.pfb(g["c_taps"], 63, 8, 4, [0], g["c_x"])
+        assert False, "buf_items % num_channels != 0 must be refused"
+    except ValueError:
+        pass
+
+
+def test_xengine_exact_and_closed_forms(oracle):
+    g = golden("xengine_golden.npz")
+    N, F, T = (int(v) for v in g["cfg"])
+    sc = 0.007874015748031496063 ** 2
+    for npol in (1, 2):
+        x = g["i8_p%d_x" % npol]
+        ref = ((g["i8_p%d_sum_re" % npol] * sc) + 1j * (g["i8_p%d_sum_im" % npol] * sc)).astype(np.complex64)
+        assert np.array_equal(oracle.xengine_ichar(N, F, npol, T, x, exact=True), ref)  # bit exact
+        assert relerr(oracle.xengine_ichar(N, F, npol, T, x, exact=False), ref) < 1e-5
+    assert relerr(oracle.xengine_cf32(N, F, 2, T, g["cf_p2_x"]), g["cf_p2_y"]) < 2e-6
+    assert relerr(oracle.xengine_packed4(N, F, T, g["p4_x"]), g["p4_y"]) < 2e-6
+    # every sample (127,0) -> V = T for every baseline
+    x = np.zeros((T, N, F, 1, 2), np.int8)
+    x[..., 0] = 127
+    v = oracle.xengine_ichar(N, F, 1, T, x.reshape(-1), exact=False)
+    assert np.allclose(v, T, rtol=1e-6)
+    # identical unit-modulus tone on every antenna -> T + 0j (lib/test-clxengine.cc:225-247)
+    ph = np.exp(2j * np.pi * np.arange(T * F) / 37.0).reshape(T, 1, F).repeat(N, 1).astype(np.complex64)
+    v = oracle.xengine_cf32(N, F, 1, T, ph.reshape(-1))
+    assert np.allclose(v, T, atol=1e-4)
+    # conjugation sense: x_s1 * conj(x_s2), s1 >= s2
+    x = np.zeros((1, 2, 1, 1, 2), np.int8)
+    x[0, 0, 0, 0] = (127, 0)    # station 0 = 1
+    x[0, 1, 0, 0] = (0, 127)    # station 1 = j
+    v = oracle.xengine_ichar(2, 1, 1, 1, x.reshape(-1), exact=True)
+    assert np.allclose(v, [1, 1j, 1])  # k=0:(0,0) k=1:(1,0)=j*conj(1) k=2:(1,1)
+    # pipeline accumulation
+    acc = oracle.xengine_ichar(N, F, 1, T, g["i8_p1_x"], exact=True)
+    acc2 = oracle.xengine_ichar(N, F, 1, T, g["i8_p1_x"], exact=True, acc=acc.copy())
+    assert np.allclose(acc2, 2 * acc)
+
+
+def test_xengine_gather_layout(oracle):
+    o = oracle
+    N, F, T = 3, 5, 4
+    rng = np.random.default_rng(3)
+    ins = [rng.integers(-127, 128, size=T * F * 2, dtype=np.int64).astype(np.int8) for _ in range(2 * N)]
+    fb = np.zeros(T * N * F * 2 * 2, np.int8)
+    o.xengine_gather(o.DTYPE_BYTE, N, F, 2, T, 0, ins, fb)
+    fb = fb.reshape(T, N, F, 2, 2)
+    for i in range(N):
+        assert np.array_equal(fb[:, i, :, 0, :].reshape(-1), ins[i])
+        assert np.array_equal(fb[:, i, :, 1, :].reshape(-1), ins[i + N])
+    fb1 = np.zeros(T * N * F * 2, np.int8)
+    o.xengine_gather(o.DTYPE_BYTE, N, F, 1, 2, 0, ins[:N], fb1)
+    o.xengine_gather(o.DTYPE_BYTE, N, F, 1, 2, 2, [a[2 * F * 2:] for a in ins[:N]], fb1)
+    assert np.array_equal(fb1.reshape(T, N, F * 2)[:, 1, :].reshape(-1), ins[1])
