@@ -49,10 +49,9 @@ static inline size_t mi355_dtype_size(int dtype)
     return 0;
 }
 
-static inline hipStream_t mi355_pick_stream(mi355_ctx *ctx, void *stream)
-{
-    return stream ? (hipStream_t)stream : ctx->stream[0];
-}
+// `stream` is a hipStream_t passed through the C ABI as void*; NULL is HIP's
+// default (null) stream, which is also torch's default stream.
+static inline hipStream_t mi355_pick_stream(mi355_ctx *, void *stream) { return (hipStream_t)stream; }
 
 // ---------------------------------------------------------------------------
 // Pinned double-buffered staging for the host-pointer work() path.

@@ -1,0 +1,368 @@
+// clFFT block as one hand-written gfx950 kernel.
+// Reference behaviour: lib/clFFT_impl.cc:65-151 (plan), :526-634 (processOpenCL:
+// per-frame H2D, MultiplyFloat window kernel, clfftEnqueueTransform batch 1,
+// D2H, host fftshift); CPU twin :464-518.
+//
+// Design: Stockham autosort FFT with the frame resident in LDS.  A workgroup of
+// 256 threads owns 4096 points (= 4096/N frames); every thread keeps 16 complex
+// points in registers and does 16/R radix-R butterflies per pass (radix 16
+// wherever possible: 4096 = 16*16*16 -> two LDS exchanges).  The first pass
+// reads global memory and the last pass writes it, both with unit stride across
+// lanes; the window multiply is fused into the load, fftshift into the store
+// index (forward) or the load index (reverse).  Workgroups are persistent
+// (grid-stride over frame groups) so the window values and the inter-pass
+// twiddles -- which depend only on the thread's position -- are loaded once into
+// registers from a double-precision-generated table and cost nothing per frame.
+// HBM traffic per frame = N*8 B in + N*8 B out (16 B/sample), nothing else.
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+#include "fft_core.cuh"
+
+using namespace fftc;
+
+namespace {
+
+template <int N> struct Geo {
+    static constexpr int TH = (N <= 4096) ? 256 : N / 16;  // threads per workgroup
+    static constexpr int PTS = TH * 16;                     // points per workgroup iteration
+    static constexpr int F = PTS / N;                       // frames per iteration
+    static constexpr int WPE = (N <= 4096) ? 3 : (N == 8192 ? 1 : 1);  // min waves per SIMD asked of the register allocator
+};
+
+// Inter-pass twiddles kept in registers.  For a radix-R butterfly only the powers
+// r in {1,2,3} and {4,8,12} of the butterfly's base twiddle are stored (exactly
+// rounded from the double-precision table); the rest are one product w[4a]*w[b].
+// Slots per butterfly: R=16 -> 6, R=8 -> 4, R=4 -> 3, R=2 -> 1  (<= 12 per pass).
+template <int R> __host__ __device__ constexpr int tw_slots() { return R == 16 ? 6 : R == 8 ? 4 : R == 4 ? 3 : 1; }
+// power held in slot i
+template <int R> __host__ __device__ constexpr int tw_power(int i) { return i < 3 ? i + 1 : (i - 2) * 4; }
+constexpr int kTwPerPass = 12;
+
+template <int N, int P>
+__device__ __forceinline__ void load_twiddles(c32 (&tw)[Plan<N>::NP > 1 ? Plan<N>::NP - 1 : 1][kTwPerPass], int tid,
+                                              const c32 *__restrict__ twtab)
+{
+    using PL = Plan<N>;
+    if constexpr (P < PL::NP) {
+        constexpr int TH = Geo<N>::TH, R = PL::radix(P), NS = PL::ns(P), B = N / R, S = tw_slots<R>();
+#pragma unroll
+        for (int q = 0; q < 16 / R; q++) {
+            const int j = (tid + TH * q) % B, k = j % NS;
+#pragma unroll
+            for (int i = 0; i < S; i++) tw[P - 1][q * S + i] = twtab[(tw_power<R>(i) * k * (N / (NS * R))) & (N - 1)];
+        }
+        load_twiddles<N, P + 1>(tw, tid, twtab);
+    }
+}
+
+// v[r] *= W^r for r = 1..R-1, W^r rebuilt from the stored powers
+template <int R> __device__ __forceinline__ void apply_twiddles(c32 *v, const c32 *w_in)
+{
+    // Opaque copies: keeps the w[4a]*w[b] products inside the frame loop instead of
+    // letting loop-invariant code motion turn them back into 15 live registers pairs.
+    c32 w[tw_slots<R>()];
+#pragma unroll
+    for (int i = 0; i < tw_slots<R>(); i++) {
+        w[i] = w_in[i];
+        asm volatile("" : "+v"(w[i].x), "+v"(w[i].y));
+    }
+#pragma unroll
+    for (int r = 1; r < R; r++) {
+        const int lo = r & 3, hi = r >> 2;
+        c32 t;
+        if (hi == 0) t = w[lo - 1];
+        else if (lo == 0) t = w[2 + hi];
+        else t = cmul(w[2 + hi], w[lo - 1]);
+        v[r] = cmul(v[r], t);
+    }
+}
+
+// LDS slot of logical index (raw + c) where c is a compile-time multiple of STEP
+template <int STEP> __device__ __forceinline__ int lds_at(int raw, int raw_swz, int c)
+{
+    if constexpr (STEP % 256 == 0) return raw_swz + c;  // the swizzle only touches the low 8 slot bits
+    else return swz(raw + c);
+}
+
+// passes P..NP-1 on the 16 points in v; pass 0's inputs are already in v.
+// out_g points at this group's first output frame; all per-thread offsets are 32-bit.
+template <int N, int SIGN, int P>
+__device__ __forceinline__ void run_passes(c32 (&v)[16], const c32 (&tw)[Plan<N>::NP > 1 ? Plan<N>::NP - 1 : 1][kTwPerPass], c32 *lds,
+                                           c32 *__restrict__ out_g, int tid, int frames_left, int out_xor)
+{
+    using PL = Plan<N>;
+    if constexpr (P < PL::NP) {
+        constexpr int TH = Geo<N>::TH, NP = PL::NP, R = PL::radix(P), NS = PL::ns(P), B = N / R;
+        if constexpr (P > 0) {
+            __syncthreads();  // previous pass' LDS writes are visible
+#pragma unroll
+            for (int q = 0; q < 16 / R; q++) {
+                const int g = tid + TH * q, raw = (g / B) * N + (g % B), rs = swz(raw);
+#pragma unroll
+                for (int r = 0; r < R; r++) v[q * R + r] = lds[lds_at<B>(raw, rs, r * B)];
+            }
+#pragma unroll
+            for (int q = 0; q < 16 / R; q++) apply_twiddles<R>(&v[q * R], &tw[P - 1][q * tw_slots<R>()]);
+            if constexpr (P < NP - 1) __syncthreads();  // everyone has read before anyone overwrites in place
+        }
+#pragma unroll
+        for (int q = 0; q < 16 / R; q++) bfly<R, SIGN>(&v[q * R]);
+        if constexpr (P < NP - 1) {
+            // registers -> LDS at the autosort position
+#pragma unroll
+            for (int q = 0; q < 16 / R; q++) {
+                const int g = tid + TH * q, fr = g / B, j = g % B;
+                const int raw = fr * N + (j / NS) * NS * R + (j % NS), rs = swz(raw);
+#pragma unroll
+                for (int s = 0; s < R; s++) lds[lds_at<NS>(raw, rs, orev<R>(s) * NS)] = v[q * R + s];
+            }
+        } else {
+            // last pass: registers -> global, unit stride across lanes, fftshift fused.
+            // out_xor is 0 or N/2, a multiple of B, so it only permutes the r*B term.
+#pragma unroll
+            for (int q = 0; q < 16 / R; q++) {
+                const int g = tid + TH * q, fr = g / B;
+                const unsigned off = (unsigned)(fr * N + (g % B));
+                if ((Geo<N>::F == 1) || fr < frames_left) {
+#pragma unroll
+                    for (int s = 0; s < R; s++) out_g[off + (unsigned)((orev<R>(s) * B) ^ out_xor)] = v[q * R + s];
+                }
+            }
+        }
+        run_passes<N, SIGN, P + 1>(v, tw, lds, out_g, tid, frames_left, out_xor);
+    }
+}
+
+template <int N, int SIGN, bool REAL>
+__global__ __launch_bounds__(Geo<N>::TH, Geo<N>::WPE) void k_fft(const void *__restrict__ in, c32 *__restrict__ out,
+                                                                 const float *__restrict__ window,
+                                                                 const c32 *__restrict__ twtab, int nframes, int ngroups,
+                                                                 int shift)
+{
+    using P = Plan<N>;
+    constexpr int TH = Geo<N>::TH, PTS = Geo<N>::PTS, F = Geo<N>::F, NP = P::NP;
+    __shared__ c32 lds[NP > 1 ? PTS : 1];
+    const int tid0 = threadIdx.x;
+    const int in_xor = (SIGN > 0 && shift) ? (N >> 1) : 0;   // reverse: halves swapped on load (:548-553)
+    const int out_xor = (SIGN < 0 && shift) ? (N >> 1) : 0;  // forward: halves swapped on store (:594-607)
+
+    // ---- per-thread constants: inter-pass twiddles and window values --------------
+    c32 tw[NP > 1 ? NP - 1 : 1][kTwPerPass];
+    load_twiddles<N, 1>(tw, tid0, twtab);
+    constexpr int R0 = P::radix(0), B0 = N / R0;
+    float win[16];  // the handle always carries a window (all ones when the block has none)
+#pragma unroll
+    for (int q = 0; q < 16 / R0; q++) {
+        const int j = (tid0 + TH * q) % B0;
+#pragma unroll
+        for (int r = 0; r < R0; r++) win[q * R0 + r] = window[j + ((r * B0) ^ in_xor)];
+    }
+
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        c32 v[16];
+        // Opaque per-iteration copy of the thread id: address arithmetic is recomputed
+        // (a few dozen integer ops) rather than hoisted into ~60 loop-carried registers.
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int frames_left = nframes - grp * F;  // frames of this group that exist
+        // ---- pass 0 inputs: global -> registers (window fused) ------------------------
+        // in_xor is 0 or N/2, a multiple of B0 (R0 >= 2), so it only permutes the r*B0 term
+        // Loads are branch free: a thread whose frame does not exist (ragged last group)
+        // reads frame 0 of the group instead and the value is discarded.
+        if constexpr (REAL) {
+            const float *src = (const float *)in + (size_t)grp * PTS;
+#pragma unroll
+            for (int q = 0; q < 16 / R0; q++) {
+                const int g = tid + TH * q, fr = g / B0;
+                const bool ok = (F == 1) || fr < frames_left;
+                const unsigned off = (unsigned)((ok ? fr * N : 0) + (g % B0));
+#pragma unroll
+                for (int r = 0; r < R0; r++) {
+                    const float x = src[off + (unsigned)((r * B0) ^ in_xor)];
+                    v[q * R0 + r] = mk(ok ? x : 0.f, 0.f);
+                }
+            }
+        } else {
+            const c32 *src = (const c32 *)in + (size_t)grp * PTS;
+#pragma unroll
+            for (int q = 0; q < 16 / R0; q++) {
+                const int g = tid + TH * q, fr = g / B0;
+                const bool ok = (F == 1) || fr < frames_left;
+                const unsigned off = (unsigned)((ok ? fr * N : 0) + (g % B0));
+#pragma unroll
+                for (int r = 0; r < R0; r++) {
+                    const c32 x = src[off + (unsigned)((r * B0) ^ in_xor)];
+                    v[q * R0 + r] = ok ? x : mk(0.f, 0.f);
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 16; s++) v[s] = scale(v[s], win[s]);
+        run_passes<N, SIGN, 0>(v, tw, lds, out + (size_t)grp * PTS, tid, frames_left, out_xor);
+        if constexpr (NP > 1) __syncthreads();  // last pass' LDS reads finish before the next group's writes
+    }
+}
+
+template <int N>
+int launch_n(mi355_ctx *ctx, int sign, const void *in, void *out, const float *window, const void *tw, int nframes, int shift,
+             int real_in, hipStream_t st)
+{
+    constexpr int F = Geo<N>::F, TH = Geo<N>::TH;
+    int ngroups = (nframes + F - 1) / F;
+    int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+    int per_cu = (N <= 4096) ? 3 : (N == 8192 ? 2 : 1);
+    int grid = ngroups < cus * per_cu ? ngroups : cus * per_cu;
+#define LAUNCH_FFT(SG, RL)                                                                                              \
+    hipLaunchKernelGGL((k_fft<N, SG, RL>), dim3(grid), dim3(TH), 0, st, in, (c32 *)out, window, (const c32 *)tw, nframes, \
+                       ngroups, shift)
+    if (sign < 0) { if (real_in) LAUNCH_FFT(-1, true); else LAUNCH_FFT(-1, false); }
+    else          { if (real_in) LAUNCH_FFT(1, true);  else LAUNCH_FFT(1, false); }
+#undef LAUNCH_FFT
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+int launch_fft(mi355_ctx *ctx, int n, int sign, const void *in, void *out, const float *window, const void *tw, int nframes,
+               int shift, int real_in, hipStream_t st)
+{
+    switch (n) {
+#define CASE_N(NN) case NN: return launch_n<NN>(ctx, sign, in, out, window, tw, nframes, shift, real_in, st)
+        CASE_N(2); CASE_N(4); CASE_N(8); CASE_N(16); CASE_N(32); CASE_N(64); CASE_N(128); CASE_N(256); CASE_N(512);
+        CASE_N(1024); CASE_N(2048); CASE_N(4096); CASE_N(8192); CASE_N(16384);
+#undef CASE_N
+    }
+    mi355_set_error("fft size %d unsupported (power of two, 2..16384)", n);
+    return MI355_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+struct mi355_fft {
+    mi355_ctx *ctx;
+    int n, sign, dtype, nstreams, shift;
+    float *d_window;  // n floats or NULL
+    void *d_tw;       // n complex: exp(sign*2*pi*i*k/n), generated in double
+    HostPipe pipe;
+};
+
+extern "C" int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, const float *window, int window_len, int dtype,
+                                int num_streams, int shift, mi355_fft **out)
+{
+    MI355_REQUIRE(ctx && out, "NULL argument");
+    *out = nullptr;
+    MI355_REQUIRE(fft_size >= 2 && fft_size <= 16384 && (fft_size & (fft_size - 1)) == 0,
+                  "fft size must be a power of two in 2..16384");
+    MI355_REQUIRE(window_len == 0 || window_len == fft_size, "window not the same length as fft_size");
+    MI355_REQUIRE(window_len == 0 || window != nullptr, "window is NULL");
+    MI355_REQUIRE(dtype == MI355_DTYPE_COMPLEX || dtype == MI355_DTYPE_FLOAT, "clFFT dtype must be complex or float");
+    MI355_REQUIRE(num_streams >= 1, "num_streams must be >= 1");
+    mi355_fft *h = new (std::nothrow) mi355_fft();
+    if (!h) return MI355_ERR_NOMEM;
+    h->ctx = ctx; h->n = fft_size;
+    // lib/clFFT_impl.cc:84-89: anything that is not CLFFT_FORWARD (-1) is a backward transform
+    h->sign = (direction == MI355_FFT_FORWARD) ? -1 : 1;
+    h->dtype = dtype; h->nstreams = num_streams; h->shift = shift ? 1 : 0;
+    h->d_window = nullptr; h->d_tw = nullptr;
+    auto fail = [&](int rc) { mi355_fft_destroy(h); return rc; };
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(MI355_ERR_HIP);
+    std::vector<float> tw(2 * (size_t)fft_size);
+    for (int k = 0; k < fft_size; k++) {
+        double a = h->sign * 2.0 * M_PI * (double)k / (double)fft_size;
+        tw[2 * k] = (float)cos(a);
+        tw[2 * k + 1] = (float)sin(a);
+    }
+    if (hipMalloc(&h->d_tw, tw.size() * sizeof(float)) != hipSuccess) return fail(MI355_ERR_NOMEM);
+    if (hipMemcpy(h->d_tw, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail(MI355_ERR_HIP);
+    {
+        std::vector<float> w(fft_size, 1.0f);  // no window == all ones: the kernel has a single code path
+        if (window_len) memcpy(w.data(), window, sizeof(float) * (size_t)fft_size);
+        if (hipMalloc((void **)&h->d_window, sizeof(float) * (size_t)fft_size) != hipSuccess) return fail(MI355_ERR_NOMEM);
+        if (hipMemcpy(h->d_window, w.data(), sizeof(float) * (size_t)fft_size, hipMemcpyHostToDevice) != hipSuccess)
+            return fail(MI355_ERR_HIP);
+    }
+    int rc = h->pipe.init(ctx);
+    if (rc) return fail(rc);
+    *out = h;
+    return MI355_OK;
+}
+
+extern "C" int mi355_fft_destroy(mi355_fft *h)
+{
+    if (!h) return MI355_OK;
+    (void)hipSetDevice(h->ctx->device);
+    h->pipe.release();
+    if (h->d_window) (void)hipFree(h->d_window);
+    if (h->d_tw) (void)hipFree(h->d_tw);
+    delete h;
+    return MI355_OK;
+}
+
+extern "C" int mi355_fft_work_dev(mi355_fft *h, int nvec, const void *in, void *out, void *stream)
+{
+    MI355_REQUIRE(h != nullptr, "handle is NULL");
+    if (nvec <= 0) return MI355_OK;
+    MI355_REQUIRE(in && out, "NULL buffer");
+    MI355_REQUIRE((reinterpret_cast<uintptr_t>(in) & 7u) == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0,
+                  "device buffers must be 8-byte aligned");
+    MI355_HIP(hipSetDevice(h->ctx->device));
+    return launch_fft(h->ctx, h->n, h->sign, in, out, h->d_window, h->d_tw, nvec, h->shift, h->dtype == MI355_DTYPE_FLOAT,
+                      mi355_pick_stream(h->ctx, stream));
+}
+
+extern "C" int mi355_fft_work(mi355_fft *h, int nvec, const void *const *in_streams, void *const *out_streams)
+{
+    MI355_REQUIRE(h != nullptr, "handle is NULL");
+    if (nvec <= 0) return MI355_OK;
+    MI355_REQUIRE(in_streams && out_streams, "NULL stream arrays");
+    std::lock_guard<std::mutex> g(h->ctx->lock);
+    MI355_HIP(hipSetDevice(h->ctx->device));
+    const size_t isz = mi355_dtype_size(h->dtype), in_frame = isz * (size_t)h->n, out_frame = 8 * (size_t)h->n;
+    size_t chunk_frames = (8u << 20) / out_frame;
+    if (chunk_frames < 1) chunk_frames = 1;
+    size_t first = (size_t)nvec < chunk_frames ? (size_t)nvec : chunk_frames;
+    size_t inb = first * in_frame;
+    int rc = h->pipe.ensure(1, &inb, first * out_frame);
+    if (rc) return rc;
+    HostPipe &p = h->pipe;
+    // all (stream, chunk) pairs run through the two staging slots back to back
+    size_t nchunks = ((size_t)nvec + chunk_frames - 1) / chunk_frames;
+    char *pend_dst[2] = {nullptr, nullptr};
+    size_t pend_bytes[2] = {0, 0};
+    size_t seq = 0;
+    for (int s_i = 0; s_i < h->nstreams; s_i++) {
+        MI355_REQUIRE(in_streams[s_i] && out_streams[s_i], "NULL stream buffer");
+        const char *pin = (const char *)in_streams[s_i];
+        char *pout = (char *)out_streams[s_i];
+        for (size_t ci = 0; ci < nchunks; ci++, seq++) {
+            int s = (int)(seq & 1);
+            hipStream_t st = h->ctx->stream[s];
+            if (pend_bytes[s]) {
+                MI355_HIP(hipEventSynchronize(p.done[s]));
+                memcpy(pend_dst[s], p.h_out[s], pend_bytes[s]);
+                pend_bytes[s] = 0;
+            }
+            size_t f0 = ci * chunk_frames;
+            size_t nf = (size_t)nvec - f0 < chunk_frames ? (size_t)nvec - f0 : chunk_frames;
+            memcpy(p.h_in[s][0], pin + f0 * in_frame, nf * in_frame);
+            MI355_HIP(hipMemcpyAsync(p.d_in[s][0], p.h_in[s][0], nf * in_frame, hipMemcpyHostToDevice, st));
+            rc = launch_fft(h->ctx, h->n, h->sign, p.d_in[s][0], p.d_out[s], h->d_window, h->d_tw, (int)nf, h->shift,
+                            h->dtype == MI355_DTYPE_FLOAT, st);
+            if (rc) return rc;
+            MI355_HIP(hipMemcpyAsync(p.h_out[s], p.d_out[s], nf * out_frame, hipMemcpyDeviceToHost, st));
+            MI355_HIP(hipEventRecord(p.done[s], st));
+            pend_dst[s] = pout + f0 * out_frame;
+            pend_bytes[s] = nf * out_frame;
+        }
+    }
+    for (int q = 0; q < 2; q++) {
+        int s = (int)((seq + q) & 1);
+        if (pend_bytes[s]) {
+            MI355_HIP(hipEventSynchronize(p.done[s]));
+            memcpy(pend_dst[s], p.h_out[s], pend_bytes[s]);
+            pend_bytes[s] = 0;
+        }
+    }
+    return MI355_OK;
+}

@@ -1,0 +1,136 @@
+// Register-level building blocks of the LDS-resident Stockham FFT (gfx950).
+// Shared by the clFFT kernel, the fused overlap-save filter and the polyphase
+// channelizer.  Everything is compile-time unrolled: a thread always owns 16
+// complex points (32 VGPRs) and performs 16/R radix-R butterflies per pass.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace fftc {
+
+struct c32 { float x, y; };
+
+__device__ __forceinline__ c32 mk(float x, float y) { c32 r; r.x = x; r.y = y; return r; }
+__device__ __forceinline__ c32 operator+(c32 a, c32 b) { return mk(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ c32 operator-(c32 a, c32 b) { return mk(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ c32 cmul(c32 a, c32 b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ c32 scale(c32 a, float s) { return mk(a.x * s, a.y * s); }
+// multiply by -i (forward) or +i (inverse): the W4^1 twiddle
+template <int SIGN> __device__ __forceinline__ c32 rot90(c32 a) { return SIGN < 0 ? mk(a.y, -a.x) : mk(-a.y, a.x); }
+// multiply by exp(SIGN * i * pi/4) * sqrt(2)/... i.e. W8^1 (normalised)
+template <int SIGN> __device__ __forceinline__ c32 rot45(c32 a)
+{
+    constexpr float h = 0.70710678118654752440f;
+    return SIGN < 0 ? mk((a.x + a.y) * h, (a.y - a.x) * h) : mk((a.x - a.y) * h, (a.y + a.x) * h);
+}
+// W8^3 = rot90(rot45)
+template <int SIGN> __device__ __forceinline__ c32 rot135(c32 a)
+{
+    constexpr float h = 0.70710678118654752440f;
+    return SIGN < 0 ? mk((a.y - a.x) * h, -(a.x + a.y) * h) : mk(-(a.x + a.y) * h, (a.x - a.y) * h);
+}
+// multiply by W16^m, m = 1 or 3 (cos/sin of pi/8), SIGN<0 forward
+template <int SIGN, int M> __device__ __forceinline__ c32 rot16(c32 a)
+{
+    constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;
+    constexpr float c = (M == 1) ? c1 : s1, s = (M == 1) ? s1 : c1;  // W16^1 = c1 - i s1 ; W16^3 = s1 - i c1
+    return SIGN < 0 ? mk(a.x * c + a.y * s, a.y * c - a.x * s) : mk(a.x * c - a.y * s, a.y * c + a.x * s);
+}
+
+// ---- butterflies: in-place DFT of R points held in v[0..R-1] --------------------
+// After the call slot s holds X[orev<R>(s)].
+template <int R> __host__ __device__ constexpr int orev(int s)
+{
+    if (R == 16) return (s >> 2) + 4 * (s & 3);
+    if (R == 8) return (s >> 2) + 2 * (s & 3);  // slots 0-3: X0,X2,X4,X6 ; 4-7: X1,X3,X5,X7
+    return s;
+}
+
+template <int SIGN> __device__ __forceinline__ void bfly2(c32 &a, c32 &b)
+{
+    c32 t = a - b;
+    a = a + b;
+    b = t;
+}
+
+template <int SIGN> __device__ __forceinline__ void bfly4(c32 &a, c32 &b, c32 &c, c32 &d)
+{
+    c32 t0 = a + c, t1 = a - c, t2 = b + d, t3 = rot90<SIGN>(b - d);
+    a = t0 + t2;  // X0
+    c = t0 - t2;  // X2
+    b = t1 + t3;  // X1
+    d = t1 - t3;  // X3
+}
+
+template <int SIGN> __device__ __forceinline__ void bfly8(c32 *v)
+{
+    // decimation in frequency: radix-2 split then two radix-4
+    c32 d0 = v[0] - v[4], d1 = rot45<SIGN>(v[1] - v[5]), d2 = rot90<SIGN>(v[2] - v[6]), d3 = rot135<SIGN>(v[3] - v[7]);
+    c32 s0 = v[0] + v[4], s1 = v[1] + v[5], s2 = v[2] + v[6], s3 = v[3] + v[7];
+    bfly4<SIGN>(s0, s1, s2, s3);  // X0 X2 X4 X6
+    bfly4<SIGN>(d0, d1, d2, d3);  // X1 X3 X5 X7
+    v[0] = s0; v[1] = s1; v[2] = s2; v[3] = s3;
+    v[4] = d0; v[5] = d1; v[6] = d2; v[7] = d3;
+}
+
+template <int SIGN> __device__ __forceinline__ void bfly16(c32 *v)
+{
+    // 4x4: inner radix-4 over m for each a (x[a+4m]) -> y_a[b] at v[a+4b]
+#pragma unroll
+    for (int a = 0; a < 4; a++) bfly4<SIGN>(v[a], v[a + 4], v[a + 8], v[a + 12]);
+    // twiddle y_a[b] *= W16^(a*b)
+    v[5] = rot16<SIGN, 1>(v[5]);               // a=1,b=1
+    v[6] = rot45<SIGN>(v[6]);                  // a=2,b=1 -> W16^2
+    v[7] = rot16<SIGN, 3>(v[7]);               // a=3,b=1 -> W16^3
+    v[9] = rot45<SIGN>(v[9]);                  // a=1,b=2 -> W16^2
+    v[10] = rot90<SIGN>(v[10]);                // a=2,b=2 -> W16^4
+    v[11] = rot135<SIGN>(v[11]);               // a=3,b=2 -> W16^6
+    v[13] = rot16<SIGN, 3>(v[13]);             // a=1,b=3 -> W16^3
+    v[14] = rot135<SIGN>(v[14]);               // a=2,b=3 -> W16^6
+    {                                          // a=3,b=3 -> W16^9 = -W16^1
+        c32 t = rot16<SIGN, 1>(v[15]);
+        v[15] = mk(-t.x, -t.y);
+    }
+    // outer radix-4 over a for each b -> X[b+4c] at v[4b+c]
+#pragma unroll
+    for (int b = 0; b < 4; b++) bfly4<SIGN>(v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3]);
+}
+
+template <int R, int SIGN> __device__ __forceinline__ void bfly(c32 *v)
+{
+    if constexpr (R == 2) bfly2<SIGN>(v[0], v[1]);
+    else if constexpr (R == 4) bfly4<SIGN>(v[0], v[1], v[2], v[3]);
+    else if constexpr (R == 8) bfly8<SIGN>(v);
+    else bfly16<SIGN>(v);
+}
+
+// ---- radix plan: as many 16s as possible, remainder last -----------------------
+template <int N> struct Plan {
+    static constexpr int log2n()
+    {
+        int l = 0;
+        for (int n = N; n > 1; n >>= 1) l++;
+        return l;
+    }
+    static constexpr int L = log2n();
+    static constexpr int NP = (L + 3) / 4;
+    __host__ __device__ static constexpr int radix(int p)
+    {
+        int full = L / 4, rem = L % 4;
+        if (p < full) return 16;
+        return 1 << rem;
+    }
+    // product of the radices of passes before p
+    __host__ __device__ static constexpr int ns(int p)
+    {
+        int s = 1;
+        for (int q = 0; q < p; q++) s *= radix(q);
+        return s;
+    }
+};
+
+// LDS slot swizzle (8-byte slots): XOR the low four slot bits with the next four.
+// Makes the three access patterns of the 16-point-per-thread passes conflict free
+// for ds_write_b64 (16-lane groups) and ds_read_b64 (32-lane groups).
+__host__ __device__ constexpr int swz(int s) { return s ^ ((s >> 4) & 15); }
+
+}  // namespace fftc

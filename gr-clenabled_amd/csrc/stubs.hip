@@ -1,10 +1,6 @@
 // TEMPORARY: entry points not implemented yet return MI355_ERR_UNSUPPORTED.
 #include "common.h"
 #define STUB(sig) extern "C" int sig { mi355_set_error("not implemented yet"); return MI355_ERR_UNSUPPORTED; }
-STUB(mi355_fft_create(mi355_ctx *, int, int, const float *, int, int, int, int, mi355_fft **))
-STUB(mi355_fft_destroy(mi355_fft *))
-STUB(mi355_fft_work(mi355_fft *, int, const void *const *, void *const *))
-STUB(mi355_fft_work_dev(mi355_fft *, int, const void *, void *, void *))
 STUB(mi355_filter_create(mi355_ctx *, int, const void *, int, int, int, mi355_filter **))
 STUB(mi355_filter_destroy(mi355_filter *))
 STUB(mi355_filter_set_taps(mi355_filter *, const void *, int))

@@ -20,8 +20,9 @@
  *     output is complete -- the contract of the reference's blocking
  *     enqueueReadBuffer (e.g. lib/clMathOp_impl.cc:438);
  *   - `*_work_dev(...)` take DEVICE pointers plus a hipStream_t (as void*; NULL
- *     = the handle's own stream) and only enqueue: this is the device-resident
- *     path chained blocks and the benchmarks use;
+ *     = HIP's default stream; pass mi355_ctx_stream() for the context's own)
+ *     and only enqueue: this is the device-resident path chained blocks and
+ *     the benchmarks use;
  *   - there is NO CPU fallback: OCLTYPE_CPU (3) is refused with
  *     MI355_ERR_UNSUPPORTED and every call fails loudly without a gfx950 GPU.
  */

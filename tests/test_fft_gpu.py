@@ -1,0 +1,150 @@
+"""GPU parity: clFFT through the C ABI vs the oracle and the golden vectors.
+
+Tolerance (DESIGN.md 'Tolerances'): max|got-ref| <= 1e-5 * max|ref| per call, ref =
+float64 DFT rounded to float; single-precision FFTs sit near 3e-7 on this metric."""
+import numpy as np
+import pytest
+
+from conftest import GPU_ARGS, crandn, golden, relerr
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _fft(gpu, n, direction, window=None, dtype=None, nstreams=1, shift=False):
+    dtype = gpu.DTYPE_COMPLEX if dtype is None else dtype
+    return gpu.clFFT(n, direction, [] if window is None else window, dtype, *GPU_ARGS, 0, nstreams, shift)
+
+
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384])
+@pytest.mark.parametrize("fwd", [True, False])
+def test_all_sizes_both_directions(gpu, oracle, n, fwd):
+    rng = np.random.default_rng(n)
+    nvec = max(3, 3 * 4096 // n + 1)  # ragged: not a multiple of the frames-per-workgroup
+    x = crandn(rng, nvec * n)
+    y = np.empty_like(x)
+    blk = _fft(gpu, n, gpu.CLFFT_FORWARD if fwd else gpu.CLFFT_BACKWARD)
+    assert blk.work(nvec, [x], [y]) == nvec
+    ref = oracle.fft_block(n, fwd, None, False, oracle.DTYPE_COMPLEX, x, f64=True)
+    assert relerr(y, ref) <= TOL
+    # and it is as accurate as a float FFT should be, not merely inside the budget
+    assert relerr(y, ref) <= 2e-6
+
+
+def test_reference_tone_known_answer(gpu):
+    # lib/clFFT_impl.cc:361-455: N=2048 one-cycle tone -> X[2047] = (0, 2048)
+    x = golden("fft_golden.npz")["tone2048"]
+    y = np.empty_like(x)
+    _fft(gpu, 2048, gpu.CLFFT_FORWARD).work(1, [x], [y])
+    assert abs(y[2047] - 2048j) < 1e-2
+    assert np.abs(np.delete(y, 2047)).max() < 1e-2
+
+
+def test_golden_vectors(gpu):
+    g = golden("fft_golden.npz")
+    for n in (8, 64, 1024, 4096):
+        x = g["x%d" % n]
+        y = np.empty_like(x)
+        _fft(gpu, n, gpu.CLFFT_FORWARD).work(2, [x], [y])
+        assert relerr(y, g["fwd%d" % n]) <= TOL
+        _fft(gpu, n, gpu.CLFFT_BACKWARD).work(2, [x], [y])
+        assert relerr(y, g["inv%d" % n]) <= TOL
+    x = g["x4096"]
+    y = np.empty_like(x)
+    _fft(gpu, 4096, gpu.CLFFT_FORWARD, g["blackman4096"], shift=True).work(2, [x], [y])
+    assert relerr(y, g["fwd_win_shift4096"]) <= TOL
+    _fft(gpu, 4096, gpu.CLFFT_BACKWARD, shift=True).work(2, [x], [y])
+    assert relerr(y, g["inv_shift4096"]) <= TOL
+    xr = g["xr1024"]
+    yr = np.empty(xr.size, np.complex64)
+    _fft(gpu, 1024, gpu.CLFFT_FORWARD, dtype=gpu.DTYPE_FLOAT).work(2, [xr], [yr])
+    assert relerr(yr, g["fwd_real1024"]) <= TOL
+
+
+@pytest.mark.parametrize("n", [16, 256, 4096])
+@pytest.mark.parametrize("fwd,shift,win", [(True, True, True), (True, False, True), (False, True, True), (False, True, False),
+                                           (True, True, False)])
+def test_window_shift_matrix_vs_oracle(gpu, oracle, n, fwd, shift, win):
+    rng = np.random.default_rng(n + 7)
+    w = oracle.window(oracle.WIN_BLACKMAN_HARRIS, n) if win else None  # GRC default window
+    x = crandn(rng, 5 * n)
+    y = np.empty_like(x)
+    _fft(gpu, n, gpu.CLFFT_FORWARD if fwd else gpu.CLFFT_BACKWARD, w, shift=shift).work(5, [x], [y])
+    assert relerr(y, oracle.fft_block(n, fwd, w, shift, oracle.DTYPE_COMPLEX, x, f64=True)) <= TOL
+
+
+def test_real_input_and_streams(gpu, oracle):
+    rng = np.random.default_rng(3)
+    n, nvec = 512, 9
+    xs = [rng.standard_normal(nvec * n).astype(np.float32) for _ in range(3)]
+    ys = [np.empty(nvec * n, np.complex64) for _ in range(3)]
+    w = oracle.window(oracle.WIN_HAMMING, n)
+    blk = _fft(gpu, n, gpu.CLFFT_FORWARD, w, dtype=gpu.DTYPE_FLOAT, nstreams=3, shift=True)
+    blk.work(nvec, xs, ys)
+    for x, y in zip(xs, ys):
+        assert relerr(y, oracle.fft_block(n, True, w, True, oracle.DTYPE_FLOAT, x, f64=True)) <= TOL
+
+
+def test_host_path_multi_chunk(gpu, oracle):
+    rng = np.random.default_rng(4)
+    n, nvec = 4096, 700  # 700 frames * 32 KiB > two 8 MiB staging chunks
+    x = crandn(rng, n * nvec)
+    y = np.empty_like(x)
+    _fft(gpu, n, gpu.CLFFT_FORWARD, shift=True).work(nvec, [x], [y])
+    ref = oracle.fft_block(n, True, None, True, oracle.DTYPE_COMPLEX, x[:8 * n], f64=True)
+    assert relerr(y[:8 * n], ref) <= TOL
+    tail = oracle.fft_block(n, True, None, True, oracle.DTYPE_COMPLEX, x[-3 * n:], f64=True)
+    assert relerr(y[-3 * n:], tail) <= TOL
+    # Parseval on every frame
+    ex = (np.abs(x.reshape(nvec, n)) ** 2).sum(1)
+    ey = (np.abs(y.reshape(nvec, n)) ** 2).sum(1) / n
+    assert np.allclose(ex, ey, rtol=1e-4)
+
+
+def test_device_path_full_size_properties(gpu, oracle):
+    """BASELINE config 2 at full size (16384 frames of 4096, 1 GiB in+out) on torch's stream:
+    round trip ifft(fft(x)) = N*x, Parseval, and a sampled oracle check."""
+    import torch
+    n, nvec = 4096, 16384
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    x = torch.randn(nvec * n, 2, device="cuda", generator=g)
+    y = torch.empty_like(x)
+    z = torch.empty_like(x)
+    w = oracle.window(oracle.WIN_BLACKMAN, n)
+    fwd = _fft(gpu, n, gpu.CLFFT_FORWARD, shift=True)
+    inv = _fft(gpu, n, gpu.CLFFT_BACKWARD, shift=True)
+    fwd.work_device(nvec, [x], [y])
+    inv.work_device(nvec, [y], [z])
+    torch.cuda.synchronize()
+    assert torch.allclose(z, x * n, rtol=0, atol=2e-5 * n * 6)
+    ex = (x * x).sum().item()
+    ey = (y * y).sum().item() / n
+    assert abs(ex - ey) / ex < 1e-5
+    fw = _fft(gpu, n, gpu.CLFFT_FORWARD, w, shift=True)
+    fw.work_device(nvec, [x], [y])
+    torch.cuda.synchronize()
+    for f0 in (0, 7777, nvec - 2):
+        xs = x[f0 * n:(f0 + 2) * n].cpu().numpy().view(np.complex64).reshape(-1)
+        ys = y[f0 * n:(f0 + 2) * n].cpu().numpy().view(np.complex64).reshape(-1)
+        assert relerr(ys, oracle.fft_block(n, True, w, True, oracle.DTYPE_COMPLEX, xs, f64=True)) <= TOL
+
+
+def test_linearity_and_impulse(gpu):
+    n = 1024
+    rng = np.random.default_rng(8)
+    a, b = crandn(rng, n), crandn(rng, n)
+    blk = _fft(gpu, n, gpu.CLFFT_FORWARD)
+    ya, yb, yab = (np.empty(n, np.complex64) for _ in range(3))
+    blk.work(1, [a], [ya]); blk.work(1, [b], [yb]); blk.work(1, [(2 * a + 3j * b).astype(np.complex64)], [yab])
+    assert relerr(yab, 2 * ya + 3j * yb) <= TOL
+    d = np.zeros(n, np.complex64); d[5] = 1
+    blk.work(1, [d], [ya])
+    assert relerr(ya, np.exp(-2j * np.pi * 5 * np.arange(n) / n)) <= TOL
+
+
+def test_zero_vectors_and_bad_sizes(gpu):
+    blk = _fft(gpu, 64, gpu.CLFFT_FORWARD)
+    e = np.empty(0, np.complex64)
+    assert blk.work(0, [e], [e]) == 0
+    with pytest.raises(gpu.Mi355Error):
+        _fft(gpu, 48, gpu.CLFFT_FORWARD)  # clFFT radix-3/5/7 sizes are not implemented: refused, not emulated
