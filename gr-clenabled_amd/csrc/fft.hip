@@ -24,117 +24,6 @@ using namespace fftc;
 
 namespace {
 
-template <int N> struct Geo {
-    static constexpr int TH = (N <= 4096) ? 256 : N / 16;  // threads per workgroup
-    static constexpr int PTS = TH * 16;                     // points per workgroup iteration
-    static constexpr int F = PTS / N;                       // frames per iteration
-    static constexpr int WPE = (N <= 4096) ? 3 : (N == 8192 ? 1 : 1);  // min waves per SIMD asked of the register allocator
-};
-
-// Inter-pass twiddles kept in registers.  For a radix-R butterfly only the powers
-// r in {1,2,3} and {4,8,12} of the butterfly's base twiddle are stored (exactly
-// rounded from the double-precision table); the rest are one product w[4a]*w[b].
-// Slots per butterfly: R=16 -> 6, R=8 -> 4, R=4 -> 3, R=2 -> 1  (<= 12 per pass).
-template <int R> __host__ __device__ constexpr int tw_slots() { return R == 16 ? 6 : R == 8 ? 4 : R == 4 ? 3 : 1; }
-// power held in slot i
-template <int R> __host__ __device__ constexpr int tw_power(int i) { return i < 3 ? i + 1 : (i - 2) * 4; }
-constexpr int kTwPerPass = 12;
-
-template <int N, int P>
-__device__ __forceinline__ void load_twiddles(c32 (&tw)[Plan<N>::NP > 1 ? Plan<N>::NP - 1 : 1][kTwPerPass], int tid,
-                                              const c32 *__restrict__ twtab)
-{
-    using PL = Plan<N>;
-    if constexpr (P < PL::NP) {
-        constexpr int TH = Geo<N>::TH, R = PL::radix(P), NS = PL::ns(P), B = N / R, S = tw_slots<R>();
-#pragma unroll
-        for (int q = 0; q < 16 / R; q++) {
-            const int j = (tid + TH * q) % B, k = j % NS;
-#pragma unroll
-            for (int i = 0; i < S; i++) tw[P - 1][q * S + i] = twtab[(tw_power<R>(i) * k * (N / (NS * R))) & (N - 1)];
-        }
-        load_twiddles<N, P + 1>(tw, tid, twtab);
-    }
-}
-
-// v[r] *= W^r for r = 1..R-1, W^r rebuilt from the stored powers
-template <int R> __device__ __forceinline__ void apply_twiddles(c32 *v, const c32 *w_in)
-{
-    // Opaque copies: keeps the w[4a]*w[b] products inside the frame loop instead of
-    // letting loop-invariant code motion turn them back into 15 live registers pairs.
-    c32 w[tw_slots<R>()];
-#pragma unroll
-    for (int i = 0; i < tw_slots<R>(); i++) {
-        w[i] = w_in[i];
-        asm volatile("" : "+v"(w[i].x), "+v"(w[i].y));
-    }
-#pragma unroll
-    for (int r = 1; r < R; r++) {
-        const int lo = r & 3, hi = r >> 2;
-        c32 t;
-        if (hi == 0) t = w[lo - 1];
-        else if (lo == 0) t = w[2 + hi];
-        else t = cmul(w[2 + hi], w[lo - 1]);
-        v[r] = cmul(v[r], t);
-    }
-}
-
-// LDS slot of logical index (raw + c) where c is a compile-time multiple of STEP
-template <int STEP> __device__ __forceinline__ int lds_at(int raw, int raw_swz, int c)
-{
-    if constexpr (STEP % 256 == 0) return raw_swz + c;  // the swizzle only touches the low 8 slot bits
-    else return swz(raw + c);
-}
-
-// passes P..NP-1 on the 16 points in v; pass 0's inputs are already in v.
-// out_g points at this group's first output frame; all per-thread offsets are 32-bit.
-template <int N, int SIGN, int P>
-__device__ __forceinline__ void run_passes(c32 (&v)[16], const c32 (&tw)[Plan<N>::NP > 1 ? Plan<N>::NP - 1 : 1][kTwPerPass], c32 *lds,
-                                           c32 *__restrict__ out_g, int tid, int frames_left, int out_xor)
-{
-    using PL = Plan<N>;
-    if constexpr (P < PL::NP) {
-        constexpr int TH = Geo<N>::TH, NP = PL::NP, R = PL::radix(P), NS = PL::ns(P), B = N / R;
-        if constexpr (P > 0) {
-            __syncthreads();  // previous pass' LDS writes are visible
-#pragma unroll
-            for (int q = 0; q < 16 / R; q++) {
-                const int g = tid + TH * q, raw = (g / B) * N + (g % B), rs = swz(raw);
-#pragma unroll
-                for (int r = 0; r < R; r++) v[q * R + r] = lds[lds_at<B>(raw, rs, r * B)];
-            }
-#pragma unroll
-            for (int q = 0; q < 16 / R; q++) apply_twiddles<R>(&v[q * R], &tw[P - 1][q * tw_slots<R>()]);
-            if constexpr (P < NP - 1) __syncthreads();  // everyone has read before anyone overwrites in place
-        }
-#pragma unroll
-        for (int q = 0; q < 16 / R; q++) bfly<R, SIGN>(&v[q * R]);
-        if constexpr (P < NP - 1) {
-            // registers -> LDS at the autosort position
-#pragma unroll
-            for (int q = 0; q < 16 / R; q++) {
-                const int g = tid + TH * q, fr = g / B, j = g % B;
-                const int raw = fr * N + (j / NS) * NS * R + (j % NS), rs = swz(raw);
-#pragma unroll
-                for (int s = 0; s < R; s++) lds[lds_at<NS>(raw, rs, orev<R>(s) * NS)] = v[q * R + s];
-            }
-        } else {
-            // last pass: registers -> global, unit stride across lanes, fftshift fused.
-            // out_xor is 0 or N/2, a multiple of B, so it only permutes the r*B term.
-#pragma unroll
-            for (int q = 0; q < 16 / R; q++) {
-                const int g = tid + TH * q, fr = g / B;
-                const unsigned off = (unsigned)(fr * N + (g % B));
-                if ((Geo<N>::F == 1) || fr < frames_left) {
-#pragma unroll
-                    for (int s = 0; s < R; s++) out_g[off + (unsigned)((orev<R>(s) * B) ^ out_xor)] = v[q * R + s];
-                }
-            }
-        }
-        run_passes<N, SIGN, P + 1>(v, tw, lds, out_g, tid, frames_left, out_xor);
-    }
-}
-
 template <int N, int SIGN, bool REAL>
 __global__ __launch_bounds__(Geo<N>::TH, Geo<N>::WPE) void k_fft(const void *__restrict__ in, c32 *__restrict__ out,
                                                                  const float *__restrict__ window,
@@ -149,8 +38,8 @@ __global__ __launch_bounds__(Geo<N>::TH, Geo<N>::WPE) void k_fft(const void *__r
     const int out_xor = (SIGN < 0 && shift) ? (N >> 1) : 0;  // forward: halves swapped on store (:594-607)
 
     // ---- per-thread constants: inter-pass twiddles and window values --------------
-    c32 tw[NP > 1 ? NP - 1 : 1][kTwPerPass];
-    load_twiddles<N, 1>(tw, tid0, twtab);
+    TwRegs<N> tw;
+    load_twiddles<N, false>(tw, tid0, twtab);
     constexpr int R0 = P::radix(0), B0 = N / R0;
     float win[16];  // the handle always carries a window (all ones when the block has none)
 #pragma unroll
@@ -200,7 +89,22 @@ __global__ __launch_bounds__(Geo<N>::TH, Geo<N>::WPE) void k_fft(const void *__r
         }
 #pragma unroll
         for (int s = 0; s < 16; s++) v[s] = scale(v[s], win[s]);
-        run_passes<N, SIGN, 0>(v, tw, lds, out + (size_t)grp * PTS, tid, frames_left, out_xor);
+        transform_regs<N, SIGN, false>(v, tw, lds, tid);
+        // registers -> global, unit stride across lanes, fftshift fused.  out_xor is 0 or
+        // N/2, a multiple of BL, so it only permutes the s*BL term.
+        {
+            constexpr int RL = P::radix(NP - 1), BL = N / RL;
+            c32 *__restrict__ out_g = out + (size_t)grp * PTS;
+#pragma unroll
+            for (int q = 0; q < 16 / RL; q++) {
+                const int g = tid + TH * q, fr = g / BL;
+                const unsigned off = (unsigned)(fr * N + (g % BL));
+                if ((F == 1) || fr < frames_left) {
+#pragma unroll
+                    for (int s = 0; s < RL; s++) out_g[off + (unsigned)((orev<RL>(s) * BL) ^ out_xor)] = v[q * RL + s];
+                }
+            }
+        }
         if constexpr (NP > 1) __syncthreads();  // last pass' LDS reads finish before the next group's writes
     }
 }

@@ -103,8 +103,9 @@ template <int R, int SIGN> __device__ __forceinline__ void bfly(c32 *v)
     else bfly16<SIGN>(v);
 }
 
-// ---- radix plan: as many 16s as possible, remainder last -----------------------
-template <int N> struct Plan {
+// ---- radix plan: as many 16s as possible; the remainder radix goes last, or first
+// when REV (used by inverse transforms that start from a forward transform's registers)
+template <int N, bool REV = false> struct Plan {
     static constexpr int log2n()
     {
         int l = 0;
@@ -116,8 +117,9 @@ template <int N> struct Plan {
     __host__ __device__ static constexpr int radix(int p)
     {
         int full = L / 4, rem = L % 4;
-        if (p < full) return 16;
-        return 1 << rem;
+        if (rem == 0) return 16;
+        if (REV) return p == 0 ? (1 << rem) : 16;
+        return p < full ? 16 : (1 << rem);
     }
     // product of the radices of passes before p
     __host__ __device__ static constexpr int ns(int p)
@@ -128,9 +130,119 @@ template <int N> struct Plan {
     }
 };
 
+// workgroup geometry: every thread owns 16 points
+template <int N> struct Geo {
+    static constexpr int TH = (N <= 4096) ? 256 : N / 16;  // threads per workgroup
+    static constexpr int PTS = TH * 16;                     // points per workgroup iteration
+    static constexpr int F = PTS / N;                       // frames per iteration
+    static constexpr int WPE = (N <= 4096) ? 3 : 1;         // min waves per SIMD asked of the register allocator
+};
+
 // LDS slot swizzle (8-byte slots): XOR the low four slot bits with the next four.
 // Makes the three access patterns of the 16-point-per-thread passes conflict free
 // for ds_write_b64 (16-lane groups) and ds_read_b64 (32-lane groups).
 __host__ __device__ constexpr int swz(int s) { return s ^ ((s >> 4) & 15); }
+
+// LDS slot of logical index (raw + c) where c is a compile-time multiple of STEP
+template <int STEP> __device__ __forceinline__ int lds_at(int raw, int raw_swz, int c)
+{
+    if constexpr (STEP % 256 == 0) return raw_swz + c;  // the swizzle only touches the low 8 slot bits
+    else return swz(raw + c);
+}
+
+// inverse of orev: slot that holds output index r
+template <int R> __host__ __device__ constexpr int irev(int r)
+{
+    if (R == 16) return (r >> 2) + 4 * (r & 3);
+    if (R == 8) return (r & 1) * 4 + (r >> 1);
+    return r;
+}
+
+// Inter-pass twiddles kept in registers.  For a radix-R butterfly only the powers
+// r in {1,2,3} and {4,8,12} of the butterfly's base twiddle are stored (exactly
+// rounded from the double-precision table); the rest are one product w[4a]*w[b].
+// Slots per butterfly: R=16 -> 6, R=8 -> 4, R=4 -> 3, R=2 -> 1  (<= 12 per pass).
+template <int R> __host__ __device__ constexpr int tw_slots() { return R == 16 ? 6 : R == 8 ? 4 : R == 4 ? 3 : 1; }
+template <int R> __host__ __device__ constexpr int tw_power(int i) { return i < 3 ? i + 1 : (i - 2) * 4; }
+constexpr int kTwPerPass = 12;
+template <int N> struct TwRegs { c32 w[Plan<N>::NP > 1 ? Plan<N>::NP - 1 : 1][kTwPerPass]; };
+
+// twtab[k] = exp(sign * 2*pi*i*k/N), k < N (generated in double on the host)
+template <int N, bool REV, int P = 1>
+__device__ __forceinline__ void load_twiddles(TwRegs<N> &tw, int tid, const c32 *__restrict__ twtab)
+{
+    using PL = Plan<N, REV>;
+    if constexpr (P < PL::NP) {
+        constexpr int TH = Geo<N>::TH, R = PL::radix(P), NS = PL::ns(P), B = N / R, S = tw_slots<R>();
+#pragma unroll
+        for (int q = 0; q < 16 / R; q++) {
+            const int j = (tid + TH * q) % B, k = j % NS;
+#pragma unroll
+            for (int i = 0; i < S; i++) tw.w[P - 1][q * S + i] = twtab[(tw_power<R>(i) * k * (N / (NS * R))) & (N - 1)];
+        }
+        load_twiddles<N, REV, P + 1>(tw, tid, twtab);
+    }
+}
+
+// v[r] *= W^r for r = 1..R-1, W^r rebuilt from the stored powers
+template <int R> __device__ __forceinline__ void apply_twiddles(c32 *v, const c32 *w_in)
+{
+    // Opaque copies: keeps the w[4a]*w[b] products inside the frame loop instead of
+    // letting loop-invariant code motion turn them back into 15 live register pairs.
+    c32 w[tw_slots<R>()];
+#pragma unroll
+    for (int i = 0; i < tw_slots<R>(); i++) {
+        w[i] = w_in[i];
+        asm volatile("" : "+v"(w[i].x), "+v"(w[i].y));
+    }
+#pragma unroll
+    for (int r = 1; r < R; r++) {
+        const int lo = r & 3, hi = r >> 2;
+        c32 t;
+        if (hi == 0) t = w[lo - 1];
+        else if (lo == 0) t = w[2 + hi];
+        else t = cmul(w[2 + hi], w[lo - 1]);
+        v[r] = cmul(v[r], t);
+    }
+}
+
+// All passes of an N-point transform on the workgroup's PTS points.
+// In : v[q*R0 + r]  = x[fr][j + r*B0]            (R0 = first radix, g = tid + TH*q, fr = g/B0, j = g%B0)
+// Out: v[q*RL + s]  = X[fr][j + orev<RL>(s)*BL]  (RL = last radix,  fr = g/BL, j = g%BL)
+// `lds` holds PTS slots and is used in place; the caller must __syncthreads() before
+// reusing it for another transform.
+template <int N, int SIGN, bool REV, int P = 0>
+__device__ __forceinline__ void transform_regs(c32 (&v)[16], const TwRegs<N> &tw, c32 *lds, int tid)
+{
+    using PL = Plan<N, REV>;
+    if constexpr (P < PL::NP) {
+        constexpr int TH = Geo<N>::TH, NP = PL::NP, R = PL::radix(P), NS = PL::ns(P), B = N / R;
+        if constexpr (P > 0) {
+            __syncthreads();  // previous pass' LDS writes are visible
+#pragma unroll
+            for (int q = 0; q < 16 / R; q++) {
+                const int g = tid + TH * q, raw = (g / B) * N + (g % B), rs = swz(raw);
+#pragma unroll
+                for (int r = 0; r < R; r++) v[q * R + r] = lds[lds_at<B>(raw, rs, r * B)];
+            }
+#pragma unroll
+            for (int q = 0; q < 16 / R; q++) apply_twiddles<R>(&v[q * R], &tw.w[P - 1][q * tw_slots<R>()]);
+            if constexpr (P < NP - 1) __syncthreads();  // everyone has read before anyone overwrites in place
+        }
+#pragma unroll
+        for (int q = 0; q < 16 / R; q++) bfly<R, SIGN>(&v[q * R]);
+        if constexpr (P < NP - 1) {
+            // registers -> LDS at the autosort position
+#pragma unroll
+            for (int q = 0; q < 16 / R; q++) {
+                const int g = tid + TH * q, fr = g / B, j = g % B;
+                const int raw = fr * N + (j / NS) * NS * R + (j % NS), rs = swz(raw);
+#pragma unroll
+                for (int s = 0; s < R; s++) lds[lds_at<NS>(raw, rs, orev<R>(s) * NS)] = v[q * R + s];
+            }
+        }
+        transform_regs<N, SIGN, REV, P + 1>(v, tw, lds, tid);
+    }
+}
 
 }  // namespace fftc

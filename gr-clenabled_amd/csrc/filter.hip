@@ -1,0 +1,501 @@
+// clFilter / clComplexFilter as gfx950 HIP kernels:  y[m] = sum_k h[k] x[m*decim - k].
+// Reference behaviour: lib/clFilter_impl.cc:50-83 (ctor), :504-589 (time domain),
+// :591-681 (frequency domain: per 192-sample block clFFT fwd -> D2H -> host multiply
+// -> H2D -> clFFT inv -> D2H -> host tail add, i.e. 5 PCIe transfers and 2 host
+// syncs per block), lib/clComplexFilter_impl.cc:796-828,959-1030; CPU twins
+// lib/fft_filter.cc:38-175, lib/fir_filter.cc:222-257,455-488.
+//
+// Frequency-domain mode = ONE fused overlap-save kernel.  With GNU Radio's history
+// (ntaps-1 old samples in front of the buffer) every FFT block is independent:
+//     block b reads in[b*L .. b*L+NF), L = NF-(ntaps-1); FFT_NF -> x H -> IFFT_NF;
+//     y_blk[n], n >= ntaps-1, is y[b*L + n-(ntaps-1)]
+// so there is no tail state (the reference's overlap-add tail, lib/fft_filter.cc:156-171,
+// gives the same y).  A workgroup owns 4096 points = 4096/NF blocks; the forward
+// transform's last pass leaves the spectrum in registers in exactly the order the
+// inverse transform's first pass consumes (reversed radix plan), so the multiply by
+// H happens in registers with no LDS trip between the two transforms.  H (pre-scaled
+// by 1/NF like lib/fft_filter.cc:52-57) and all twiddles are per-thread constants
+// held in registers across the persistent block loop.
+// HBM traffic: 8 B read + 8 B written per input sample (the ntaps-1 overlap is
+// re-read from L1/L2 by the neighbouring block of the same workgroup).
+//
+// Time-domain mode = register-tiled direct form: 8 outputs per thread, input tile in
+// LDS, reversed taps fetched through the scalar cache.
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+#include "common.h"
+#include "fft_core.cuh"
+
+using namespace fftc;
+
+namespace {
+
+// ------------------------------------------------------------------------------------
+// fused overlap-save fast convolution
+// ------------------------------------------------------------------------------------
+template <int NF>
+__global__ __launch_bounds__(Geo<NF>::TH, Geo<NF>::WPE) void k_ols(const c32 *__restrict__ in, c32 *__restrict__ out,
+                                                                   const c32 *__restrict__ Hspec,
+                                                                   const c32 *__restrict__ tw_fwd,
+                                                                   const c32 *__restrict__ tw_inv, int ntaps, int decim,
+                                                                   long long n_in,   // readable input samples
+                                                                   long long n_y,    // undecimated outputs wanted
+                                                                   int nblocks, int ngroups)
+{
+    using PF = Plan<NF, false>;
+    using PI = Plan<NF, true>;
+    constexpr int TH = Geo<NF>::TH, PTS = Geo<NF>::PTS, F = Geo<NF>::F, NP = PF::NP;
+    __shared__ c32 lds[NP > 1 ? PTS : 1];
+    const int tid0 = threadIdx.x;
+    const int L = NF - (ntaps - 1);
+
+    TwRegs<NF> twf, twi;
+    load_twiddles<NF, false>(twf, tid0, tw_fwd);
+    load_twiddles<NF, true>(twi, tid0, tw_inv);
+    // spectrum of the taps at the bins this thread holds after the forward transform
+    constexpr int RL = PF::radix(NP - 1), BL = NF / RL;
+    static_assert(PI::radix(0) == RL, "inverse plan must start with the forward plan's last radix");
+    c32 Hreg[16];
+#pragma unroll
+    for (int q = 0; q < 16 / RL; q++) {
+        const int j = (tid0 + TH * q) % BL;
+#pragma unroll
+        for (int s = 0; s < RL; s++) Hreg[q * RL + s] = Hspec[j + orev<RL>(s) * BL];
+    }
+
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        c32 v[16];
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));  // keep address arithmetic inside the loop (see fft.hip)
+        // Group base sample (uniform); everything per thread is a 32-bit offset from it.
+        const long long g0 = (long long)grp * F * L;
+        const c32 *__restrict__ in_g = in + g0;
+        const long long in_left64 = n_in - g0, y_left64 = n_y - g0;
+        const unsigned in_left = in_left64 > 0x7fffffffLL ? 0x7fffffffu : (unsigned)in_left64;
+        const unsigned y_left = y_left64 > 0x7fffffffLL ? 0x7fffffffu : (unsigned)(y_left64 > 0 ? y_left64 : 0);
+        // ---- load: block fr of the group covers in_g[fr*L + n], n < NF; zero beyond the buffer ----
+        constexpr int R0 = PF::radix(0), B0 = NF / R0;
+#pragma unroll
+        for (int q = 0; q < 16 / R0; q++) {
+            const int g = tid + TH * q, fr = g / B0, j = g % B0;
+            const unsigned base = (unsigned)(fr * L + j);
+#pragma unroll
+            for (int r = 0; r < R0; r++) {
+                const unsigned e = base + (unsigned)(r * B0);
+                const bool ok = e < in_left;
+                const c32 x = in_g[ok ? e : 0u];
+                v[q * R0 + r] = ok ? x : mk(0.f, 0.f);
+            }
+        }
+        transform_regs<NF, -1, false>(v, twf, lds, tid);
+        // ---- spectrum multiply in registers, permuted into the inverse plan's input order ----
+        c32 w[16];
+#pragma unroll
+        for (int q = 0; q < 16 / RL; q++) {
+#pragma unroll
+            for (int r = 0; r < RL; r++) w[q * RL + r] = cmul(v[q * RL + irev<RL>(r)], Hreg[q * RL + irev<RL>(r)]);
+        }
+        if constexpr (NP > 1) __syncthreads();  // forward transform's LDS reads are done
+        transform_regs<NF, 1, true>(w, twi, lds, tid);
+        // ---- store the valid part (n >= ntaps-1), decimated ---------------------------------
+        constexpr int RO = PI::radix(NP - 1), BO = NF / RO;
+        c32 *__restrict__ out_g = out + g0;  // decim == 1 fast path
+#pragma unroll
+        for (int q = 0; q < 16 / RO; q++) {
+            const int g = tid + TH * q, fr = g / BO, j = g % BO;
+            const int rel0 = fr * L + j - (ntaps - 1);
+#pragma unroll
+            for (int s = 0; s < RO; s++) {
+                const int n = j + orev<RO>(s) * BO;
+                const int rel = rel0 + orev<RO>(s) * BO;  // output index relative to g0
+                if (n >= ntaps - 1 && (unsigned)rel < y_left) {
+                    if (decim == 1) out_g[(unsigned)rel] = w[q * RO + s];
+                    else {
+                        const long long t = g0 + rel;
+                        if (t % decim == 0) out[t / decim] = w[q * RO + s];
+                    }
+                }
+            }
+        }
+        if constexpr (NP > 1) __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// direct-form FIR, decimation 1.  256 threads x 8 CONSECUTIVE outputs; the thread
+// slides an 8+8 register window over its inputs, so U+K-1 LDS reads feed U*K FMAs.
+// The tile is stored transposed in LDS -- sample n at slot (n%8)*S + n/8 with
+// S = 2 (mod 16) -- which makes both the coalesced fill (ds_write_b64) and the
+// per-lane window reads (ds_read_b64) bank-conflict free.
+// ------------------------------------------------------------------------------------
+constexpr int kTdThreads = 256, kTdU = 8, kTdTile = kTdThreads * kTdU;
+
+__host__ __device__ inline int td_rows(int kpad)
+{
+    int rows = (kTdTile + kpad + kTdU) / kTdU + 1;
+    return rows + ((2 - rows) & 15);  // smallest S >= rows with S % 16 == 2
+}
+
+template <bool CTAPS>
+__global__ __launch_bounds__(kTdThreads) void k_fir_td(const c32 *__restrict__ in, c32 *__restrict__ out,
+                                                       const float *__restrict__ taps_rev,  // reversed, zero padded to kpad
+                                                       int K, long long n_out, int kpad /* K rounded up to kTdU */)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    c32 *tile = (c32 *)smem;
+    const int tid = threadIdx.x;
+    const int S = td_rows(kpad);
+    const int span = kTdTile + kpad + kTdU;
+    const long long ntiles = (n_out + kTdTile - 1) / kTdTile;
+    const long long n_in = n_out + K - 1;
+    for (long long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const long long base = tl * kTdTile;
+        const c32 *__restrict__ in_t = in + base;
+        const long long left64 = n_in - base;
+        const unsigned left = left64 > 0x7fffffffLL ? 0x7fffffffu : (unsigned)left64;
+        __syncthreads();
+        for (int i = tid; i < span; i += kTdThreads)
+            tile[(i & (kTdU - 1)) * S + (i >> 3)] = ((unsigned)i < left) ? in_t[i] : mk(0.f, 0.f);
+        __syncthreads();
+        c32 acc[kTdU], win[2 * kTdU];
+#pragma unroll
+        for (int u = 0; u < kTdU; u++) {
+            acc[u] = mk(0.f, 0.f);
+            win[u] = tile[u * S + tid];  // x[tid*8 + u]
+        }
+        for (int k0 = 0; k0 < kpad; k0 += kTdU) {
+            const int row = tid + (k0 >> 3) + 1;
+#pragma unroll
+            for (int u = 0; u < kTdU; u++) win[kTdU + u] = tile[u * S + row];  // x[tid*8 + k0 + 8 + u]
+#pragma unroll
+            for (int i = 0; i < kTdU; i++) {
+                if constexpr (CTAPS) {
+                    const float hr = taps_rev[2 * (k0 + i)], hi = taps_rev[2 * (k0 + i) + 1];  // uniform -> scalar loads
+#pragma unroll
+                    for (int u = 0; u < kTdU; u++) {
+                        const c32 x = win[i + u];
+                        acc[u].x += hr * x.x - hi * x.y;
+                        acc[u].y += hr * x.y + hi * x.x;
+                    }
+                } else {
+                    const float h = taps_rev[k0 + i];
+#pragma unroll
+                    for (int u = 0; u < kTdU; u++) {
+                        acc[u].x += h * win[i + u].x;
+                        acc[u].y += h * win[i + u].y;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kTdU; u++) win[u] = win[kTdU + u];
+        }
+        // 8 consecutive outputs per thread = 64 contiguous bytes
+        const long long m0 = base + (long long)tid * kTdU;
+#pragma unroll
+        for (int u = 0; u < kTdU; u++)
+            if (m0 + u < n_out) out[m0 + u] = acc[u];
+    }
+}
+
+// direct form with decimation > 1: one output per thread straight from L1/L2
+template <bool CTAPS>
+__global__ __launch_bounds__(256) void k_fir_td_dec(const c32 *__restrict__ in, c32 *__restrict__ out,
+                                                    const float *__restrict__ taps_rev, int K, int decim, long long n_out)
+{
+    for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < n_out; m += (long long)gridDim.x * 256) {
+        const c32 *x = in + m * decim;
+        c32 acc = mk(0.f, 0.f);
+        for (int k = 0; k < K; k++) {
+            const c32 s = x[k];
+            if constexpr (CTAPS) {
+                const float hr = taps_rev[2 * k], hi = taps_rev[2 * k + 1];
+                acc.x += hr * s.x - hi * s.y;
+                acc.y += hr * s.y + hi * s.x;
+            } else {
+                const float h = taps_rev[k];
+                acc.x += h * s.x;
+                acc.y += h * s.y;
+            }
+        }
+        out[m] = acc;
+    }
+}
+
+}  // namespace
+
+struct mi355_filter {
+    mi355_ctx *ctx;
+    int decim, ntaps, complex_taps, use_time;
+    int nf;                        // FFT size of the fast-convolution kernel (0 in time-domain mode)
+    std::vector<float> taps_host;  // ntaps floats or 2*ntaps floats
+    float *d_taps_rev = nullptr;
+    void *d_H = nullptr, *d_twf = nullptr, *d_twi = nullptr;
+    HostPipe pipe;
+    std::mutex lock;
+};
+
+namespace {
+
+int pick_fft_size(int ntaps)
+{
+    // reference rule (lib/fft_filter.cc:72-97): 2 * 2^ceil(log2(ntaps)); never below 256 so
+    // the plan is two radix-16 passes, never above 4096 (one workgroup iteration).
+    // MI355_FILTER_FFT overrides (tuning aid).
+    int nf = 2;
+    while (nf < 2 * ntaps) nf <<= 1;
+    if (nf < 256) nf = 256;
+    if (const char *e = getenv("MI355_FILTER_FFT")) {
+        int v = atoi(e);
+        if (v >= 2 * ntaps && v >= 64 && v <= 4096 && (v & (v - 1)) == 0) nf = v;
+    }
+    return nf;
+}
+
+void free_dev(mi355_filter *h)
+{
+    (void)hipSetDevice(h->ctx->device);
+    if (h->d_taps_rev) (void)hipFree(h->d_taps_rev);
+    if (h->d_H) (void)hipFree(h->d_H);
+    if (h->d_twf) (void)hipFree(h->d_twf);
+    if (h->d_twi) (void)hipFree(h->d_twi);
+    h->d_taps_rev = nullptr;
+    h->d_H = h->d_twf = h->d_twi = nullptr;
+}
+
+int upload_taps(mi355_filter *h, const void *taps, int ntaps)
+{
+    MI355_REQUIRE(taps && ntaps >= 1, "taps must hold at least one tap");
+    const int per = h->complex_taps ? 2 : 1;
+    int nf = 0;
+    if (!h->use_time) {
+        nf = pick_fft_size(ntaps);
+        if (nf > 4096) {
+            mi355_set_error("fast-convolution mode supports up to 2048 taps (got %d)", ntaps);
+            return MI355_ERR_UNSUPPORTED;
+        }
+    }
+    MI355_HIP(hipSetDevice(h->ctx->device));
+    free_dev(h);
+    h->ntaps = ntaps;
+    h->nf = nf;
+    h->taps_host.assign((const float *)taps, (const float *)taps + (size_t)per * ntaps);
+    // reversed taps for the direct form (lib/fir_filter.cc:187-189 reverses them too)
+    const int kpad = (ntaps + kTdU - 1) / kTdU * kTdU;
+    std::vector<float> rev((size_t)per * kpad, 0.0f);  // zero padded: the kernel loops to kpad without a bound test
+    for (int k = 0; k < ntaps; k++)
+        for (int c = 0; c < per; c++) rev[(size_t)per * k + c] = h->taps_host[(size_t)per * (ntaps - 1 - k) + c];
+    MI355_HIP(hipMalloc((void **)&h->d_taps_rev, rev.size() * sizeof(float)));
+    MI355_HIP(hipMemcpy(h->d_taps_rev, rev.data(), rev.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (nf) {
+        // H[k] = sum_n (h[n]/NF) exp(-2 pi i k n / NF), evaluated in double (lib/fft_filter.cc:52-66)
+        std::vector<float> H(2 * (size_t)nf), twf(2 * (size_t)nf), twi(2 * (size_t)nf);
+        std::vector<double> cs(nf), sn(nf);
+        for (int k = 0; k < nf; k++) {
+            double a = -2.0 * M_PI * (double)k / (double)nf;
+            cs[k] = cos(a); sn[k] = sin(a);
+            twf[2 * k] = (float)cs[k]; twf[2 * k + 1] = (float)sn[k];
+            twi[2 * k] = (float)cs[k]; twi[2 * k + 1] = (float)(-sn[k]);
+        }
+        for (int k = 0; k < nf; k++) {
+            double re = 0, im = 0;
+            for (int n = 0; n < ntaps; n++) {
+                double hr = h->taps_host[(size_t)per * n], hi = h->complex_taps ? h->taps_host[2 * (size_t)n + 1] : 0.0;
+                int idx = (int)(((long long)k * n) % nf);
+                re += hr * cs[idx] - hi * sn[idx];
+                im += hr * sn[idx] + hi * cs[idx];
+            }
+            H[2 * k] = (float)(re / nf); H[2 * k + 1] = (float)(im / nf);
+        }
+        size_t bytes = 2 * (size_t)nf * sizeof(float);
+        MI355_HIP(hipMalloc(&h->d_H, bytes));
+        MI355_HIP(hipMalloc(&h->d_twf, bytes));
+        MI355_HIP(hipMalloc(&h->d_twi, bytes));
+        MI355_HIP(hipMemcpy(h->d_H, H.data(), bytes, hipMemcpyHostToDevice));
+        MI355_HIP(hipMemcpy(h->d_twf, twf.data(), bytes, hipMemcpyHostToDevice));
+        MI355_HIP(hipMemcpy(h->d_twi, twi.data(), bytes, hipMemcpyHostToDevice));
+    }
+    return MI355_OK;
+}
+
+template <int NF>
+int launch_ols(mi355_filter *h, size_t nout, const void *in, void *out, hipStream_t st)
+{
+    constexpr int F = Geo<NF>::F, TH = Geo<NF>::TH;
+    const long long n_y = (long long)nout * h->decim;
+    const long long n_in = n_y + h->ntaps - 1;
+    const int L = NF - (h->ntaps - 1);
+    const long long nblocks = (n_y + L - 1) / L;
+    const long long ngroups = (nblocks + F - 1) / F;
+    if (nblocks > 0x7fffffffLL) { mi355_set_error("work() call too large"); return MI355_ERR_INVALID_ARG; }
+    int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
+    long long grid = ngroups < (long long)cus * 3 ? ngroups : (long long)cus * 3;
+    hipLaunchKernelGGL((k_ols<NF>), dim3((unsigned)grid), dim3(TH), 0, st, (const c32 *)in, (c32 *)out, (const c32 *)h->d_H,
+                       (const c32 *)h->d_twf, (const c32 *)h->d_twi, h->ntaps, h->decim, n_in, n_y, (int)nblocks, (int)ngroups);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+int launch_filter(mi355_filter *h, size_t nout, const void *in, void *out, hipStream_t st)
+{
+    if (nout == 0) return MI355_OK;
+    if (!h->use_time) {
+        switch (h->nf) {
+        case 64: return launch_ols<64>(h, nout, in, out, st);
+        case 128: return launch_ols<128>(h, nout, in, out, st);
+        case 256: return launch_ols<256>(h, nout, in, out, st);
+        case 512: return launch_ols<512>(h, nout, in, out, st);
+        case 1024: return launch_ols<1024>(h, nout, in, out, st);
+        case 2048: return launch_ols<2048>(h, nout, in, out, st);
+        case 4096: return launch_ols<4096>(h, nout, in, out, st);
+        }
+        mi355_set_error("internal: no fast-convolution kernel for FFT size %d", h->nf);
+        return MI355_ERR_STATE;
+    }
+    int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
+    if (h->decim == 1) {
+        const int kpad = (h->ntaps + kTdU - 1) / kTdU * kTdU;
+        const size_t smem = (size_t)td_rows(kpad) * kTdU * sizeof(c32);
+        if (smem > 160 * 1024) { mi355_set_error("time-domain mode supports up to ~18000 taps"); return MI355_ERR_UNSUPPORTED; }
+        long long ntiles = ((long long)nout + kTdTile - 1) / kTdTile;
+        int per_cu = (int)((160 * 1024) / smem);
+        if (per_cu > 8) per_cu = 8;
+        if (per_cu < 1) per_cu = 1;
+        long long grid = ntiles < (long long)cus * per_cu ? ntiles : (long long)cus * per_cu;
+        if (h->complex_taps) {
+            if (smem > 64 * 1024)
+                MI355_HIP(hipFuncSetAttribute((const void *)k_fir_td<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL((k_fir_td<true>), dim3((unsigned)grid), dim3(kTdThreads), smem, st, (const c32 *)in, (c32 *)out,
+                               h->d_taps_rev, h->ntaps, (long long)nout, kpad);
+        } else {
+            if (smem > 64 * 1024)
+                MI355_HIP(hipFuncSetAttribute((const void *)k_fir_td<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL((k_fir_td<false>), dim3((unsigned)grid), dim3(kTdThreads), smem, st, (const c32 *)in, (c32 *)out,
+                               h->d_taps_rev, h->ntaps, (long long)nout, kpad);
+        }
+    } else {
+        long long blocks = ((long long)nout + 255) / 256;
+        long long grid = blocks < (long long)cus * 8 ? blocks : (long long)cus * 8;
+        if (h->complex_taps)
+            hipLaunchKernelGGL((k_fir_td_dec<true>), dim3((unsigned)grid), dim3(256), 0, st, (const c32 *)in, (c32 *)out,
+                               h->d_taps_rev, h->ntaps, h->decim, (long long)nout);
+        else
+            hipLaunchKernelGGL((k_fir_td_dec<false>), dim3((unsigned)grid), dim3(256), 0, st, (const c32 *)in, (c32 *)out,
+                               h->d_taps_rev, h->ntaps, h->decim, (long long)nout);
+    }
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+}  // namespace
+
+extern "C" int mi355_filter_create(mi355_ctx *ctx, int decimation, const void *taps, int ntaps, int complex_taps, int use_time,
+                                   mi355_filter **out)
+{
+    MI355_REQUIRE(ctx && out, "NULL argument");
+    *out = nullptr;
+    MI355_REQUIRE(decimation >= 1, "decimation must be >= 1");
+    mi355_filter *h = new (std::nothrow) mi355_filter();
+    if (!h) return MI355_ERR_NOMEM;
+    h->ctx = ctx; h->decim = decimation; h->complex_taps = complex_taps ? 1 : 0; h->use_time = use_time ? 1 : 0;
+    h->ntaps = 0; h->nf = 0;
+    int rc = upload_taps(h, taps, ntaps);
+    if (rc == MI355_OK) rc = h->pipe.init(ctx);
+    if (rc != MI355_OK) { free_dev(h); h->pipe.release(); delete h; return rc; }
+    *out = h;
+    return MI355_OK;
+}
+
+extern "C" int mi355_filter_destroy(mi355_filter *h)
+{
+    if (!h) return MI355_OK;
+    free_dev(h);
+    h->pipe.release();
+    delete h;
+    return MI355_OK;
+}
+
+extern "C" int mi355_filter_set_taps(mi355_filter *h, const void *taps, int ntaps)
+{
+    MI355_REQUIRE(h != nullptr, "handle is NULL");
+    std::lock_guard<std::mutex> g(h->lock);  // lib/clFilter_impl.cc:443 takes d_mutex here
+    MI355_HIP(hipSetDevice(h->ctx->device));
+    MI355_HIP(hipDeviceSynchronize());
+    return upload_taps(h, taps, ntaps);
+}
+
+extern "C" int mi355_filter_ntaps(const mi355_filter *h) { return h ? h->ntaps : MI355_ERR_INVALID_ARG; }
+
+extern "C" int mi355_filter_fftsize(const mi355_filter *h) { return h ? h->nf : MI355_ERR_INVALID_ARG; }
+
+extern "C" int mi355_filter_get_taps(const mi355_filter *h, void *taps_out, int cap)
+{
+    MI355_REQUIRE(h && taps_out, "NULL argument");
+    MI355_REQUIRE(cap >= h->ntaps, "taps_out too small");
+    memcpy(taps_out, h->taps_host.data(), h->taps_host.size() * sizeof(float));
+    return h->ntaps;
+}
+
+extern "C" int mi355_filter_work_dev(mi355_filter *h, size_t noutput_items, const void *in, void *out, void *stream)
+{
+    MI355_REQUIRE(h != nullptr, "handle is NULL");
+    if (noutput_items == 0) return MI355_OK;
+    MI355_REQUIRE(in && out, "NULL buffer");
+    MI355_REQUIRE((reinterpret_cast<uintptr_t>(in) & 7u) == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0,
+                  "device buffers must be 8-byte aligned");
+    std::lock_guard<std::mutex> g(h->lock);
+    MI355_HIP(hipSetDevice(h->ctx->device));
+    return launch_filter(h, noutput_items, in, out, mi355_pick_stream(h->ctx, stream));
+}
+
+extern "C" int mi355_filter_work(mi355_filter *h, size_t noutput_items, const void *in, void *out)
+{
+    MI355_REQUIRE(h != nullptr, "handle is NULL");
+    if (noutput_items == 0) return MI355_OK;
+    MI355_REQUIRE(in && out, "NULL buffer");
+    std::lock_guard<std::mutex> g(h->lock);
+    std::lock_guard<std::mutex> gc(h->ctx->lock);
+    MI355_HIP(hipSetDevice(h->ctx->device));
+    // chunks of outputs; each chunk re-sends its ntaps-1 samples of history
+    const size_t hist = (size_t)h->ntaps - 1;
+    size_t chunk_out = (1u << 20) / (size_t)h->decim;
+    if (chunk_out < 1) chunk_out = 1;
+    size_t first = noutput_items < chunk_out ? noutput_items : chunk_out;
+    size_t inb = (first * h->decim + hist) * 8;
+    int rc = h->pipe.ensure(1, &inb, first * 8);
+    if (rc) return rc;
+    HostPipe &p = h->pipe;
+    const char *pin = (const char *)in;
+    char *pout = (char *)out;
+    size_t nchunks = (noutput_items + chunk_out - 1) / chunk_out;
+    size_t pend_off[2] = {0, 0}, pend_bytes[2] = {0, 0};
+    for (size_t ci = 0; ci < nchunks; ci++) {
+        int s = (int)(ci & 1);
+        hipStream_t st = h->ctx->stream[s];
+        if (pend_bytes[s]) {
+            MI355_HIP(hipEventSynchronize(p.done[s]));
+            memcpy(pout + pend_off[s], p.h_out[s], pend_bytes[s]);
+            pend_bytes[s] = 0;
+        }
+        size_t o0 = ci * chunk_out;
+        size_t no = noutput_items - o0 < chunk_out ? noutput_items - o0 : chunk_out;
+        size_t in_bytes = (no * h->decim + hist) * 8;
+        memcpy(p.h_in[s][0], pin + o0 * h->decim * 8, in_bytes);
+        MI355_HIP(hipMemcpyAsync(p.d_in[s][0], p.h_in[s][0], in_bytes, hipMemcpyHostToDevice, st));
+        rc = launch_filter(h, no, p.d_in[s][0], p.d_out[s], st);
+        if (rc) return rc;
+        MI355_HIP(hipMemcpyAsync(p.h_out[s], p.d_out[s], no * 8, hipMemcpyDeviceToHost, st));
+        MI355_HIP(hipEventRecord(p.done[s], st));
+        pend_off[s] = o0 * 8; pend_bytes[s] = no * 8;
+    }
+    for (int q = 0; q < 2; q++) {
+        int s = (int)((nchunks + q) & 1);
+        if (pend_bytes[s]) {
+            MI355_HIP(hipEventSynchronize(p.done[s]));
+            memcpy(pout + pend_off[s], p.h_out[s], pend_bytes[s]);
+            pend_bytes[s] = 0;
+        }
+    }
+    return MI355_OK;
+}

@@ -1,14 +1,6 @@
 // TEMPORARY: entry points not implemented yet return MI355_ERR_UNSUPPORTED.
 #include "common.h"
 #define STUB(sig) extern "C" int sig { mi355_set_error("not implemented yet"); return MI355_ERR_UNSUPPORTED; }
-STUB(mi355_filter_create(mi355_ctx *, int, const void *, int, int, int, mi355_filter **))
-STUB(mi355_filter_destroy(mi355_filter *))
-STUB(mi355_filter_set_taps(mi355_filter *, const void *, int))
-STUB(mi355_filter_ntaps(const mi355_filter *))
-STUB(mi355_filter_get_taps(const mi355_filter *, void *, int))
-STUB(mi355_filter_fftsize(const mi355_filter *))
-STUB(mi355_filter_work(mi355_filter *, size_t, const void *, void *))
-STUB(mi355_filter_work_dev(mi355_filter *, size_t, const void *, void *, void *))
 STUB(mi355_pfb_create(mi355_ctx *, const float *, int, int, int, int, const int *, int, mi355_pfb **))
 STUB(mi355_pfb_destroy(mi355_pfb *))
 STUB(mi355_pfb_noutput(const mi355_pfb *))

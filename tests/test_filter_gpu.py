@@ -1,0 +1,161 @@
+"""GPU parity: clFilter / clComplexFilter (fast-convolution and direct-form kernels)
+through the C ABI vs the oracle's fir_filter / fft_filter restatements and the golden vectors.
+Semantics under test: y[m] = sum_k h[k] x[m*decim - k] on GNU Radio's history-prefixed buffer."""
+import numpy as np
+import pytest
+
+from conftest import GPU_ARGS, crandn, golden, relerr
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _hist(x, ntaps):
+    return np.concatenate([np.zeros(ntaps - 1, np.complex64), x])
+
+
+@pytest.mark.parametrize("use_time", [False, True])
+def test_golden_65_taps_all_decimations(gpu, use_time):
+    g = golden("filter_golden.npz")
+    x, t = g["x"], g["taps65"]
+    xh = _hist(x, 65)
+    for d in (1, 2, 3):
+        blk = gpu.clFilter(*GPU_ARGS, d, t, 1, 0, use_time)
+        n = x.size // d
+        y = np.empty(n, np.complex64)
+        assert blk.work(n, [xh], [y]) == n
+        assert relerr(y, g["y_d%d" % d][:n]) <= TOL
+    blk = gpu.clFilter(*GPU_ARGS, 1, g["taps7"], 1, 0, use_time)
+    y = np.empty(x.size, np.complex64)
+    blk.work(x.size, [_hist(x, 7)], [y])
+    assert relerr(y, g["y7_d1"]) <= TOL
+
+
+@pytest.mark.parametrize("use_time", [False, True])
+def test_golden_complex_taps(gpu, use_time):
+    g = golden("filter_golden.npz")
+    x, t = g["x"], g["ctaps65"]
+    xh = _hist(x, 65)
+    for d in (1, 2):
+        blk = gpu.clComplexFilter(*GPU_ARGS, d, t, 1, 0, use_time=use_time)
+        n = x.size // d
+        y = np.empty(n, np.complex64)
+        blk.work(n, [xh], [y])
+        assert relerr(y, g["yc_d%d" % d][:n]) <= TOL
+
+
+@pytest.mark.parametrize("use_time", [False, True])
+@pytest.mark.parametrize("ntaps", [1, 2, 8, 9, 64, 65, 128, 129, 300, 1000, 2048])
+def test_vs_oracle_fir_various_lengths(gpu, oracle, ntaps, use_time):
+    rng = np.random.default_rng(ntaps)
+    taps = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    n = 5000 + ntaps  # ragged: not a multiple of any block length
+    xh = crandn(rng, n + ntaps - 1)  # non-zero history
+    blk = gpu.clFilter(*GPU_ARGS, 1, taps, 1, 0, use_time)
+    assert blk.history() == ntaps
+    y = np.empty(n, np.complex64)
+    blk.work(n, [xh], [y])
+    assert relerr(y, oracle.fir_ccf(taps, xh, n)) <= TOL
+
+
+def test_reference_fft_sizes_and_stateful_oracle(gpu, oracle):
+    """The fused overlap-save kernel equals the reference's stateful overlap-add
+    (lib/fft_filter.cc:133-175) run over the same stream from a zero tail."""
+    taps = oracle.firdes_low_pass(1.0, 10e6, 1e6, 372000.0)
+    blk = gpu.clFilter(*GPU_ARGS, 1, taps)
+    f = oracle.FFTFilter(1, taps)
+    assert (blk.fftsize(), f.fftsize, f.nsamples) == (256, 256, 192)  # lib/fft_filter.cc:72-97
+    rng = np.random.default_rng(5)
+    x = crandn(rng, 192 * 171)  # the reference's block count for a 32768-sample buffer
+    y = np.empty_like(x)
+    blk.work(x.size, [_hist(x, taps.size)], [y])
+    assert relerr(y, f.filter(x.size, x)) <= TOL
+
+
+def test_streaming_calls_equal_one_call(gpu, oracle):
+    """work() is stateless given history: consecutive 32768-sample calls (BASELINE config 3)
+    reproduce one long call."""
+    taps = oracle.firdes_low_pass(1.0, 10e6, 1e6, 372000.0)
+    rng = np.random.default_rng(6)
+    x = crandn(rng, 4 * 32768)
+    xh = _hist(x, 65)
+    for use_time in (False, True):
+        blk = gpu.clFilter(*GPU_ARGS, 1, taps, 1, 0, use_time)
+        whole = np.empty_like(x)
+        blk.work(x.size, [xh], [whole])
+        parts = np.empty_like(x)
+        for c in range(4):
+            blk.work(32768, [xh[c * 32768:(c + 1) * 32768 + 64]], [parts[c * 32768:(c + 1) * 32768]])
+        assert relerr(parts, whole) <= 2e-6
+        assert relerr(whole, oracle.fir_ccf(taps, xh, x.size)) <= TOL
+
+
+def test_set_taps_and_taps_roundtrip(gpu, oracle):
+    rng = np.random.default_rng(7)
+    t1 = rng.standard_normal(33).astype(np.float32)
+    t2 = rng.standard_normal(200).astype(np.float32)
+    xh = crandn(rng, 3000 + 199)
+    for use_time in (False, True):
+        blk = gpu.clFilter(*GPU_ARGS, 1, t1, 1, 0, use_time)
+        assert np.array_equal(blk.taps(), t1)
+        blk.set_taps2(t2)
+        assert np.array_equal(blk.taps(), t2) and blk.ntaps() == 200
+        y = np.empty(3000, np.complex64)
+        blk.work(3000, [xh], [y])
+        assert relerr(y, oracle.fir_ccf(t2, xh, 3000)) <= TOL
+
+
+def test_impulse_response_is_the_taps(gpu):
+    taps = np.arange(1, 66, dtype=np.float32) / 1000  # lib/test-clfilter.cc:98-100 style taps i/1000
+    x = np.zeros(1000, np.complex64)
+    x[10] = 1 + 2j
+    for use_time in (False, True):
+        y = np.empty_like(x)
+        gpu.clFilter(*GPU_ARGS, 1, taps, 1, 0, use_time).work(x.size, [_hist(x, 65)], [y])
+        exp = np.zeros_like(x)
+        exp[10:75] = taps * (1 + 2j)
+        assert relerr(y, exp) <= TOL
+
+
+def test_host_path_multi_chunk_with_decimation(gpu, oracle):
+    rng = np.random.default_rng(8)
+    taps = oracle.firdes_low_pass(1.0, 10e6, 1e6, 372000.0)
+    d, n = 2, (1 << 20) + 777  # > 2 staging chunks
+    xh = crandn(rng, n * d + 64)
+    y = np.empty(n, np.complex64)
+    gpu.clFilter(*GPU_ARGS, d, taps).work(n, [xh], [y])
+    for o0 in (0, 524288 - 50, n - 3000):  # around chunk boundaries and the ragged end
+        ref = oracle.fir_ccf(taps, xh[o0 * d:], min(3000, n - o0), d)
+        assert relerr(y[o0:o0 + ref.size], ref) <= TOL
+
+
+def test_device_path_full_size_two_kernels_agree(gpu, oracle):
+    """BASELINE config 3 at full size: 2^27 samples device resident, 65 taps, decim 1.
+    The fast-convolution kernel and the direct-form kernel are independent implementations;
+    they must agree everywhere, and a sampled window must match the oracle."""
+    import torch
+    taps = oracle.firdes_low_pass(1.0, 10e6, 1e6, 372000.0)
+    n = 1 << 27
+    g = torch.Generator(device="cuda").manual_seed(99)
+    x = torch.randn(n + 64, 2, device="cuda", generator=g)
+    yf = torch.empty(n, 2, device="cuda")
+    yt = torch.empty(n, 2, device="cuda")
+    gpu.clFilter(*GPU_ARGS, 1, taps, 1, 0, False).work_device(n, [x], [yf])
+    gpu.clFilter(*GPU_ARGS, 1, taps, 1, 0, True).work_device(n, [x], [yt])
+    torch.cuda.synchronize()
+    scale = yt.abs().max().item()
+    assert (yf - yt).abs().max().item() <= 4e-6 * scale
+    for o0 in (0, 12345678, n - 5000):
+        xs = x[o0:o0 + 5000 + 64].cpu().numpy().view(np.complex64).reshape(-1)
+        ys = yf[o0:o0 + 5000].cpu().numpy().view(np.complex64).reshape(-1)
+        assert relerr(ys, oracle.fir_ccf(taps, xs, 5000)) <= TOL
+
+
+def test_zero_outputs_and_bad_args(gpu):
+    blk = gpu.clFilter(*GPU_ARGS, 1, [1.0, 2.0])
+    e = np.empty(0, np.complex64)
+    assert blk.work(0, [np.zeros(1, np.complex64)], [e]) == 0
+    with pytest.raises(ValueError):
+        blk.work(10, [np.zeros(5, np.complex64)], [np.empty(10, np.complex64)])  # not enough input for the history
+    with pytest.raises(gpu.Mi355Error):
+        gpu.clFilter(*GPU_ARGS, 0, [1.0])  # decimation < 1
