@@ -1,0 +1,368 @@
+// clPolyphaseChannelizer as gfx950 HIP kernels.
+// Reference behaviour (lib/clPolyphaseChannelizer_impl.cc): general_work :83-109 =
+// H2D, kernel filterpfb2 (:156-167), batched clFFT BACKWARD of size M (:208-225),
+// kernel channel_map (:169-177), blocking D2H.  Semantics, K taps,
+// M channels, R inputs per output step, buf[] history-prefixed:
+//   a_j(i)   = sum_{k = j, j+M, .. < K} buf[i*R - k + K-1] * taps[k]
+//   v_i[(j + i*(M-R)) % M] = a_j(i)
+//   u_i[c]   = sum_m v_i[m] exp(+2 pi i m c / M)
+//   out[i*nmap + q] = u_i[ch_map[q]]
+//
+// Fast path (M a power of two <= 256, critically sampled R == M, <= 64 taps per arm):
+// ONE fused kernel.  A workgroup owns 4096/M consecutive output steps.  Phase 1: the
+// input span is staged once in LDS; lane = arm, each lane slides a register window over
+// its arm's decimated sequence and produces 16 consecutive steps (arm taps live in
+// registers across the persistent loop).  Phase 2: the branch outputs go through LDS
+// into the 16-points-per-thread layout of fft_core and the M-point backward DFT runs
+// there; the channel map is applied on the store (identity map: straight from
+// registers).  HBM traffic: 8 B read + 8 B*nmap/M written per input sample.
+// Everything else (oversampled R != M, M not a power of two such as the reference
+// flowgraph's M=3, very long arms) takes the generic two-kernel path.
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+#include "fft_core.cuh"
+
+using namespace fftc;
+
+namespace {
+
+// ------------------------------------------------------------------------------------
+// fast path
+// ------------------------------------------------------------------------------------
+template <int M, int PMAX> struct PfbGeo {
+    static constexpr int T = 4096 / M;
+    static constexpr int SPAN = (T + PMAX) * M;  // staged input samples per group (+1 row: the window prefetch overshoots)
+    static constexpr int LDS_SLOTS = SPAN > 4096 ? SPAN : 4096;
+    static constexpr int PER_CU = (160 * 1024) / (LDS_SLOTS * 8);          // workgroups the LDS admits
+    static constexpr int WPE = PER_CU >= 3 ? 3 : (PER_CU >= 2 ? 2 : 1);     // register target follows the LDS limit
+};
+
+template <int M, int PMAX, bool IDENT>
+__global__ __launch_bounds__(256, (PfbGeo<M, PMAX>::WPE)) void k_pfb(const c32 *__restrict__ in, c32 *__restrict__ out,
+                                                const float *__restrict__ taps_pad,  // PMAX*M floats, zero padded
+                                                const c32 *__restrict__ tw_inv, const int *__restrict__ ch_map, int nmap,
+                                                int K, long long n_in, int nsteps, int ngroups)
+{
+    using PL = Plan<M, false>;
+    constexpr int TH = 256, T = 4096 / M, NP = PL::NP;
+    constexpr int SEG = TH / M;            // time segments handled side by side (lane = arm)
+    constexpr int U = 16;                  // consecutive steps per thread: SEG * U == T
+    static_assert(SEG * U == T, "geometry");
+    constexpr int SPAN = PfbGeo<M, PMAX>::SPAN, LDS_SLOTS = PfbGeo<M, PMAX>::LDS_SLOTS;
+    __shared__ c32 lds[LDS_SLOTS];
+    const int tid0 = threadIdx.x;
+
+    // arm taps, reversed so the window slides upward: hrev[pp] = taps[jb + (PMAX-1-pp)*M]
+    const int jb0 = tid0 % M;
+    float hrev[PMAX];
+#pragma unroll
+    for (int pp = 0; pp < PMAX; pp++) hrev[pp] = taps_pad[jb0 + (PMAX - 1 - pp) * M];
+    TwRegs<M> tw;
+    load_twiddles<M, false>(tw, tid0, tw_inv);
+
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int jb = tid % M, sg = tid / M;
+        // ---- stage input samples n_lo .. n_lo+SPAN of the history-prefixed buffer --------------
+        const long long n_lo = (long long)grp * T * M + K - (long long)PMAX * M;
+        __syncthreads();  // previous group's LDS reads are done
+        for (int i = tid; i < SPAN; i += TH) {
+            const long long n = n_lo + i;
+            const bool ok = n >= 0 && n < n_in;
+            const c32 x = in[ok ? n : 0];
+            lds[i] = ok ? x : mk(0.f, 0.f);
+        }
+        __syncthreads();
+        // ---- phase 1: acc[u] = sum_pp hrev[pp] * X[u + pp], X[w] = stage[(sg*16 + w)*M + (M-1-jb)] ----
+        c32 acc[U], win[U + 8];
+        const int col = (sg * U) * M + (M - 1 - jb);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            acc[u] = mk(0.f, 0.f);
+            win[u] = lds[col + u * M];
+        }
+#pragma unroll
+        for (int p0 = 0; p0 < PMAX; p0 += 8) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) win[U + i] = lds[col + (p0 + U + i) * M];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                float h = hrev[p0 + i];
+                asm volatile("" : "+v"(h));  // keep the taps as 1 register each; no hoisted products
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    acc[u].x = fmaf(win[i + u].x, h, acc[u].x);  // fma like the reference kernel (:163)
+                    acc[u].y = fmaf(win[i + u].y, h, acc[u].y);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) win[u] = win[u + 8];
+        }
+        __syncthreads();  // every wave is done with the staged input: reuse LDS for the transform
+        // ---- phase 2: branch outputs -> transform layout (R == M: no rotation) ---------------
+#pragma unroll
+        for (int u = 0; u < U; u++) lds[swz((sg * U + u) * M + jb)] = acc[u];
+        __syncthreads();
+        c32 v[16];
+        constexpr int R0 = PL::radix(0), B0 = M / R0;
+#pragma unroll
+        for (int q = 0; q < 16 / R0; q++) {
+            const int g = tid + TH * q, raw = (g / B0) * M + (g % B0);
+#pragma unroll
+            for (int r = 0; r < R0; r++) v[q * R0 + r] = lds[swz(raw + r * B0)];
+        }
+        if constexpr (NP > 1) __syncthreads();  // pass 0 writes LDS in place
+        transform_regs<M, 1, false>(v, tw, lds, tid);
+        // ---- store: out[(i0+fr)*nmap + q] = u[ch_map[q]] ---------------------------------------
+        constexpr int RL = PL::radix(NP - 1), BL = M / RL;
+        const int i0 = grp * T;
+        if constexpr (IDENT) {
+#pragma unroll
+            for (int q = 0; q < 16 / RL; q++) {
+                const int g = tid + TH * q, fr = g / BL, j = g % BL;
+                if (i0 + fr < nsteps) {
+                    c32 *__restrict__ o = out + (size_t)(i0 + fr) * M + j;
+#pragma unroll
+                    for (int s = 0; s < RL; s++) o[orev<RL>(s) * BL] = v[q * RL + s];
+                }
+            }
+        } else {
+            __syncthreads();  // transform's LDS reads are done
+#pragma unroll
+            for (int q = 0; q < 16 / RL; q++) {
+                const int g = tid + TH * q, fr = g / BL, j = g % BL;
+#pragma unroll
+                for (int s = 0; s < RL; s++) lds[fr * M + j + orev<RL>(s) * BL] = v[q * RL + s];
+            }
+            __syncthreads();
+            const int steps = (nsteps - i0) < T ? (nsteps - i0) : T;
+            for (int e = tid; e < steps * nmap; e += TH) {
+                const int fr = e / nmap, qq = e - fr * nmap;
+                out[(size_t)i0 * nmap + e] = lds[fr * M + ch_map[qq]];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// generic path: one thread per branch output, then a direct M-point DFT per mapped channel
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pfb_branches(const c32 *__restrict__ in, c32 *__restrict__ filt,
+                                                      const float *__restrict__ taps, int K, int M, int R, long long total)
+{
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long i = e / M;
+        const int j = (int)(e - i * M);
+        float sr = 0.f, si = 0.f;
+        for (int k = j; k < K; k += M) {
+            const c32 x = in[i * R - k + K - 1];
+            sr = fmaf(x.x, taps[k], sr);
+            si = fmaf(x.y, taps[k], si);
+        }
+        const int slot = (int)((j + i * (long long)(M - R)) % M);
+        filt[i * M + slot] = mk(sr, si);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pfb_dft_map(const c32 *__restrict__ filt, c32 *__restrict__ out,
+                                                     const c32 *__restrict__ twM,  // exp(+2 pi i t / M), t < M
+                                                     const int *__restrict__ ch_map, int nmap, int M, long long total)
+{
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long i = e / nmap;
+        const int c = ch_map[(int)(e - i * nmap)];
+        const c32 *v = filt + i * M;
+        float sr = 0.f, si = 0.f;
+        int t = 0;
+        for (int m = 0; m < M; m++) {
+            const c32 w = twM[t], x = v[m];
+            sr += x.x * w.x - x.y * w.y;
+            si += x.x * w.y + x.y * w.x;
+            t += c;
+            if (t >= M) t -= M;
+        }
+        out[e] = mk(sr, si);
+    }
+}
+
+}  // namespace
+
+struct mi355_pfb {
+    mi355_ctx *ctx;
+    int K, M, R, buf_items, nmap, nsteps;
+    bool fast, ident;
+    int pmax;
+    float *d_taps = nullptr;      // K floats (generic) or pmax*M zero padded (fast)
+    void *d_tw = nullptr;         // M complex, exp(+2 pi i t / M)
+    int *d_map = nullptr;
+    void *d_filt = nullptr;       // generic path scratch: nsteps*M complex
+    HostPipe pipe;
+};
+
+namespace {
+
+template <int M, int PMAX>
+int launch_fast(mi355_pfb *h, const void *in, void *out, hipStream_t st)
+{
+    constexpr int T = 4096 / M;
+    int ngroups = (h->nsteps + T - 1) / T;
+    int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
+    int grid = ngroups < cus * PfbGeo<M, PMAX>::WPE ? ngroups : cus * PfbGeo<M, PMAX>::WPE;
+    long long n_in = (long long)h->buf_items - h->R + h->K;
+    if (h->ident)
+        hipLaunchKernelGGL((k_pfb<M, PMAX, true>), dim3(grid), dim3(256), 0, st, (const c32 *)in, (c32 *)out, h->d_taps,
+                           (const c32 *)h->d_tw, h->d_map, h->nmap, h->K, n_in, h->nsteps, ngroups);
+    else
+        hipLaunchKernelGGL((k_pfb<M, PMAX, false>), dim3(grid), dim3(256), 0, st, (const c32 *)in, (c32 *)out, h->d_taps,
+                           (const c32 *)h->d_tw, h->d_map, h->nmap, h->K, n_in, h->nsteps, ngroups);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+template <int M>
+int launch_fast_m(mi355_pfb *h, const void *in, void *out, hipStream_t st)
+{
+    switch (h->pmax) {
+    case 8: return launch_fast<M, 8>(h, in, out, st);
+    case 16: return launch_fast<M, 16>(h, in, out, st);
+    case 32: return launch_fast<M, 32>(h, in, out, st);
+    case 64: return launch_fast<M, 64>(h, in, out, st);
+    }
+    return MI355_ERR_STATE;
+}
+
+int launch_pfb(mi355_pfb *h, const void *in, void *out, hipStream_t st)
+{
+    if (h->fast) {
+        switch (h->M) {
+        case 2: return launch_fast_m<2>(h, in, out, st);
+        case 4: return launch_fast_m<4>(h, in, out, st);
+        case 8: return launch_fast_m<8>(h, in, out, st);
+        case 16: return launch_fast_m<16>(h, in, out, st);
+        case 32: return launch_fast_m<32>(h, in, out, st);
+        case 64: return launch_fast_m<64>(h, in, out, st);
+        case 128: return launch_fast_m<128>(h, in, out, st);
+        case 256: return launch_fast_m<256>(h, in, out, st);
+        }
+        return MI355_ERR_STATE;
+    }
+    int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
+    long long total = (long long)h->nsteps * h->M;
+    long long blocks = (total + 255) / 256;
+    long long grid = blocks < (long long)cus * 8 ? blocks : (long long)cus * 8;
+    hipLaunchKernelGGL(k_pfb_branches, dim3((unsigned)grid), dim3(256), 0, st, (const c32 *)in, (c32 *)h->d_filt, h->d_taps, h->K,
+                       h->M, h->R, total);
+    total = (long long)h->nsteps * h->nmap;
+    blocks = (total + 255) / 256;
+    grid = blocks < (long long)cus * 8 ? blocks : (long long)cus * 8;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_pfb_dft_map, dim3((unsigned)grid), dim3(256), 0, st, (const c32 *)h->d_filt, (c32 *)out,
+                       (const c32 *)h->d_tw, h->d_map, h->nmap, h->M, total);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+}  // namespace
+
+extern "C" int mi355_pfb_destroy(mi355_pfb *h)
+{
+    if (!h) return MI355_OK;
+    (void)hipSetDevice(h->ctx->device);
+    h->pipe.release();
+    if (h->d_taps) (void)hipFree(h->d_taps);
+    if (h->d_tw) (void)hipFree(h->d_tw);
+    if (h->d_map) (void)hipFree(h->d_map);
+    if (h->d_filt) (void)hipFree(h->d_filt);
+    delete h;
+    return MI355_OK;
+}
+
+extern "C" int mi355_pfb_create(mi355_ctx *ctx, const float *taps, int ntaps, int buf_items, int num_channels, int ninputs_per_iter,
+                                const int *ch_map, int nmap, mi355_pfb **out)
+{
+    MI355_REQUIRE(ctx && out, "NULL argument");
+    *out = nullptr;
+    MI355_REQUIRE(taps && ntaps >= 1, "taps must hold at least one tap");
+    MI355_REQUIRE(num_channels >= 1 && ninputs_per_iter >= 1 && ninputs_per_iter <= num_channels,
+                  "need 1 <= ninputs_per_iter <= num_channels");
+    MI355_REQUIRE(buf_items > 0 && buf_items % num_channels == 0, "buf_items must be a multiple of num_channels");  // :59-62
+    MI355_REQUIRE(buf_items % ninputs_per_iter == 0, "buf_items must be a multiple of ninputs_per_iter");
+    MI355_REQUIRE(ch_map && nmap >= 1, "ch_map must hold at least one channel");
+    for (int q = 0; q < nmap; q++) MI355_REQUIRE(ch_map[q] >= 0 && ch_map[q] < num_channels, "ch_map entry out of range");
+    mi355_pfb *h = new (std::nothrow) mi355_pfb();
+    if (!h) return MI355_ERR_NOMEM;
+    h->ctx = ctx; h->K = ntaps; h->M = num_channels; h->R = ninputs_per_iter; h->buf_items = buf_items; h->nmap = nmap;
+    h->nsteps = buf_items / ninputs_per_iter;
+    const int M = h->M;
+    const int per_arm = (ntaps + M - 1) / M;
+    h->fast = (M >= 2 && M <= 256 && (M & (M - 1)) == 0 && h->R == M && per_arm <= 64);
+    h->pmax = per_arm <= 8 ? 8 : per_arm <= 16 ? 16 : per_arm <= 32 ? 32 : 64;
+    h->ident = (nmap == M);
+    for (int q = 0; q < nmap && h->ident; q++) h->ident = (ch_map[q] == q);
+    auto fail = [&](int rc) { mi355_pfb_destroy(h); return rc; };
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(MI355_ERR_HIP);
+    std::vector<float> t;
+    if (h->fast) {
+        t.assign((size_t)h->pmax * M, 0.0f);
+        for (int k = 0; k < ntaps; k++) t[k] = taps[k];
+    } else {
+        t.assign(taps, taps + ntaps);
+    }
+    std::vector<float> tw(2 * (size_t)M);
+    for (int k = 0; k < M; k++) {
+        double a = 2.0 * M_PI * (double)k / (double)M;
+        tw[2 * k] = (float)cos(a); tw[2 * k + 1] = (float)sin(a);
+    }
+    if (hipMalloc((void **)&h->d_taps, t.size() * sizeof(float)) != hipSuccess) return fail(MI355_ERR_NOMEM);
+    if (hipMalloc(&h->d_tw, tw.size() * sizeof(float)) != hipSuccess) return fail(MI355_ERR_NOMEM);
+    if (hipMalloc((void **)&h->d_map, (size_t)nmap * sizeof(int)) != hipSuccess) return fail(MI355_ERR_NOMEM);
+    if (!h->fast && hipMalloc(&h->d_filt, (size_t)h->nsteps * M * 8) != hipSuccess) return fail(MI355_ERR_NOMEM);
+    if (hipMemcpy(h->d_taps, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail(MI355_ERR_HIP);
+    if (hipMemcpy(h->d_tw, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail(MI355_ERR_HIP);
+    if (hipMemcpy(h->d_map, ch_map, (size_t)nmap * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return fail(MI355_ERR_HIP);
+    int rc = h->pipe.init(ctx);
+    if (rc) return fail(rc);
+    *out = h;
+    return MI355_OK;
+}
+
+extern "C" int mi355_pfb_noutput(const mi355_pfb *h) { return h ? h->nmap * h->nsteps : MI355_ERR_INVALID_ARG; }
+
+// input items one call reads, history included (buf_items - R + ntaps; equals the reference's
+// buf_items + history() - num_channels for R == M, lib/clPolyphaseChannelizer_impl.cc:97)
+extern "C" int mi355_pfb_ninput(const mi355_pfb *h) { return h ? h->buf_items - h->R + h->K : MI355_ERR_INVALID_ARG; }
+
+extern "C" int mi355_pfb_work_dev(mi355_pfb *h, const void *in, void *out, void *stream)
+{
+    MI355_REQUIRE(h != nullptr, "handle is NULL");
+    MI355_REQUIRE(in && out, "NULL buffer");
+    MI355_REQUIRE((reinterpret_cast<uintptr_t>(in) & 7u) == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0,
+                  "device buffers must be 8-byte aligned");
+    MI355_HIP(hipSetDevice(h->ctx->device));
+    return launch_pfb(h, in, out, mi355_pick_stream(h->ctx, stream));
+}
+
+extern "C" int mi355_pfb_work(mi355_pfb *h, const void *in, void *out)
+{
+    MI355_REQUIRE(h != nullptr, "handle is NULL");
+    MI355_REQUIRE(in && out, "NULL buffer");
+    std::lock_guard<std::mutex> g(h->ctx->lock);
+    MI355_HIP(hipSetDevice(h->ctx->device));
+    // one general_work() is one fixed-size transfer (buf_items is a block parameter): single slot
+    size_t inb = (size_t)mi355_pfb_ninput(h) * 8, outb = (size_t)mi355_pfb_noutput(h) * 8;
+    int rc = h->pipe.ensure(1, &inb, outb);
+    if (rc) return rc;
+    HostPipe &p = h->pipe;
+    hipStream_t st = h->ctx->stream[0];
+    memcpy(p.h_in[0][0], in, inb);
+    MI355_HIP(hipMemcpyAsync(p.d_in[0][0], p.h_in[0][0], inb, hipMemcpyHostToDevice, st));
+    rc = launch_pfb(h, p.d_in[0][0], p.d_out[0], st);
+    if (rc) return rc;
+    MI355_HIP(hipMemcpyAsync(p.h_out[0], p.d_out[0], outb, hipMemcpyDeviceToHost, st));
+    MI355_HIP(hipStreamSynchronize(st));
+    memcpy(out, p.h_out[0], outb);
+    return MI355_OK;
+}

@@ -1,0 +1,112 @@
+"""GPU parity: clPolyphaseChannelizer through the C ABI vs the oracle and the float64
+closed form.  The reference holds no vectors for this block (parity
+unpinned): the anchors are the closed-form golden fixtures."""
+import numpy as np
+import pytest
+
+from conftest import GPU_ARGS, crandn, golden, relerr
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _run(gpu, taps, buf, M, R, chmap, xh):
+    blk = gpu.clPolyphaseChannelizer(*GPU_ARGS, taps, buf, M, R, chmap)
+    y = np.empty(blk.noutput(), np.complex64)
+    assert blk.ninput() == buf - R + len(taps)
+    assert blk.general_work(y.size, [xh.size], [xh], [y]) == len(chmap) * buf // R
+    return y
+
+
+def test_golden_closed_form_cases(gpu):
+    g = golden("pfb_golden.npz")
+    for c in "abc":  # a: reference flowgraph M=3,R=2,145 taps; b: config-4 shape M=64; c: oversampled M=8,R=4 permuted map
+        M, R, buf = (int(v) for v in g[c + "_cfg"])
+        y = _run(gpu, g[c + "_taps"], buf, M, R, g[c + "_chmap"], g[c + "_x"])
+        assert relerr(y, g[c + "_y"]) <= TOL, c
+
+
+@pytest.mark.parametrize("M", [2, 4, 8, 16, 32, 64, 128, 256])
+@pytest.mark.parametrize("per_arm", [1, 5, 8, 13, 32, 33, 64])
+def test_fast_path_all_channel_counts(gpu, oracle, M, per_arm):
+    rng = np.random.default_rng(M * 100 + per_arm)
+    K = M * per_arm - (3 if per_arm > 1 and M > 4 else 0)  # ragged last arm
+    taps = (rng.standard_normal(K) / np.sqrt(per_arm)).astype(np.float32)
+    buf = M * (4096 // M + 37)  # more than one workgroup iteration, ragged
+    xh = crandn(rng, buf - M + K)
+    chmap = list(range(M))
+    y = _run(gpu, taps, buf, M, M, chmap, xh)
+    assert relerr(y, oracle.pfb(taps, buf, M, M, chmap, xh, f64=True)) <= TOL
+
+
+def test_channel_map_gather_with_duplicates(gpu, oracle):
+    rng = np.random.default_rng(11)
+    M, K, buf = 64, 2048, 64 * 100
+    taps = rng.standard_normal(K).astype(np.float32) / 8
+    xh = crandn(rng, buf - M + K)
+    for chmap in ([5], [63, 0, 1, 1, 32], list(range(63, -1, -1))):
+        y = _run(gpu, taps, buf, M, M, chmap, xh)
+        assert relerr(y, oracle.pfb(taps, buf, M, M, chmap, xh, f64=True)) <= TOL
+
+
+@pytest.mark.parametrize("M,R", [(3, 2), (3, 3), (8, 4), (16, 8), (5, 5), (12, 3), (512, 512)])
+def test_generic_path_oversampled_and_odd(gpu, oracle, M, R):
+    rng = np.random.default_rng(M * 7 + R)
+    K = 7 * M + 1
+    taps = rng.standard_normal(K).astype(np.float32) / 3
+    lcm = M * R // np.gcd(M, R)
+    buf = lcm * 11
+    xh = crandn(rng, buf - R + K)
+    chmap = [M - 1, 0] + list(range(min(M, 3)))
+    y = _run(gpu, taps, buf, M, R, chmap, xh)
+    assert relerr(y, oracle.pfb(taps, buf, M, R, chmap, xh, f64=True)) <= TOL
+
+
+def test_baseline_config4_shape_and_streaming(gpu, oracle):
+    """64 channels x 32 taps/arm, buf_items 65536 (BASELINE configs[3]); two consecutive calls
+    with GNU Radio's history equal one double-length call."""
+    taps = np.concatenate([oracle.firdes_low_pass(1.0, 64.0, 0.5, 0.0753), [0.0]]).astype(np.float32)
+    assert taps.size == 2048
+    rng = np.random.default_rng(1000)
+    M, buf = 64, 65536
+    x = crandn(rng, 2 * buf + 2048 - M)
+    chmap = list(range(M))
+    one = gpu.clPolyphaseChannelizer(*GPU_ARGS, taps, buf, M, M, chmap)
+    two = gpu.clPolyphaseChannelizer(*GPU_ARGS, taps, 2 * buf, M, M, chmap)
+    ya, yb, yw = np.empty(buf, np.complex64), np.empty(buf, np.complex64), np.empty(2 * buf, np.complex64)
+    one.general_work(buf, [0], [x[:one.ninput()]], [ya])
+    one.general_work(buf, [0], [x[buf:buf + one.ninput()]], [yb])  # scheduler consumed buf_items (:105)
+    two.general_work(2 * buf, [0], [x], [yw])
+    assert np.array_equal(np.concatenate([ya, yb]), yw)
+    ref = oracle.pfb(taps, 64 * 40, M, M, chmap, x, f64=True)
+    assert relerr(yw[:ref.size], ref) <= TOL
+    # a tone in channel 5 comes out of channel 5 (channel 0 = centre, increasing c = increasing frequency)
+    n = np.arange(x.size)
+    tone = np.exp(2j * np.pi * 5 / 64 * n).astype(np.complex64)
+    two.general_work(2 * buf, [0], [tone], [yw])
+    p = (np.abs(yw.reshape(-1, 64)[64:]) ** 2).mean(0)
+    assert p.argmax() == 5 and p[5] > 1e3 * np.delete(p, 5).max()
+
+
+def test_device_path_full_size_linearity(gpu, oracle):
+    import torch
+    taps = np.concatenate([oracle.firdes_low_pass(1.0, 64.0, 0.5, 0.0753), [0.0]]).astype(np.float32)
+    M, buf = 64, 1 << 24
+    blk = gpu.clPolyphaseChannelizer(*GPU_ARGS, taps, buf, M, M, list(range(M)))
+    g = torch.Generator(device="cuda").manual_seed(4)
+    a = torch.randn(blk.ninput(), 2, device="cuda", generator=g)
+    b = torch.randn(blk.ninput(), 2, device="cuda", generator=g)
+    ya, yb, yab = (torch.empty(blk.noutput(), 2, device="cuda") for _ in range(3))
+    blk.work_device([a], [ya]); blk.work_device([b], [yb]); blk.work_device([2 * a - 3 * b], [yab])
+    torch.cuda.synchronize()
+    assert torch.allclose(yab, 2 * ya - 3 * yb, atol=1e-4, rtol=1e-4)
+    xs = a[:2048 - 64 + 64 * 50].cpu().numpy().view(np.complex64).reshape(-1)
+    ref = oracle.pfb(taps, 64 * 50, M, M, list(range(M)), xs, f64=True)
+    assert relerr(ya[:ref.size].cpu().numpy().view(np.complex64).reshape(-1), ref) <= TOL
+
+
+def test_constructor_errors(gpu):
+    with pytest.raises(ValueError):
+        gpu.clPolyphaseChannelizer(*GPU_ARGS, [1.0] * 8, 10, 4, 4, [0])  # lib/clPolyphaseChannelizer_impl.cc:59-62
+    with pytest.raises(gpu.Mi355Error):
+        gpu.clPolyphaseChannelizer(*GPU_ARGS, [1.0] * 8, 16, 4, 4, [4])  # channel outside 0..M-1
