@@ -1,0 +1,435 @@
+// clXEngine (FX-correlator X-engine) as gfx950 HIP kernels.
+// Reference behaviour: lib/clXEngine_impl.h:150-201 (xcorrelate overloads: H2D, CharToComplex
+// kernel into a 4x larger float copy, then one work-item per (channel, baseline) walking t with
+// stride-frame_size loads), kernels lib/clXEngine_impl.cc:605-916, host gather :987-1061.
+//   V[f][k][p1 p2] = sum_t x_{s1,p1}(t,f) * conj(x_{s2,p2}(t,f)),  k = s1(s1+1)/2 + s2, s1 >= s2
+//
+// int8 (IChar) and packed-4-bit inputs run on the matrix cores with EXACT integer arithmetic:
+//   rows r = (station, pol); planes I_r(t), Q_r(t) (de-interleaved, so no byte negation is needed
+//   and -128 is handled exactly);  per 16x16 row-tile pair (bi >= bj), K = time:
+//       re  += I_bi I_bj^T + Q_bi Q_bj^T      (one accumulator)
+//       u   += Q_bi I_bj^T ,  w += I_bi Q_bj^T   ->  im = u - w
+//   with v_mfma_i32_16x16x64_i8 (K = 64 time steps per instruction), int32 accumulators, and one
+//   double-precision scale by (1/127)^2 (or (1/7)^2) at the end -- bit-identical to the oracle's
+//   exact path.  4 real MACs per complex MAC: no redundancy beyond the diagonal tiles.
+// Two kernels: (1) k_xe_turn: corner turn of the reference's [t][station][chan][pol]{I,Q} buffer
+//   into MFMA-operand order  [chan][kblock][plane][rowtile][lane*16 B]  (a tile = 16 rows x 64 t
+//   = 1 KiB, exactly one dwordx4 per lane, so the correlator streams operands with unit stride);
+//   reads are whole 128-B lines, the byte transposition is done in registers with v_perm_b32;
+// (2) k_xe_corr: one workgroup per (channel, chunk of 12 tile pairs), 4 waves, 3 pairs per wave.
+// HBM traffic today: input read + tile write + tile read + output write (2.8x the algorithmic
+// bytes); fusing (1) into (2) or producing tile order in the host gather is the next step.
+//
+// Complex-float input keeps fp32 arithmetic (register-tiled VALU kernel, 8x8 station blocks).
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+struct c32 { float x, y; };
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+constexpr int kRowTile = 16, kKBlock = 64, kTileBytes = kRowTile * kKBlock;  // 1 KiB
+
+// ------------------------------------------------------------------------------------
+// (1) corner turn.  Work item = (16 consecutive t) x (one 4-byte unit of the input row).
+//   IChar npol=1 : unit = channels (2u, 2u+1) of station s  -> samples a=(f0,row s), b=(f1,row s)
+//   IChar npol=2 : unit = channel u, pols X,Y of station s   -> a=(f,row 2s), b=(f,row 2s+1)
+//   packed 4-bit : unit = channels (2u, 2u+1), bytes X,Y      -> four samples, rows 2s, 2s+1
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned perm(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+
+// 4 dwords (bytes b0..b3 each) -> 4 dwords where out[j] = byte j of each input dword (4x4 byte transpose)
+__device__ __forceinline__ void transpose4x4(const unsigned (&in)[4], unsigned (&out)[4])
+{
+    // v_perm_b32 selector: bytes 0-3 = lo operand, 4-7 = hi operand
+    const unsigned t0 = perm(in[1], in[0], 0x05010400u);  // in0.b0 in1.b0 in0.b1 in1.b1
+    const unsigned t1 = perm(in[1], in[0], 0x07030602u);  // in0.b2 in1.b2 in0.b3 in1.b3
+    const unsigned t2 = perm(in[3], in[2], 0x05010400u);
+    const unsigned t3 = perm(in[3], in[2], 0x07030602u);
+    out[0] = perm(t2, t0, 0x05040100u);  // b0 of in0..in3
+    out[1] = perm(t2, t0, 0x07060302u);  // b1
+    out[2] = perm(t3, t1, 0x05040100u);  // b2
+    out[3] = perm(t3, t1, 0x07060302u);  // b3
+}
+
+struct XeGeo {
+    int N, F, npol, T;     // stations, channels, pols, integration frames
+    int A, NT, KB;         // rows = N*npol, row tiles, K blocks of 64 time steps
+    int mode;              // 0 = IChar, 1 = packed 4-bit
+};
+
+__device__ __forceinline__ size_t tile_off(const XeGeo &g, int f, int kb, int plane, int rt)
+{
+    return ((((size_t)f * g.KB + kb) * 2 + plane) * g.NT + rt) * kTileBytes;
+}
+
+// sign-extended 4-bit code with the reference's LUT quirk (code 8 -> 0), for 4 packed bytes
+__device__ __forceinline__ unsigned nib_to_i8x4(unsigned n /* one nibble per byte, 0..15 */)
+{
+    // v = n < 8 ? n : (n == 8 ? 0 : n - 16)
+    const unsigned ge8 = (n >> 3) & 0x01010101u;            // 1 where n >= 8
+    const unsigned low = n & 0x07070707u;                   // n - 8 where n >= 8
+    const unsigned nz = ((low + 0x07070707u) >> 3) & 0x01010101u;  // 1 where low != 0
+    const unsigned neg = ge8 & nz;                          // 1 where 9..15
+    // negative: low - 8 = low | 0xF8 ; n == 8: 0 ; else n
+    const unsigned pos = n & ~(ge8 * 0xFFu);
+    return pos | (neg * 0xF8u) | (low & (neg * 0xFFu));
+}
+
+__global__ __launch_bounds__(256) void k_xe_turn(const unsigned *__restrict__ in, unsigned char *__restrict__ tiles, XeGeo g)
+{
+    // grid.x = ceil(units_per_row/32), grid.y = ceil(stations/2), grid.z = KB
+    // block = 32 units (one 128-byte line of the input row) x 4 time chunks x 2 stations
+    const int lane_u = threadIdx.x & 31;
+    const int sub = threadIdx.x >> 5;  // 0..7
+    const int kc = sub & 3;
+    const int units_per_row = (g.mode == 0) ? (g.F * g.npol * 2) / 4 : (g.F * 2) / 4;  // 4-byte units per (t, station)
+    const int u = blockIdx.x * 32 + lane_u;
+    const int s = blockIdx.y * 2 + (sub >> 2), kb = blockIdx.z;
+    if (u >= units_per_row || s >= g.N) return;
+    const size_t row_units = (size_t)units_per_row;
+    {
+        unsigned w[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int t = kb * kKBlock + kc * 16 + i;
+            w[i] = (t < g.T) ? in[((size_t)t * g.N + s) * row_units + u] : 0u;
+        }
+        // byte-transpose 16 dwords -> 4 vectors of 16 bytes (byte j of every dword)
+        unsigned col[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const unsigned a[4] = {w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+            unsigned o[4];
+            transpose4x4(a, o);
+#pragma unroll
+            for (int j = 0; j < 4; j++) col[j][q] = o[j];
+        }
+        if (g.mode == 0) {
+            // bytes: a.I a.Q b.I b.Q
+            int fa, fb, ra, rb;
+            if (g.npol == 1) { fa = 2 * u; fb = 2 * u + 1; ra = rb = s; }
+            else { fa = fb = u; ra = 2 * s; rb = 2 * s + 1; }
+            const int f_[2] = {fa, fb}, r_[2] = {ra, rb};
+#pragma unroll
+            for (int smp = 0; smp < 2; smp++) {
+#pragma unroll
+                for (int plane = 0; plane < 2; plane++) {
+                    unsigned char *dst = tiles + tile_off(g, f_[smp], kb, plane, r_[smp] / kRowTile) +
+                                         (size_t)(kc * 16 + (r_[smp] % kRowTile)) * 16;
+                    *(uint4 *)dst = make_uint4(col[smp * 2 + plane][0], col[smp * 2 + plane][1], col[smp * 2 + plane][2],
+                                               col[smp * 2 + plane][3]);
+                }
+            }
+        } else {
+            // bytes: (f0,X) (f0,Y) (f1,X) (f1,Y), each byte = re nibble (high), im nibble (low)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int f = 2 * u + (b >> 1), r = 2 * s + (b & 1);
+                unsigned re[4], im[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    re[q] = nib_to_i8x4((col[b][q] >> 4) & 0x0F0F0F0Fu);
+                    im[q] = nib_to_i8x4(col[b][q] & 0x0F0F0F0Fu);
+                }
+                unsigned char *d0 = tiles + tile_off(g, f, kb, 0, r / kRowTile) + (size_t)(kc * 16 + (r % kRowTile)) * 16;
+                unsigned char *d1 = tiles + tile_off(g, f, kb, 1, r / kRowTile) + (size_t)(kc * 16 + (r % kRowTile)) * 16;
+                *(uint4 *)d0 = make_uint4(re[0], re[1], re[2], re[3]);
+                *(uint4 *)d1 = make_uint4(im[0], im[1], im[2], im[3]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// (2) MFMA correlator
+// ------------------------------------------------------------------------------------
+constexpr int kPairsPerWave = 3, kWaves = 4, kPairsPerWG = kPairsPerWave * kWaves;
+
+__device__ __forceinline__ void pair_to_tiles(int p, int &bi, int &bj)
+{
+    // p = bi(bi+1)/2 + bj, bi >= bj
+    int a = (int)((-1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
+    while ((a + 1) * (a + 2) / 2 <= p) a++;
+    while (a * (a + 1) / 2 > p) a--;
+    bi = a;
+    bj = p - a * (a + 1) / 2;
+}
+
+__global__ __launch_bounds__(256) void k_xe_corr(const unsigned char *__restrict__ tiles, c32 *__restrict__ out, XeGeo g,
+                                                 int npairs, double scale2, int accumulate)
+{
+    const int f = blockIdx.x, chunk = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int bi[kPairsPerWave], bj[kPairsPerWave];
+    bool live[kPairsPerWave];
+#pragma unroll
+    for (int q = 0; q < kPairsPerWave; q++) {
+        const int p = chunk * kPairsPerWG + q * kWaves + wave;
+        live[q] = p < npairs;
+        pair_to_tiles(live[q] ? p : 0, bi[q], bj[q]);
+    }
+    v4i re[kPairsPerWave], uu[kPairsPerWave], ww[kPairsPerWave];
+#pragma unroll
+    for (int q = 0; q < kPairsPerWave; q++) re[q] = uu[q] = ww[q] = (v4i){0, 0, 0, 0};
+
+    const unsigned char *base = tiles + (size_t)f * g.KB * 2 * g.NT * kTileBytes + (size_t)lane * 16;
+    const size_t plane_stride = (size_t)g.NT * kTileBytes;
+    for (int kb = 0; kb < g.KB; kb++) {
+        const unsigned char *pI = base + (size_t)kb * 2 * plane_stride;
+        const unsigned char *pQ = pI + plane_stride;
+#pragma unroll
+        for (int q = 0; q < kPairsPerWave; q++) {
+            if (live[q]) {  // wave-uniform
+                const v4i Ia = *(const v4i *)(pI + (size_t)bi[q] * kTileBytes);
+                const v4i Qa = *(const v4i *)(pQ + (size_t)bi[q] * kTileBytes);
+                const v4i Ib = *(const v4i *)(pI + (size_t)bj[q] * kTileBytes);
+                const v4i Qb = *(const v4i *)(pQ + (size_t)bj[q] * kTileBytes);
+                re[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ia, Ib, re[q], 0, 0, 0);
+                re[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Qa, Qb, re[q], 0, 0, 0);
+                uu[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Qa, Ib, uu[q], 0, 0, 0);
+                ww[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ia, Qb, ww[q], 0, 0, 0);
+            }
+        }
+    }
+    // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+    const int nb = g.N * (g.N + 1) / 2, np2 = g.npol * g.npol;
+#pragma unroll
+    for (int q = 0; q < kPairsPerWave; q++) {
+        if (!live[q]) continue;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int r1 = bi[q] * kRowTile + (lane >> 4) * 4 + reg, r2 = bj[q] * kRowTile + (lane & 15);
+            if (r1 >= g.A || r2 >= g.A) continue;
+            const int s1 = r1 / g.npol, p1 = r1 - s1 * g.npol, s2 = r2 / g.npol, p2 = r2 - s2 * g.npol;
+            if (s1 < s2) continue;
+            const int k = s1 * (s1 + 1) / 2 + s2;
+            const size_t o = ((size_t)f * nb + k) * np2 + p1 * g.npol + p2;
+            // same expression as the oracle's exact path: (double)S * kd * kd, rounded once
+            const double kd = scale2;  // 1/127 or 1/7
+            c32 v;
+            v.x = (float)((double)re[q][reg] * kd * kd);
+            v.y = (float)((double)(uu[q][reg] - ww[q][reg]) * kd * kd);
+            if (accumulate) { v.x += out[o].x; v.y += out[o].y; }
+            out[o] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// complex-float input: fp32 arithmetic, 8x8 station blocks per thread, lanes along channels
+// ------------------------------------------------------------------------------------
+constexpr int kCfBlk = 4;  // rows per side of a thread's block
+
+__global__ __launch_bounds__(256) void k_xe_cf32(const c32 *__restrict__ in, c32 *__restrict__ out, XeGeo g, int nblk,
+                                                 int accumulate)
+{
+    // grid.x over channels (256 per block), grid.y over block pairs (bi >= bj) of kCfBlk rows
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    int bi, bj;
+    pair_to_tiles(blockIdx.y, bi, bj);
+    if (f >= g.F) return;
+    (void)nblk;
+    c32 acc[kCfBlk][kCfBlk];
+#pragma unroll
+    for (int i = 0; i < kCfBlk; i++)
+#pragma unroll
+        for (int j = 0; j < kCfBlk; j++) acc[i][j].x = acc[i][j].y = 0.f;
+    const size_t frame = (size_t)g.F * g.A;  // elements per time step; element (t, s, f, p) at ((t*N+s)*F+f)*npol+p
+    for (int t = 0; t < g.T; t++) {
+        c32 a[kCfBlk], b[kCfBlk];
+#pragma unroll
+        for (int i = 0; i < kCfBlk; i++) {
+            const int r1 = bi * kCfBlk + i, r2 = bj * kCfBlk + i;
+            const int s1 = r1 / g.npol, p1 = r1 - s1 * g.npol, s2 = r2 / g.npol, p2 = r2 - s2 * g.npol;
+            a[i].x = a[i].y = b[i].x = b[i].y = 0.f;
+            if (r1 < g.A) a[i] = in[(size_t)t * frame + ((size_t)s1 * g.F + f) * g.npol + p1];
+            if (r2 < g.A) b[i] = in[(size_t)t * frame + ((size_t)s2 * g.F + f) * g.npol + p2];
+        }
+#pragma unroll
+        for (int i = 0; i < kCfBlk; i++)
+#pragma unroll
+            for (int j = 0; j < kCfBlk; j++) {
+                // cxmac, lib/clXEngine_impl.cc:728-737: acc += z0 * conj(z1)
+                acc[i][j].x += a[i].x * b[j].x + a[i].y * b[j].y;
+                acc[i][j].y += a[i].y * b[j].x - a[i].x * b[j].y;
+            }
+    }
+    const int nb = g.N * (g.N + 1) / 2, np2 = g.npol * g.npol;
+#pragma unroll
+    for (int i = 0; i < kCfBlk; i++)
+#pragma unroll
+        for (int j = 0; j < kCfBlk; j++) {
+            const int r1 = bi * kCfBlk + i, r2 = bj * kCfBlk + j;
+            if (r1 >= g.A || r2 >= g.A) continue;
+            const int s1 = r1 / g.npol, p1 = r1 - s1 * g.npol, s2 = r2 / g.npol, p2 = r2 - s2 * g.npol;
+            if (s1 < s2) continue;
+            const size_t o = ((size_t)f * nb + (s1 * (s1 + 1) / 2 + s2)) * np2 + p1 * g.npol + p2;
+            c32 v = acc[i][j];
+            if (accumulate) { v.x += out[o].x; v.y += out[o].y; }
+            out[o] = v;
+        }
+}
+
+}  // namespace
+
+struct mi355_xengine {
+    mi355_ctx *ctx;
+    int data_type;
+    XeGeo g;
+    size_t in_bytes, out_items, tile_bytes;
+    unsigned char *d_tiles = nullptr;
+    void *d_in = nullptr, *d_out = nullptr;  // device staging of the host path
+    void *h_in = nullptr, *h_out = nullptr;  // pinned
+};
+
+namespace {
+
+int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipStream_t st)
+{
+    const XeGeo &g = h->g;
+    if (h->data_type == MI355_DTYPE_COMPLEX) {
+        const int nblk = (g.A + kCfBlk - 1) / kCfBlk;
+        dim3 grid((g.F + 255) / 256, nblk * (nblk + 1) / 2);
+        hipLaunchKernelGGL(k_xe_cf32, grid, dim3(256), 0, st, (const c32 *)in, (c32 *)out, g, nblk, accumulate);
+        MI355_HIP(hipGetLastError());
+        return MI355_OK;
+    }
+    const int units_per_row = (g.mode == 0) ? (g.F * g.npol * 2) / 4 : (g.F * 2) / 4;
+    // padding rows (A not a multiple of 16) were zeroed once at create and are never written
+    dim3 tgrid((units_per_row + 31) / 32, (g.N + 1) / 2, g.KB);
+    hipLaunchKernelGGL(k_xe_turn, tgrid, dim3(256), 0, st, (const unsigned *)in, h->d_tiles, g);
+    MI355_HIP(hipGetLastError());
+    const int npairs = g.NT * (g.NT + 1) / 2;
+    dim3 cgrid(g.F, (npairs + kPairsPerWG - 1) / kPairsPerWG);
+    const double kd = (g.mode == 0) ? 0.007874015748031496063 : 0.142857142857142857143;  // :861, :835
+    hipLaunchKernelGGL(k_xe_corr, cgrid, dim3(256), 0, st, (const unsigned char *)h->d_tiles, (c32 *)out, g, npairs, kd, accumulate);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+}  // namespace
+
+extern "C" int mi355_xengine_destroy(mi355_xengine *h)
+{
+    if (!h) return MI355_OK;
+    (void)hipSetDevice(h->ctx->device);
+    if (h->d_tiles) (void)hipFree(h->d_tiles);
+    if (h->d_in) (void)hipFree(h->d_in);
+    if (h->d_out) (void)hipFree(h->d_out);
+    if (h->h_in) (void)hipHostFree(h->h_in);
+    if (h->h_out) (void)hipHostFree(h->h_out);
+    delete h;
+    return MI355_OK;
+}
+
+extern "C" int mi355_xengine_create(mi355_ctx *ctx, int data_type, int npol, int num_inputs, int num_channels, int integration,
+                                    mi355_xengine **out)
+{
+    MI355_REQUIRE(ctx && out, "NULL argument");
+    *out = nullptr;
+    MI355_REQUIRE(data_type == MI355_DTYPE_COMPLEX || data_type == MI355_DTYPE_BYTE || data_type == MI355_DTYPE_PACKEDXY,
+                  "X-engine data type must be complex, byte (IChar) or packed-4-bit");
+    if (data_type == MI355_DTYPE_PACKEDXY) npol = 2;  // lib/clXEngine_impl.cc:176-178
+    MI355_REQUIRE(npol == 1 || npol == 2, "polarization must be 1 or 2");
+    MI355_REQUIRE(num_inputs >= 2, "Please specify at least 2 inputs to correlate.");  // :106-109
+    MI355_REQUIRE(num_channels >= 1 && integration >= 1, "num_channels and integration must be positive");
+    MI355_REQUIRE(integration <= 65536, "integration above 65536 frames would overflow the int32 accumulators");
+    if (data_type != MI355_DTYPE_COMPLEX) {
+        // the corner turn consumes 4-byte units of the input rows
+        MI355_REQUIRE(((size_t)num_channels * (data_type == MI355_DTYPE_BYTE ? npol * 2 : 2)) % 4 == 0,
+                      "num_channels * bytes per channel must be a multiple of 4");
+    }
+    mi355_xengine *h = new (std::nothrow) mi355_xengine();
+    if (!h) return MI355_ERR_NOMEM;
+    h->ctx = ctx; h->data_type = data_type;
+    XeGeo &g = h->g;
+    g.N = num_inputs; g.F = num_channels; g.npol = npol; g.T = integration;
+    g.A = g.N * npol; g.NT = (g.A + kRowTile - 1) / kRowTile; g.KB = (g.T + kKBlock - 1) / kKBlock;
+    g.mode = (data_type == MI355_DTYPE_PACKEDXY) ? 1 : 0;
+    const size_t items = (size_t)g.N * g.F * npol * g.T;
+    h->in_bytes = items * mi355_dtype_size(data_type);  // frame_size_times_integration_bytes, :198
+    h->out_items = (size_t)g.F * ((size_t)g.N * (g.N + 1) / 2) * npol * npol;
+    h->tile_bytes = (data_type == MI355_DTYPE_COMPLEX) ? 0 : (size_t)g.F * g.KB * 2 * g.NT * kTileBytes;
+    if (hipSetDevice(ctx->device) != hipSuccess) { delete h; return MI355_ERR_HIP; }
+    if (h->tile_bytes && hipMalloc((void **)&h->d_tiles, h->tile_bytes) != hipSuccess) {
+        mi355_set_error("cannot allocate %zu bytes of tile workspace", h->tile_bytes);
+        delete h;
+        return MI355_ERR_NOMEM;
+    }
+    if (h->tile_bytes && hipMemset(h->d_tiles, 0, h->tile_bytes) != hipSuccess) { mi355_xengine_destroy(h); return MI355_ERR_HIP; }
+    *out = h;
+    return MI355_OK;
+}
+
+extern "C" size_t mi355_xengine_input_bytes(const mi355_xengine *h) { return h ? h->in_bytes : 0; }
+extern "C" size_t mi355_xengine_output_items(const mi355_xengine *h) { return h ? h->out_items : 0; }
+
+extern "C" int mi355_xengine_xcorrelate_dev(mi355_xengine *h, const void *in_dev, void *out_dev, int accumulate, void *stream)
+{
+    MI355_REQUIRE(h && in_dev && out_dev, "NULL argument");
+    MI355_REQUIRE((reinterpret_cast<uintptr_t>(in_dev) & 3u) == 0 && (reinterpret_cast<uintptr_t>(out_dev) & 7u) == 0,
+                  "device buffers must be 4-byte (input) / 8-byte (output) aligned");
+    MI355_HIP(hipSetDevice(h->ctx->device));
+    return launch_xe(h, in_dev, out_dev, accumulate, mi355_pick_stream(h->ctx, stream));
+}
+
+extern "C" int mi355_xengine_xcorrelate(mi355_xengine *h, const void *in_host, void *out_host, int accumulate)
+{
+    MI355_REQUIRE(h && in_host && out_host, "NULL argument");
+    std::lock_guard<std::mutex> g(h->ctx->lock);
+    MI355_HIP(hipSetDevice(h->ctx->device));
+    const size_t outb = h->out_items * 8;
+    if (!h->d_in) {
+        MI355_HIP(hipMalloc(&h->d_in, h->in_bytes));
+        MI355_HIP(hipMalloc(&h->d_out, outb));
+        MI355_HIP(hipHostMalloc(&h->h_in, h->in_bytes, hipHostMallocDefault));
+        MI355_HIP(hipHostMalloc(&h->h_out, outb, hipHostMallocDefault));
+    }
+    hipStream_t st = h->ctx->stream[0];
+    memcpy(h->h_in, in_host, h->in_bytes);
+    MI355_HIP(hipMemcpyAsync(h->d_in, h->h_in, h->in_bytes, hipMemcpyHostToDevice, st));
+    if (accumulate) {
+        memcpy(h->h_out, out_host, outb);
+        MI355_HIP(hipMemcpyAsync(h->d_out, h->h_out, outb, hipMemcpyHostToDevice, st));
+    }
+    int rc = launch_xe(h, h->d_in, h->d_out, accumulate, st);
+    if (rc) return rc;
+    MI355_HIP(hipMemcpyAsync(h->h_out, h->d_out, outb, hipMemcpyDeviceToHost, st));
+    MI355_HIP(hipStreamSynchronize(st));
+    memcpy(out_host, h->h_out, outb);
+    return MI355_OK;
+}
+
+// Host frame gather of work_processor, lib/clXEngine_impl.cc:987-1061 (plain memcpy loops on the
+// caller's thread, like the reference; the frame buffer keeps the reference's layout).
+extern "C" int mi355_xengine_gather(const mi355_xengine *h, int nframes, int frame0, const void *const *inputs, void *frame_buffer)
+{
+    MI355_REQUIRE(h && inputs && frame_buffer, "NULL argument");
+    const XeGeo &g = h->g;
+    MI355_REQUIRE(nframes >= 0 && frame0 >= 0 && frame0 + nframes <= g.T, "frames outside the integration window");
+    const size_t esz = mi355_dtype_size(h->data_type);
+    const size_t frame_bytes = (size_t)g.F * g.N * g.npol * esz;
+    char *dst = (char *)frame_buffer;
+    for (int b = 0; b < nframes; b++) {
+        char *fb = dst + frame_bytes * (size_t)(frame0 + b);
+        for (int i = 0; i < g.N; i++) {
+            if (g.npol == 1 || h->data_type == MI355_DTYPE_PACKEDXY) {
+                const size_t row = (size_t)g.F * g.npol * esz;
+                memcpy(fb + (size_t)i * row, (const char *)inputs[i] + (size_t)b * row, row);
+            } else {
+                const char *x = (const char *)inputs[i] + (size_t)b * g.F * esz;
+                const char *y = (const char *)inputs[i + g.N] + (size_t)b * g.F * esz;
+                char *row = fb + (size_t)i * g.F * 2 * esz;
+                for (int c = 0; c < g.F; c++) {
+                    memcpy(row + (size_t)c * 2 * esz, x + (size_t)c * esz, esz);
+                    memcpy(row + (size_t)c * 2 * esz + esz, y + (size_t)c * esz, esz);
+                }
+            }
+        }
+    }
+    return MI355_OK;
+}

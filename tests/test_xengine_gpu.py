@@ -1,0 +1,159 @@
+"""GPU parity: clXEngine through the C ABI vs the oracle.  The reference holds no vectors
+for this block (parity unpinned); anchors are exact integer sums (golden fixtures),
+closed-form cases and the oracle's restatement of the kernel text.
+Integer paths (IChar, packed 4-bit sums) are required BIT EXACT against the oracle's exact mode."""
+import numpy as np
+import pytest
+
+from conftest import GPU_ARGS, crandn, golden, relerr
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _xe(gpu, dtype, npol, N, F, T):
+    return gpu.clXEngine(*GPU_ARGS, False, dtype, npol, N, gpu.CLXCORR_TRIANGULAR_ORDER, 0, F, T, [])
+
+
+def test_golden_exact_integer_sums(gpu):
+    g = golden("xengine_golden.npz")
+    N, F, T = (int(v) for v in g["cfg"])
+    sc = 0.007874015748031496063
+    for npol in (1, 2):
+        blk = _xe(gpu, gpu.DTYPE_BYTE, npol, N, F, T)
+        out = np.empty(blk.get_output_buffer_size(), np.complex64)
+        blk.xcorrelate(g["i8_p%d_x" % npol], out)
+        ref = ((g["i8_p%d_sum_re" % npol] * sc * sc) + 1j * (g["i8_p%d_sum_im" % npol] * sc * sc)).astype(np.complex64)
+        assert np.array_equal(out, ref)  # bit exact
+    blk = _xe(gpu, gpu.DTYPE_COMPLEX, 2, N, F, T)
+    out = np.empty(blk.get_output_buffer_size(), np.complex64)
+    blk.xcorrelate(g["cf_p2_x"], out)
+    assert relerr(out, g["cf_p2_y"]) <= TOL
+    blk = _xe(gpu, gpu.DTYPE_PACKEDXY, 2, N, F, T)
+    out = np.empty(blk.get_output_buffer_size(), np.complex64)
+    blk.xcorrelate(g["p4_x"], out)
+    assert relerr(out, g["p4_y"]) <= TOL  # includes the code-8 -> 0 LUT quirk (lib/clXEngine_impl.cc:833)
+
+
+@pytest.mark.parametrize("N,F,T,npol", [(2, 2, 1, 1), (3, 6, 5, 1), (16, 8, 64, 1), (17, 4, 65, 1), (33, 10, 130, 2),
+                                        (64, 16, 256, 1), (64, 4, 128, 2), (40, 6, 200, 2), (100, 2, 70, 1)])
+def test_ichar_bit_exact_vs_oracle(gpu, oracle, N, F, T, npol):
+    rng = np.random.default_rng(N * 1000 + T)
+    x = rng.integers(-128, 128, size=T * N * F * npol * 2, dtype=np.int64).astype(np.int8)  # full range incl. -128
+    blk = _xe(gpu, gpu.DTYPE_BYTE, npol, N, F, T)
+    assert blk.get_output_buffer_size() == oracle.xengine_out_len(N, F, npol)
+    out = np.empty(blk.get_output_buffer_size(), np.complex64)
+    blk.xcorrelate(x, out)
+    assert np.array_equal(out, oracle.xengine_ichar(N, F, npol, T, x, exact=True))
+    # and the reference's own float arithmetic agrees within the budget
+    assert relerr(out, oracle.xengine_ichar(N, F, npol, T, x, exact=False)) <= TOL
+
+
+def test_closed_form_cases(gpu):
+    N, F, T = 8, 6, 32
+    blk = _xe(gpu, gpu.DTYPE_BYTE, 1, N, F, T)
+    out = np.empty(blk.get_output_buffer_size(), np.complex64)
+    x = np.zeros((T, N, F, 1, 2), np.int8)
+    x[..., 0] = 127
+    blk.xcorrelate(x.reshape(-1), out)
+    assert np.allclose(out, T, rtol=1e-6)  # every sample (127,0) -> V = T
+    x[:, 1::2, :, :, 0] = -127
+    x[:, 1::2, :, :, 1] = 127  # odd antennas (-127, 127): sign / conjugation sense
+    blk.xcorrelate(x.reshape(-1), out)
+    v = out.reshape(F, N * (N + 1) // 2)
+    for s1 in range(N):
+        for s2 in range(s1 + 1):
+            z1 = (-1 + 1j) if s1 % 2 else 1
+            z2 = (-1 + 1j) if s2 % 2 else 1
+            assert np.allclose(v[:, s1 * (s1 + 1) // 2 + s2], T * z1 * np.conj(z2), rtol=1e-6)
+    blk = _xe(gpu, gpu.DTYPE_COMPLEX, 1, N, F, T)
+    ph = np.exp(2j * np.pi * np.arange(T * F) / 37.0).reshape(T, 1, F).repeat(N, 1).astype(np.complex64)
+    blk.xcorrelate(ph.reshape(-1), out)  # identical unit-modulus tone on every antenna (lib/test-clxengine.cc:225-247)
+    assert np.allclose(out, T, atol=1e-3)
+
+
+@pytest.mark.parametrize("N,F,T,npol", [(4, 8, 16, 1), (9, 5, 33, 2), (16, 32, 64, 1)])
+def test_complex_float_vs_oracle(gpu, oracle, N, F, T, npol):
+    rng = np.random.default_rng(N + T)
+    x = crandn(rng, T * N * F * npol)
+    blk = _xe(gpu, gpu.DTYPE_COMPLEX, npol, N, F, T)
+    out = np.empty(blk.get_output_buffer_size(), np.complex64)
+    blk.xcorrelate(x, out)
+    assert relerr(out, oracle.xengine_cf32(N, F, npol, T, x)) <= TOL
+
+
+@pytest.mark.parametrize("N,F,T", [(2, 2, 3), (5, 6, 70), (16, 8, 64)])
+def test_packed4_vs_oracle(gpu, oracle, N, F, T):
+    rng = np.random.default_rng(N * 7 + T)
+    x = rng.integers(0, 256, size=T * N * F * 2, dtype=np.int64).astype(np.uint8)
+    blk = _xe(gpu, gpu.DTYPE_PACKEDXY, 2, N, F, T)
+    out = np.empty(blk.get_output_buffer_size(), np.complex64)
+    blk.xcorrelate(x, out)
+    assert relerr(out, oracle.xengine_packed4(N, F, T, x)) <= TOL
+
+
+def test_pipeline_integration_accumulates(gpu, oracle):
+    N, F, T = 6, 4, 48
+    rng = np.random.default_rng(77)
+    x1 = rng.integers(-127, 128, size=T * N * F * 2, dtype=np.int64).astype(np.int8)
+    x2 = rng.integers(-127, 128, size=T * N * F * 2, dtype=np.int64).astype(np.int8)
+    blk = _xe(gpu, gpu.DTYPE_BYTE, 1, N, F, T)
+    out = np.zeros(blk.get_output_buffer_size(), np.complex64)  # zero-filled accumulator (:289-292)
+    blk.xcorrelate(x1, out, accumulate=True)
+    blk.xcorrelate(x2, out, accumulate=True)  # "+=" (:785-796)
+    ref = oracle.xengine_ichar(N, F, 1, T, x1, exact=True)
+    ref = oracle.xengine_ichar(N, F, 1, T, x2, exact=True, acc=ref)
+    assert np.array_equal(out, ref)
+
+
+def test_gather_matches_reference_layout(gpu, oracle):
+    N, F, T = 3, 6, 4
+    rng = np.random.default_rng(3)
+    for dtype, npol, esz, nin in ((gpu.DTYPE_BYTE, 2, 2, 2 * N), (gpu.DTYPE_BYTE, 1, 2, N), (gpu.DTYPE_COMPLEX, 2, 8, 2 * N),
+                                  (gpu.DTYPE_PACKEDXY, 2, 1, N)):
+        per = F * esz * (2 if dtype == gpu.DTYPE_PACKEDXY else 1)
+        ins = [rng.integers(-127, 128, size=T * per, dtype=np.int64).astype(np.int8) for _ in range(nin)]
+        blk = _xe(gpu, dtype, npol, N, F, T)
+        a = np.zeros(blk.input_bytes(), np.int8)
+        b = np.zeros(blk.input_bytes(), np.int8)
+        blk.gather(2, 0, ins, a)
+        blk.gather(2, 2, [i[2 * per:] for i in ins], a)
+        oracle.xengine_gather(dtype, N, F, npol, T, 0, ins, b)
+        assert np.array_equal(a, b)
+
+
+def test_baseline_config5_full_size(gpu, oracle):
+    """64 antennas x 1024 channels x 1024 frames, IChar (BASELINE configs[4]), device resident.
+    Checks: a slab of channels bit-exact vs the oracle, Hermitian self-consistency of the
+    autocorrelations (imag == 0, real == sum |x|^2), and the accumulate path doubling the result."""
+    import torch
+    N, F, T = 64, 1024, 1024
+    g = torch.Generator(device="cuda").manual_seed(42)
+    x = torch.randint(-127, 128, (T, N, F, 2), dtype=torch.int8, device="cuda", generator=g)
+    blk = _xe(gpu, gpu.DTYPE_BYTE, 1, N, F, T)
+    out = torch.zeros(blk.get_output_buffer_size(), 2, device="cuda")
+    blk.xcorrelate_device(x, out)
+    torch.cuda.synchronize()
+    nb = N * (N + 1) // 2
+    v = out.view(F, nb, 2)
+    diag = torch.tensor([s * (s + 1) // 2 + s for s in range(N)], device="cuda")
+    auto = v[:, diag, :]
+    assert torch.all(auto[..., 1] == 0)
+    pw = (x.to(torch.int64) ** 2).sum(dim=(0, 3)).t().to(torch.float64) * (0.007874015748031496063 ** 2)  # [F][N]
+    assert torch.allclose(auto[..., 0].to(torch.float64), pw, rtol=1e-6)
+    fs = [0, 1, 511, 1022, 1023]
+    xs = x[:, :, fs, :].contiguous().cpu().numpy()
+    ref = oracle.xengine_ichar(N, len(fs), 1, T, xs.reshape(-1), exact=True).reshape(len(fs), nb)
+    got = v[fs].cpu().numpy().view(np.complex64).reshape(len(fs), nb)
+    assert np.array_equal(got, ref)
+    blk.xcorrelate_device(x, out, accumulate=True)
+    torch.cuda.synchronize()
+    got2 = out.view(F, nb, 2)[fs].cpu().numpy().view(np.complex64).reshape(len(fs), nb)
+    assert np.array_equal(got2, ref + ref)
+
+
+def test_constructor_errors(gpu):
+    with pytest.raises(IndexError):
+        _xe(gpu, gpu.DTYPE_BYTE, 1, 1, 16, 16)  # lib/clXEngine_impl.cc:106-109
+    with pytest.raises(gpu.Mi355Error):
+        _xe(gpu, gpu.DTYPE_BYTE, 3, 4, 16, 16)
