@@ -78,13 +78,20 @@ def time_steps(fn, steps, warmup, world):
 
 
 def max_over_ranks(x, world):
-    if world == 1:
-        return x
-    import torch
-    import torch.distributed as dist
-    t = torch.tensor([x], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+    return entry.load_package().shard.max_over_ranks(x)
+
+
+def lowpass_taps(gain, fs, cutoff, tw, atten=53.0):
+    """Hamming windowed-sinc low-pass (the definition of firdes::low_pass, lib/firdes.cc:92-137)."""
+    nt = int(atten * fs / (22.0 * tw))
+    nt += (nt & 1) == 0
+    m = (nt - 1) // 2
+    k = np.arange(-m, m + 1)
+    w = 0.54 - 0.46 * np.cos(2 * np.pi * np.arange(nt) / (nt - 1))
+    w0 = 2 * np.pi * cutoff / fs
+    with np.errstate(invalid="ignore", divide="ignore"):
+        t = np.where(k == 0, w0 / np.pi, np.sin(k * w0) / (k * np.pi)) * w
+    return (t * (gain / t.sum())).astype(np.float32)
 
 
 def cpu_baseline_fft(o, window, budget_s=12.0):
@@ -105,17 +112,22 @@ def cpu_baseline_fft(o, window, budget_s=12.0):
             "sample": "%d frames of %d-pt complex FFT (window+shift), oracle fft_block f32, %.1f s" % (reps * probe, FFT_N, dt)}
 
 
-def extra_blocks(pkg, dev, steps, warmup, world):
-    """Secondary lines: the other hot-path blocks, device resident, same timing method."""
+def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank):
+    """Secondary lines: the other hot-path blocks, device resident, same timing method
+    (per-GPU figures of this rank; the headline above carries the multi-GPU aggregate)."""
     import torch
     out = {}
     args = (1, 2, 0, dev)
 
-    def rate(fn, nsamples, bytes_per_sample):
+    def rate(fn, nsamples, bytes_per_sample, extra=None):
         _, ev = time_steps(fn, steps, warmup, world)
         dt = ev / steps
-        return {"MSamples_per_s": round(nsamples / dt / 1e6, 1), "GBps": round(nsamples * bytes_per_sample / dt / 1e9, 1),
-                "hbm_frac": round(nsamples * bytes_per_sample / dt / 1e9 / HBM_PEAK_GBS, 4)}
+        d = {"MSamples_per_s": round(nsamples / dt / 1e6, 1), "us_per_launch": round(dt * 1e6, 2),
+             "GBps": round(nsamples * bytes_per_sample / dt / 1e9, 1),
+             "hbm_frac": round(nsamples * bytes_per_sample / dt / 1e9 / HBM_PEAK_GBS, 4)}
+        if extra:
+            d.update(extra(dt))
+        return d
 
     n = 1 << 25
     a = torch.randn(n, 2, device="cuda")
@@ -125,8 +137,57 @@ def extra_blocks(pkg, dev, steps, warmup, world):
     out["clMathOp_multiply_complex"] = rate(lambda: mul.work_device(n, [a, b], [c]), n, 24)
     mc = pkg.clMathConst(pkg.DTYPE_COMPLEX, *args, 2.0, pkg.MATHOP_MULTIPLY)
     out["clMathConst_multiply_complex"] = rate(lambda: mc.work_device(n, [a], [c]), n, 16)
-    del a, b, c
+    del b
+    # BASELINE configs[2]: low-pass FFT filter, 65 taps, decim 1 (device-resident stream of 2^25 samples)
+    taps65, taps2048 = o_taps
+    nf = n - 64
+    flt = pkg.clFilter(*args, 1, taps65, 1, 0, False)
+    out["clFilter_fft_65taps"] = rate(lambda: flt.work_device(nf, [a], [c]), nf, 16)
+    out["clFilter_fft_65taps"]["fft_size"] = flt.fftsize()
+    fir = pkg.clFilter(*args, 1, taps65, 1, 0, True)
+    out["clFilter_fir_65taps"] = rate(lambda: fir.work_device(nf, [a], [c]), nf, 16)
+    ct = (taps65 * np.exp(1j * np.pi * np.arange(65) / 8)).astype(np.complex64)
+    cfl = pkg.clComplexFilter(*args, 1, ct, 1, 0, use_time=False)
+    out["clComplexFilter_fft_65ctaps"] = rate(lambda: cfl.work_device(nf, [a], [c]), nf, 16)
+    # BASELINE configs[3]: polyphase channelizer 64 ch x 32 taps/arm; streaming buffer and the 65536-item call
+    for buf, key in ((1 << 24, "clPolyphaseChannelizer_64x32_stream"), (65536, "clPolyphaseChannelizer_64x32_buf65536")):
+        pfb = pkg.clPolyphaseChannelizer(*args, taps2048, buf, 64, 64, list(range(64)))
+        xi = a[:pfb.ninput()]
+        yo = c[:pfb.noutput()]
+        out[key] = rate(lambda: pfb.work_device([xi], [yo]), buf, 16)
+    del a, c
     torch.cuda.empty_cache()
+    # BASELINE configs[4]: X-engine 64 antennas x 1024 channels x 1024 frames, IChar.  Both fractions.
+    N, F, T = 64, 1024, 1024
+    Fw = F // world  # channel slab of this rank after the corner turn (gr-clenabled_amd/shard.py)
+    g = torch.Generator(device="cuda").manual_seed(42 + rank)
+    xe = pkg.clXEngine(*args, False, pkg.DTYPE_BYTE, 1, N, 1, 0, Fw, T, [])
+    x8 = torch.randint(-127, 128, (T, N, Fw, 1, 2), dtype=torch.int8, device="cuda", generator=g)
+    vis = torch.zeros(xe.get_output_buffer_size(), 2, device="cuda")
+    nb = N * (N + 1) // 2
+    flop = 8.0 * Fw * nb * T
+    alg_bytes = x8.numel() + vis.numel() * 4
+
+    def xe_extra(dt):
+        return {"TFLOPs": round(flop / dt / 1e12, 1), "mfma_frac_i8_5POPS": round(flop / dt / 5e15, 4),
+                "hbm_frac_algorithmic": round(alg_bytes / dt / 1e9 / HBM_PEAK_GBS, 4), "channels_this_rank": Fw}
+
+    r = rate(lambda: xe.xcorrelate_device(x8, vis), N * Fw * T, 2, xe_extra)
+    r.pop("hbm_frac", None)
+    out["clXEngine_64ant_1024ch_1024t_ichar"] = r
+    if world > 1:
+        # sharded config 5: antenna-group ingest + all-to-all corner turn (RCCL over xGMI) + local correlation
+        sh = pkg.shard
+        ctn = sh.XEngineCornerTurn(N, F, T, 1)
+        loc = torch.randint(-127, 128, ctn.local_shape(), dtype=torch.int8, device="cuda", generator=g)
+
+        def sharded():
+            slab = ctn.exchange(loc)
+            xe.xcorrelate_device(slab, vis)
+
+        r2 = rate(sharded, N * Fw * T, 2, xe_extra)
+        r2.pop("hbm_frac", None)
+        out["clXEngine_sharded_alltoall_plus_correlate"] = r2
     return out
 
 
@@ -164,10 +225,21 @@ def main():
 
     extras = {}
     if not a.no_extra:
-        extras = extra_blocks(pkg, local, max(5, a.steps // 5), 2, world)
+        # fixture taps: firdes.low_pass(1,10e6,1e6,372e3) = 65 taps; low_pass(1,64,.5,.0753)+[0] = 2048 taps.
+        # Designed by the product-independent formula below (same definition as tests/golden/gen_golden.py).
+        extras = extra_blocks(pkg, (lowpass_taps(1.0, 10e6, 1e6, 372000.0),
+                                    np.concatenate([lowpass_taps(1.0, 64.0, 0.5, 0.0753), [0.0]]).astype(np.float32)),
+                              local, max(5, a.steps // 5), 2, world, rank)
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu:
         cpu = cpu_baseline_fft(entry.load_oracle(), window)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "fft4096_pmc.json")) as fh:
+            pmc = json.load(fh)
+        traffic = pmc["hbm_bytes_per_launch"]
+    except Exception:
+        pmc = None
 
     if rank == 0:
         line = {
@@ -188,7 +260,8 @@ def main():
                        "fft_size": FFT_N, "frames_per_step": FRAMES_PER_STEP, "parallelism": "replica-per-gpu x%d" % world},
             "per_gpu_MSamples_per_s": round(value / world, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": (pmc or {}).get("source"),
                          "kernel": "k_fft<4096,-1,false>", "kernel_us": round(kernel_s * 1e6, 2),
                          "algorithmic_bytes_per_launch": samples_per_step * BYTES_PER_SAMPLE},
             "cpu_baseline": cpu,

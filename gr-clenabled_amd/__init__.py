@@ -8,3 +8,4 @@ load it with ``importlib`` under the module name ``gr_clenabled_amd`` -- see
 from ._lib import LIB_PATH, Mi355Error, lib  # noqa: F401
 from .blocks import *  # noqa: F401,F403
 from . import blocks as clenabled  # noqa: F401  (flowgraph-style alias: clenabled.clFFT(...))
+from . import shard  # noqa: F401

@@ -1,0 +1,103 @@
+"""CPU, gloo, world_size 2: the N>1 paths -- replica sharding + timing reduction of bench.py and
+the X-engine corner turn (all-to-all of antenna groups into channel slabs).  The arithmetic on the
+slabs is checked with the oracle (test infrastructure); on GPUs the same exchange runs over RCCL and
+the slab goes to the C-ABI X-engine."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from conftest import ROOT
+
+
+def test_assignment_helpers(pkg):
+    import importlib
+    sh = importlib.import_module("gr_clenabled_amd.shard")
+    assert sh.replica_assignment(8, 8) == [[i] for i in range(8)]
+    assert sh.replica_assignment(8, 2) == [[0, 2, 4, 6], [1, 3, 5, 7]]
+    assert sh.replica_assignment(3, 4) == [[0], [1], [2], []]
+    assert sh.channel_slices(1024, 8)[3] == (384, 512)
+    assert sh.antenna_groups(64, 8)[7] == (56, 64)
+    for bad in (lambda: sh.channel_slices(10, 4), lambda: sh.antenna_groups(10, 4)):
+        try:
+            bad()
+            assert False
+        except ValueError:
+            pass
+    assert sh.max_over_ranks(3.5) == 3.5  # world 1: identity
+
+
+WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, %(root)r)
+    import __graft_entry__ as entry
+    pkg = entry.load_package()
+    import importlib
+    sh = importlib.import_module("gr_clenabled_amd.shard")
+    o = entry.load_oracle()
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    assert (rank, world) == sh.rank_env()[:2]
+    # timing reduction: max over ranks
+    assert sh.max_over_ranks(1.0 + rank) == float(world)
+    # replicas: every instance on exactly one rank
+    mine = sh.replica_assignment(5, world)[rank]
+    t = torch.zeros(5, dtype=torch.int64); t[mine] = 1
+    dist.all_reduce(t)
+    assert t.tolist() == [1] * 5
+    # X-engine corner turn
+    N, F, T, npol = 6, 8, 16, %(npol)d
+    rng = np.random.default_rng(5)                      # same stream on every rank
+    full = rng.integers(-127, 128, size=(T, N, F, npol, 2), dtype=np.int64).astype(np.int8)
+    ct = sh.XEngineCornerTurn(N, F, T, npol)
+    g0, g1 = ct.groups[rank]
+    local = torch.from_numpy(np.ascontiguousarray(full[:, g0:g1]))
+    slab = ct.exchange(local).numpy()
+    f0, f1 = ct.output_slice()
+    assert slab.shape == (T, N, F // world, npol, 2)
+    assert np.array_equal(slab, full[:, :, f0:f1])       # bit exact: pure data movement
+    # correlating the slab == the rank's channel rows of the full result
+    ref = o.xengine_ichar(N, F, npol, T, full.reshape(-1), exact=True).reshape(F, -1)
+    got = o.xengine_ichar(N, F // world, npol, T, slab.reshape(-1), exact=True).reshape(F // world, -1)
+    assert np.array_equal(got, ref[f0:f1])
+    # gather the rows back on rank 0 in channel order
+    gf = torch.from_numpy(got.view(np.float32))           # gloo has no complex gather: ship as floats
+    rows = [torch.empty_like(gf) for _ in range(world)] if rank == 0 else None
+    dist.gather(gf, rows, dst=0)
+    if rank == 0:
+        assert np.array_equal(torch.cat(rows).numpy().view(np.complex64), ref)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank %%d ok" %% rank)
+''')
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_world2(tmp_path, npol):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT, "npol": npol})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
+def test_world2_gloo_single_pol(pkg, oracle, tmp_path):
+    _run_world2(tmp_path, 1)
+
+
+def test_world2_gloo_dual_pol(pkg, oracle, tmp_path):
+    _run_world2(tmp_path, 2)
