@@ -15,6 +15,7 @@
 // registers from a double-precision-generated table and cost nothing per frame.
 // HBM traffic per frame = N*8 B in + N*8 B out (16 B/sample), nothing else.
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -23,6 +24,37 @@
 using namespace fftc;
 
 namespace {
+
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+// Raw pass-0 inputs of one frame group: v[q*R0 + r] = x[fr][(j + r*B0) ^ in_xor].  Streaming
+// (nontemporal) loads, branch free: a thread whose frame does not exist (ragged last group) reads
+// frame 0 of the group instead and the value is discarded.  in_xor is 0 or N/2, a multiple of B0
+// (R0 >= 2), so it only permutes the r*B0 term.
+template <int N, bool REAL>
+__device__ __forceinline__ void load_group(c32 (&v)[16], const void *__restrict__ in, int grp, int tid, int nframes, int in_xor)
+{
+    using P = Plan<N>;
+    constexpr int TH = Geo<N>::TH, PTS = Geo<N>::PTS, F = Geo<N>::F, R0 = P::radix(0), B0 = N / R0;
+    const int frames_left = nframes - grp * F;
+#pragma unroll
+    for (int q = 0; q < 16 / R0; q++) {
+        const int g = tid + TH * q, fr = g / B0;
+        const bool ok = (F == 1) || fr < frames_left;
+        const unsigned off = (unsigned)((ok ? fr * N : 0) + (g % B0));
+#pragma unroll
+        for (int r = 0; r < R0; r++) {
+            const unsigned e = off + (unsigned)((r * B0) ^ in_xor);
+            if constexpr (REAL) {
+                const float x = __builtin_nontemporal_load((const float *)in + (size_t)grp * PTS + e);
+                v[q * R0 + r] = mk(ok ? x : 0.f, 0.f);
+            } else {
+                const f2v x = __builtin_nontemporal_load((const f2v *)in + (size_t)grp * PTS + e);
+                v[q * R0 + r] = ok ? mk(x.x, x.y) : mk(0.f, 0.f);
+            }
+        }
+    }
+}
 
 template <int N, int SIGN, bool REAL>
 __global__ __launch_bounds__(Geo<N>::TH, Geo<N>::WPE) void k_fft(const void *__restrict__ in, c32 *__restrict__ out,
@@ -49,62 +81,46 @@ __global__ __launch_bounds__(Geo<N>::TH, Geo<N>::WPE) void k_fft(const void *__r
         for (int r = 0; r < R0; r++) win[q * R0 + r] = window[j + ((r * B0) ^ in_xor)];
     }
 
+    // Software pipeline over the persistent loop: the loads of the NEXT frame group are issued
+    // before the current group is transformed, so every workgroup always has 32 KiB in flight.
+    c32 cur[16];
+    if ((int)blockIdx.x < ngroups) load_group<N, REAL>(cur, in, blockIdx.x, tid0, nframes, in_xor);
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        c32 v[16];
         // Opaque per-iteration copy of the thread id: address arithmetic is recomputed
         // (a few dozen integer ops) rather than hoisted into ~60 loop-carried registers.
         int tid = tid0;
         asm volatile("" : "+v"(tid));
         const int frames_left = nframes - grp * F;  // frames of this group that exist
-        // ---- pass 0 inputs: global -> registers (window fused) ------------------------
-        // in_xor is 0 or N/2, a multiple of B0 (R0 >= 2), so it only permutes the r*B0 term
-        // Loads are branch free: a thread whose frame does not exist (ragged last group)
-        // reads frame 0 of the group instead and the value is discarded.
-        if constexpr (REAL) {
-            const float *src = (const float *)in + (size_t)grp * PTS;
+        c32 nxt[16];
+        const int gnext = grp + gridDim.x;
+        if (gnext < ngroups) load_group<N, REAL>(nxt, in, gnext, tid, nframes, in_xor);
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the transform
+        c32 v[16];
 #pragma unroll
-            for (int q = 0; q < 16 / R0; q++) {
-                const int g = tid + TH * q, fr = g / B0;
-                const bool ok = (F == 1) || fr < frames_left;
-                const unsigned off = (unsigned)((ok ? fr * N : 0) + (g % B0));
-#pragma unroll
-                for (int r = 0; r < R0; r++) {
-                    const float x = src[off + (unsigned)((r * B0) ^ in_xor)];
-                    v[q * R0 + r] = mk(ok ? x : 0.f, 0.f);
-                }
-            }
-        } else {
-            const c32 *src = (const c32 *)in + (size_t)grp * PTS;
-#pragma unroll
-            for (int q = 0; q < 16 / R0; q++) {
-                const int g = tid + TH * q, fr = g / B0;
-                const bool ok = (F == 1) || fr < frames_left;
-                const unsigned off = (unsigned)((ok ? fr * N : 0) + (g % B0));
-#pragma unroll
-                for (int r = 0; r < R0; r++) {
-                    const c32 x = src[off + (unsigned)((r * B0) ^ in_xor)];
-                    v[q * R0 + r] = ok ? x : mk(0.f, 0.f);
-                }
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < 16; s++) v[s] = scale(v[s], win[s]);
+        for (int s = 0; s < 16; s++) v[s] = scale(cur[s], win[s]);
         transform_regs<N, SIGN, false>(v, tw, lds, tid);
-        // registers -> global, unit stride across lanes, fftshift fused.  out_xor is 0 or
-        // N/2, a multiple of BL, so it only permutes the s*BL term.
+        // registers -> global (streaming stores), unit stride across lanes, fftshift fused.
+        // out_xor is 0 or N/2, a multiple of BL, so it only permutes the s*BL term.
         {
             constexpr int RL = P::radix(NP - 1), BL = N / RL;
-            c32 *__restrict__ out_g = out + (size_t)grp * PTS;
+            f2v *__restrict__ out_g = (f2v *)out + (size_t)grp * PTS;
 #pragma unroll
             for (int q = 0; q < 16 / RL; q++) {
                 const int g = tid + TH * q, fr = g / BL;
                 const unsigned off = (unsigned)(fr * N + (g % BL));
                 if ((F == 1) || fr < frames_left) {
 #pragma unroll
-                    for (int s = 0; s < RL; s++) out_g[off + (unsigned)((orev<RL>(s) * BL) ^ out_xor)] = v[q * RL + s];
+                    for (int s = 0; s < RL; s++) {
+                        f2v o;
+                        o.x = v[q * RL + s].x;
+                        o.y = v[q * RL + s].y;
+                        __builtin_nontemporal_store(o, out_g + off + (unsigned)((orev<RL>(s) * BL) ^ out_xor));
+                    }
                 }
             }
         }
+#pragma unroll
+        for (int s = 0; s < 16; s++) cur[s] = nxt[s];
         if constexpr (NP > 1) __syncthreads();  // last pass' LDS reads finish before the next group's writes
     }
 }
@@ -116,7 +132,8 @@ int launch_n(mi355_ctx *ctx, int sign, const void *in, void *out, const float *w
     constexpr int F = Geo<N>::F, TH = Geo<N>::TH;
     int ngroups = (nframes + F - 1) / F;
     int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
-    int per_cu = (N <= 4096) ? 3 : (N == 8192 ? 2 : 1);
+    int per_cu = (N <= 4096) ? 2 : 1;  // resident workgroups per CU at the kernel's register budget
+    if (const char *e = getenv("MI355_FFT_WG_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
     int grid = ngroups < cus * per_cu ? ngroups : cus * per_cu;
 #define LAUNCH_FFT(SG, RL)                                                                                              \
     hipLaunchKernelGGL((k_fft<N, SG, RL>), dim3(grid), dim3(TH), 0, st, in, (c32 *)out, window, (const c32 *)tw, nframes, \

@@ -135,7 +135,7 @@ template <int N> struct Geo {
     static constexpr int TH = (N <= 4096) ? 256 : N / 16;  // threads per workgroup
     static constexpr int PTS = TH * 16;                     // points per workgroup iteration
     static constexpr int F = PTS / N;                       // frames per iteration
-    static constexpr int WPE = (N <= 4096) ? 3 : 1;         // min waves per SIMD asked of the register allocator
+    static constexpr int WPE = (N <= 4096) ? 2 : 1;         // min waves per SIMD asked of the register allocator
 };
 
 // LDS slot swizzle (8-byte slots): XOR the low four slot bits with the next four.
