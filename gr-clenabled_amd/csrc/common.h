@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -52,6 +53,28 @@ static inline size_t mi355_dtype_size(int dtype)
 // `stream` is a hipStream_t passed through the C ABI as void*; NULL is HIP's
 // default (null) stream, which is also torch's default stream.
 static inline hipStream_t mi355_pick_stream(mi355_ctx *, void *stream) { return (hipStream_t)stream; }
+
+// Persistent-kernel grid: k workgroups per CU, k in [kmin, kmax] (all resident).  More resident
+// workgroups hide latency better, so kmax is the default; a smaller k is taken only when it divides
+// the work units more evenly by more than 8% (a ragged last round costs up to 1/rounds of the
+// run time).  MI355_WG_PER_CU overrides (tuning aid).
+static inline int mi355_balanced_grid(const mi355_ctx *ctx, long long units, int kmin, int kmax)
+{
+    const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+    if (const char *e = getenv("MI355_WG_PER_CU")) {
+        const int k = atoi(e);
+        if (k > 0) return units < (long long)cus * k ? (units < 1 ? 1 : (int)units) : cus * k;
+    }
+    if (units <= (long long)cus * kmin) return units < 1 ? 1 : (int)units;
+    auto eff = [&](int k) {
+        const long long grid = (long long)cus * k, rounds = (units + grid - 1) / grid;
+        return (double)units / (double)(rounds * grid);
+    };
+    int best = kmax;
+    for (int k = kmax - 1; k >= kmin; k--)
+        if (eff(k) > eff(best) + 0.08) best = k;
+    return cus * best;
+}
 
 // ---------------------------------------------------------------------------
 // Pinned double-buffered staging for the host-pointer work() path.

@@ -56,8 +56,8 @@ __device__ __forceinline__ void load_group(c32 (&v)[16], const void *__restrict_
     }
 }
 
-template <int N, int SIGN, bool REAL>
-__global__ __launch_bounds__(Geo<N>::TH, Geo<N>::WPE) void k_fft(const void *__restrict__ in, c32 *__restrict__ out,
+template <int N, int SIGN, bool REAL, bool PF>
+__global__ __launch_bounds__(Geo<N>::TH, (PF ? Geo<N>::WPE : (N <= 4096 ? 3 : 1))) void k_fft(const void *__restrict__ in, c32 *__restrict__ out,
                                                                  const float *__restrict__ window,
                                                                  const c32 *__restrict__ twtab, int nframes, int ngroups,
                                                                  int shift)
@@ -92,9 +92,13 @@ __global__ __launch_bounds__(Geo<N>::TH, Geo<N>::WPE) void k_fft(const void *__r
         asm volatile("" : "+v"(tid));
         const int frames_left = nframes - grp * F;  // frames of this group that exist
         c32 nxt[16];
-        const int gnext = grp + gridDim.x;
-        if (gnext < ngroups) load_group<N, REAL>(nxt, in, gnext, tid, nframes, in_xor);
-        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the transform
+        if constexpr (PF) {
+            const int gnext = grp + gridDim.x;
+            if (gnext < ngroups) load_group<N, REAL>(nxt, in, gnext, tid, nframes, in_xor);
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the transform
+        } else if (grp != (int)blockIdx.x) {
+            load_group<N, REAL>(cur, in, grp, tid, nframes, in_xor);
+        }
         c32 v[16];
 #pragma unroll
         for (int s = 0; s < 16; s++) v[s] = scale(cur[s], win[s]);
@@ -119,8 +123,10 @@ __global__ __launch_bounds__(Geo<N>::TH, Geo<N>::WPE) void k_fft(const void *__r
                 }
             }
         }
+        if constexpr (PF) {
 #pragma unroll
-        for (int s = 0; s < 16; s++) cur[s] = nxt[s];
+            for (int s = 0; s < 16; s++) cur[s] = nxt[s];
+        }
         if constexpr (NP > 1) __syncthreads();  // last pass' LDS reads finish before the next group's writes
     }
 }
@@ -132,12 +138,23 @@ int launch_n(mi355_ctx *ctx, int sign, const void *in, void *out, const float *w
     constexpr int F = Geo<N>::F, TH = Geo<N>::TH;
     int ngroups = (nframes + F - 1) / F;
     int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
-    int per_cu = (N <= 4096) ? 2 : 1;  // resident workgroups per CU at the kernel's register budget
-    if (const char *e = getenv("MI355_FFT_WG_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
-    int grid = ngroups < cus * per_cu ? ngroups : cus * per_cu;
+    // MI355_FFT_PREFETCH=1 selects the register-prefetch variant (2 workgroups/CU); measured equal to the
+    // plain variant at 3 workgroups/CU on MI355X, so it is off by default.
+    static const bool pf = getenv("MI355_FFT_PREFETCH") ? atoi(getenv("MI355_FFT_PREFETCH")) != 0 : false;
+    (void)cus;
+    int grid = (N <= 4096) ? mi355_balanced_grid(ctx, ngroups, 2, pf ? 2 : 3) : mi355_balanced_grid(ctx, ngroups, 1, 1);
+    if (const char *e = getenv("MI355_FFT_WG_PER_CU")) {
+        if (atoi(e) > 0) grid = ngroups < cus * atoi(e) ? ngroups : cus * atoi(e);
+    }
 #define LAUNCH_FFT(SG, RL)                                                                                              \
-    hipLaunchKernelGGL((k_fft<N, SG, RL>), dim3(grid), dim3(TH), 0, st, in, (c32 *)out, window, (const c32 *)tw, nframes, \
-                       ngroups, shift)
+    do {                                                                                                                     \
+        if (pf)                                                                                                              \
+            hipLaunchKernelGGL((k_fft<N, SG, RL, true>), dim3(grid), dim3(TH), 0, st, in, (c32 *)out, window, (const c32 *)tw, \
+                               nframes, ngroups, shift);                                                                     \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((k_fft<N, SG, RL, false>), dim3(grid), dim3(TH), 0, st, in, (c32 *)out, window,                \
+                               (const c32 *)tw, nframes, ngroups, shift);                                                    \
+    } while (0)
     if (sign < 0) { if (real_in) LAUNCH_FFT(-1, true); else LAUNCH_FFT(-1, false); }
     else          { if (real_in) LAUNCH_FFT(1, true);  else LAUNCH_FFT(1, false); }
 #undef LAUNCH_FFT

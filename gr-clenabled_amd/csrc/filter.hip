@@ -32,6 +32,10 @@ using namespace fftc;
 
 namespace {
 
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void st_stream(c32 *p, c32 v) { f2v o; o.x = v.x; o.y = v.y; __builtin_nontemporal_store(o, (f2v *)p); }
+
 // ------------------------------------------------------------------------------------
 // fused overlap-save fast convolution
 // ------------------------------------------------------------------------------------
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(Geo<NF>::TH, Geo<NF>::WPE) void k_ols(const c32 *__
             for (int r = 0; r < R0; r++) {
                 const unsigned e = base + (unsigned)(r * B0);
                 const bool ok = e < in_left;
-                const c32 x = in_g[ok ? e : 0u];
+                const c32 x = in_g[ok ? e : 0u];  // plain load: the ntaps-1 overlap is re-read by the next block and should stay cached
                 v[q * R0 + r] = ok ? x : mk(0.f, 0.f);
             }
         }
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(Geo<NF>::TH, Geo<NF>::WPE) void k_ols(const c32 *__
                 const int n = j + orev<RO>(s) * BO;
                 const int rel = rel0 + orev<RO>(s) * BO;  // output index relative to g0
                 if (n >= ntaps - 1 && (unsigned)rel < y_left) {
-                    if (decim == 1) out_g[(unsigned)rel] = w[q * RO + s];
+                    if (decim == 1) st_stream(out_g + (unsigned)rel, w[q * RO + s]);
                     else {
                         const long long t = g0 + rel;
                         if (t % decim == 0) out[t / decim] = w[q * RO + s];
@@ -329,8 +333,7 @@ int launch_ols(mi355_filter *h, size_t nout, const void *in, void *out, hipStrea
     const long long nblocks = (n_y + L - 1) / L;
     const long long ngroups = (nblocks + F - 1) / F;
     if (nblocks > 0x7fffffffLL) { mi355_set_error("work() call too large"); return MI355_ERR_INVALID_ARG; }
-    int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
-    long long grid = ngroups < (long long)cus * 3 ? ngroups : (long long)cus * 3;
+    long long grid = mi355_balanced_grid(h->ctx, ngroups, 2, 3);
     hipLaunchKernelGGL((k_ols<NF>), dim3((unsigned)grid), dim3(TH), 0, st, (const c32 *)in, (c32 *)out, (const c32 *)h->d_H,
                        (const c32 *)h->d_twf, (const c32 *)h->d_twi, h->ntaps, h->decim, n_in, n_y, (int)nblocks, (int)ngroups);
     MI355_HIP(hipGetLastError());

@@ -28,6 +28,9 @@ using namespace fftc;
 
 namespace {
 
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_stream(c32 *p, c32 v) { f2v o; o.x = v.x; o.y = v.y; __builtin_nontemporal_store(o, (f2v *)p); }
+
 // ------------------------------------------------------------------------------------
 // fast path
 // ------------------------------------------------------------------------------------
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256, (PfbGeo<M, PMAX>::WPE)) void k_pfb(const c32 *
                 if (i0 + fr < nsteps) {
                     c32 *__restrict__ o = out + (size_t)(i0 + fr) * M + j;
 #pragma unroll
-                    for (int s = 0; s < RL; s++) o[orev<RL>(s) * BL] = v[q * RL + s];
+                    for (int s = 0; s < RL; s++) st_stream(o + orev<RL>(s) * BL, v[q * RL + s]);
                 }
             }
         } else {
@@ -209,8 +212,7 @@ int launch_fast(mi355_pfb *h, const void *in, void *out, hipStream_t st)
 {
     constexpr int T = 4096 / M;
     int ngroups = (h->nsteps + T - 1) / T;
-    int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
-    int grid = ngroups < cus * PfbGeo<M, PMAX>::WPE ? ngroups : cus * PfbGeo<M, PMAX>::WPE;
+    int grid = mi355_balanced_grid(h->ctx, ngroups, PfbGeo<M, PMAX>::WPE >= 2 ? 2 : 1, PfbGeo<M, PMAX>::WPE);
     long long n_in = (long long)h->buf_items - h->R + h->K;
     if (h->ident)
         hipLaunchKernelGGL((k_pfb<M, PMAX, true>), dim3(grid), dim3(256), 0, st, (const c32 *)in, (c32 *)out, h->d_taps,
