@@ -22,6 +22,7 @@
 //
 // Complex-float input keeps fp32 arithmetic (register-tiled VALU kernel, 8x8 station blocks).
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -145,6 +146,65 @@ __global__ __launch_bounds__(256) void k_xe_turn(const unsigned *__restrict__ in
 }
 
 // ------------------------------------------------------------------------------------
+// (1b) fast corner turn for IChar when an input row (t, station) is a whole number of 128-byte
+// lines.  One workgroup = 16 rows (one row tile) x 16 time steps (one kc chunk) x one 128-byte
+// line of channels = 32 KiB.  Load phase: whole lines, 16 B per lane, into LDS (station stride
+// padded so the transposed reads are conflict free).  Store phase: lanes run over the tile rows
+// first, so every store instruction writes 256 contiguous bytes (16 rows x 16 B) of each tile.
+// ------------------------------------------------------------------------------------
+template <int NPOL>
+__global__ __launch_bounds__(256) void k_xe_turn_lds(const uint4 *__restrict__ in, unsigned char *__restrict__ tiles, XeGeo g)
+{
+    constexpr int SIN = kRowTile / NPOL;                 // stations per row tile
+    constexpr int SSTRIDE = 2048 + (NPOL == 1 ? 8 : 16);  // bytes between stations in LDS (bank spread)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[SIN * SSTRIDE];
+    const int line = blockIdx.x, rt = blockIdx.y, kb = blockIdx.z >> 2, kc = blockIdx.z & 3;
+    const int tid = threadIdx.x;
+    const int lines_per_row = (g.F * NPOL * 2) / 128;
+    const int t0 = kb * kKBlock + kc * 16;
+    // ---- load: SIN stations x 16 t rows of 128 B; 8 lanes per row ----
+#pragma unroll
+    for (int it = 0; it < (SIN * 16 * 8) / 256; it++) {
+        const int idx = tid + 256 * it, seg = idx & 7, row = idx >> 3, t = row & 15, sl = row >> 4;
+        const int s = rt * SIN + sl;
+        v4i v = (v4i){0, 0, 0, 0};
+        if (s < g.N && t0 + t < g.T)
+            v = __builtin_nontemporal_load((const v4i *)in + (((size_t)(t0 + t) * g.N + s) * lines_per_row + line) * 8 + seg);
+        *(v4i *)(lds + sl * SSTRIDE + t * 128 + seg * 16) = v;
+    }
+    __syncthreads();
+    // ---- transpose + store: item = (station sl, 4-byte unit u of the line) ----
+#pragma unroll
+    for (int it = 0; it < (SIN * 32) / 256; it++) {
+        const int item = tid + 256 * it, sl = item % SIN, u = item / SIN;
+        unsigned w[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) w[t] = *(const unsigned *)(lds + sl * SSTRIDE + t * 128 + u * 4);
+        unsigned col[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const unsigned a[4] = {w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+            unsigned o[4];
+            transpose4x4(a, o);
+#pragma unroll
+            for (int j = 0; j < 4; j++) col[j][q] = o[j];
+        }
+        // bytes of a unit: a.I a.Q b.I b.Q ;  NPOL 1: a,b = channels 2U,2U+1 of row sl ; NPOL 2: a,b = rows 2sl,2sl+1 of channel U
+        const int U = line * 32 + u;
+#pragma unroll
+        for (int smp = 0; smp < 2; smp++) {
+            const int f = (NPOL == 1) ? 2 * U + smp : U;
+            const int rr = (NPOL == 1) ? sl : 2 * sl + smp;
+#pragma unroll
+            for (int plane = 0; plane < 2; plane++) {
+                uint4 o = make_uint4(col[smp * 2 + plane][0], col[smp * 2 + plane][1], col[smp * 2 + plane][2], col[smp * 2 + plane][3]);
+                *(uint4 *)(tiles + tile_off(g, f, kb, plane, rt) + (size_t)(kc * 16 + rr) * 16) = o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // (2) MFMA correlator
 // ------------------------------------------------------------------------------------
 constexpr int kPairsPerWave = 3, kWaves = 4, kPairsPerWG = kPairsPerWave * kWaves;
@@ -210,6 +270,82 @@ __global__ __launch_bounds__(256) void k_xe_corr(const unsigned char *__restrict
             const size_t o = ((size_t)f * nb + k) * np2 + p1 * g.npol + p2;
             // same expression as the oracle's exact path: (double)S * kd * kd, rounded once
             const double kd = scale2;  // 1/127 or 1/7
+            c32 v;
+            v.x = (float)((double)re[q][reg] * kd * kd);
+            v.y = (float)((double)(uu[q][reg] - ww[q][reg]) * kd * kd);
+            if (accumulate) { v.x += out[o].x; v.y += out[o].y; }
+            out[o] = v;
+        }
+    }
+}
+
+// (2b) LDS-staged correlator: the workgroup stages each K block's tiles (2 planes x NT tiles) in LDS
+// once (coalesced 16 B per lane, register prefetch of the next K block) and the four waves read
+// their MFMA operands from LDS instead of each re-reading them through L1.
+template <int NTT>  // row tiles (compile time so the staging loops unroll); NTT <= 8
+__global__ __launch_bounds__(256) void k_xe_corr_lds(const unsigned char *__restrict__ tiles, c32 *__restrict__ out, XeGeo g,
+                                                     int npairs, double scale2, int accumulate)
+{
+    constexpr int KBYTES = 2 * NTT * kTileBytes;      // bytes per K block
+    constexpr int PER_THREAD = KBYTES / (256 * 16);    // dwordx4 loads per thread per K block (NTT/2, >= 1)
+    static_assert(KBYTES % (256 * 16) == 0, "tile bytes per K block must split over 256 threads");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][KBYTES];
+    const int f = blockIdx.x, chunk = blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int bi[kPairsPerWave], bj[kPairsPerWave];
+    bool live[kPairsPerWave];
+#pragma unroll
+    for (int q = 0; q < kPairsPerWave; q++) {
+        const int p = chunk * kPairsPerWG + q * kWaves + wave;
+        live[q] = p < npairs;
+        pair_to_tiles(live[q] ? p : 0, bi[q], bj[q]);
+    }
+    v4i re[kPairsPerWave], uu[kPairsPerWave], ww[kPairsPerWave];
+#pragma unroll
+    for (int q = 0; q < kPairsPerWave; q++) re[q] = uu[q] = ww[q] = (v4i){0, 0, 0, 0};
+
+    const unsigned char *src = tiles + (size_t)f * g.KB * KBYTES + (size_t)tid * 16;
+    v4i stage[PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; i++) stage[i] = __builtin_nontemporal_load((const v4i *)(src + (size_t)i * 4096));
+    for (int kb = 0; kb < g.KB; kb++) {
+        unsigned char *buf = lds[kb & 1];
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; i++) *(v4i *)(buf + tid * 16 + i * 4096) = stage[i];
+        if (kb + 1 < g.KB) {
+#pragma unroll
+            for (int i = 0; i < PER_THREAD; i++)
+                stage[i] = __builtin_nontemporal_load((const v4i *)(src + (size_t)(kb + 1) * KBYTES + (size_t)i * 4096));
+        }
+        __syncthreads();  // one barrier per K block: the other buffer was last read before the previous barrier
+        const unsigned char *pI = buf + lane * 16, *pQ = pI + NTT * kTileBytes;
+#pragma unroll
+        for (int q = 0; q < kPairsPerWave; q++) {
+            if (live[q]) {  // wave-uniform
+                const v4i Ia = *(const v4i *)(pI + bi[q] * kTileBytes);
+                const v4i Qa = *(const v4i *)(pQ + bi[q] * kTileBytes);
+                const v4i Ib = *(const v4i *)(pI + bj[q] * kTileBytes);
+                const v4i Qb = *(const v4i *)(pQ + bj[q] * kTileBytes);
+                re[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ia, Ib, re[q], 0, 0, 0);
+                re[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Qa, Qb, re[q], 0, 0, 0);
+                uu[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Qa, Ib, uu[q], 0, 0, 0);
+                ww[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Ia, Qb, ww[q], 0, 0, 0);
+            }
+        }
+    }
+    const int nb = g.N * (g.N + 1) / 2, np2 = g.npol * g.npol;
+#pragma unroll
+    for (int q = 0; q < kPairsPerWave; q++) {
+        if (!live[q]) continue;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int r1 = bi[q] * kRowTile + (lane >> 4) * 4 + reg, r2 = bj[q] * kRowTile + (lane & 15);
+            if (r1 >= g.A || r2 >= g.A) continue;
+            const int s1 = r1 / g.npol, p1 = r1 - s1 * g.npol, s2 = r2 / g.npol, p2 = r2 - s2 * g.npol;
+            if (s1 < s2) continue;
+            const int k = s1 * (s1 + 1) / 2 + s2;
+            const size_t o = ((size_t)f * nb + k) * np2 + p1 * g.npol + p2;
+            const double kd = scale2;
             c32 v;
             v.x = (float)((double)re[q][reg] * kd * kd);
             v.y = (float)((double)(uu[q][reg] - ww[q][reg]) * kd * kd);
@@ -300,13 +436,29 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
     }
     const int units_per_row = (g.mode == 0) ? (g.F * g.npol * 2) / 4 : (g.F * 2) / 4;
     // padding rows (A not a multiple of 16) were zeroed once at create and are never written
-    dim3 tgrid((units_per_row + 31) / 32, (g.N + 1) / 2, g.KB);
-    hipLaunchKernelGGL(k_xe_turn, tgrid, dim3(256), 0, st, (const unsigned *)in, h->d_tiles, g);
+    const bool fast_turn = g.mode == 0 && ((size_t)g.F * g.npol * 2) % 128 == 0 && (reinterpret_cast<uintptr_t>(in) & 15u) == 0 &&
+                           !getenv("MI355_XE_SLOW_TURN");
+    if (fast_turn) {
+        dim3 tgrid((g.F * g.npol * 2) / 128, g.NT, g.KB * 4);
+        if (g.npol == 1) hipLaunchKernelGGL((k_xe_turn_lds<1>), tgrid, dim3(256), 0, st, (const uint4 *)in, h->d_tiles, g);
+        else hipLaunchKernelGGL((k_xe_turn_lds<2>), tgrid, dim3(256), 0, st, (const uint4 *)in, h->d_tiles, g);
+    } else {
+        dim3 tgrid((units_per_row + 31) / 32, (g.N + 1) / 2, g.KB);
+        hipLaunchKernelGGL(k_xe_turn, tgrid, dim3(256), 0, st, (const unsigned *)in, h->d_tiles, g);
+    }
     MI355_HIP(hipGetLastError());
     const int npairs = g.NT * (g.NT + 1) / 2;
     dim3 cgrid(g.F, (npairs + kPairsPerWG - 1) / kPairsPerWG);
     const double kd = (g.mode == 0) ? 0.007874015748031496063 : 0.142857142857142857143;  // :861, :835
-    hipLaunchKernelGGL(k_xe_corr, cgrid, dim3(256), 0, st, (const unsigned char *)h->d_tiles, (c32 *)out, g, npairs, kd, accumulate);
+    const bool lds_corr = !getenv("MI355_XE_NO_LDS");
+#define CORR_LDS(NTT) hipLaunchKernelGGL((k_xe_corr_lds<NTT>), cgrid, dim3(256), 0, st, (const unsigned char *)h->d_tiles, (c32 *)out, g, npairs, kd, accumulate)
+    if (lds_corr && g.NT == 2) CORR_LDS(2);
+    else if (lds_corr && g.NT == 4) CORR_LDS(4);
+    else if (lds_corr && g.NT == 6) CORR_LDS(6);
+    else if (lds_corr && g.NT == 8) CORR_LDS(8);
+    else
+        hipLaunchKernelGGL(k_xe_corr, cgrid, dim3(256), 0, st, (const unsigned char *)h->d_tiles, (c32 *)out, g, npairs, kd, accumulate);
+#undef CORR_LDS
     MI355_HIP(hipGetLastError());
     return MI355_OK;
 }
