@@ -65,18 +65,55 @@ __global__ __launch_bounds__(256, (PfbGeo<M, PMAX>::WPE)) void k_pfb(const c32 *
     TwRegs<M> tw;
     load_twiddles<M, false>(tw, tid0, tw_inv);
 
-    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    // Each workgroup owns a CONTIGUOUS range of groups: consecutive groups overlap by PMAX rows, so
+    // after the first group only the T new rows are fetched (the tail rows survive phase 2, which
+    // only uses the first 4096 LDS slots, and are moved to the front).
+    const int per_wg = (ngroups + gridDim.x - 1) / gridDim.x;
+    const int g_begin = blockIdx.x * per_wg, g_end = (g_begin + per_wg < ngroups) ? g_begin + per_wg : ngroups;
+    constexpr int TAIL = PMAX * M, NEW = T * M;          // slots kept / fetched per group
+    constexpr int TAIL_PT = (TAIL + TH - 1) / TH, NEW_PT = NEW / TH, FULL_PT = (SPAN + TH - 1) / TH;
+    for (int grp = g_begin; grp < g_end; grp++) {
         int tid = tid0;
         asm volatile("" : "+v"(tid));
         const int jb = tid % M, sg = tid / M;
         // ---- stage input samples n_lo .. n_lo+SPAN of the history-prefixed buffer --------------
         const long long n_lo = (long long)grp * T * M + K - (long long)PMAX * M;
-        __syncthreads();  // previous group's LDS reads are done
-        for (int i = tid; i < SPAN; i += TH) {
-            const long long n = n_lo + i;
-            const bool ok = n >= 0 && n < n_in;
-            const c32 x = in[ok ? n : 0];
-            lds[i] = ok ? x : mk(0.f, 0.f);
+        if (grp == g_begin) {
+            __syncthreads();
+            c32 st[FULL_PT];
+#pragma unroll
+            for (int q = 0; q < FULL_PT; q++) {  // all loads in flight before the first LDS write
+                const long long n = n_lo + tid + q * TH;
+                const bool ok = n >= 0 && n < n_in && tid + q * TH < SPAN;
+                const c32 x = in[ok ? n : 0];
+                st[q] = ok ? x : mk(0.f, 0.f);
+            }
+#pragma unroll
+            for (int q = 0; q < FULL_PT; q++)
+                if (tid + q * TH < SPAN) lds[tid + q * TH] = st[q];
+        } else {
+            // new rows first (their latency hides behind the tail move), then tail -> front
+            const c32 *__restrict__ src = in + (n_lo + TAIL);
+            const long long left64 = n_in - (n_lo + TAIL);
+            const unsigned left = left64 > 0x7fffffffLL ? 0x7fffffffu : (unsigned)(left64 > 0 ? left64 : 0);
+            c32 st[NEW_PT], tl[TAIL_PT];
+#pragma unroll
+            for (int q = 0; q < NEW_PT; q++) {
+                const unsigned e = (unsigned)(tid + q * TH);
+                const bool ok = e < left;
+                const c32 x = src[ok ? e : 0u];
+                st[q] = ok ? x : mk(0.f, 0.f);
+            }
+            __syncthreads();  // previous group's phase 2 is done with LDS
+#pragma unroll
+            for (int q = 0; q < TAIL_PT; q++)
+                if (tid + q * TH < TAIL) tl[q] = lds[NEW + tid + q * TH];
+            __syncthreads();  // tail fully read before it is overwritten (source and destination may overlap)
+#pragma unroll
+            for (int q = 0; q < TAIL_PT; q++)
+                if (tid + q * TH < TAIL) lds[tid + q * TH] = tl[q];
+#pragma unroll
+            for (int q = 0; q < NEW_PT; q++) lds[TAIL + tid + q * TH] = st[q];
         }
         __syncthreads();
         // ---- phase 1: acc[u] = sum_pp hrev[pp] * X[u + pp], X[w] = stage[(sg*16 + w)*M + (M-1-jb)] ----

@@ -11,7 +11,8 @@ def timeit(fn, iters=10):
     for _ in range(iters): fn()
     t.record(); torch.cuda.synchronize()
     return s.elapsed_time(t) / iters * 1e-3
-for (N, F, T, npol) in ((64, 1024, 1024, 1), (64, 1024, 1024, 2)):
+import sys
+for (N, F, T, npol) in [(64, 1024, 1024, 1), (64, 1024, 1024, 2)][:int(sys.argv[1]) if len(sys.argv) > 1 else 2]:
     x = torch.randint(-127, 128, (T, N, F, npol, 2), dtype=torch.int8, device="cuda")
     blk = pkg.clXEngine(1, 2, 0, 0, False, pkg.DTYPE_BYTE, npol, N, 1, 0, F, T, [])
     out = torch.zeros(blk.get_output_buffer_size(), 2, device="cuda")
