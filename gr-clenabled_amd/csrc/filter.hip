@@ -160,8 +160,22 @@ __global__ __launch_bounds__(kTdThreads) void k_fir_td(const c32 *__restrict__ i
         const long long left64 = n_in - base;
         const unsigned left = left64 > 0x7fffffffLL ? 0x7fffffffu : (unsigned)left64;
         __syncthreads();
-        for (int i = tid; i < span; i += kTdThreads)
-            tile[(i & (kTdU - 1)) * S + (i >> 3)] = ((unsigned)i < left) ? in_t[i] : mk(0.f, 0.f);
+        // fill in batches of 8 loads per thread so the loads are all in flight before the LDS writes
+        for (int i0 = tid; i0 < span; i0 += 8 * kTdThreads) {
+            c32 st[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int i = i0 + q * kTdThreads;
+                const bool ok = i < span && (unsigned)i < left;
+                const c32 x = in_t[ok ? i : 0];
+                st[q] = ok ? x : mk(0.f, 0.f);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int i = i0 + q * kTdThreads;
+                if (i < span) tile[(i & (kTdU - 1)) * S + (i >> 3)] = st[q];
+            }
+        }
         __syncthreads();
         c32 acc[kTdU], win[2 * kTdU];
 #pragma unroll

@@ -1,0 +1,161 @@
+// test-clenabled-mi355: standalone timing harness for the hot-path blocks, the counterpart of the
+// reference's test-clenabled / test-clenabled-fft / test-clfilter / test-clxengine tools
+// (lib/test_clenabled.cc:1562-1691, lib/test-clenabled-fft.cc:54-92, lib/test-clfilter.cc:88-366,
+// lib/test-clxengine.cc:175-548).  Method as in the reference's study: each block in isolation,
+// 1 untimed warm-up + N timed calls with std::chrono::steady_clock, host buffers in and out
+// (so every figure includes H2D and D2H).  Every block's output is also checked against the
+// closed-form answer the reference's own tools use, and the program exits non-zero on a mismatch.
+#include <clenabled/clenabled.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+
+using namespace gr::clenabled;
+
+static int g_dev = 0, g_iter = 100, g_fail = 0;
+
+template <class F> static double time_calls(F &&fn)
+{
+    fn();  // warm-up
+    auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < g_iter; i++) fn();
+    std::chrono::duration<double> dt = std::chrono::steady_clock::now() - t0;
+    return dt.count() / g_iter;
+}
+
+static void report(const char *name, size_t nsamples, double sec, bool ok)
+{
+    printf("%-44s %10.1f us/call  %10.2f MSPS  %s\n", name, sec * 1e6, nsamples / sec / 1e6, ok ? "ok" : "MISMATCH");
+    if (!ok) g_fail++;
+}
+
+static bool close_to(gr_complex a, gr_complex b, float tol) { return std::abs(a - b) <= tol; }
+
+static void test_math(size_t n)
+{
+    std::vector<gr_complex> a(n, gr_complex(1.0f, 0.5f)), b(n, gr_complex(1.0f, 0.5f)), c(n);  // lib/test_clenabled.cc:1596-1600
+    gr_vector_const_void_star in = {a.data(), b.data()};
+    gr_vector_void_star out = {c.data()};
+    gr_vector_int ni;
+    auto mul = clMathOp::make(DTYPE_COMPLEX, OCLTYPE_GPU, OCLDEVICESELECTOR_SPECIFIC, 0, g_dev, MATHOP_MULTIPLY);
+    double t = time_calls([&] { mul->testOpenCL((int)n, ni, in, out); });
+    report("clMathOp multiply (complex)", n, t, c[0] == gr_complex(0.75f, 1.0f) && c[n - 1] == gr_complex(0.75f, 1.0f));
+    auto mc = clMathConst::make(DTYPE_COMPLEX, OCLTYPE_GPU, OCLDEVICESELECTOR_SPECIFIC, 0, g_dev, 2.0f, MATHOP_MULTIPLY);
+    gr_vector_const_void_star in1 = {a.data()};
+    t = time_calls([&] { mc->testOpenCL((int)n, ni, in1, out); });
+    report("clMathConst multiply by 2 (complex)", n, t, c[0] == gr_complex(2.0f, 1.0f));  // :1351-1356
+}
+
+static void test_fft(int fft_size, size_t n)
+{
+    n = n / fft_size * fft_size;
+    if (n == 0) n = fft_size;
+    std::vector<gr_complex> x(n), y(n);
+    for (size_t i = 0; i < n; i++) {  // one-cycle tone per frame, lib/clFFT_impl.cc:369-377
+        double ph = 2 * M_PI * (double)(i % fft_size) / fft_size;
+        x[i] = gr_complex((float)sin(ph), (float)cos(ph));
+    }
+    gr_vector_const_void_star in = {x.data()};
+    gr_vector_void_star out = {y.data()};
+    auto f = clFFT::make(fft_size, CLFFT_FORWARD, {}, DTYPE_COMPLEX, OCLTYPE_GPU, OCLDEVICESELECTOR_SPECIFIC, 0, g_dev);
+    double t = time_calls([&] { f->testOpenCL((int)n, in, out); });
+    bool ok = close_to(y[fft_size - 1], gr_complex(0.0f, (float)fft_size), 1e-3f * fft_size);  // X[N-1] = (0, N)
+    float other = 0;
+    for (int k = 0; k < fft_size - 1; k++) other = std::max(other, std::abs(y[k]));
+    char name[64];
+    snprintf(name, sizeof name, "clFFT forward N=%d", fft_size);
+    report(name, n, t, ok && other < 1e-3f * fft_size);
+}
+
+static void test_filter(int ntaps, size_t n)
+{
+    std::vector<float> taps(ntaps);
+    for (int i = 0; i < ntaps; i++) taps[i] = (i + 1) / 1000.0f;  // lib/test-clfilter.cc:98-100
+    std::vector<gr_complex> x(n + ntaps - 1, gr_complex(0, 0)), y(n);
+    x[ntaps - 1 + 10] = gr_complex(1.0f, 2.0f);  // impulse at sample 10 (history-prefixed buffer)
+    gr_vector_const_void_star in = {x.data()};
+    gr_vector_void_star out = {y.data()};
+    for (int use_time = 0; use_time < 2; use_time++) {
+        auto f = clFilter::make(OCLTYPE_GPU, OCLDEVICESELECTOR_SPECIFIC, 0, g_dev, 1, taps, 1, 0, use_time != 0);
+        double t = time_calls([&] { f->testOpenCL((int)n, in, out); });
+        bool ok = true;
+        for (int k = 0; k < ntaps && 10 + k < (int)n; k++) ok = ok && close_to(y[10 + k], taps[k] * gr_complex(1.0f, 2.0f), 2e-5f);
+        char name[64];
+        snprintf(name, sizeof name, "clFilter %d taps, %s", ntaps, use_time ? "time domain" : "frequency domain");
+        report(name, n, t, ok && close_to(y[0], gr_complex(0, 0), 2e-5f));
+    }
+}
+
+static void test_pfb()
+{
+    const int M = 64, K = 2048, buf = 65536;
+    std::vector<float> taps(K, 0.0f);
+    for (int j = 0; j < M; j++) taps[j] = 1.0f;  // first tap of every arm = 1: y_i[c] = M-point IDFT of one input row
+    std::vector<int> chmap(M);
+    for (int c = 0; c < M; c++) chmap[c] = c;
+    std::vector<gr_complex> x(buf + K - M), y(buf);
+    for (size_t i = 0; i < x.size(); i++) x[i] = gr_complex(i % M == (size_t)((K - 1) % M) ? 1.0f : 0.0f, 0.0f);
+    gr_vector_const_void_star in = {x.data()};
+    gr_vector_void_star out = {y.data()};
+    gr_vector_int ni;
+    auto p = clPolyphaseChannelizer::make(OCLTYPE_GPU, OCLDEVICESELECTOR_SPECIFIC, 0, g_dev, taps, buf, M, M, chmap);
+    double t = time_calls([&] { p->general_work(buf, ni, in, out); });
+    // only arm 0 sees the ones (buf[i*M + K-1] == 1, tap 0) -> v_i = delta[0] -> every channel = 1
+    bool ok = true;
+    for (int c = 0; c < M; c++) ok = ok && close_to(y[5 * M + c], gr_complex(1.0f, 0.0f), 1e-5f);
+    report("clPolyphaseChannelizer 64 ch, buf_items 65536", buf, t, ok);
+}
+
+static void test_xengine(int nant, int nchan, int ntime)
+{
+    auto xe = clXEngine::make(OCLTYPE_GPU, OCLDEVICESELECTOR_SPECIFIC, 0, g_dev, false, DTYPE_BYTE, 1, nant, CLXCORR_TRIANGULAR_ORDER, 0,
+                              nchan, ntime, {});
+    std::vector<char> x((size_t)xe->get_input_buffer_size() * 2);
+    for (size_t i = 0; i < x.size(); i += 2) { x[i] = 127; x[i + 1] = 0; }  // every sample (127,0) -> every visibility = T
+    std::vector<XComplex> v(xe->get_output_buffer_size());
+    int save = g_iter;
+    g_iter = std::max(1, g_iter / 10);
+    double t = time_calls([&] { xe->xcorrelate(x.data(), v.data()); });
+    g_iter = save;
+    bool ok = true;
+    for (size_t i = 0; i < v.size(); i += 997) ok = ok && std::fabs(v[i].real - ntime) < 1e-3f * ntime && v[i].imag == 0.0f;
+    char name[80];
+    snprintf(name, sizeof name, "clXEngine %d ant x %d ch x %d frames (IChar)", nant, nchan, ntime);
+    report(name, (size_t)nant * nchan * ntime, t, ok);
+}
+
+int main(int argc, char **argv)
+{
+    size_t n = 8192;  // the reference's default block size
+    int fft_size = 4096, ntaps = 65;
+    bool only_fft = false;
+    for (int i = 1; i < argc; i++) {
+        if (!strncmp(argv[i], "--device=", 9)) g_dev = atoi(argv[i] + 9);
+        else if (!strncmp(argv[i], "--iterations=", 13)) g_iter = atoi(argv[i] + 13);
+        else if (!strncmp(argv[i], "--fft-size=", 11)) fft_size = atoi(argv[i] + 11);
+        else if (!strncmp(argv[i], "--ntaps=", 8)) ntaps = atoi(argv[i] + 8);
+        else if (!strcmp(argv[i], "--fft-only")) only_fft = true;
+        else if (!strcmp(argv[i], "--help")) {
+            printf("usage: %s [--device=N] [--iterations=N] [--fft-size=N] [--ntaps=N] [--fft-only] [block size]\n", argv[0]);
+            return 0;
+        } else n = strtoull(argv[i], nullptr, 10);
+    }
+    try {
+        printf("test-clenabled-mi355: block size %zu, %d iterations, device %d (times include H2D + D2H)\n", n, g_iter, g_dev);
+        if (!only_fft) test_math(n);
+        test_fft(fft_size, std::max<size_t>(n, fft_size));
+        if (!only_fft) {
+            test_filter(ntaps, std::max<size_t>(n, 32768));
+            test_pfb();
+            test_xengine(16, 256, 256);
+        }
+    } catch (const std::exception &e) {
+        std::cerr << "error: " << e.what() << std::endl;
+        return 2;
+    }
+    return g_fail ? 1 : 0;
+}
