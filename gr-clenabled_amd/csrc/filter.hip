@@ -177,33 +177,34 @@ __global__ __launch_bounds__(kTdThreads) void k_fir_td(const c32 *__restrict__ i
             }
         }
         __syncthreads();
-        c32 acc[kTdU], win[2 * kTdU];
+        // (re, im) pairs as explicit 2-vectors -> v_pk_fma_f32: two FMAs per lane per instruction
+        f2v acc[kTdU], win[2 * kTdU];
+        const f2v *tl2 = (const f2v *)tile;
 #pragma unroll
         for (int u = 0; u < kTdU; u++) {
-            acc[u] = mk(0.f, 0.f);
-            win[u] = tile[u * S + tid];  // x[tid*8 + u]
+            acc[u] = (f2v){0.f, 0.f};
+            win[u] = tl2[u * S + tid];  // x[tid*8 + u]
         }
         for (int k0 = 0; k0 < kpad; k0 += kTdU) {
             const int row = tid + (k0 >> 3) + 1;
 #pragma unroll
-            for (int u = 0; u < kTdU; u++) win[kTdU + u] = tile[u * S + row];  // x[tid*8 + k0 + 8 + u]
+            for (int u = 0; u < kTdU; u++) win[kTdU + u] = tl2[u * S + row];  // x[tid*8 + k0 + 8 + u]
 #pragma unroll
             for (int i = 0; i < kTdU; i++) {
                 if constexpr (CTAPS) {
                     const float hr = taps_rev[2 * (k0 + i)], hi = taps_rev[2 * (k0 + i) + 1];  // uniform -> scalar loads
+                    const f2v hrr = {hr, hr}, hii = {-hi, hi};
 #pragma unroll
                     for (int u = 0; u < kTdU; u++) {
-                        const c32 x = win[i + u];
-                        acc[u].x += hr * x.x - hi * x.y;
-                        acc[u].y += hr * x.y + hi * x.x;
+                        const f2v x = win[i + u];
+                        acc[u] = __builtin_elementwise_fma(x, hrr, acc[u]);                    // (hr*x.x, hr*x.y)
+                        acc[u] = __builtin_elementwise_fma((f2v){x.y, x.x}, hii, acc[u]);       // (-hi*x.y, hi*x.x)
                     }
                 } else {
                     const float h = taps_rev[k0 + i];
+                    const f2v hh = {h, h};
 #pragma unroll
-                    for (int u = 0; u < kTdU; u++) {
-                        acc[u].x += h * win[i + u].x;
-                        acc[u].y += h * win[i + u].y;
-                    }
+                    for (int u = 0; u < kTdU; u++) acc[u] = __builtin_elementwise_fma(win[i + u], hh, acc[u]);
                 }
             }
 #pragma unroll
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(kTdThreads) void k_fir_td(const c32 *__restrict__ i
         const long long m0 = base + (long long)tid * kTdU;
 #pragma unroll
         for (int u = 0; u < kTdU; u++)
-            if (m0 + u < n_out) out[m0 + u] = acc[u];
+            if (m0 + u < n_out) out[m0 + u] = mk(acc[u].x, acc[u].y);
     }
 }
 

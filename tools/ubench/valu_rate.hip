@@ -1,0 +1,74 @@
+// Microbenchmark: issue rate of v_fma_f32 vs v_pk_fma_f32 vs v_pk_add_f32 vs v_mov_b32 (wave64, gfx950).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <int MODE> __global__ __launch_bounds__(256) void k(float *out, int iters)
+{
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, p4 = {a1, a0}, p5 = {a3, a2}, p6 = {a5, a4}, p7 = {a7, a6};
+    const float c = 1.0001f;
+    const f2 cc = {1.0001f, 0.9999f};
+    for (int i = 0; i < iters; i++) {
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                asm volatile("v_fma_f32 %0, %0, %1, %1\n v_fma_f32 %2, %2, %1, %1\n v_fma_f32 %3, %3, %1, %1\n v_fma_f32 %4, %4, %1, %1\n"
+                             "v_fma_f32 %5, %5, %1, %1\n v_fma_f32 %6, %6, %1, %1\n v_fma_f32 %7, %7, %1, %1\n v_fma_f32 %8, %8, %1, %1"
+                             : "+v"(a0) : "v"(c), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7));
+            }
+        } else if constexpr (MODE == 1) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %1\n v_pk_fma_f32 %2, %2, %1, %1\n v_pk_fma_f32 %3, %3, %1, %1\n v_pk_fma_f32 %4, %4, %1, %1\n"
+                             "v_pk_fma_f32 %5, %5, %1, %1\n v_pk_fma_f32 %6, %6, %1, %1\n v_pk_fma_f32 %7, %7, %1, %1\n v_pk_fma_f32 %8, %8, %1, %1"
+                             : "+v"(p0) : "v"(cc), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7));
+            }
+        } else if constexpr (MODE == 2) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                asm volatile("v_pk_add_f32 %0, %0, %1\n v_pk_add_f32 %2, %2, %1\n v_pk_add_f32 %3, %3, %1\n v_pk_add_f32 %4, %4, %1\n"
+                             "v_pk_add_f32 %5, %5, %1\n v_pk_add_f32 %6, %6, %1\n v_pk_add_f32 %7, %7, %1\n v_pk_add_f32 %8, %8, %1"
+                             : "+v"(p0) : "v"(cc), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7));
+            }
+        } else if constexpr (MODE == 3) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                asm volatile("v_add_f32 %0, %0, %1\n v_add_f32 %2, %2, %1\n v_add_f32 %3, %3, %1\n v_add_f32 %4, %4, %1\n"
+                             "v_add_f32 %5, %5, %1\n v_add_f32 %6, %6, %1\n v_add_f32 %7, %7, %1\n v_add_f32 %8, %8, %1"
+                             : "+v"(a0) : "v"(c), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7));
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                asm volatile("v_mov_b32 %0, %1\n v_mov_b32 %2, %1\n v_mov_b32 %3, %1\n v_mov_b32 %4, %1\n"
+                             "v_mov_b32 %5, %1\n v_mov_b32 %6, %1\n v_mov_b32 %7, %1\n v_mov_b32 %8, %1"
+                             : "+v"(a0) : "v"(c), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7));
+            }
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + p0.x + p1.y;
+}
+
+template <int MODE> void run(const char *name, float *out, int waves_per_simd)
+{
+    const int iters = 4096, grid = 256 * waves_per_simd;  // 256 threads = 1 wave per SIMD per block
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), 0, 0, out, iters);
+    (void)hipEventRecord(a);
+    hipLaunchKernelGGL(k<MODE>, dim3(grid), dim3(256), 0, 0, out, iters);
+    (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+    float ms; (void)hipEventElapsedTime(&ms, a, b);
+    double insts_per_simd = (double)iters * 64 * waves_per_simd;  // wave-instructions issued on each SIMD
+    printf("%-14s waves/SIMD=%d: %.2f ns per wave-instruction per SIMD (%.2f cycles @2.4GHz)\n", name, waves_per_simd,
+           ms * 1e6 / insts_per_simd, ms * 1e6 / insts_per_simd * 2.4);
+}
+
+int main()
+{
+    float *out; (void)hipMalloc(&out, 4 * 256 * 8 * 256);
+    for (int w : {1, 2, 4}) {
+        run<0>("v_fma_f32", out, w); run<1>("v_pk_fma_f32", out, w); run<2>("v_pk_add_f32", out, w); run<3>("v_add_f32", out, w); run<4>("v_mov_b32", out, w);
+    }
+    return 0;
+}
