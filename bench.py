@@ -129,7 +129,7 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank):
             d.update(extra(dt))
         return d
 
-    n = 1 << 25
+    n = 1 << 26  # 512 MiB per buffer: past the 256 MiB Infinity Cache
     a = torch.randn(n, 2, device="cuda")
     b = torch.randn(n, 2, device="cuda")
     c = torch.empty_like(a)
@@ -138,7 +138,7 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank):
     mc = pkg.clMathConst(pkg.DTYPE_COMPLEX, *args, 2.0, pkg.MATHOP_MULTIPLY)
     out["clMathConst_multiply_complex"] = rate(lambda: mc.work_device(n, [a], [c]), n, 16)
     del b
-    # BASELINE configs[2]: low-pass FFT filter, 65 taps, decim 1 (device-resident stream of 2^25 samples)
+    # BASELINE configs[2]: low-pass FFT filter, 65 taps, decim 1 (device-resident stream of 2^26 samples)
     taps65, taps2048 = o_taps
     nf = n - 64
     flt = pkg.clFilter(*args, 1, taps65, 1, 0, False)
@@ -150,7 +150,7 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank):
     cfl = pkg.clComplexFilter(*args, 1, ct, 1, 0, use_time=False)
     out["clComplexFilter_fft_65ctaps"] = rate(lambda: cfl.work_device(nf, [a], [c]), nf, 16)
     # BASELINE configs[3]: polyphase channelizer 64 ch x 32 taps/arm; streaming buffer and the 65536-item call
-    for buf, key in ((1 << 24, "clPolyphaseChannelizer_64x32_stream"), (65536, "clPolyphaseChannelizer_64x32_buf65536")):
+    for buf, key in ((1 << 26, "clPolyphaseChannelizer_64x32_stream"), (65536, "clPolyphaseChannelizer_64x32_buf65536")):
         pfb = pkg.clPolyphaseChannelizer(*args, taps2048, buf, 64, 64, list(range(64)))
         xi = a[:pfb.ninput()]
         yo = c[:pfb.noutput()]

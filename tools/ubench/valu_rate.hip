@@ -38,6 +38,41 @@ template <int MODE> __global__ __launch_bounds__(256) void k(float *out, int ite
                              "v_add_f32 %5, %5, %1\n v_add_f32 %6, %6, %1\n v_add_f32 %7, %7, %1\n v_add_f32 %8, %8, %1"
                              : "+v"(a0) : "v"(c), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7));
             }
+        } else if constexpr (MODE == 5) {  // v_pk_fma_f32 with three distinct 64-bit VGPR operands
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                asm volatile("v_pk_fma_f32 %0, %4, %5, %0\n v_pk_fma_f32 %1, %6, %5, %1\n v_pk_fma_f32 %2, %7, %5, %2\n v_pk_fma_f32 %3, %8, %5, %3\n"
+                             "v_pk_fma_f32 %0, %6, %5, %0\n v_pk_fma_f32 %1, %7, %5, %1\n v_pk_fma_f32 %2, %8, %5, %2\n v_pk_fma_f32 %3, %4, %5, %3"
+                             : "+v"(p0), "+v"(p2), "+v"(p4), "+v"(p6) : "v"(p1), "v"(cc), "v"(p3), "v"(p5), "v"(p7));
+            }
+        } else if constexpr (MODE == 6) {  // v_fma_f32 with three distinct VGPR operands
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                asm volatile("v_fma_f32 %0, %4, %5, %0\n v_fma_f32 %1, %6, %5, %1\n v_fma_f32 %2, %7, %5, %2\n v_fma_f32 %3, %8, %5, %3\n"
+                             "v_fma_f32 %0, %6, %5, %0\n v_fma_f32 %1, %7, %5, %1\n v_fma_f32 %2, %8, %5, %2\n v_fma_f32 %3, %4, %5, %3"
+                             : "+v"(a0), "+v"(a2), "+v"(a4), "+v"(a6) : "v"(a1), "v"(c), "v"(a3), "v"(a5), "v"(a7));
+            }
+        } else if constexpr (MODE == 7) {  // v_fmac_f32 (2-operand encoding, accumulator in place)
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                asm volatile("v_fmac_f32 %0, %4, %5\n v_fmac_f32 %1, %6, %5\n v_fmac_f32 %2, %7, %5\n v_fmac_f32 %3, %8, %5\n"
+                             "v_fmac_f32 %0, %6, %5\n v_fmac_f32 %1, %7, %5\n v_fmac_f32 %2, %8, %5\n v_fmac_f32 %3, %4, %5"
+                             : "+v"(a0), "+v"(a2), "+v"(a4), "+v"(a6) : "v"(a1), "v"(c), "v"(a3), "v"(a5), "v"(a7));
+            }
+        } else if constexpr (MODE == 8) {  // v_pk_mul_f32 distinct operands
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                asm volatile("v_pk_mul_f32 %0, %4, %5\n v_pk_mul_f32 %1, %6, %5\n v_pk_mul_f32 %2, %7, %5\n v_pk_mul_f32 %3, %8, %5\n"
+                             "v_pk_mul_f32 %0, %6, %5\n v_pk_mul_f32 %1, %7, %5\n v_pk_mul_f32 %2, %8, %5\n v_pk_mul_f32 %3, %4, %5"
+                             : "+v"(p0), "+v"(p2), "+v"(p4), "+v"(p6) : "v"(p1), "v"(cc), "v"(p3), "v"(p5), "v"(p7));
+            }
+        } else if constexpr (MODE == 9) {  // v_mul_f32 distinct
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                asm volatile("v_mul_f32 %0, %4, %5\n v_mul_f32 %1, %6, %5\n v_mul_f32 %2, %7, %5\n v_mul_f32 %3, %8, %5\n"
+                             "v_mul_f32 %0, %6, %5\n v_mul_f32 %1, %7, %5\n v_mul_f32 %2, %8, %5\n v_mul_f32 %3, %4, %5"
+                             : "+v"(a0), "+v"(a2), "+v"(a4), "+v"(a6) : "v"(a1), "v"(c), "v"(a3), "v"(a5), "v"(a7));
+            }
         } else {
 #pragma unroll
             for (int u = 0; u < 8; u++) {
@@ -69,6 +104,7 @@ int main()
     float *out; (void)hipMalloc(&out, 4 * 256 * 8 * 256);
     for (int w : {1, 2, 4}) {
         run<0>("v_fma_f32", out, w); run<1>("v_pk_fma_f32", out, w); run<2>("v_pk_add_f32", out, w); run<3>("v_add_f32", out, w); run<4>("v_mov_b32", out, w);
+        run<5>("pk_fma 3src", out, w); run<6>("fma 3src", out, w); run<7>("fmac", out, w); run<8>("pk_mul", out, w); run<9>("mul", out, w);
     }
     return 0;
 }
