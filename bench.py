@@ -36,24 +36,22 @@ def dist_setup(ngpus):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world != ngpus:
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: launch N>1 through torch.distributed.run" % (ngpus, world))
+    torch.cuda.set_device(local)
+    if "RANK" in os.environ:  # launched by torch.distributed.run (also with one rank, so that path is exercised)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    else:
-        torch.cuda.set_device(local)
-    if world != ngpus:
-        raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: launch N>1 through torch.distributed.run" % (ngpus, world))
     return rank, world, local
 
 
 def barrier(world):
     import torch
+    import torch.distributed as dist
     torch.cuda.synchronize()
-    if world > 1:
-        import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
 
@@ -150,8 +148,9 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank):
     cfl = pkg.clComplexFilter(*args, 1, ct, 1, 0, use_time=False)
     out["clComplexFilter_fft_65ctaps"] = rate(lambda: cfl.work_device(nf, [a], [c]), nf, 16)
     # BASELINE configs[3]: polyphase channelizer 64 ch x 32 taps/arm; streaming buffer and the 65536-item call
-    for buf, key in ((1 << 26, "clPolyphaseChannelizer_64x32_stream"), (65536, "clPolyphaseChannelizer_64x32_buf65536")):
+    for buf, key in (((1 << 26) - (1 << 16), "clPolyphaseChannelizer_64x32_stream"), (65536, "clPolyphaseChannelizer_64x32_buf65536")):
         pfb = pkg.clPolyphaseChannelizer(*args, taps2048, buf, 64, 64, list(range(64)))
+        assert pfb.ninput() <= a.shape[0] and pfb.noutput() <= c.shape[0]
         xi = a[:pfb.ninput()]
         yo = c[:pfb.noutput()]
         out[key] = rate(lambda: pfb.work_device([xi], [yo]), buf, 16)
@@ -268,8 +267,8 @@ def main():
             "blocks": extras,
         }
         print(json.dumps(line))
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 
