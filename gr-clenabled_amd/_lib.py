@@ -91,6 +91,9 @@ def lib():
         "mi355_xengine_xcorrelate": (i, [vp, vp, vp, i]),
         "mi355_xengine_xcorrelate_dev": (i, [vp, vp, vp, i, vp]),
         "mi355_xengine_gather": (i, [vp, i, i, pp, vp]),
+        "mi355_xengine_submit": (i, [vp, vp, vp]),
+        "mi355_xengine_wait": (i, [vp, vp]),
+        "mi355_xengine_pending": (i, [vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)  # AttributeError here = header/library mismatch: fail loudly

@@ -345,6 +345,24 @@ class clXEngine(_Block):
         check(self._L.mi355_xengine_xcorrelate(self._h, _hp(x), _hp(y), 1 if accumulate else 0), "mi355_xengine_xcorrelate")
         return self.get_output_buffer_size()
 
+    def submit(self, input_matrix, accumulator=None):
+        """Asynchronous xcorrelate: enqueue one integration (at most two in flight); the pinned
+        double buffers + worker thread of start()/runThread() (lib/clXEngine_impl.cc:304-382,1234-1299)."""
+        x = np.ascontiguousarray(input_matrix)
+        if x.nbytes < self.input_bytes():
+            raise ValueError("submit: input needs %d bytes" % self.input_bytes())
+        acc = None if accumulator is None else _hp(_host(accumulator, np.complex64))
+        check(self._L.mi355_xengine_submit(self._h, _hp(x), acc), "mi355_xengine_submit")
+
+    def wait(self, cross_correlation):
+        """Block for the oldest submitted integration and return its matrix."""
+        y = _host(cross_correlation, np.complex64, writable=True)
+        check(self._L.mi355_xengine_wait(self._h, _hp(y)), "mi355_xengine_wait")
+        return self.get_output_buffer_size()
+
+    def pending(self):
+        return self._L.mi355_xengine_pending(self._h)
+
     def xcorrelate_device(self, input_matrix, cross_correlation, accumulate=False):
         check(self._L.mi355_xengine_xcorrelate_dev(self._h, _dp(input_matrix), _dp(cross_correlation),
                                                    1 if accumulate else 0, _torch_stream(self.device)),

@@ -417,14 +417,22 @@ struct mi355_xengine {
     int data_type;
     XeGeo g;
     size_t in_bytes, out_items, tile_bytes;
-    unsigned char *d_tiles = nullptr;
-    void *d_in = nullptr, *d_out = nullptr;  // device staging of the host path
-    void *h_in = nullptr, *h_out = nullptr;  // pinned
+    unsigned char *d_tiles = nullptr;        // tile workspace of the device-pointer path and of slot 0
+    // Host path: two slots (pinned host + device buffers + tile workspace), slot s runs on ctx->stream[s].
+    // They replace the reference's pinned double buffers and worker thread (lib/clXEngine_impl.cc:304-382,
+    // 1234-1299): submit() returns once the integration is enqueued, wait() hands back the oldest result.
+    struct Slot {
+        void *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
+        unsigned char *d_tiles = nullptr;
+        hipEvent_t done = nullptr;
+        bool busy = false;
+    } slot[2];
+    int next_submit = 0, next_wait = 0, pending = 0;
 };
 
 namespace {
 
-int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipStream_t st)
+int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipStream_t st, unsigned char *tiles)
 {
     const XeGeo &g = h->g;
     if (h->data_type == MI355_DTYPE_COMPLEX) {
@@ -440,24 +448,24 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
                            !getenv("MI355_XE_SLOW_TURN");
     if (fast_turn) {
         dim3 tgrid((g.F * g.npol * 2) / 128, g.NT, g.KB * 4);
-        if (g.npol == 1) hipLaunchKernelGGL((k_xe_turn_lds<1>), tgrid, dim3(256), 0, st, (const uint4 *)in, h->d_tiles, g);
-        else hipLaunchKernelGGL((k_xe_turn_lds<2>), tgrid, dim3(256), 0, st, (const uint4 *)in, h->d_tiles, g);
+        if (g.npol == 1) hipLaunchKernelGGL((k_xe_turn_lds<1>), tgrid, dim3(256), 0, st, (const uint4 *)in, tiles, g);
+        else hipLaunchKernelGGL((k_xe_turn_lds<2>), tgrid, dim3(256), 0, st, (const uint4 *)in, tiles, g);
     } else {
         dim3 tgrid((units_per_row + 31) / 32, (g.N + 1) / 2, g.KB);
-        hipLaunchKernelGGL(k_xe_turn, tgrid, dim3(256), 0, st, (const unsigned *)in, h->d_tiles, g);
+        hipLaunchKernelGGL(k_xe_turn, tgrid, dim3(256), 0, st, (const unsigned *)in, tiles, g);
     }
     MI355_HIP(hipGetLastError());
     const int npairs = g.NT * (g.NT + 1) / 2;
     dim3 cgrid(g.F, (npairs + kPairsPerWG - 1) / kPairsPerWG);
     const double kd = (g.mode == 0) ? 0.007874015748031496063 : 0.142857142857142857143;  // :861, :835
     const bool lds_corr = !getenv("MI355_XE_NO_LDS");
-#define CORR_LDS(NTT) hipLaunchKernelGGL((k_xe_corr_lds<NTT>), cgrid, dim3(256), 0, st, (const unsigned char *)h->d_tiles, (c32 *)out, g, npairs, kd, accumulate)
+#define CORR_LDS(NTT) hipLaunchKernelGGL((k_xe_corr_lds<NTT>), cgrid, dim3(256), 0, st, (const unsigned char *)tiles, (c32 *)out, g, npairs, kd, accumulate)
     if (lds_corr && g.NT == 2) CORR_LDS(2);
     else if (lds_corr && g.NT == 4) CORR_LDS(4);
     else if (lds_corr && g.NT == 6) CORR_LDS(6);
     else if (lds_corr && g.NT == 8) CORR_LDS(8);
     else
-        hipLaunchKernelGGL(k_xe_corr, cgrid, dim3(256), 0, st, (const unsigned char *)h->d_tiles, (c32 *)out, g, npairs, kd, accumulate);
+        hipLaunchKernelGGL(k_xe_corr, cgrid, dim3(256), 0, st, (const unsigned char *)tiles, (c32 *)out, g, npairs, kd, accumulate);
 #undef CORR_LDS
     MI355_HIP(hipGetLastError());
     return MI355_OK;
@@ -470,10 +478,14 @@ extern "C" int mi355_xengine_destroy(mi355_xengine *h)
     if (!h) return MI355_OK;
     (void)hipSetDevice(h->ctx->device);
     if (h->d_tiles) (void)hipFree(h->d_tiles);
-    if (h->d_in) (void)hipFree(h->d_in);
-    if (h->d_out) (void)hipFree(h->d_out);
-    if (h->h_in) (void)hipHostFree(h->h_in);
-    if (h->h_out) (void)hipHostFree(h->h_out);
+    for (auto &sl : h->slot) {
+        if (sl.d_in) (void)hipFree(sl.d_in);
+        if (sl.d_out) (void)hipFree(sl.d_out);
+        if (sl.h_in) (void)hipHostFree(sl.h_in);
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
+        if (sl.d_tiles && sl.d_tiles != h->d_tiles) (void)hipFree(sl.d_tiles);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
     delete h;
     return MI355_OK;
 }
@@ -526,34 +538,93 @@ extern "C" int mi355_xengine_xcorrelate_dev(mi355_xengine *h, const void *in_dev
     MI355_REQUIRE((reinterpret_cast<uintptr_t>(in_dev) & 3u) == 0 && (reinterpret_cast<uintptr_t>(out_dev) & 7u) == 0,
                   "device buffers must be 4-byte (input) / 8-byte (output) aligned");
     MI355_HIP(hipSetDevice(h->ctx->device));
-    return launch_xe(h, in_dev, out_dev, accumulate, mi355_pick_stream(h->ctx, stream));
+    return launch_xe(h, in_dev, out_dev, accumulate, mi355_pick_stream(h->ctx, stream), h->d_tiles);
 }
 
+namespace {
+int slot_prepare(mi355_xengine *h, int s)
+{
+    mi355_xengine::Slot &sl = h->slot[s];
+    if (sl.d_in) return MI355_OK;
+    const size_t outb = h->out_items * 8;
+    MI355_HIP(hipMalloc(&sl.d_in, h->in_bytes));
+    MI355_HIP(hipMalloc(&sl.d_out, outb));
+    MI355_HIP(hipHostMalloc(&sl.h_in, h->in_bytes, hipHostMallocDefault));
+    MI355_HIP(hipHostMalloc(&sl.h_out, outb, hipHostMallocDefault));
+    MI355_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    if (s == 0 || h->tile_bytes == 0) sl.d_tiles = h->d_tiles;
+    else {
+        MI355_HIP(hipMalloc((void **)&sl.d_tiles, h->tile_bytes));
+        MI355_HIP(hipMemset(sl.d_tiles, 0, h->tile_bytes));  // padding rows stay zero
+    }
+    return MI355_OK;
+}
+}  // namespace
+
+// Enqueue one integration: copy into the slot's pinned buffer, H2D, kernels, D2H on the slot's stream.
+// At most two integrations are in flight; a third submit() is refused until wait() frees a slot.
+// accumulate != 0 adds into the slot's previous result only when used with one slot in flight
+// (pipeline integration keeps the accumulator on the host side of the block, like the reference).
+extern "C" int mi355_xengine_submit(mi355_xengine *h, const void *in_host, const void *acc_host)
+{
+    MI355_REQUIRE(h && in_host, "NULL argument");
+    std::lock_guard<std::mutex> g(h->ctx->lock);
+    MI355_HIP(hipSetDevice(h->ctx->device));
+    if (h->pending == 2) {
+        mi355_set_error("two integrations already in flight: call mi355_xengine_wait first");
+        return MI355_ERR_STATE;
+    }
+    const int s = h->next_submit;
+    int rc = slot_prepare(h, s);
+    if (rc) return rc;
+    mi355_xengine::Slot &sl = h->slot[s];
+    hipStream_t st = h->ctx->stream[s];
+    const size_t outb = h->out_items * 8;
+    memcpy(sl.h_in, in_host, h->in_bytes);
+    MI355_HIP(hipMemcpyAsync(sl.d_in, sl.h_in, h->in_bytes, hipMemcpyHostToDevice, st));
+    if (acc_host) {
+        memcpy(sl.h_out, acc_host, outb);
+        MI355_HIP(hipMemcpyAsync(sl.d_out, sl.h_out, outb, hipMemcpyHostToDevice, st));
+    }
+    rc = launch_xe(h, sl.d_in, sl.d_out, acc_host != nullptr, st, sl.d_tiles);
+    if (rc) return rc;
+    MI355_HIP(hipMemcpyAsync(sl.h_out, sl.d_out, outb, hipMemcpyDeviceToHost, st));
+    MI355_HIP(hipEventRecord(sl.done, st));
+    sl.busy = true;
+    h->next_submit ^= 1;
+    h->pending++;
+    return MI355_OK;
+}
+
+// Block until the OLDEST submitted integration is complete and copy its matrix to out_host.
+extern "C" int mi355_xengine_wait(mi355_xengine *h, void *out_host)
+{
+    MI355_REQUIRE(h && out_host, "NULL argument");
+    std::lock_guard<std::mutex> g(h->ctx->lock);
+    MI355_HIP(hipSetDevice(h->ctx->device));
+    if (h->pending == 0) {
+        mi355_set_error("nothing in flight");
+        return MI355_ERR_STATE;
+    }
+    mi355_xengine::Slot &sl = h->slot[h->next_wait];
+    MI355_HIP(hipEventSynchronize(sl.done));
+    memcpy(out_host, sl.h_out, h->out_items * 8);
+    sl.busy = false;
+    h->next_wait ^= 1;
+    h->pending--;
+    return MI355_OK;
+}
+
+extern "C" int mi355_xengine_pending(const mi355_xengine *h) { return h ? h->pending : MI355_ERR_INVALID_ARG; }
+
+// Synchronous form = the reference's xcorrelate() + blocking read-back (lib/clXEngine_impl.h:179-201, .cc:1257)
 extern "C" int mi355_xengine_xcorrelate(mi355_xengine *h, const void *in_host, void *out_host, int accumulate)
 {
     MI355_REQUIRE(h && in_host && out_host, "NULL argument");
-    std::lock_guard<std::mutex> g(h->ctx->lock);
-    MI355_HIP(hipSetDevice(h->ctx->device));
-    const size_t outb = h->out_items * 8;
-    if (!h->d_in) {
-        MI355_HIP(hipMalloc(&h->d_in, h->in_bytes));
-        MI355_HIP(hipMalloc(&h->d_out, outb));
-        MI355_HIP(hipHostMalloc(&h->h_in, h->in_bytes, hipHostMallocDefault));
-        MI355_HIP(hipHostMalloc(&h->h_out, outb, hipHostMallocDefault));
-    }
-    hipStream_t st = h->ctx->stream[0];
-    memcpy(h->h_in, in_host, h->in_bytes);
-    MI355_HIP(hipMemcpyAsync(h->d_in, h->h_in, h->in_bytes, hipMemcpyHostToDevice, st));
-    if (accumulate) {
-        memcpy(h->h_out, out_host, outb);
-        MI355_HIP(hipMemcpyAsync(h->d_out, h->h_out, outb, hipMemcpyHostToDevice, st));
-    }
-    int rc = launch_xe(h, h->d_in, h->d_out, accumulate, st);
+    MI355_REQUIRE(h->pending == 0, "asynchronous integrations are still in flight");
+    int rc = mi355_xengine_submit(h, in_host, accumulate ? out_host : nullptr);
     if (rc) return rc;
-    MI355_HIP(hipMemcpyAsync(h->h_out, h->d_out, outb, hipMemcpyDeviceToHost, st));
-    MI355_HIP(hipStreamSynchronize(st));
-    memcpy(out_host, h->h_out, outb);
-    return MI355_OK;
+    return mi355_xengine_wait(h, out_host);
 }
 
 // Host frame gather of work_processor, lib/clXEngine_impl.cc:987-1061 (plain memcpy loops on the

@@ -126,6 +126,10 @@ public:
     virtual long get_output_buffer_size() = 0;
     virtual void xcorrelate(XComplex *input_matrix, XComplex *cross_correlation) = 0;
     virtual void xcorrelate(char *input_matrix, XComplex *cross_correlation) = 0;
+    // asynchronous, double-buffered form (what start()/runThread() do with a worker thread in the
+    // reference, lib/clXEngine_impl.cc:304-382,1234-1299): at most two integrations in flight
+    virtual void submit(const void *input_matrix, const XComplex *accumulator = nullptr) = 0;
+    virtual void wait(XComplex *cross_correlation) = 0;
     // frames of every input stream -> the frame buffer, lib/clXEngine_impl.cc:987-1061
     virtual int gather_frames(int nframes, int frame0, gr_vector_const_void_star &input_items, void *frame_buffer) = 0;
 protected:

@@ -205,6 +205,8 @@ public:
     {
         chk(mi355_xengine_xcorrelate(d_h, in, out, d_pipeline_integration > 1), "mi355_xengine_xcorrelate");
     }
+    void submit(const void *in, const XComplex *acc) override { chk(mi355_xengine_submit(d_h, in, acc), "mi355_xengine_submit"); }
+    void wait(XComplex *out) override { chk(mi355_xengine_wait(d_h, out), "mi355_xengine_wait"); }
     int gather_frames(int nframes, int frame0, gr_vector_const_void_star &in, void *fb) override
     {
         chk(mi355_xengine_gather(d_h, nframes, frame0, in.data(), fb), "mi355_xengine_gather");

@@ -200,6 +200,14 @@ size_t mi355_xengine_output_items(const mi355_xengine *h);
 /* accumulate=0: out = V ; accumulate=1: out += V (pipeline integration) */
 int mi355_xengine_xcorrelate(mi355_xengine *h, const void *in_host, void *out_host, int accumulate);
 int mi355_xengine_xcorrelate_dev(mi355_xengine *h, const void *in_dev, void *out_dev, int accumulate, void *stream);
+/* Double-buffered asynchronous form of the host path: replaces the reference's pinned double
+ * buffers + worker thread (lib/clXEngine_impl.cc:304-382 start(), :1234-1299 runThread()).
+ * submit() copies the integration window into a pinned slot and enqueues H2D + kernels + D2H on that
+ * slot's stream (acc_host != NULL: out = acc + V, pipeline integration); at most two are in flight.
+ * wait() blocks for the OLDEST one and writes its matrix. */
+int mi355_xengine_submit(mi355_xengine *h, const void *in_host, const void *acc_host);
+int mi355_xengine_wait(mi355_xengine *h, void *out_host);
+int mi355_xengine_pending(const mi355_xengine *h);
 /* host gather: copy frames [0,nframes) of each input stream into time slots
  * frame0.. of a frame buffer laid out as the reference's pinned host buffer */
 int mi355_xengine_gather(const mi355_xengine *h, int nframes, int frame0, const void *const *inputs, void *frame_buffer);

@@ -157,3 +157,33 @@ def test_constructor_errors(gpu):
         _xe(gpu, gpu.DTYPE_BYTE, 1, 1, 16, 16)  # lib/clXEngine_impl.cc:106-109
     with pytest.raises(gpu.Mi355Error):
         _xe(gpu, gpu.DTYPE_BYTE, 3, 4, 16, 16)
+
+
+def test_async_double_buffered_submit_wait(gpu, oracle):
+    """submit()/wait(): two integrations in flight, results in order, equal to the synchronous path."""
+    N, F, T = 16, 32, 128
+    rng = np.random.default_rng(21)
+    xs = [rng.integers(-128, 128, size=T * N * F * 2, dtype=np.int64).astype(np.int8) for _ in range(5)]
+    refs = [oracle.xengine_ichar(N, F, 1, T, x, exact=True) for x in xs]
+    blk = _xe(gpu, gpu.DTYPE_BYTE, 1, N, F, T)
+    out = np.empty(blk.get_output_buffer_size(), np.complex64)
+    got = []
+    blk.submit(xs[0])
+    for i in range(1, 5):
+        blk.submit(xs[i])          # second one in flight while the first computes
+        assert blk.pending() == 2
+        with pytest.raises(gpu.Mi355Error):
+            blk.submit(xs[i])      # a third is refused, not queued silently
+        blk.wait(out)
+        got.append(out.copy())
+    blk.wait(out)
+    got.append(out.copy())
+    assert blk.pending() == 0
+    with pytest.raises(gpu.Mi355Error):
+        blk.wait(out)
+    for g, r in zip(got, refs):
+        assert np.array_equal(g, r)
+    acc = refs[0].copy()
+    blk.submit(xs[1], accumulator=acc)  # pipeline integration through the async path
+    blk.wait(out)
+    assert np.array_equal(out, refs[0] + refs[1])
