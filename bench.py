@@ -110,6 +110,38 @@ def cpu_baseline_fft(o, window, budget_s=12.0):
             "sample": "%d frames of %d-pt complex FFT (window+shift), oracle fft_block f32, %.1f s" % (reps * probe, FFT_N, dt)}
 
 
+def cpu_extras(o, o_taps):
+    """Oracle (port of the reference's CPU paths) on ONE host core, ~1-2 s each, for the secondary blocks."""
+    rng = np.random.default_rng(7)
+    out = {}
+
+    def timed(fn, nsamples, min_s=1.0):
+        fn()
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < min_s:
+            fn()
+            reps += 1
+        return round(reps * nsamples / (time.perf_counter() - t0) / 1e6, 2)
+
+    n = 1 << 20
+    a = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    out["clMathOp_multiply_complex"] = timed(lambda: o.mathop(o.DTYPE_COMPLEX, o.OP_MULTIPLY, a, a), n)   # clMathOp_impl::testCPU
+    out["clMathConst_multiply_complex"] = timed(lambda: o.mathconst(o.DTYPE_COMPLEX, o.OP_MULTIPLY, 2.0, a), n)
+    taps65, taps2048 = o_taps
+    m = 192 * 1024
+    f = o.FFTFilter(1, taps65)
+    out["clFilter_fft_65taps"] = timed(lambda: f.filter(m, a[:m]), m)                                       # fft_filter_ccf::filter
+    out["clFilter_fir_65taps"] = timed(lambda: o.fir_ccf(taps65, a[:m + 64], m), m)                         # fir_filter_ccf::filterN
+    ct = (taps65 * np.exp(1j * np.pi * np.arange(65) / 8)).astype(np.complex64)
+    out["clComplexFilter_fft_65ctaps"] = timed(lambda: o.fir_ccc(ct, a[:m + 64], m), m)                     # fir_filter_ccc (the reference has no FFT mode for complex taps)
+    buf = 65536
+    out["clPolyphaseChannelizer_64x32_stream"] = timed(lambda: o.pfb(taps2048, buf, 64, 64, list(range(64)), a[:buf + 2048 - 64]), buf)
+    N, F, T = 64, 2, 1024
+    x8 = rng.integers(-127, 128, size=T * N * F * 2, dtype=np.int64).astype(np.int8)
+    out["clXEngine_64ant_1024ch_1024t_ichar"] = timed(lambda: o.xengine_ichar(N, F, 1, T, x8, exact=False), N * F * T)  # kernel text restated
+    return out
+
+
 def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank):
     """Secondary lines: the other hot-path blocks, device resident, same timing method
     (per-GPU figures of this rank; the headline above carries the multi-GPU aggregate)."""
@@ -232,6 +264,11 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu:
         cpu = cpu_baseline_fft(entry.load_oracle(), window)
+        if extras:
+            taps_pair = (lowpass_taps(1.0, 10e6, 1e6, 372000.0), np.concatenate([lowpass_taps(1.0, 64.0, 0.5, 0.0753), [0.0]]).astype(np.float32))
+            for k, v in cpu_extras(entry.load_oracle(), taps_pair).items():
+                if k in extras:
+                    extras[k]["cpu_1core_MSamples_per_s"] = v
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "fft4096_pmc.json")) as fh:
