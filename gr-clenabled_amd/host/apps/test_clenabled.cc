@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <string>
 
 using namespace gr::clenabled;
 
@@ -128,6 +129,61 @@ static void test_xengine(int nant, int nchan, int ntime)
     report(name, (size_t)nant * nchan * ntime, t, ok);
 }
 
+// Streams frames through clXEngine::work_test() the way the scheduler would (ragged call sizes), with the file
+// sink + JSON sidecar + MB rollover (lib/clXEngine_impl.cc:393-465,1259-1277) and with the result handler that
+// stands for the "xcorr" PDU port.  Known answer: every sample (127,0) -> every visibility = T.
+static size_t g_handler_calls = 0;
+static bool g_handler_ok = true;
+static void on_matrix(void *user, const XComplex *m, size_t n)
+{
+    const int T = *(int *)user;
+    g_handler_calls++;
+    for (size_t i = 0; i < n; i += 13) g_handler_ok = g_handler_ok && std::fabs(m[i].real - T) < 1e-3f * T && m[i].imag == 0.0f;
+}
+
+static int xengine_stream_test(const std::string &dir)
+{
+    const int N = 8, F = 64, T = 16, nint = 60, chunk = 7;
+    std::vector<char> stream((size_t)nint * T * F * 2);
+    for (size_t i = 0; i < stream.size(); i += 2) { stream[i] = 127; stream[i + 1] = 0; }
+    auto run = [&](clXEngine::sptr xe, int frames_total) {
+        gr_vector_void_star out;
+        int done = 0;
+        while (done < frames_total) {
+            gr_vector_const_void_star in(N);
+            for (int a = 0; a < N; a++) in[a] = stream.data() + (size_t)done * F * 2;
+            int want = std::min(chunk, frames_total - done);
+            done += xe->work_test(want, in, out);  // may consume fewer than offered at a window boundary (:925-934)
+        }
+        xe->stop();
+    };
+    int T_user = T;
+    {   // PDU-style delivery
+        auto xe = clXEngine::make(OCLTYPE_GPU, OCLDEVICESELECTOR_SPECIFIC, 0, g_dev, false, DTYPE_BYTE, 1, N, CLXCORR_TRIANGULAR_ORDER, 0, F, T, {});
+        xe->set_result_handler(on_matrix, &T_user);
+        run(xe, nint * T + 5);  // 5 frames of an unfinished window are never delivered
+        bool ok = g_handler_calls == (size_t)nint && g_handler_ok && xe->integrations_delivered() == nint;
+        report("clXEngine work_test -> result handler (60 windows)", (size_t)nint * T * F * N, 1.0, ok);
+    }
+    {   // file sink with 1 MB rollover + JSON sidecars
+        auto xe = clXEngine::make(OCLTYPE_GPU, OCLDEVICESELECTOR_SPECIFIC, 0, g_dev, false, DTYPE_BYTE, 1, N, CLXCORR_TRIANGULAR_ORDER, 100, F, T,
+                                  {"a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7"}, true, dir + "/xcorr", 1, false, 1234567, "3C286", 1.4e9,
+                                  250e3);
+        run(xe, nint * T);
+        report("clXEngine work_test -> file sink, rollover 1 MB", (size_t)nint * T * F * N, 1.0, xe->integrations_delivered() == nint);
+    }
+    {   // pipeline integration: 3 device windows per delivered matrix -> values 3T
+        T_user = 3 * T;
+        g_handler_calls = 0;
+        auto xe = clXEngine::make(OCLTYPE_GPU, OCLDEVICESELECTOR_SPECIFIC, 0, g_dev, false, DTYPE_BYTE, 1, N, CLXCORR_TRIANGULAR_ORDER, 0, F, T, {},
+                                  false, "", 0, false, 0, "", 0.0, 0.0, false, 3);
+        xe->set_result_handler(on_matrix, &T_user);
+        run(xe, 9 * T);
+        report("clXEngine pipeline_integration=3 (9 windows -> 3)", (size_t)9 * T * F * N, 1.0, g_handler_calls == 3 && g_handler_ok);
+    }
+    return g_fail ? 1 : 0;
+}
+
 int main(int argc, char **argv)
 {
     size_t n = 8192;  // the reference's default block size
@@ -139,6 +195,10 @@ int main(int argc, char **argv)
         else if (!strncmp(argv[i], "--fft-size=", 11)) fft_size = atoi(argv[i] + 11);
         else if (!strncmp(argv[i], "--ntaps=", 8)) ntaps = atoi(argv[i] + 8);
         else if (!strcmp(argv[i], "--fft-only")) only_fft = true;
+        else if (!strncmp(argv[i], "--xengine-stream=", 17)) {
+            try { return xengine_stream_test(argv[i] + 17); }
+            catch (const std::exception &e) { std::cerr << "error: " << e.what() << std::endl; return 2; }
+        }
         else if (!strcmp(argv[i], "--help")) {
             printf("usage: %s [--device=N] [--iterations=N] [--fft-size=N] [--ntaps=N] [--fft-only] [block size]\n", argv[0]);
             return 0;

@@ -130,6 +130,15 @@ public:
     // reference, lib/clXEngine_impl.cc:304-382,1234-1299): at most two integrations in flight
     virtual void submit(const void *input_matrix, const XComplex *accumulator = nullptr) = 0;
     virtual void wait(XComplex *cross_correlation) = 0;
+    // work_test(): the scheduler-free entry the reference's CLI times (lib/clXEngine_impl.cc:1144-1150 ->
+    // work_processor :918-1142): gathers up to noutput_items frames of every input stream into the
+    // integration window; a full window is correlated asynchronously, and the PREVIOUS result is
+    // delivered (result handler = the "xcorr" PDU port in standalone mode; file sink + JSON sidecar).
+    virtual int work_test(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &output_items) = 0;
+    // stands for message_port_pub(pmt::mp("xcorr"), cons("triang_matrix", c32vector)) (:1076-1077)
+    typedef void (*result_handler_t)(void *user, const XComplex *matrix, size_t matrix_flat_length);
+    virtual void set_result_handler(result_handler_t fn, void *user) = 0;
+    virtual long integrations_delivered() const = 0;
     // frames of every input stream -> the frame buffer, lib/clXEngine_impl.cc:987-1061
     virtual int gather_frames(int nframes, int frame0, gr_vector_const_void_star &input_items, void *frame_buffer) = 0;
 protected:

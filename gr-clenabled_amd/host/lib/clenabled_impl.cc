@@ -4,6 +4,7 @@
 #include <clenabled/clenabled.h>
 #include <mi355_clenabled.h>
 
+#include <cstdio>
 #include <mutex>
 #include <stdexcept>
 
@@ -179,24 +180,156 @@ public:
 
 class clXEngine_impl : public clXEngine, public MI355Base {
     mi355_xengine *d_h = nullptr;
-    int d_pipeline_integration;
+    int d_npol, d_num_inputs, d_num_channels, d_integration, d_pipeline_integration, d_first_channel;
     long d_in_items;
+    size_t d_matrix_len, d_in_bytes;
+    // integration window being filled (the reference's pinned char_input/complex_input, :325-362)
+    std::vector<char> d_frames;
+    std::vector<XComplex> d_result, d_accum;
+    int d_tracker = 0, d_pipe_count = 0;
+    long d_delivered = 0, d_frame_counter = 0;
+    result_handler_t d_handler = nullptr;
+    void *d_handler_user = nullptr;
+    bool d_disable_output;
+    // file sink (lib/clXEngine_impl.cc:393-465)
+    bool d_output_file, d_rollover = false, d_wrote_json = false;
+    std::string d_file_base, d_filename, d_object_name, d_antenna_json;
+    size_t d_rollover_bytes = 0, d_bytes_written = 0;
+    int d_rollover_index = 1;
+    long d_sync_timestamp;
+    double d_start_freq, d_chan_width;
+    FILE *d_fp = nullptr;
+    std::mutex d_lock;
+
+    bool open_file()
+    {
+        d_wrote_json = false;
+        d_filename = d_file_base;
+        if (d_rollover) {  // "_001", "_002", ... (:406-413)
+            char idx[16];
+            snprintf(idx, sizeof idx, "_%03d", d_rollover_index++);
+            d_filename += idx;
+        }
+        if (d_fp) fclose(d_fp);
+        d_fp = fopen(d_filename.c_str(), "wb");
+        d_bytes_written = 0;
+        return d_fp != nullptr;
+    }
+    void write_json(long seq_num)
+    {
+        // same keys, order and formats as lib/clXEngine_impl.cc:438-465
+        FILE *f = fopen((d_filename + ".json").c_str(), "w");
+        if (!f) return;
+        const long integ_frames = d_pipeline_integration < 2 ? (long)d_integration : (long)d_integration * d_pipeline_integration;
+        const int nb = (d_num_inputs + 1) * d_num_inputs / 2;
+        fprintf(f,
+                "{\n\"sync_timestamp\":%ld,\n\"first_seq_num\":%ld,\n\"object_name\":\"%s\",\n\"num_baselines\":%d,\n"
+                "\"first_channel\":%d,\n\"first_channel_center_freq\":%f,\n\"channels\":%d,\n\"channel_width\":%f,\n"
+                "\"polarizations\":%d,\n\"antennas\":%d,\n\"antenna_names\":%s,\n\"ntime\":%ld,\n\"samples_per_block\":%ld,\n"
+                "\"bytes_per_block\":%ld,\n\"data_type\":\"cf32_le\",\n\"data_format\": \"triangular order\"\n}\n",
+                d_sync_timestamp, seq_num, d_object_name.c_str(), nb, d_first_channel, d_start_freq, d_num_channels, d_chan_width, d_npol,
+                d_num_inputs, d_antenna_json.c_str(), integ_frames, (long)d_matrix_len, (long)(d_matrix_len * sizeof(XComplex)));
+        fclose(f);
+        d_wrote_json = true;
+    }
+    void deliver(const XComplex *m, long first_frame)
+    {
+        d_delivered++;
+        if (d_disable_output) return;
+        if (d_fp) {
+            if (d_rollover && d_bytes_written >= d_rollover_bytes) open_file();  // :1264-1267
+            if (!d_wrote_json) write_json(first_frame);
+            if (fwrite(m, d_matrix_len * sizeof(XComplex), 1, d_fp) == 1) d_bytes_written += d_matrix_len * sizeof(XComplex);
+        } else if (d_handler) {
+            d_handler(d_handler_user, m, d_matrix_len);
+        }
+    }
+    void collect_one()
+    {
+        chk(mi355_xengine_wait(d_h, d_result.data()), "mi355_xengine_wait");
+        deliver(d_result.data(), d_pending_first.front());
+        d_pending_first.erase(d_pending_first.begin());
+    }
+    std::vector<long> d_pending_first;  // first frame number of each integration in flight
+
 public:
-    clXEngine_impl(int p, int s, int pl, int d, bool dbg, int data_type, int polarization, int num_inputs, int num_channels,
-                   int integration, int pipeline_integration)
-        : gr::block("clXEngine"), MI355Base(p, s, pl, d, dbg), d_pipeline_integration(pipeline_integration)
+    clXEngine_impl(int p, int s, int pl, int d, bool dbg, int data_type, int polarization, int num_inputs, int first_channel,
+                   int num_channels, int integration, const std::vector<std::string> &antennas, bool output_file,
+                   const std::string &file_base, int rollover_size_mb, long sync_timestamp, const std::string &object_name,
+                   double start_freq, double chan_width, bool disable_output, int pipeline_integration)
+        : gr::block("clXEngine"), MI355Base(p, s, pl, d, dbg), d_npol(data_type == DTYPE_PACKEDXY ? 2 : polarization),
+          d_num_inputs(num_inputs), d_num_channels(num_channels), d_integration(integration),
+          d_pipeline_integration(pipeline_integration), d_first_channel(first_channel), d_disable_output(disable_output),
+          d_output_file(output_file && !disable_output), d_file_base(file_base), d_object_name(object_name),
+          d_sync_timestamp(sync_timestamp), d_start_freq(start_freq), d_chan_width(chan_width)
     {
         if (num_inputs < 2)  // lib/clXEngine_impl.cc:106-109
             throw std::out_of_range("Please specify at least 2 inputs to correlate.");
         chk(mi355_xengine_create(d_ctx, data_type, polarization, num_inputs, num_channels, integration, &d_h), "mi355_xengine_create");
-        const int npol = data_type == DTYPE_PACKEDXY ? 2 : polarization;
-        d_in_items = (long)num_inputs * num_channels * npol * integration;
+        d_in_items = (long)num_inputs * num_channels * d_npol * integration;
+        d_in_bytes = mi355_xengine_input_bytes(d_h);
+        d_matrix_len = mi355_xengine_output_items(d_h);
+        d_frames.resize(d_in_bytes);
+        d_result.resize(d_matrix_len);
+        if (d_pipeline_integration > 1) d_accum.assign(d_matrix_len, XComplex());
+        d_antenna_json = "[";  // :141-165
+        if (antennas.size() > 1)
+            for (size_t i = 0; i < antennas.size(); i++) d_antenna_json += "\"" + antennas[i] + "\"" + (i + 1 < antennas.size() ? "," : "");
+        d_antenna_json += "]";
+        if (d_output_file) {
+            if (rollover_size_mb > 0) { d_rollover = true; d_rollover_bytes = (size_t)rollover_size_mb * 1000000; }  // :121-125
+            if (!open_file()) throw std::runtime_error("[X-Engine] can't open file: " + d_filename);                 // :130-137
+        }
     }
-    ~clXEngine_impl() override { mi355_xengine_destroy(d_h); }
+    ~clXEngine_impl() override
+    {
+        try { stop(); } catch (...) {}
+        mi355_xengine_destroy(d_h);
+    }
+    bool stop() override
+    {
+        std::lock_guard<std::mutex> g(d_lock);
+        while (mi355_xengine_pending(d_h) > 0) collect_one();
+        if (d_fp) { fclose(d_fp); d_fp = nullptr; }
+        return true;
+    }
     void forecast(int n, gr_vector_int &req) override { for (auto &r : req) r = n; }
-    int general_work(int, gr_vector_int &, gr_vector_const_void_star &, gr_vector_void_star &) override { return 0; }
+    int general_work(int n, gr_vector_int &, gr_vector_const_void_star &in, gr_vector_void_star &out) override
+    {
+        return work_test(n, in, out);  // + consume_each(items_processed) with a real scheduler (:1230)
+    }
+    int work_test(int noutput_items, gr_vector_const_void_star &in, gr_vector_void_star &) override
+    {
+        std::lock_guard<std::mutex> g(d_lock);
+        const int remaining = d_integration - d_tracker;
+        const int n = noutput_items > remaining ? remaining : noutput_items;  // :925-934
+        chk(mi355_xengine_gather(d_h, n, d_tracker, in.data(), d_frames.data()), "mi355_xengine_gather");
+        d_tracker += n;
+        d_frame_counter += n;
+        if (d_tracker == d_integration) {
+            const long first = d_frame_counter - d_integration;
+            if (d_pipeline_integration > 1) {
+                // device "+=" into the running matrix, read back every pipeline_integration windows (:785-796,1250-1285)
+                chk(mi355_xengine_xcorrelate(d_h, d_frames.data(), d_accum.data(), 1), "mi355_xengine_xcorrelate");
+                if (++d_pipe_count >= d_pipeline_integration) {
+                    deliver(d_accum.data(), first - (long)d_integration * (d_pipeline_integration - 1));
+                    d_accum.assign(d_matrix_len, XComplex());
+                    d_pipe_count = 0;
+                }
+            } else {
+                if (mi355_xengine_pending(d_h) == 2) collect_one();  // previous result goes out before the swap (:1070-1094)
+                chk(mi355_xengine_submit(d_h, d_frames.data(), nullptr), "mi355_xengine_submit");
+                d_pending_first.push_back(first);
+                if (mi355_xengine_pending(d_h) == 2) collect_one();  // keep one in flight: overlap with the next window's gather
+            }
+            d_tracker = 0;
+        }
+        return n;
+    }
+    void set_result_handler(result_handler_t fn, void *user) override { d_handler = fn; d_handler_user = user; }
+    long integrations_delivered() const override { return d_delivered; }
     long get_input_buffer_size() override { return d_in_items; }
-    long get_output_buffer_size() override { return (long)mi355_xengine_output_items(d_h); }
+    long get_output_buffer_size() override { return (long)d_matrix_len; }
     void xcorrelate(XComplex *in, XComplex *out) override
     {
         chk(mi355_xengine_xcorrelate(d_h, in, out, d_pipeline_integration > 1), "mi355_xengine_xcorrelate");
@@ -249,12 +382,17 @@ clPolyphaseChannelizer::sptr clPolyphaseChannelizer::make(int openCLPlatformType
                                                 ninputs_per_iter, ch_map, setDebug == 1));
 }
 clXEngine::sptr clXEngine::make(int openCLPlatformType, int devSelector, int platformId, int devId, bool setDebug, int data_type,
-                                int polarization, int num_inputs, int, int, int num_channels, int integration,
-                                std::vector<std::string>, bool, std::string, int, bool, long, std::string, double, double, bool,
+                                int polarization, int num_inputs, int /*output_format: the kernel always writes triangular
+                                order, lib/clXEngine_impl.cc:208-211*/, int first_channel, int num_channels, int integration,
+                                std::vector<std::string> antenna_list, bool output_file, std::string file_base, int rollover_size_mb,
+                                bool /*internal_synchronizer: ATA tag alignment needs the scheduler's tags*/, long sync_timestamp,
+                                std::string object_name, double starting_chan_center_freq, double channel_width, bool disable_output,
                                 int pipeline_integration)
 {
     return sptr(new clXEngine_impl(openCLPlatformType, devSelector, platformId, devId, setDebug, data_type, polarization, num_inputs,
-                                   num_channels, integration, pipeline_integration));
+                                   first_channel, num_channels, integration, antenna_list, output_file, file_base, rollover_size_mb,
+                                   sync_timestamp, object_name, starting_chan_center_freq, channel_width, disable_output,
+                                   pipeline_integration));
 }
 
 }  // namespace clenabled
