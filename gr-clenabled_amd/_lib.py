@@ -94,6 +94,11 @@ def lib():
         "mi355_xengine_submit": (i, [vp, vp, vp]),
         "mi355_xengine_wait": (i, [vp, vp]),
         "mi355_xengine_pending": (i, [vp]),
+        "mi355_elem_create": (i, [vp, i, f, f, pp]),
+        "mi355_elem_destroy": (i, [vp]),
+        "mi355_elem_history": (i, [vp]),
+        "mi355_elem_work": (i, [vp, sz, vp, vp, vp, vp]),
+        "mi355_elem_work_dev": (i, [vp, sz, vp, vp, vp, vp, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)  # AttributeError here = header/library mismatch: fail loudly

@@ -375,3 +375,87 @@ class clXEngine(_Block):
         p = (C.c_void_p * len(ins))(*[x.ctypes.data for x in ins])
         check(self._L.mi355_xengine_gather(self._h, int(nframes), int(frame0), p, _hp(frame_buffer)), "mi355_xengine_gather")
         return nframes
+
+
+class _Elem(_Block):
+    """Remaining elementwise family over mi355_elem_*."""
+    _destroy = "mi355_elem_destroy"
+    _kind = 0
+    _in = ()
+    _out = ()
+
+    def _create(self, p0=0.0, p1=0.0):
+        check(self._L.mi355_elem_create(self._ctx, self._kind, float(p0), float(p1), C.byref(self._h)), "mi355_elem_create")
+
+    def history(self):
+        return self._L.mi355_elem_history(self._h)
+
+    def work(self, noutput_items, input_items, output_items):
+        ins = [_host(x, t) for x, t in zip(input_items, self._in)]
+        need = noutput_items + self.history() - 1
+        if any(x.size < need for x in ins):
+            raise ValueError("work(): need %d input items (history included)" % need)
+        outs = [_host(y, t, writable=True) for y, t in zip(output_items, self._out)]
+        check(self._L.mi355_elem_work(self._h, noutput_items, _hp(ins[0]), _hp(ins[1]) if len(ins) > 1 else None,
+                                      _hp(outs[0]), _hp(outs[1]) if len(outs) > 1 else None), "mi355_elem_work")
+        return noutput_items
+
+    testOpenCL = work
+
+    def work_device(self, noutput_items, input_items, output_items):
+        i, o = input_items, output_items
+        check(self._L.mi355_elem_work_dev(self._h, noutput_items, _dp(i[0]), _dp(i[1]) if len(self._in) > 1 else None, _dp(o[0]),
+                                          _dp(o[1]) if len(self._out) > 1 else None, _torch_stream(self.device)), "mi355_elem_work_dev")
+        return noutput_items
+
+
+class clLog(_Elem):
+    """clLog::make(openCLPlatformType, devSelector, platformId, devId, nValue, kValue, setDebug=0) -- clLog.h:49"""
+    _kind, _in, _out = 1, (np.float32,), (np.float32,)
+
+    def __init__(self, openCLPlatformType, devSelector, platformId, devId, nValue, kValue, setDebug=0):
+        super().__init__(openCLPlatformType, devSelector, platformId, devId, setDebug)
+        self._create(nValue, kValue)
+
+
+class clSNR(_Elem):
+    """clSNR::make(openCLPlatformType, devSelector, platformId, devId, nValue, kValue, setDebug=0) -- clSNR.h:49"""
+    _kind, _in, _out = 2, (np.float32, np.float32), (np.float32,)
+
+    def __init__(self, openCLPlatformType, devSelector, platformId, devId, nValue, kValue, setDebug=0):
+        super().__init__(openCLPlatformType, devSelector, platformId, devId, setDebug)
+        self._create(nValue, kValue)
+
+
+class clComplexToMag(_Elem):
+    """clComplexToMag::make(openCLPlatformType, devSelector, platformId, devId, setDebug=0) -- clComplexToMag.h:49"""
+    _kind, _in, _out = 3, (np.complex64,), (np.float32,)
+
+    def __init__(self, openCLPlatformType, devSelector, platformId, devId, setDebug=0):
+        super().__init__(openCLPlatformType, devSelector, platformId, devId, setDebug)
+        self._create()
+
+
+class clComplexToArg(clComplexToMag):
+    """clComplexToArg::make(...) -- clComplexToArg.h:49"""
+    _kind = 4
+
+
+class clComplexToMagPhase(clComplexToMag):
+    """clComplexToMagPhase::make(...) -- clComplexToMagPhase.h:49; outputs (mag, phase)"""
+    _kind, _out = 5, (np.float32, np.float32)
+
+
+class clMagPhaseToComplex(clComplexToMag):
+    """clMagPhaseToComplex::make(...) -- clMagPhaseToComplex.h:49; inputs (mag, phase)"""
+    _kind, _in, _out = 6, (np.float32, np.float32), (np.complex64,)
+
+
+class clQuadratureDemod(_Elem):
+    """clQuadratureDemod::make(gain, openCLPlatformType, devSelector, platformId, devId, setDebug=0)
+    -- clQuadratureDemod.h:49; history 2 (lib/clQuadratureDemod_impl.cc:81)"""
+    _kind, _in, _out = 7, (np.complex64,), (np.float32,)
+
+    def __init__(self, gain, openCLPlatformType, devSelector, platformId, devId, setDebug=0):
+        super().__init__(openCLPlatformType, devSelector, platformId, devId, setDebug)
+        self._create(gain, 0.0)

@@ -78,6 +78,7 @@ typedef struct mi355_fft     mi355_fft;
 typedef struct mi355_filter  mi355_filter;
 typedef struct mi355_pfb     mi355_pfb;
 typedef struct mi355_xengine mi355_xengine;
+typedef struct mi355_elem    mi355_elem;
 
 /* ---------------------------------------------------------------------------
  * Runtime: replaces GRCLBase::InitOpenCL / cleanup (lib/GRCLBase.cpp:17-369,
@@ -211,6 +212,31 @@ int mi355_xengine_pending(const mi355_xengine *h);
 /* host gather: copy frames [0,nframes) of each input stream into time slots
  * frame0.. of a frame buffer laid out as the reference's pinned host buffer */
 int mi355_xengine_gather(const mi355_xengine *h, int nframes, int frame0, const void *const *inputs, void *frame_buffer);
+
+/* ---------------------------------------------------------------------------
+ * Remaining elementwise family.  One handle type; `kind` selects the block:
+ *   LOG10       float -> float            c = p0*log10(a) + p1            clLog   (lib/clLog_impl.cc:113-147)
+ *   SNR         float,float -> float      c = |p0*log10(a/b) + p1|        clSNR   (lib/clSNR_impl.cc:98-116)
+ *   C2MAG       complex -> float          sqrt(im^2+re^2)                 clComplexToMag (:138-148)
+ *   C2ARG       complex -> float          (float)atan2((double)im,(double)re)   clComplexToArg (:136-151)
+ *   C2MAGPHASE  complex -> float,float    both of the above               clComplexToMagPhase (:150-164)
+ *   MAGPHASE2C  float,float -> complex    (mag*cos ph, mag*sin ph) in double    clMagPhaseToComplex (:170-191)
+ *   QUADDEMOD   complex -> float          p0*atan2(a[i+1]*conj(a[i])) in double, input carries 1 item of
+ *                                         history (set_history(2))        clQuadratureDemod (:81,118-146)
+ * Unused in/out pointers are NULL.  n = output items.
+ * ------------------------------------------------------------------------- */
+#define MI355_ELEM_LOG10      1
+#define MI355_ELEM_SNR        2
+#define MI355_ELEM_C2MAG      3
+#define MI355_ELEM_C2ARG      4
+#define MI355_ELEM_C2MAGPHASE 5
+#define MI355_ELEM_MAGPHASE2C 6
+#define MI355_ELEM_QUADDEMOD  7
+int mi355_elem_create(mi355_ctx *ctx, int kind, float p0, float p1, mi355_elem **out);
+int mi355_elem_destroy(mi355_elem *h);
+int mi355_elem_history(const mi355_elem *h);
+int mi355_elem_work(mi355_elem *h, size_t n, const void *in0, const void *in1, void *out0, void *out1);
+int mi355_elem_work_dev(mi355_elem *h, size_t n, const void *in0, const void *in1, void *out0, void *out1, void *stream);
 
 #ifdef __cplusplus
 }

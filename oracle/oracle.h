@@ -93,6 +93,9 @@ int oracle_xengine_packed4(int ninputs, int nchan, int ntime, const uint8_t *in,
 int oracle_xengine_gather(int dtype, int ninputs, int nchan, int npol, int nframes, int frame0,
                           const void *const *inputs, void *frame_buffer);
 
+/* ---- remaining elementwise blocks; kind = MI355_ELEM_* code ---- */
+int oracle_elem(int kind, float p0, float p1, size_t n, const void *in0, const void *in1, void *out0, void *out1);
+
 #ifdef __cplusplus
 }
 #endif

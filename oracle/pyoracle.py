@@ -62,6 +62,7 @@ def lib():
         L.oracle_xengine_ichar.argtypes = [i, i, i, i, vp, vp, i, i]
         L.oracle_xengine_packed4.argtypes = [i, i, i, vp, vp, i]
         L.oracle_xengine_gather.argtypes = [i, i, i, i, i, i, vp, vp]
+        L.oracle_elem.argtypes = [i, f, f, sz, vp, vp, vp, vp]
         _LIB = L
     return _LIB
 
@@ -234,3 +235,21 @@ def xengine_gather(dtype, ninputs, nchan, npol, nframes, frame0, inputs, frame_b
     if rc:
         raise ValueError("oracle_xengine_gather rc=%d" % rc)
     return frame_buffer
+
+
+ELEM_LOG10, ELEM_SNR, ELEM_C2MAG, ELEM_C2ARG, ELEM_C2MAGPHASE, ELEM_MAGPHASE2C, ELEM_QUADDEMOD = range(1, 8)
+_ELEM_IO = {1: ((np.float32,), (np.float32,)), 2: ((np.float32, np.float32), (np.float32,)), 3: ((np.complex64,), (np.float32,)),
+            4: ((np.complex64,), (np.float32,)), 5: ((np.complex64,), (np.float32, np.float32)),
+            6: ((np.float32, np.float32), (np.complex64,)), 7: ((np.complex64,), (np.float32,))}
+
+
+def elem(kind, n, ins, p0=1.0, p1=0.0):
+    """Remaining elementwise blocks; returns a tuple of outputs. QUADDEMOD input carries 1 item of history."""
+    it, ot = _ELEM_IO[kind]
+    ins = [_c(x, t) for x, t in zip(ins, it)]
+    outs = [np.empty(n, t) for t in ot]
+    rc = lib().oracle_elem(kind, float(p0), float(p1), n, _p(ins[0]), _p(ins[1]) if len(ins) > 1 else None,
+                           _p(outs[0]), _p(outs[1]) if len(outs) > 1 else None)
+    if rc:
+        raise ValueError("oracle_elem rc=%d" % rc)
+    return tuple(outs)

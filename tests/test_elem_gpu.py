@@ -1,0 +1,69 @@
+"""Remaining elementwise family: oracle vs float64 formulas (CPU) and GPU parity."""
+import numpy as np
+import pytest
+
+from conftest import GPU_ARGS, crandn, relerr
+
+TOL = 1e-5
+
+
+def _cases(rng, n):
+    a = (np.abs(rng.standard_normal(n)) + 0.05).astype(np.float32)
+    b = (np.abs(rng.standard_normal(n)) + 0.05).astype(np.float32)
+    z = crandn(rng, n + 1)
+    ph = (rng.uniform(-10, 10, n)).astype(np.float32)
+    z64 = z.astype(np.complex128)
+    return {
+        1: ((a,), (2.5 * np.log10(a.astype(np.float64)) - 3.0,), (2.5, -3.0)),
+        2: ((a, b), (np.abs(10 * np.log10((a / b).astype(np.float64)) + 1.0),), (10.0, 1.0)),
+        3: ((z[:n],), (np.abs(z64[:n]),), (0, 0)),
+        4: ((z[:n],), (np.angle(z64[:n]),), (0, 0)),
+        5: ((z[:n],), (np.abs(z64[:n]), np.angle(z64[:n])), (0, 0)),
+        6: ((a, ph), (a.astype(np.float64) * np.exp(1j * ph.astype(np.float64)),), (0, 0)),
+        7: ((z,), (0.75 * np.angle(z64[1:] * np.conj(z64[:-1])),), (0.75, 0)),
+    }
+
+
+def test_oracle_matches_float64_formulas(oracle):
+    rng = np.random.default_rng(42)
+    n = 5001
+    for kind, (ins, refs, (p0, p1)) in _cases(rng, n).items():
+        outs = oracle.elem(kind, n, ins, p0, p1)
+        for o, r in zip(outs, refs):
+            assert relerr(o, r) < 2e-6, kind
+    # quadrature demod of a pure tone = gain * angular step (the FM discriminator identity)
+    w = 0.3
+    tone = np.exp(1j * w * np.arange(1000)).astype(np.complex64)
+    assert np.allclose(oracle.elem(oracle.ELEM_QUADDEMOD, 999, (tone,), 2.0)[0], 2.0 * w, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 63, 8192, 100001])
+def test_gpu_parity_all_kinds(gpu, oracle, n):
+    rng = np.random.default_rng(n)
+    mk = {1: lambda: gpu.clLog(*GPU_ARGS, 2.5, -3.0), 2: lambda: gpu.clSNR(*GPU_ARGS, 10.0, 1.0),
+          3: lambda: gpu.clComplexToMag(*GPU_ARGS), 4: lambda: gpu.clComplexToArg(*GPU_ARGS),
+          5: lambda: gpu.clComplexToMagPhase(*GPU_ARGS), 6: lambda: gpu.clMagPhaseToComplex(*GPU_ARGS),
+          7: lambda: gpu.clQuadratureDemod(0.75, *GPU_ARGS)}
+    for kind, (ins, refs, (p0, p1)) in _cases(rng, n).items():
+        blk = mk[kind]()
+        assert blk.history() == (2 if kind == 7 else 1)
+        outs = [np.empty(n, r.dtype if kind != 6 else np.complex64).astype(np.complex64 if kind == 6 else np.float32) for r in refs]
+        assert blk.work(n, list(ins), outs) == n
+        exp = oracle.elem(kind, n, ins, p0, p1)
+        for o, e, r in zip(outs, exp, refs):
+            assert relerr(o, e) <= TOL and relerr(o, r) <= TOL, kind
+
+
+@pytest.mark.gpu
+def test_gpu_device_path_and_errors(gpu):
+    import torch
+    n = 1 << 22
+    z = torch.randn(n, 2, device="cuda")
+    mag = torch.empty(n, device="cuda")
+    gpu.clComplexToMag(*GPU_ARGS).work_device(n, [z], [mag])
+    torch.cuda.synchronize()
+    assert torch.allclose(mag, torch.linalg.vector_norm(z, dim=1), rtol=1e-6, atol=1e-6)
+    blk = gpu.clQuadratureDemod(1.0, *GPU_ARGS)
+    with pytest.raises(ValueError):
+        blk.work(10, [np.zeros(10, np.complex64)], [np.empty(10, np.float32)])  # history item missing
