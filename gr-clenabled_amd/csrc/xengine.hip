@@ -152,15 +152,16 @@ __global__ __launch_bounds__(256) void k_xe_turn(const unsigned *__restrict__ in
 // padded so the transposed reads are conflict free).  Store phase: lanes run over the tile rows
 // first, so every store instruction writes 256 contiguous bytes (16 rows x 16 B) of each tile.
 // ------------------------------------------------------------------------------------
-template <int NPOL>
+template <int NPOL, bool PACKED>  // PACKED: 4-bit X,Y bytes (rows 2s, 2s+1), two channels per 4-byte unit
 __global__ __launch_bounds__(256) void k_xe_turn_lds(const uint4 *__restrict__ in, unsigned char *__restrict__ tiles, XeGeo g)
 {
+    static_assert(!PACKED || NPOL == 2, "packed input is dual polarisation");
     constexpr int SIN = kRowTile / NPOL;                 // stations per row tile
     constexpr int SSTRIDE = 2048 + (NPOL == 1 ? 8 : 16);  // bytes between stations in LDS (bank spread)
     __shared__ __attribute__((aligned(16))) unsigned char lds[SIN * SSTRIDE];
     const int line = blockIdx.x, rt = blockIdx.y, kb = blockIdx.z >> 2, kc = blockIdx.z & 3;
     const int tid = threadIdx.x;
-    const int lines_per_row = (g.F * NPOL * 2) / 128;
+    const int lines_per_row = PACKED ? (g.F * 2) / 128 : (g.F * NPOL * 2) / 128;
     const int t0 = kb * kKBlock + kc * 16;
     // ---- load: SIN stations x 16 t rows of 128 B; 8 lanes per row ----
 #pragma unroll
@@ -189,16 +190,32 @@ __global__ __launch_bounds__(256) void k_xe_turn_lds(const uint4 *__restrict__ i
 #pragma unroll
             for (int j = 0; j < 4; j++) col[j][q] = o[j];
         }
-        // bytes of a unit: a.I a.Q b.I b.Q ;  NPOL 1: a,b = channels 2U,2U+1 of row sl ; NPOL 2: a,b = rows 2sl,2sl+1 of channel U
         const int U = line * 32 + u;
+        if constexpr (PACKED) {
+            // bytes of a unit: (f0,X) (f0,Y) (f1,X) (f1,Y); byte = re nibble (high) | im nibble (low)
 #pragma unroll
-        for (int smp = 0; smp < 2; smp++) {
-            const int f = (NPOL == 1) ? 2 * U + smp : U;
-            const int rr = (NPOL == 1) ? sl : 2 * sl + smp;
+            for (int b = 0; b < 4; b++) {
+                const int f = 2 * U + (b >> 1), rr = 2 * sl + (b & 1);
+                unsigned re[4], im[4];
 #pragma unroll
-            for (int plane = 0; plane < 2; plane++) {
-                uint4 o = make_uint4(col[smp * 2 + plane][0], col[smp * 2 + plane][1], col[smp * 2 + plane][2], col[smp * 2 + plane][3]);
-                *(uint4 *)(tiles + tile_off(g, f, kb, plane, rt) + (size_t)(kc * 16 + rr) * 16) = o;
+                for (int q = 0; q < 4; q++) {
+                    re[q] = nib_to_i8x4((col[b][q] >> 4) & 0x0F0F0F0Fu);
+                    im[q] = nib_to_i8x4(col[b][q] & 0x0F0F0F0Fu);
+                }
+                *(uint4 *)(tiles + tile_off(g, f, kb, 0, rt) + (size_t)(kc * 16 + rr) * 16) = make_uint4(re[0], re[1], re[2], re[3]);
+                *(uint4 *)(tiles + tile_off(g, f, kb, 1, rt) + (size_t)(kc * 16 + rr) * 16) = make_uint4(im[0], im[1], im[2], im[3]);
+            }
+        } else {
+            // bytes of a unit: a.I a.Q b.I b.Q ;  NPOL 1: a,b = channels 2U,2U+1 of row sl ; NPOL 2: a,b = rows 2sl,2sl+1 of channel U
+#pragma unroll
+            for (int smp = 0; smp < 2; smp++) {
+                const int f = (NPOL == 1) ? 2 * U + smp : U;
+                const int rr = (NPOL == 1) ? sl : 2 * sl + smp;
+#pragma unroll
+                for (int plane = 0; plane < 2; plane++) {
+                    uint4 o = make_uint4(col[smp * 2 + plane][0], col[smp * 2 + plane][1], col[smp * 2 + plane][2], col[smp * 2 + plane][3]);
+                    *(uint4 *)(tiles + tile_off(g, f, kb, plane, rt) + (size_t)(kc * 16 + rr) * 16) = o;
+                }
             }
         }
     }
@@ -282,13 +299,14 @@ __global__ __launch_bounds__(256) void k_xe_corr(const unsigned char *__restrict
 // (2b) LDS-staged correlator: the workgroup stages each K block's tiles (2 planes x NT tiles) in LDS
 // once (coalesced 16 B per lane, register prefetch of the next K block) and the four waves read
 // their MFMA operands from LDS instead of each re-reading them through L1.
-template <int NTT>  // row tiles (compile time so the staging loops unroll); NTT <= 8
-__global__ __launch_bounds__(256) void k_xe_corr_lds(const unsigned char *__restrict__ tiles, c32 *__restrict__ out, XeGeo g,
-                                                     int npairs, double scale2, int accumulate)
+template <int NTT, int WAVES, int PPW>  // row tiles; waves per workgroup; tile pairs per wave (WAVES*PPW >= pairs => one WG per channel)
+__global__ __launch_bounds__(WAVES * 64) void k_xe_corr_lds(const unsigned char *__restrict__ tiles, c32 *__restrict__ out, XeGeo g,
+                                                            int npairs, double scale2, int accumulate)
 {
-    constexpr int KBYTES = 2 * NTT * kTileBytes;      // bytes per K block
-    constexpr int PER_THREAD = KBYTES / (256 * 16);    // dwordx4 loads per thread per K block (NTT/2, >= 1)
-    static_assert(KBYTES % (256 * 16) == 0, "tile bytes per K block must split over 256 threads");
+    constexpr int kPairsPerWave = PPW, kWaves = WAVES, kPairsPerWG = PPW * WAVES, NTHR = WAVES * 64;
+    constexpr int KBYTES = 2 * NTT * kTileBytes;        // bytes per K block
+    constexpr int PER_THREAD = KBYTES / (NTHR * 16);     // dwordx4 loads per thread per K block
+    static_assert(KBYTES % (NTHR * 16) == 0 && PER_THREAD >= 1, "tile bytes per K block must split over the workgroup");
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][KBYTES];
     const int f = blockIdx.x, chunk = blockIdx.y;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -307,15 +325,15 @@ __global__ __launch_bounds__(256) void k_xe_corr_lds(const unsigned char *__rest
     const unsigned char *src = tiles + (size_t)f * g.KB * KBYTES + (size_t)tid * 16;
     v4i stage[PER_THREAD];
 #pragma unroll
-    for (int i = 0; i < PER_THREAD; i++) stage[i] = __builtin_nontemporal_load((const v4i *)(src + (size_t)i * 4096));
+    for (int i = 0; i < PER_THREAD; i++) stage[i] = __builtin_nontemporal_load((const v4i *)(src + (size_t)i * NTHR * 16));
     for (int kb = 0; kb < g.KB; kb++) {
         unsigned char *buf = lds[kb & 1];
 #pragma unroll
-        for (int i = 0; i < PER_THREAD; i++) *(v4i *)(buf + tid * 16 + i * 4096) = stage[i];
+        for (int i = 0; i < PER_THREAD; i++) *(v4i *)(buf + tid * 16 + i * NTHR * 16) = stage[i];
         if (kb + 1 < g.KB) {
 #pragma unroll
             for (int i = 0; i < PER_THREAD; i++)
-                stage[i] = __builtin_nontemporal_load((const v4i *)(src + (size_t)(kb + 1) * KBYTES + (size_t)i * 4096));
+                stage[i] = __builtin_nontemporal_load((const v4i *)(src + (size_t)(kb + 1) * KBYTES + (size_t)i * NTHR * 16));
         }
         __syncthreads();  // one barrier per K block: the other buffer was last read before the previous barrier
         const unsigned char *pI = buf + lane * 16, *pQ = pI + NTT * kTileBytes;
@@ -444,12 +462,13 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
     }
     const int units_per_row = (g.mode == 0) ? (g.F * g.npol * 2) / 4 : (g.F * 2) / 4;
     // padding rows (A not a multiple of 16) were zeroed once at create and are never written
-    const bool fast_turn = g.mode == 0 && ((size_t)g.F * g.npol * 2) % 128 == 0 && (reinterpret_cast<uintptr_t>(in) & 15u) == 0 &&
-                           !getenv("MI355_XE_SLOW_TURN");
+    const size_t row_bytes = (g.mode == 0) ? (size_t)g.F * g.npol * 2 : (size_t)g.F * 2;
+    const bool fast_turn = row_bytes % 128 == 0 && (reinterpret_cast<uintptr_t>(in) & 15u) == 0 && !getenv("MI355_XE_SLOW_TURN");
     if (fast_turn) {
-        dim3 tgrid((g.F * g.npol * 2) / 128, g.NT, g.KB * 4);
-        if (g.npol == 1) hipLaunchKernelGGL((k_xe_turn_lds<1>), tgrid, dim3(256), 0, st, (const uint4 *)in, tiles, g);
-        else hipLaunchKernelGGL((k_xe_turn_lds<2>), tgrid, dim3(256), 0, st, (const uint4 *)in, tiles, g);
+        dim3 tgrid((unsigned)(row_bytes / 128), g.NT, g.KB * 4);
+        if (g.mode == 1) hipLaunchKernelGGL((k_xe_turn_lds<2, true>), tgrid, dim3(256), 0, st, (const uint4 *)in, tiles, g);
+        else if (g.npol == 1) hipLaunchKernelGGL((k_xe_turn_lds<1, false>), tgrid, dim3(256), 0, st, (const uint4 *)in, tiles, g);
+        else hipLaunchKernelGGL((k_xe_turn_lds<2, false>), tgrid, dim3(256), 0, st, (const uint4 *)in, tiles, g);
     } else {
         dim3 tgrid((units_per_row + 31) / 32, (g.N + 1) / 2, g.KB);
         hipLaunchKernelGGL(k_xe_turn, tgrid, dim3(256), 0, st, (const unsigned *)in, tiles, g);
@@ -459,11 +478,13 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
     dim3 cgrid(g.F, (npairs + kPairsPerWG - 1) / kPairsPerWG);
     const double kd = (g.mode == 0) ? 0.007874015748031496063 : 0.142857142857142857143;  // :861, :835
     const bool lds_corr = !getenv("MI355_XE_NO_LDS");
-#define CORR_LDS(NTT) hipLaunchKernelGGL((k_xe_corr_lds<NTT>), cgrid, dim3(256), 0, st, (const unsigned char *)tiles, (c32 *)out, g, npairs, kd, accumulate)
-    if (lds_corr && g.NT == 2) CORR_LDS(2);
-    else if (lds_corr && g.NT == 4) CORR_LDS(4);
-    else if (lds_corr && g.NT == 6) CORR_LDS(6);
-    else if (lds_corr && g.NT == 8) CORR_LDS(8);
+#define CORR_LDS(NTT, WV, PPW)                                                                                               \
+    hipLaunchKernelGGL((k_xe_corr_lds<NTT, WV, PPW>), dim3(g.F, (npairs + WV * PPW - 1) / (WV * PPW)), dim3(WV * 64), 0, st,    \
+                       (const unsigned char *)tiles, (c32 *)out, g, npairs, kd, accumulate)
+    if (lds_corr && g.NT == 2) CORR_LDS(2, 4, 1);        //  3 pairs
+    else if (lds_corr && g.NT == 4) CORR_LDS(4, 4, 3);   // 10 pairs
+    else if (lds_corr && g.NT == 6) CORR_LDS(6, 4, 6);   // 21 pairs
+    else if (lds_corr && g.NT == 8) CORR_LDS(8, 8, 5);   // 36 pairs: one workgroup per channel
     else
         hipLaunchKernelGGL(k_xe_corr, cgrid, dim3(256), 0, st, (const unsigned char *)tiles, (c32 *)out, g, npairs, kd, accumulate);
 #undef CORR_LDS
