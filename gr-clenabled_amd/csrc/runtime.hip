@@ -78,8 +78,13 @@ extern "C" int mi355_ctx_create(int ocl_type, int dev_selector, int platform_id,
     c->device = dev;
     c->debug = debug;
     c->num_cus = prop.multiProcessorCount;
-    MI355_HIP(hipSetDevice(dev));
-    for (int i = 0; i < 2; i++) MI355_HIP(hipStreamCreateWithFlags(&c->stream[i], hipStreamNonBlocking));
+    hipError_t e = hipSetDevice(dev);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipStreamCreateWithFlags(&c->stream[i], hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        mi355_set_error("creating the context's streams on device %d -> %s", dev, hipGetErrorString(e));
+        mi355_ctx_destroy(c);
+        return MI355_ERR_HIP;
+    }
     if (debug)
         fprintf(stderr, "[mi355] context on device %d (%s, %d CUs, %.1f GB)\n", dev, prop.gcnArchName, prop.multiProcessorCount,
                 prop.totalGlobalMem / 1e9);
