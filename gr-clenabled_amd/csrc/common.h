@@ -56,9 +56,9 @@ static inline hipStream_t mi355_pick_stream(mi355_ctx *, void *stream) { return 
 
 // Persistent-kernel grid: k workgroups per CU, k in [kmin, kmax] (all resident).  More resident
 // workgroups hide latency better, so kmax is the default; a smaller k is taken only when it divides
-// the work units more evenly by more than 8% (a ragged last round costs up to 1/rounds of the
-// run time).  MI355_WG_PER_CU overrides (tuning aid).
-static inline int mi355_balanced_grid(const mi355_ctx *ctx, long long units, int kmin, int kmax)
+// the work units more evenly by more than `tol` (a ragged last round costs up to 1/rounds of the
+// run time; latency-bound kernels pass a large tol, the bandwidth-bound FFT a small one).  MI355_WG_PER_CU overrides (tuning aid).
+static inline int mi355_balanced_grid(const mi355_ctx *ctx, long long units, int kmin, int kmax, double tol = 0.08)
 {
     const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
     if (const char *e = getenv("MI355_WG_PER_CU")) {
@@ -72,7 +72,7 @@ static inline int mi355_balanced_grid(const mi355_ctx *ctx, long long units, int
     };
     int best = kmax;
     for (int k = kmax - 1; k >= kmin; k--)
-        if (eff(k) > eff(best) + 0.08) best = k;
+        if (eff(k) > eff(best) + tol) best = k;
     return cus * best;
 }
 

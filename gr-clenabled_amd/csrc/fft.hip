@@ -142,7 +142,7 @@ int launch_n(mi355_ctx *ctx, int sign, const void *in, void *out, const float *w
     // plain variant at 3 workgroups/CU on MI355X, so it is off by default.
     static const bool pf = getenv("MI355_FFT_PREFETCH") ? atoi(getenv("MI355_FFT_PREFETCH")) != 0 : false;
     (void)cus;
-    int grid = (N <= 4096) ? mi355_balanced_grid(ctx, ngroups, 2, pf ? 2 : 3) : mi355_balanced_grid(ctx, ngroups, 1, 1);
+    int grid = (N <= 4096) ? mi355_balanced_grid(ctx, ngroups, 2, pf ? 2 : 3, 0.015) : mi355_balanced_grid(ctx, ngroups, 1, 1);
     if (const char *e = getenv("MI355_FFT_WG_PER_CU")) {
         if (atoi(e) > 0) grid = ngroups < cus * atoi(e) ? ngroups : cus * atoi(e);
     }
