@@ -200,8 +200,11 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank):
     alg_bytes = x8.numel() + vis.numel() * 4
 
     def xe_extra(dt):
+        # plus the reference tool's own figures of merit (lib/test-clxengine.cc:287-300): total input
+        # samples/s, per-stream rate, input bits/s
         return {"TFLOPs": round(flop / dt / 1e12, 1), "mfma_frac_i8_5POPS": round(flop / dt / 5e15, 4),
-                "hbm_frac_algorithmic": round(alg_bytes / dt / 1e9 / HBM_PEAK_GBS, 4), "channels_this_rank": Fw}
+                "hbm_frac_algorithmic": round(alg_bytes / dt / 1e9 / HBM_PEAK_GBS, 4), "channels_this_rank": Fw,
+                "per_stream_MSamples_per_s": round(Fw * T / dt / 1e6, 1), "input_Gbit_per_s": round(N * Fw * T * 16 / dt / 1e9, 1)}
 
     r = rate(lambda: xe.xcorrelate_device(x8, vis), N * Fw * T, 2, xe_extra)
     r.pop("hbm_frac", None)
