@@ -60,11 +60,12 @@ struct XeGeo {
     int N, F, npol, T;     // stations, channels, pols, integration frames
     int A, NT, KB;         // rows = N*npol, row tiles, K blocks of 64 time steps
     int mode;              // 0 = IChar, 1 = packed 4-bit
+    int f0, Fs;            // channel slab handled by this launch: [f0, f0 + Fs); the tile workspace holds one slab
 };
 
 __device__ __forceinline__ size_t tile_off(const XeGeo &g, int f, int kb, int plane, int rt)
 {
-    return ((((size_t)f * g.KB + kb) * 2 + plane) * g.NT + rt) * kTileBytes;
+    return ((((size_t)(f - g.f0) * g.KB + kb) * 2 + plane) * g.NT + rt) * kTileBytes;
 }
 
 // sign-extended 4-bit code with the reference's LUT quirk (code 8 -> 0), for 4 packed bytes
@@ -88,9 +89,10 @@ __global__ __launch_bounds__(256) void k_xe_turn(const unsigned *__restrict__ in
     const int sub = threadIdx.x >> 5;  // 0..7
     const int kc = sub & 3;
     const int units_per_row = (g.mode == 0) ? (g.F * g.npol * 2) / 4 : (g.F * 2) / 4;  // 4-byte units per (t, station)
-    const int u = blockIdx.x * 32 + lane_u;
+    const int upc = (g.mode == 0 && g.npol == 2) ? 1 : 2;  // channels per 4-byte unit
+    const int u = g.f0 / upc + blockIdx.x * 32 + lane_u;
     const int s = blockIdx.y * 2 + (sub >> 2), kb = blockIdx.z;
-    if (u >= units_per_row || s >= g.N) return;
+    if (u >= (g.f0 + g.Fs) / upc || u >= units_per_row || s >= g.N) return;
     const size_t row_units = (size_t)units_per_row;
     {
         unsigned w[16];
@@ -159,7 +161,8 @@ __global__ __launch_bounds__(256) void k_xe_turn_lds(const uint4 *__restrict__ i
     constexpr int SIN = kRowTile / NPOL;                 // stations per row tile
     constexpr int SSTRIDE = 2048 + (NPOL == 1 ? 8 : 16);  // bytes between stations in LDS (bank spread)
     __shared__ __attribute__((aligned(16))) unsigned char lds[SIN * SSTRIDE];
-    const int line = blockIdx.x, rt = blockIdx.y, kb = blockIdx.z >> 2, kc = blockIdx.z & 3;
+    const int cpl = PACKED ? 64 : 64 / NPOL;  // channels per 128-byte line
+    const int line = g.f0 / cpl + blockIdx.x, rt = blockIdx.y, kb = blockIdx.z >> 2, kc = blockIdx.z & 3;
     const int tid = threadIdx.x;
     const int lines_per_row = PACKED ? (g.F * 2) / 128 : (g.F * NPOL * 2) / 128;
     const int t0 = kb * kKBlock + kc * 16;
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(256) void k_xe_corr(const unsigned char *__restrict
 #pragma unroll
     for (int q = 0; q < kPairsPerWave; q++) re[q] = uu[q] = ww[q] = (v4i){0, 0, 0, 0};
 
-    const unsigned char *base = tiles + (size_t)f * g.KB * 2 * g.NT * kTileBytes + (size_t)lane * 16;
+    const unsigned char *base = tiles + (size_t)f * g.KB * 2 * g.NT * kTileBytes + (size_t)lane * 16;  // f = channel within the slab
     const size_t plane_stride = (size_t)g.NT * kTileBytes;
     for (int kb = 0; kb < g.KB; kb++) {
         const unsigned char *pI = base + (size_t)kb * 2 * plane_stride;
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(256) void k_xe_corr(const unsigned char *__restrict
             const int s1 = r1 / g.npol, p1 = r1 - s1 * g.npol, s2 = r2 / g.npol, p2 = r2 - s2 * g.npol;
             if (s1 < s2) continue;
             const int k = s1 * (s1 + 1) / 2 + s2;
-            const size_t o = ((size_t)f * nb + k) * np2 + p1 * g.npol + p2;
+            const size_t o = ((size_t)(f + g.f0) * nb + k) * np2 + p1 * g.npol + p2;
             // same expression as the oracle's exact path: (double)S * kd * kd, rounded once
             const double kd = scale2;  // 1/127 or 1/7
             c32 v;
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_xe_corr_lds(const unsigned char 
             const int s1 = r1 / g.npol, p1 = r1 - s1 * g.npol, s2 = r2 / g.npol, p2 = r2 - s2 * g.npol;
             if (s1 < s2) continue;
             const int k = s1 * (s1 + 1) / 2 + s2;
-            const size_t o = ((size_t)f * nb + k) * np2 + p1 * g.npol + p2;
+            const size_t o = ((size_t)(f + g.f0) * nb + k) * np2 + p1 * g.npol + p2;
             const double kd = scale2;
             c32 v;
             v.x = (float)((double)re[q][reg] * kd * kd);
@@ -435,6 +438,7 @@ struct mi355_xengine {
     int data_type;
     XeGeo g;
     size_t in_bytes, out_items, tile_bytes;
+    int nslab = 1, slab_channels = 0;  // channel slabs per integration; channels the tile workspace holds
     unsigned char *d_tiles = nullptr;        // tile workspace of the device-pointer path and of slot 0
     // Host path: two slots (pinned host + device buffers + tile workspace), slot s runs on ctx->stream[s].
     // They replace the reference's pinned double buffers and worker thread (lib/clXEngine_impl.cc:304-382,
@@ -460,34 +464,50 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
         MI355_HIP(hipGetLastError());
         return MI355_OK;
     }
-    const int units_per_row = (g.mode == 0) ? (g.F * g.npol * 2) / 4 : (g.F * 2) / 4;
-    // padding rows (A not a multiple of 16) were zeroed once at create and are never written
+    // The integration can be processed in channel slabs that reuse one tile workspace.  Measured on
+    // MI355X: slabs small enough for the Infinity Cache (4-8 per integration at config 5) are SLOWER
+    // than one pass (108-190 us vs 81 us: twice the launches at a fraction of the parallelism and no
+    // visible cache benefit), so slabs are only used to bound the workspace (4 GiB) for huge problems.
     const size_t row_bytes = (g.mode == 0) ? (size_t)g.F * g.npol * 2 : (size_t)g.F * 2;
     const bool fast_turn = row_bytes % 128 == 0 && (reinterpret_cast<uintptr_t>(in) & 15u) == 0 && !getenv("MI355_XE_SLOW_TURN");
-    if (fast_turn) {
-        dim3 tgrid((unsigned)(row_bytes / 128), g.NT, g.KB * 4);
-        if (g.mode == 1) hipLaunchKernelGGL((k_xe_turn_lds<2, true>), tgrid, dim3(256), 0, st, (const uint4 *)in, tiles, g);
-        else if (g.npol == 1) hipLaunchKernelGGL((k_xe_turn_lds<1, false>), tgrid, dim3(256), 0, st, (const uint4 *)in, tiles, g);
-        else hipLaunchKernelGGL((k_xe_turn_lds<2, false>), tgrid, dim3(256), 0, st, (const uint4 *)in, tiles, g);
-    } else {
-        dim3 tgrid((units_per_row + 31) / 32, (g.N + 1) / 2, g.KB);
-        hipLaunchKernelGGL(k_xe_turn, tgrid, dim3(256), 0, st, (const unsigned *)in, tiles, g);
-    }
-    MI355_HIP(hipGetLastError());
+    const int cpl = (g.mode == 1) ? 64 : 64 / g.npol;              // channels per 128-byte input line
+    const int align = fast_turn ? cpl : 2;                          // slab boundaries: whole lines / whole 4-byte units
+    int nslab = h->nslab;
+    if (const char *e = getenv("MI355_XE_SLABS")) nslab = atoi(e) > 0 ? atoi(e) : nslab;
+    int per = (g.F + nslab - 1) / nslab;
+    per = (per + align - 1) / align * align;
+    if (per > h->slab_channels) per = h->slab_channels / align * align;  // workspace capacity
     const int npairs = g.NT * (g.NT + 1) / 2;
-    dim3 cgrid(g.F, (npairs + kPairsPerWG - 1) / kPairsPerWG);
     const double kd = (g.mode == 0) ? 0.007874015748031496063 : 0.142857142857142857143;  // :861, :835
     const bool lds_corr = !getenv("MI355_XE_NO_LDS");
+    for (int f0 = 0; f0 < g.F; f0 += per) {
+        XeGeo gs = g;
+        gs.f0 = f0;
+        gs.Fs = (g.F - f0 < per) ? g.F - f0 : per;
+        if (fast_turn) {
+            dim3 tgrid((unsigned)(gs.Fs / cpl), g.NT, g.KB * 4);
+            if (g.mode == 1) hipLaunchKernelGGL((k_xe_turn_lds<2, true>), tgrid, dim3(256), 0, st, (const uint4 *)in, tiles, gs);
+            else if (g.npol == 1) hipLaunchKernelGGL((k_xe_turn_lds<1, false>), tgrid, dim3(256), 0, st, (const uint4 *)in, tiles, gs);
+            else hipLaunchKernelGGL((k_xe_turn_lds<2, false>), tgrid, dim3(256), 0, st, (const uint4 *)in, tiles, gs);
+        } else {
+            const int upc = (g.mode == 0 && g.npol == 2) ? 1 : 2;
+            dim3 tgrid((gs.Fs / upc + 31) / 32, (g.N + 1) / 2, g.KB);
+            hipLaunchKernelGGL(k_xe_turn, tgrid, dim3(256), 0, st, (const unsigned *)in, tiles, gs);
+        }
+        MI355_HIP(hipGetLastError());
 #define CORR_LDS(NTT, WV, PPW)                                                                                               \
-    hipLaunchKernelGGL((k_xe_corr_lds<NTT, WV, PPW>), dim3(g.F, (npairs + WV * PPW - 1) / (WV * PPW)), dim3(WV * 64), 0, st,    \
-                       (const unsigned char *)tiles, (c32 *)out, g, npairs, kd, accumulate)
-    if (lds_corr && g.NT == 2) CORR_LDS(2, 4, 1);        //  3 pairs
-    else if (lds_corr && g.NT == 4) CORR_LDS(4, 4, 3);   // 10 pairs
-    else if (lds_corr && g.NT == 6) CORR_LDS(6, 4, 6);   // 21 pairs
-    else if (lds_corr && g.NT == 8) CORR_LDS(8, 8, 5);   // 36 pairs: one workgroup per channel
-    else
-        hipLaunchKernelGGL(k_xe_corr, cgrid, dim3(256), 0, st, (const unsigned char *)tiles, (c32 *)out, g, npairs, kd, accumulate);
+    hipLaunchKernelGGL((k_xe_corr_lds<NTT, WV, PPW>), dim3(gs.Fs, (npairs + WV * PPW - 1) / (WV * PPW)), dim3(WV * 64), 0, st,  \
+                       (const unsigned char *)tiles, (c32 *)out, gs, npairs, kd, accumulate)
+        if (lds_corr && g.NT == 2) CORR_LDS(2, 4, 1);        //  3 pairs
+        else if (lds_corr && g.NT == 4) CORR_LDS(4, 4, 3);   // 10 pairs
+        else if (lds_corr && g.NT == 6) CORR_LDS(6, 4, 6);   // 21 pairs
+        else if (lds_corr && g.NT == 8) CORR_LDS(8, 8, 5);   // 36 pairs: one workgroup per channel
+        else
+            hipLaunchKernelGGL(k_xe_corr, dim3(gs.Fs, (npairs + kPairsPerWG - 1) / kPairsPerWG), dim3(256), 0, st,
+                               (const unsigned char *)tiles, (c32 *)out, gs, npairs, kd, accumulate);
 #undef CORR_LDS
+        MI355_HIP(hipGetLastError());
+    }
     MI355_HIP(hipGetLastError());
     return MI355_OK;
 }
@@ -538,7 +558,19 @@ extern "C" int mi355_xengine_create(mi355_ctx *ctx, int data_type, int npol, int
     const size_t items = (size_t)g.N * g.F * npol * g.T;
     h->in_bytes = items * mi355_dtype_size(data_type);  // frame_size_times_integration_bytes, :198
     h->out_items = (size_t)g.F * ((size_t)g.N * (g.N + 1) / 2) * npol * npol;
-    h->tile_bytes = (data_type == MI355_DTYPE_COMPLEX) ? 0 : (size_t)g.F * g.KB * 2 * g.NT * kTileBytes;
+    g.f0 = 0; g.Fs = g.F;
+    // slab size: bound the tile workspace to 4 GiB
+    {
+        const size_t per_chan = (size_t)g.KB * 2 * g.NT * kTileBytes;  // tile bytes per channel (>= input bytes per channel)
+        int nslab = (int)((per_chan * g.F + ((size_t)4 << 30) - 1) / ((size_t)4 << 30));
+        if (nslab < 1) nslab = 1;
+        int per = (g.F + nslab - 1) / nslab;
+        per = (per + 63) / 64 * 64;  // whole 128-byte input lines for every mode
+        if (per > g.F) per = (g.F + 63) / 64 * 64;
+        h->nslab = (g.F + per - 1) / per;
+        h->slab_channels = per;
+        h->tile_bytes = (data_type == MI355_DTYPE_COMPLEX) ? 0 : per_chan * per;
+    }
     if (hipSetDevice(ctx->device) != hipSuccess) { delete h; return MI355_ERR_HIP; }
     if (h->tile_bytes && hipMalloc((void **)&h->d_tiles, h->tile_bytes) != hipSuccess) {
         mi355_set_error("cannot allocate %zu bytes of tile workspace", h->tile_bytes);
