@@ -377,6 +377,131 @@ __global__ __launch_bounds__(WAVES * 64) void k_xe_corr_lds(const unsigned char 
 }
 
 // ------------------------------------------------------------------------------------
+// (3) complex-float input on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 fma chains at
+// the fp32 vector peak).  Same two-kernel structure as the int8 path with 16-time-step K blocks:
+//   tile = 16 rows x 16 t floats = 1 KiB; lane l holds row l%16, time steps 4*(l/16) .. +3 as one
+//   float4, i.e. the operands of the four consecutive MFMA steps of the K block.
+// ------------------------------------------------------------------------------------
+constexpr int kKB32 = 16;
+typedef float v4f __attribute__((ext_vector_type(4)));
+// row tiles are padded (with zero rows) up to a count the staged correlator is instantiated for; 0 = use the VALU kernel
+static inline int xe_f32_row_tiles(int nt) { return nt <= 2 ? nt : nt <= 4 ? 4 : nt <= 6 ? 6 : nt <= 8 ? 8 : 0; }
+
+template <int NPOL>
+__global__ __launch_bounds__(256) void k_xe_turn_f32(const v4i *__restrict__ in, unsigned char *__restrict__ tiles, XeGeo g)
+{
+    constexpr int SIN = kRowTile / NPOL;                  // stations per row tile
+    constexpr int SSTRIDE = 2048 + (NPOL == 1 ? 16 : 32);  // LDS bytes between stations: conflict-free b64 reads
+    __shared__ __attribute__((aligned(16))) unsigned char lds[SIN * SSTRIDE];
+    const int line = blockIdx.x, rt = blockIdx.y, kb = blockIdx.z;  // one 128-byte line = 16 complex floats
+    const int tid = threadIdx.x;
+    const int lines_per_row = (g.F * NPOL * 8) / 128;
+    const int t0 = kb * kKB32;
+#pragma unroll
+    for (int it = 0; it < (SIN * 16 * 8) / 256; it++) {
+        const int idx = tid + 256 * it, seg = idx & 7, row = idx >> 3, t = row & 15, sl = row >> 4;
+        const int s = rt * SIN + sl;
+        v4i v = (v4i){0, 0, 0, 0};
+        if (s < g.N && t0 + t < g.T) v = __builtin_nontemporal_load(in + (((size_t)(t0 + t) * g.N + s) * lines_per_row + line) * 8 + seg);
+        *(v4i *)(lds + sl * SSTRIDE + t * 128 + seg * 16) = v;
+    }
+    __syncthreads();
+    const size_t tile_stride = kTileBytes;  // [chan][kb][plane][rt]
+#pragma unroll
+    for (int it = 0; it < (SIN * 16 + 255) / 256; it++) {
+        const int item = tid + 256 * it;
+        if (item >= SIN * 16) break;
+        const int sl = item % SIN, c = item / SIN;  // c = complex value within the line
+        float re[16], im[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const float2 z = *(const float2 *)(lds + sl * SSTRIDE + t * 128 + c * 8);
+            re[t] = z.x;
+            im[t] = z.y;
+        }
+        const int f = (NPOL == 1) ? line * 16 + c : line * 8 + (c >> 1);
+        const int rr = (NPOL == 1) ? sl : 2 * sl + (c & 1);
+        unsigned char *tre = tiles + ((((size_t)f * g.KB + kb) * 2 + 0) * g.NT + rt) * tile_stride;
+        unsigned char *tim = tre + (size_t)g.NT * tile_stride;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            *(float4 *)(tre + (ks * 16 + rr) * 16) = make_float4(re[4 * ks], re[4 * ks + 1], re[4 * ks + 2], re[4 * ks + 3]);
+            *(float4 *)(tim + (ks * 16 + rr) * 16) = make_float4(im[4 * ks], im[4 * ks + 1], im[4 * ks + 2], im[4 * ks + 3]);
+        }
+    }
+}
+
+template <int NTT, int WAVES, int PPW>
+__global__ __launch_bounds__(WAVES * 64) void k_xe_corr_f32(const unsigned char *__restrict__ tiles, c32 *__restrict__ out, XeGeo g,
+                                                            int npairs, int accumulate)
+{
+    constexpr int NTHR = WAVES * 64, KBYTES = 2 * NTT * kTileBytes, PER_THREAD = KBYTES / (NTHR * 16);
+    static_assert(KBYTES % (NTHR * 16) == 0 && PER_THREAD >= 1, "tile bytes per K block must split over the workgroup");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][KBYTES];
+    const int f = blockIdx.x, chunk = blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int bi[PPW], bj[PPW];
+    bool live[PPW];
+#pragma unroll
+    for (int q = 0; q < PPW; q++) {
+        const int p = chunk * (PPW * WAVES) + q * WAVES + wave;
+        live[q] = p < npairs;
+        pair_to_tiles(live[q] ? p : 0, bi[q], bj[q]);
+    }
+    v4f re[PPW], uu[PPW], ww[PPW];
+#pragma unroll
+    for (int q = 0; q < PPW; q++) re[q] = uu[q] = ww[q] = (v4f){0.f, 0.f, 0.f, 0.f};
+    const unsigned char *src = tiles + (size_t)f * g.KB * KBYTES + (size_t)tid * 16;
+    v4i stage[PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; i++) stage[i] = __builtin_nontemporal_load((const v4i *)(src + (size_t)i * NTHR * 16));
+    for (int kb = 0; kb < g.KB; kb++) {
+        unsigned char *buf = lds[kb & 1];
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; i++) *(v4i *)(buf + tid * 16 + i * NTHR * 16) = stage[i];
+        if (kb + 1 < g.KB) {
+#pragma unroll
+            for (int i = 0; i < PER_THREAD; i++)
+                stage[i] = __builtin_nontemporal_load((const v4i *)(src + (size_t)(kb + 1) * KBYTES + (size_t)i * NTHR * 16));
+        }
+        __syncthreads();
+        const unsigned char *pI = buf + lane * 16, *pQ = pI + NTT * kTileBytes;
+#pragma unroll
+        for (int q = 0; q < PPW; q++) {
+            if (live[q]) {
+                const v4f Ia = *(const v4f *)(pI + bi[q] * kTileBytes), Qa = *(const v4f *)(pQ + bi[q] * kTileBytes);
+                const v4f Ib = *(const v4f *)(pI + bj[q] * kTileBytes), Qb = *(const v4f *)(pQ + bj[q] * kTileBytes);
+#pragma unroll
+                for (int kc = 0; kc < 4; kc++) {
+                    re[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ia[kc], Ib[kc], re[q], 0, 0, 0);
+                    re[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(Qa[kc], Qb[kc], re[q], 0, 0, 0);
+                    uu[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(Qa[kc], Ib[kc], uu[q], 0, 0, 0);
+                    ww[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ia[kc], Qb[kc], ww[q], 0, 0, 0);
+                }
+            }
+        }
+    }
+    const int nb = g.N * (g.N + 1) / 2, np2 = g.npol * g.npol;
+#pragma unroll
+    for (int q = 0; q < PPW; q++) {
+        if (!live[q]) continue;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int r1 = bi[q] * kRowTile + (lane >> 4) * 4 + reg, r2 = bj[q] * kRowTile + (lane & 15);
+            if (r1 >= g.A || r2 >= g.A) continue;
+            const int s1 = r1 / g.npol, p1 = r1 - s1 * g.npol, s2 = r2 / g.npol, p2 = r2 - s2 * g.npol;
+            if (s1 < s2) continue;
+            const size_t o = ((size_t)f * nb + (s1 * (s1 + 1) / 2 + s2)) * np2 + p1 * g.npol + p2;
+            c32 v;
+            v.x = re[q][reg];
+            v.y = uu[q][reg] - ww[q][reg];
+            if (accumulate) { v.x += out[o].x; v.y += out[o].y; }
+            out[o] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // complex-float input: fp32 arithmetic, 8x8 station blocks per thread, lanes along channels
 // ------------------------------------------------------------------------------------
 constexpr int kCfBlk = 4;  // rows per side of a thread's block
@@ -458,6 +583,29 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
 {
     const XeGeo &g = h->g;
     if (h->data_type == MI355_DTYPE_COMPLEX) {
+        const bool mfma = ((size_t)g.F * g.npol * 8) % 128 == 0 && (reinterpret_cast<uintptr_t>(in) & 15u) == 0 && tiles &&
+                          xe_f32_row_tiles(g.NT) != 0 && !getenv("MI355_XE_CF32_VALU");
+        if (mfma) {
+            XeGeo gf = g;
+            gf.KB = (g.T + kKB32 - 1) / kKB32;
+            gf.NT = xe_f32_row_tiles(g.NT);
+            dim3 tgrid((unsigned)(((size_t)g.F * g.npol * 8) / 128), gf.NT, gf.KB);
+            if (g.npol == 1) hipLaunchKernelGGL((k_xe_turn_f32<1>), tgrid, dim3(256), 0, st, (const v4i *)in, tiles, gf);
+            else hipLaunchKernelGGL((k_xe_turn_f32<2>), tgrid, dim3(256), 0, st, (const v4i *)in, tiles, gf);
+            MI355_HIP(hipGetLastError());
+            const int npairs = gf.NT * (gf.NT + 1) / 2;
+#define CORR_F32(NTT, WV, PPW)                                                                                             \
+    hipLaunchKernelGGL((k_xe_corr_f32<NTT, WV, PPW>), dim3(g.F, (npairs + WV * PPW - 1) / (WV * PPW)), dim3(WV * 64), 0, st, \
+                       (const unsigned char *)tiles, (c32 *)out, gf, npairs, accumulate)
+            if (gf.NT == 1) CORR_F32(1, 1, 1);
+            else if (gf.NT == 2) CORR_F32(2, 4, 1);
+            else if (gf.NT == 4) CORR_F32(4, 4, 3);
+            else if (gf.NT == 6) CORR_F32(6, 4, 6);
+            else CORR_F32(8, 8, 5);
+#undef CORR_F32
+            MI355_HIP(hipGetLastError());
+            return MI355_OK;
+        }
         const int nblk = (g.A + kCfBlk - 1) / kCfBlk;
         dim3 grid((g.F + 255) / 256, nblk * (nblk + 1) / 2);
         hipLaunchKernelGGL(k_xe_cf32, grid, dim3(256), 0, st, (const c32 *)in, (c32 *)out, g, nblk, accumulate);
@@ -569,7 +717,9 @@ extern "C" int mi355_xengine_create(mi355_ctx *ctx, int data_type, int npol, int
         if (per > g.F) per = (g.F + 63) / 64 * 64;
         h->nslab = (g.F + per - 1) / per;
         h->slab_channels = per;
-        h->tile_bytes = (data_type == MI355_DTYPE_COMPLEX) ? 0 : per_chan * per;
+        h->tile_bytes = per_chan * per;
+        if (data_type == MI355_DTYPE_COMPLEX)  // fp32 tiles: 16-time-step K blocks, whole problem in one pass
+            h->tile_bytes = (size_t)g.F * ((g.T + kKB32 - 1) / kKB32) * 2 * xe_f32_row_tiles(g.NT) * kTileBytes;
     }
     if (hipSetDevice(ctx->device) != hipSuccess) { delete h; return MI355_ERR_HIP; }
     if (h->tile_bytes && hipMalloc((void **)&h->d_tiles, h->tile_bytes) != hipSuccess) {

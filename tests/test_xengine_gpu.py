@@ -72,14 +72,19 @@ def test_closed_form_cases(gpu):
     assert np.allclose(out, T, atol=1e-3)
 
 
-@pytest.mark.parametrize("N,F,T,npol", [(4, 8, 16, 1), (9, 5, 33, 2), (16, 32, 64, 1)])
+# F*npol % 16 == 0 takes the fp32 matrix-core path (row tiles 1, 2, 3->4, 4, 5->6, 8); the others the VALU kernel
+@pytest.mark.parametrize("N,F,T,npol", [(4, 8, 16, 1), (9, 5, 33, 2), (16, 32, 64, 1), (16, 16, 64, 1), (20, 16, 50, 1),
+                                        (40, 32, 33, 1), (64, 16, 100, 1), (33, 8, 130, 2), (64, 8, 40, 2), (70, 16, 20, 2)])
 def test_complex_float_vs_oracle(gpu, oracle, N, F, T, npol):
     rng = np.random.default_rng(N + T)
     x = crandn(rng, T * N * F * npol)
     blk = _xe(gpu, gpu.DTYPE_COMPLEX, npol, N, F, T)
-    out = np.empty(blk.get_output_buffer_size(), np.complex64)
+    out = np.zeros(blk.get_output_buffer_size(), np.complex64)
     blk.xcorrelate(x, out)
-    assert relerr(out, oracle.xengine_cf32(N, F, npol, T, x)) <= TOL
+    ref = oracle.xengine_cf32(N, F, npol, T, x)
+    assert relerr(out, ref) <= TOL
+    blk.xcorrelate(x, out, accumulate=True)
+    assert relerr(out, ref + ref) <= TOL
 
 
 @pytest.mark.parametrize("N,F,T", [(2, 2, 3), (5, 6, 70), (16, 8, 64)])
