@@ -431,60 +431,77 @@ __global__ __launch_bounds__(256) void k_xe_turn_f32(const v4i *__restrict__ in,
     }
 }
 
+// One workgroup per channel; the NTT(NTT+1)/2 tile pairs are split EXACTLY over the waves (PPW each), so
+// there is no per-pair predicate in the K loop and the accumulators stay in AGPRs.
 template <int NTT, int WAVES, int PPW>
 __global__ __launch_bounds__(WAVES * 64) void k_xe_corr_f32(const unsigned char *__restrict__ tiles, c32 *__restrict__ out, XeGeo g,
                                                             int npairs, int accumulate)
 {
     constexpr int NTHR = WAVES * 64, KBYTES = 2 * NTT * kTileBytes, PER_THREAD = KBYTES / (NTHR * 16);
     static_assert(KBYTES % (NTHR * 16) == 0 && PER_THREAD >= 1, "tile bytes per K block must split over the workgroup");
+    static_assert(NTT * (NTT + 1) / 2 == WAVES * PPW, "tile pairs must split exactly over the waves");
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][KBYTES];
-    const int f = blockIdx.x, chunk = blockIdx.y;
+    const int f = blockIdx.x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int bi[PPW], bj[PPW];
-    bool live[PPW];
 #pragma unroll
-    for (int q = 0; q < PPW; q++) {
-        const int p = chunk * (PPW * WAVES) + q * WAVES + wave;
-        live[q] = p < npairs;
-        pair_to_tiles(live[q] ? p : 0, bi[q], bj[q]);
-    }
+    for (int q = 0; q < PPW; q++) pair_to_tiles(q * WAVES + wave, bi[q], bj[q]);
     v4f re[PPW], uu[PPW], ww[PPW];
 #pragma unroll
     for (int q = 0; q < PPW; q++) re[q] = uu[q] = ww[q] = (v4f){0.f, 0.f, 0.f, 0.f};
     const unsigned char *src = tiles + (size_t)f * g.KB * KBYTES + (size_t)tid * 16;
-    v4i stage[PER_THREAD];
+    // two register stages: the load for K block kb+2 is issued while block kb is multiplied (the HBM round
+    // trip under load is longer than one K block of MFMAs)
+    constexpr int DEPTH = (NTT <= 4) ? 2 : 1;  // larger triangles need the registers for their accumulators
+    v4i stage[DEPTH][PER_THREAD];
 #pragma unroll
-    for (int i = 0; i < PER_THREAD; i++) stage[i] = __builtin_nontemporal_load((const v4i *)(src + (size_t)i * NTHR * 16));
-    for (int kb = 0; kb < g.KB; kb++) {
+    for (int u = 0; u < DEPTH; u++)
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; i++)
+            stage[u][i] = (u < g.KB) ? __builtin_nontemporal_load((const v4i *)(src + (size_t)u * KBYTES + (size_t)i * NTHR * 16)) : (v4i){0, 0, 0, 0};
+    auto step = [&](int kb, v4i(&st)[PER_THREAD]) {
         unsigned char *buf = lds[kb & 1];
 #pragma unroll
-        for (int i = 0; i < PER_THREAD; i++) *(v4i *)(buf + tid * 16 + i * NTHR * 16) = stage[i];
-        if (kb + 1 < g.KB) {
+        for (int i = 0; i < PER_THREAD; i++) *(v4i *)(buf + tid * 16 + i * NTHR * 16) = st[i];
+        if (kb + DEPTH < g.KB) {
 #pragma unroll
             for (int i = 0; i < PER_THREAD; i++)
-                stage[i] = __builtin_nontemporal_load((const v4i *)(src + (size_t)(kb + 1) * KBYTES + (size_t)i * NTHR * 16));
+                st[i] = __builtin_nontemporal_load((const v4i *)(src + (size_t)(kb + DEPTH) * KBYTES + (size_t)i * NTHR * 16));
         }
         __syncthreads();
         const unsigned char *pI = buf + lane * 16, *pQ = pI + NTT * kTileBytes;
+        // operands of pair q+1 are read from LDS before the MFMAs of pair q are issued
+        v4f op[2][4];
+        auto fetch = [&](int q, v4f(&o)[4]) {
+            o[0] = *(const v4f *)(pI + bi[q] * kTileBytes);
+            o[1] = *(const v4f *)(pQ + bi[q] * kTileBytes);
+            o[2] = *(const v4f *)(pI + bj[q] * kTileBytes);
+            o[3] = *(const v4f *)(pQ + bj[q] * kTileBytes);
+        };
+        fetch(0, op[0]);
 #pragma unroll
         for (int q = 0; q < PPW; q++) {
-            if (live[q]) {
-                const v4f Ia = *(const v4f *)(pI + bi[q] * kTileBytes), Qa = *(const v4f *)(pQ + bi[q] * kTileBytes);
-                const v4f Ib = *(const v4f *)(pI + bj[q] * kTileBytes), Qb = *(const v4f *)(pQ + bj[q] * kTileBytes);
+            if (q + 1 < PPW) fetch(q + 1, op[(q + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the MFMAs (the scheduler sinks it otherwise)
+            const v4f(&o)[4] = op[q & 1];
 #pragma unroll
-                for (int kc = 0; kc < 4; kc++) {
-                    re[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ia[kc], Ib[kc], re[q], 0, 0, 0);
-                    re[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(Qa[kc], Qb[kc], re[q], 0, 0, 0);
-                    uu[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(Qa[kc], Ib[kc], uu[q], 0, 0, 0);
-                    ww[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ia[kc], Qb[kc], ww[q], 0, 0, 0);
-                }
+            for (int kc = 0; kc < 4; kc++) {
+                // dependent-accumulator latency is 40 cycles vs 32 issue: never two MFMAs into re[] back to back
+                re[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(o[0][kc], o[2][kc], re[q], 0, 0, 0);
+                uu[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(o[1][kc], o[2][kc], uu[q], 0, 0, 0);
+                re[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(o[1][kc], o[3][kc], re[q], 0, 0, 0);
+                ww[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(o[0][kc], o[3][kc], ww[q], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+    };
+    for (int kb = 0; kb < g.KB; kb += DEPTH) {
+        step(kb, stage[0]);
+        if (DEPTH == 2 && kb + 1 < g.KB) step(kb + 1, stage[DEPTH - 1]);
     }
     const int nb = g.N * (g.N + 1) / 2, np2 = g.npol * g.npol;
 #pragma unroll
     for (int q = 0; q < PPW; q++) {
-        if (!live[q]) continue;
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
             const int r1 = bi[q] * kRowTile + (lane >> 4) * 4 + reg, r2 = bj[q] * kRowTile + (lane & 15);
@@ -595,13 +612,13 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
             MI355_HIP(hipGetLastError());
             const int npairs = gf.NT * (gf.NT + 1) / 2;
 #define CORR_F32(NTT, WV, PPW)                                                                                             \
-    hipLaunchKernelGGL((k_xe_corr_f32<NTT, WV, PPW>), dim3(g.F, (npairs + WV * PPW - 1) / (WV * PPW)), dim3(WV * 64), 0, st, \
+    hipLaunchKernelGGL((k_xe_corr_f32<NTT, WV, PPW>), dim3(g.F), dim3(WV * 64), 0, st, \
                        (const unsigned char *)tiles, (c32 *)out, gf, npairs, accumulate)
             if (gf.NT == 1) CORR_F32(1, 1, 1);
-            else if (gf.NT == 2) CORR_F32(2, 4, 1);
-            else if (gf.NT == 4) CORR_F32(4, 4, 3);
-            else if (gf.NT == 6) CORR_F32(6, 4, 6);
-            else CORR_F32(8, 8, 5);
+            else if (gf.NT == 2) CORR_F32(2, 1, 3);
+            else if (gf.NT == 4) CORR_F32(4, 2, 5);
+            else if (gf.NT == 6) CORR_F32(6, 3, 7);
+            else CORR_F32(8, 4, 9);
 #undef CORR_F32
             MI355_HIP(hipGetLastError());
             return MI355_OK;
