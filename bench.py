@@ -186,6 +186,25 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank):
         xi = a[:pfb.ninput()]
         yo = c[:pfb.noutput()]
         out[key] = rate(lambda: pfb.work_device([xi], [yo]), buf, 16)
+    # frequency-domain cross-correlator, 4 time-series inputs of 1024-point vectors (reference + 3):
+    # algorithmic bytes per input sample = 8 read + 4 written per non-reference input
+    xn, xin = 1024, 4
+    xfr = (n // xin) // xn
+    xc = pkg.clxcorrelate_fft_vcf(xn, xin, *args, 2)
+    xi = [a[i * xfr * xn:(i + 1) * xfr * xn] for i in range(xin)]
+    xo = [c.view(-1)[i * xfr * xn:(i + 1) * xfr * xn] for i in range(xin - 1)]
+    out["clxcorrelate_fft_vcf_1024_4in_timeseries"] = rate(lambda: xc.work_device(xfr, xi, xo), xin * xfr * xn, (8 * xin + 4 * (xin - 1)) / xin)
+    # X-engine on complex-float input (fp32 matrix cores), same shape as configs[4]
+    Nc, Fc, Tc = 64, 1024, 1024
+    if a.shape[0] * 2 >= Tc * Nc * Fc * 2:
+        xf = a.view(-1)[:Tc * Nc * Fc * 2]
+        xec = pkg.clXEngine(*args, False, pkg.DTYPE_COMPLEX, 1, Nc, 1, 0, Fc, Tc, [])
+        visc = torch.zeros(xec.get_output_buffer_size(), 2, device="cuda")
+        flopc = 8.0 * Fc * (Nc * (Nc + 1) // 2) * Tc
+        rc = rate(lambda: xec.xcorrelate_device(xf, visc), Nc * Fc * Tc, 8,
+                  lambda dt: {"TFLOPs": round(flopc / dt / 1e12, 1), "mfma_frac_f32_157TF": round(flopc / dt / 157.3e12, 4)})
+        out["clXEngine_64ant_1024ch_1024t_cf32"] = rc
+        del xec, visc
     del a, c
     torch.cuda.empty_cache()
     # BASELINE configs[4]: X-engine 64 antennas x 1024 channels x 1024 frames, IChar.  Both fractions.

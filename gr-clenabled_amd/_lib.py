@@ -99,6 +99,10 @@ def lib():
         "mi355_elem_history": (i, [vp]),
         "mi355_elem_work": (i, [vp, sz, vp, vp, vp, vp]),
         "mi355_elem_work_dev": (i, [vp, sz, vp, vp, vp, vp, vp]),
+        "mi355_xcorr_fft_create": (i, [vp, i, i, i, pp]),
+        "mi355_xcorr_fft_destroy": (i, [vp]),
+        "mi355_xcorr_fft_work": (i, [vp, i, vp, vp]),
+        "mi355_xcorr_fft_work_dev": (i, [vp, i, vp, vp, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)  # AttributeError here = header/library mismatch: fail loudly

@@ -459,3 +459,38 @@ class clQuadratureDemod(_Elem):
     def __init__(self, gain, openCLPlatformType, devSelector, platformId, devId, setDebug=0):
         super().__init__(openCLPlatformType, devSelector, platformId, devId, setDebug)
         self._create(gain, 0.0)
+
+
+class clxcorrelate_fft_vcf(_Block):
+    """clxcorrelate_fft_vcf::make(fftSize, num_inputs, openCLPlatformType, devSelector, platformId, devId, input_type=1)
+    -- include/clenabled/clxcorrelate_fft_vcf.h:50.  Input 0 is the reference; output s-1 is the half-swapped magnitude of
+    the unscaled inverse FFT of X0 * conj(Xs) (lib/clxcorrelate_fft_vcf_impl.cc:1058-1143).  input_type 1 = the inputs
+    are spectra, 2 = time series (forward FFT first)."""
+    _destroy = "mi355_xcorr_fft_destroy"
+
+    def __init__(self, fftSize, num_inputs, openCLPlatformType, devSelector, platformId, devId, input_type=1):
+        super().__init__(openCLPlatformType, devSelector, platformId, devId, 0)
+        self.fft_size, self.num_inputs, self.input_type = int(fftSize), int(num_inputs), int(input_type)
+        check(self._L.mi355_xcorr_fft_create(self._ctx, self.fft_size, self.num_inputs, self.input_type, C.byref(self._h)),
+              "mi355_xcorr_fft_create")
+
+    def work(self, noutput_items, input_items, output_items):
+        if len(input_items) != self.num_inputs or len(output_items) != self.num_inputs - 1:
+            raise ValueError("work(): %d inputs and %d outputs expected" % (self.num_inputs, self.num_inputs - 1))
+        ins = [_host(x, np.complex64) for x in input_items]
+        outs = [_host(y, np.float32, writable=True) for y in output_items]
+        need = noutput_items * self.fft_size
+        if any(x.size < need for x in ins) or any(y.size < need for y in outs):
+            raise ValueError("work(): every buffer must hold noutput_items vectors of fft_size items")
+        ip = (C.c_void_p * len(ins))(*[_hp(x) for x in ins])
+        op = (C.c_void_p * len(outs))(*[_hp(y) for y in outs])
+        check(self._L.mi355_xcorr_fft_work(self._h, noutput_items, ip, op), "mi355_xcorr_fft_work")
+        return noutput_items
+
+    work_test = work
+
+    def work_device(self, noutput_items, input_items, output_items):
+        ip = (C.c_void_p * len(input_items))(*[_dp(x) for x in input_items])
+        op = (C.c_void_p * len(output_items))(*[_dp(y) for y in output_items])
+        check(self._L.mi355_xcorr_fft_work_dev(self._h, noutput_items, ip, op, _torch_stream(self.device)), "mi355_xcorr_fft_work_dev")
+        return noutput_items

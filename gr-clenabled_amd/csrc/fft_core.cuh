@@ -13,6 +13,7 @@ __device__ __forceinline__ c32 mk(float x, float y) { c32 r; r.x = x; r.y = y; r
 __device__ __forceinline__ c32 operator+(c32 a, c32 b) { return mk(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ c32 operator-(c32 a, c32 b) { return mk(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ c32 cmul(c32 a, c32 b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ c32 cconj(c32 a) { return mk(a.x, -a.y); }
 __device__ __forceinline__ c32 scale(c32 a, float s) { return mk(a.x * s, a.y * s); }
 // multiply by -i (forward) or +i (inverse): the W4^1 twiddle
 template <int SIGN> __device__ __forceinline__ c32 rot90(c32 a) { return SIGN < 0 ? mk(a.y, -a.x) : mk(-a.y, a.x); }

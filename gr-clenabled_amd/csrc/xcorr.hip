@@ -1,0 +1,283 @@
+// clxcorrelate_fft_vcf as ONE fused gfx950 kernel.
+// Reference behaviour: lib/clxcorrelate_fft_vcf_impl.cc:689-711 (make / ctor: io = num_inputs vectors of fftSize
+// complex in, num_inputs-1 vectors of fftSize float out; input_type 1 = spectra, 2 = time series), :886-910
+// (MultConj: b <- a * conj(b), a = reference input 0), :912-935 (ComplexToMag: sqrt(fma(re,re,im*im))), :1058-1143
+// (work: per frame and per signal s >= 1: [FFT both] -> ref * conj(sig) -> unscaled backward FFT (:731) -> magnitude
+// -> D2H, then the host swaps the two halves of every output vector, vlen_2 = fftSize/2, :1133-1140).
+// The reference enqueues 2-3 writes, up to 3 clFFT transforms, 2 kernels and a read PER FRAME PER SIGNAL.
+//
+// Here a workgroup owns 4096/N frames: the reference spectrum is produced once per frame group and kept in
+// registers; for every other signal the forward transform's registers are multiplied with it in place (the
+// reversed radix plan of the inverse consumes exactly the forward plan's output order -- same trick as the
+// overlap-save filter), inverse-transformed, and |.| is stored straight into the half-swapped position.
+// HBM traffic = the algorithmic minimum: every input sample read once (8 B), every output written once (4 B).
+#include <cmath>
+#include <cstdlib>
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+#include "fft_core.cuh"
+
+using namespace fftc;
+
+namespace {
+
+constexpr int kMaxInputs = 32;
+
+struct XcArgs {
+    const c32 *in[kMaxInputs];
+    float *out[kMaxInputs];  // out[s] belongs to input s (s >= 1)
+};
+
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+// load one group of frames in the input order of plan PL's first pass; frames >= nframes read as zero
+template <int N, class PL>
+__device__ __forceinline__ void load_frames(c32 (&v)[16], const c32 *__restrict__ src, int tid, int frames_left)
+{
+    constexpr int TH = Geo<N>::TH, R0 = PL::radix(0), B0 = N / R0;
+#pragma unroll
+    for (int q = 0; q < 16 / R0; q++) {
+        const int g = tid + TH * q, fr = g / B0, j = g % B0;
+        const bool ok = fr < frames_left;
+        const c32 *p = src + (ok ? fr * N + j : 0);
+#pragma unroll
+        for (int r = 0; r < R0; r++) {
+            const f2v x = __builtin_nontemporal_load((const f2v *)(p + r * B0));
+            v[q * R0 + r] = ok ? mk(x.x, x.y) : mk(0.f, 0.f);
+        }
+    }
+}
+
+template <int N, bool TIME>
+__global__ __launch_bounds__(Geo<N>::TH, Geo<N>::WPE) void k_xcorr(XcArgs a, const c32 *__restrict__ tw_fwd,
+                                                                  const c32 *__restrict__ tw_inv, int num_inputs, int nframes,
+                                                                  int ngroups)
+{
+    using PF = Plan<N, false>;
+    using PI = Plan<N, true>;
+    constexpr int TH = Geo<N>::TH, PTS = Geo<N>::PTS, F = Geo<N>::F, NP = PF::NP;
+    constexpr int RL = PF::radix(NP - 1);
+    static_assert(PI::radix(0) == RL, "inverse plan must start with the forward plan's last radix");
+    __shared__ c32 lds[NP > 1 ? PTS : 1];
+    const int tid0 = threadIdx.x;
+    TwRegs<N> twf, twi;
+    if constexpr (TIME) load_twiddles<N, false>(twf, tid0, tw_fwd);
+    load_twiddles<N, true>(twi, tid0, tw_inv);
+
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));  // keep address arithmetic inside the loop (see fft.hip)
+        const size_t base = (size_t)grp * PTS;
+        const int frames_left = nframes - grp * F;
+        // ---- reference spectrum, in the inverse plan's input order: R[q*RL + r] = X0[fr][j + r*BL] ----
+        c32 R[16];
+        if constexpr (TIME) {
+            c32 v[16];
+            load_frames<N, PF>(v, a.in[0] + base, tid, frames_left);
+            transform_regs<N, -1, false>(v, twf, lds, tid);
+#pragma unroll
+            for (int q = 0; q < 16 / RL; q++)
+#pragma unroll
+                for (int r = 0; r < RL; r++) R[q * RL + r] = v[q * RL + irev<RL>(r)];
+            if constexpr (NP > 1) __syncthreads();
+        } else {
+            load_frames<N, PI>(R, a.in[0] + base, tid, frames_left);
+        }
+        for (int s = 1; s < num_inputs; s++) {
+            c32 w[16];
+            if constexpr (TIME) {
+                c32 v[16];
+                load_frames<N, PF>(v, a.in[s] + base, tid, frames_left);
+                transform_regs<N, -1, false>(v, twf, lds, tid);
+#pragma unroll
+                for (int q = 0; q < 16 / RL; q++)
+#pragma unroll
+                    for (int r = 0; r < RL; r++) w[q * RL + r] = cmul(R[q * RL + r], cconj(v[q * RL + irev<RL>(r)]));
+                if constexpr (NP > 1) __syncthreads();  // the forward transform's LDS reads are done
+            } else {
+                load_frames<N, PI>(w, a.in[s] + base, tid, frames_left);
+#pragma unroll
+                for (int i = 0; i < 16; i++) w[i] = cmul(R[i], cconj(w[i]));
+            }
+            transform_regs<N, 1, true>(w, twi, lds, tid);
+            // ---- |.|, stored with the two halves of the vector swapped ----
+            constexpr int RO = PI::radix(NP - 1), BO = N / RO;
+            float *__restrict__ dst = a.out[s] + base;
+#pragma unroll
+            for (int q = 0; q < 16 / RO; q++) {
+                const int g = tid + TH * q, fr = g / BO, j = g % BO;
+                if (fr < frames_left) {
+#pragma unroll
+                    for (int t = 0; t < RO; t++) {
+                        const int n = j + orev<RO>(t) * BO;
+                        const c32 z = w[q * RO + t];
+                        __builtin_nontemporal_store(sqrtf(fmaf(z.x, z.x, z.y * z.y)), dst + fr * N + (n ^ (N / 2)));
+                    }
+                }
+            }
+            if constexpr (NP > 1) __syncthreads();
+        }
+    }
+}
+
+}  // namespace
+
+struct mi355_xcorr_fft {
+    mi355_ctx *ctx;
+    int n, num_inputs, time_series;
+    void *d_twf = nullptr, *d_twi = nullptr;
+    // device staging for the host-pointer path (grow only)
+    void *d_in = nullptr, *d_out = nullptr;
+    size_t cap_frames = 0;
+};
+
+namespace {
+
+template <int N> int launch_xcorr_n(mi355_xcorr_fft *h, const XcArgs &a, int nframes, hipStream_t st)
+{
+    constexpr int F = Geo<N>::F, TH = Geo<N>::TH;
+    const int ngroups = (nframes + F - 1) / F;
+    const int grid = mi355_balanced_grid(h->ctx, ngroups, 2, 3);
+    if (h->time_series)
+        hipLaunchKernelGGL((k_xcorr<N, true>), dim3(grid), dim3(TH), 0, st, a, (const c32 *)h->d_twf, (const c32 *)h->d_twi,
+                           h->num_inputs, nframes, ngroups);
+    else
+        hipLaunchKernelGGL((k_xcorr<N, false>), dim3(grid), dim3(TH), 0, st, a, (const c32 *)h->d_twf, (const c32 *)h->d_twi,
+                           h->num_inputs, nframes, ngroups);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+int launch_xcorr(mi355_xcorr_fft *h, const XcArgs &a, int nframes, hipStream_t st)
+{
+    switch (h->n) {
+    case 16: return launch_xcorr_n<16>(h, a, nframes, st);
+    case 32: return launch_xcorr_n<32>(h, a, nframes, st);
+    case 64: return launch_xcorr_n<64>(h, a, nframes, st);
+    case 128: return launch_xcorr_n<128>(h, a, nframes, st);
+    case 256: return launch_xcorr_n<256>(h, a, nframes, st);
+    case 512: return launch_xcorr_n<512>(h, a, nframes, st);
+    case 1024: return launch_xcorr_n<1024>(h, a, nframes, st);
+    case 2048: return launch_xcorr_n<2048>(h, a, nframes, st);
+    case 4096: return launch_xcorr_n<4096>(h, a, nframes, st);
+    }
+    mi355_set_error("internal: no cross-correlator kernel for FFT size %d", h->n);
+    return MI355_ERR_STATE;
+}
+
+}  // namespace
+
+extern "C" int mi355_xcorr_fft_create(mi355_ctx *ctx, int fft_size, int num_inputs, int input_type, mi355_xcorr_fft **out)
+{
+    MI355_REQUIRE(ctx && out, "NULL argument");
+    *out = nullptr;
+    MI355_REQUIRE(num_inputs >= 2, "the cross-correlator needs a reference input and at least one more (num_inputs >= 2)");
+    if (num_inputs > kMaxInputs) {
+        mi355_set_error("num_inputs %d exceeds the supported maximum of %d", num_inputs, kMaxInputs);
+        return MI355_ERR_UNSUPPORTED;
+    }
+    MI355_REQUIRE(input_type == 1 || input_type == 2, "input_type must be 1 (spectra) or 2 (time series)");
+    if (fft_size < 16 || fft_size > 4096 || (fft_size & (fft_size - 1))) {
+        mi355_set_error("cross-correlator FFT size %d not supported (power of two, 16..4096)", fft_size);
+        return MI355_ERR_UNSUPPORTED;
+    }
+    mi355_xcorr_fft *h = new (std::nothrow) mi355_xcorr_fft();
+    if (!h) return MI355_ERR_NOMEM;
+    h->ctx = ctx; h->n = fft_size; h->num_inputs = num_inputs; h->time_series = input_type == 2;
+    if (hipSetDevice(ctx->device) != hipSuccess) { delete h; mi355_set_error("hipSetDevice failed"); return MI355_ERR_HIP; }
+    const int n = fft_size;
+    std::vector<float> twf(2 * (size_t)n), twi(2 * (size_t)n);
+    for (int k = 0; k < n; k++) {
+        const double ang = -2.0 * M_PI * (double)k / (double)n;
+        twf[2 * k] = (float)cos(ang); twf[2 * k + 1] = (float)sin(ang);
+        twi[2 * k] = (float)cos(ang); twi[2 * k + 1] = (float)(-sin(ang));
+    }
+    const size_t bytes = 2 * (size_t)n * sizeof(float);
+    if (hipMalloc(&h->d_twf, bytes) != hipSuccess || hipMalloc(&h->d_twi, bytes) != hipSuccess ||
+        hipMemcpy(h->d_twf, twf.data(), bytes, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->d_twi, twi.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        if (h->d_twf) (void)hipFree(h->d_twf);
+        if (h->d_twi) (void)hipFree(h->d_twi);
+        delete h;
+        mi355_set_error("device allocation of the twiddle tables failed");
+        return MI355_ERR_NOMEM;
+    }
+    *out = h;
+    return MI355_OK;
+}
+
+extern "C" int mi355_xcorr_fft_destroy(mi355_xcorr_fft *h)
+{
+    if (!h) return MI355_OK;
+    (void)hipSetDevice(h->ctx->device);
+    if (h->d_twf) (void)hipFree(h->d_twf);
+    if (h->d_twi) (void)hipFree(h->d_twi);
+    if (h->d_in) (void)hipFree(h->d_in);
+    if (h->d_out) (void)hipFree(h->d_out);
+    delete h;
+    return MI355_OK;
+}
+
+extern "C" int mi355_xcorr_fft_work_dev(mi355_xcorr_fft *h, int nframes, const void *const *d_inputs, void *const *d_outputs,
+                                        void *stream)
+{
+    MI355_REQUIRE(h != nullptr, "handle is NULL");
+    if (nframes <= 0) return MI355_OK;
+    MI355_REQUIRE(d_inputs && d_outputs, "NULL pointer arrays");
+    if ((long long)nframes * h->n > 0x7fffffffLL) { mi355_set_error("work() call too large"); return MI355_ERR_INVALID_ARG; }
+    XcArgs a{};
+    for (int s = 0; s < h->num_inputs; s++) {
+        MI355_REQUIRE(d_inputs[s] != nullptr, "NULL input buffer");
+        a.in[s] = (const c32 *)d_inputs[s];
+        if (s >= 1) {
+            MI355_REQUIRE(d_outputs[s - 1] != nullptr, "NULL output buffer");
+            a.out[s] = (float *)d_outputs[s - 1];
+        }
+    }
+    MI355_HIP(hipSetDevice(h->ctx->device));
+    return launch_xcorr(h, a, nframes, mi355_pick_stream(h->ctx, stream));
+}
+
+extern "C" int mi355_xcorr_fft_work(mi355_xcorr_fft *h, int nframes, const void *const *inputs, void *const *outputs)
+{
+    MI355_REQUIRE(h != nullptr, "handle is NULL");
+    if (nframes <= 0) return MI355_OK;
+    MI355_REQUIRE(inputs && outputs, "NULL pointer arrays");
+    std::lock_guard<std::mutex> g(h->ctx->lock);
+    MI355_HIP(hipSetDevice(h->ctx->device));
+    const size_t in_frame = 8 * (size_t)h->n, out_frame = 4 * (size_t)h->n;
+    // chunks of frames so the staging stays bounded (64 MiB of input per chunk at most)
+    size_t chunk = (64u << 20) / (in_frame * (size_t)h->num_inputs);
+    if (chunk < 1) chunk = 1;
+    if (chunk > (size_t)nframes) chunk = (size_t)nframes;
+    if (chunk > h->cap_frames) {
+        if (h->d_in) (void)hipFree(h->d_in);
+        if (h->d_out) (void)hipFree(h->d_out);
+        h->d_in = h->d_out = nullptr; h->cap_frames = 0;
+        MI355_HIP(hipMalloc(&h->d_in, chunk * in_frame * (size_t)h->num_inputs));
+        MI355_HIP(hipMalloc(&h->d_out, chunk * out_frame * (size_t)(h->num_inputs - 1)));
+        h->cap_frames = chunk;
+    }
+    hipStream_t st = h->ctx->stream[0];
+    for (size_t f0 = 0; f0 < (size_t)nframes; f0 += chunk) {
+        const size_t nf = (size_t)nframes - f0 < chunk ? (size_t)nframes - f0 : chunk;
+        XcArgs a{};
+        for (int s = 0; s < h->num_inputs; s++) {
+            MI355_REQUIRE(inputs[s] != nullptr, "NULL input buffer");
+            char *d = (char *)h->d_in + (size_t)s * chunk * in_frame;
+            MI355_HIP(hipMemcpyAsync(d, (const char *)inputs[s] + f0 * in_frame, nf * in_frame, hipMemcpyHostToDevice, st));
+            a.in[s] = (const c32 *)d;
+            if (s >= 1) a.out[s] = (float *)((char *)h->d_out + (size_t)(s - 1) * chunk * out_frame);
+        }
+        int rc = launch_xcorr(h, a, (int)nf, st);
+        if (rc) return rc;
+        for (int s = 1; s < h->num_inputs; s++) {
+            MI355_REQUIRE(outputs[s - 1] != nullptr, "NULL output buffer");
+            MI355_HIP(hipMemcpyAsync((char *)outputs[s - 1] + f0 * out_frame, a.out[s], nf * out_frame, hipMemcpyDeviceToHost, st));
+        }
+        MI355_HIP(hipStreamSynchronize(st));
+    }
+    return MI355_OK;
+}

@@ -184,6 +184,83 @@ static int xengine_stream_test(const std::string &dir)
     return g_fail ? 1 : 0;
 }
 
+static void test_elem(size_t n)
+{
+    // known answers for the remaining elementwise family (kernels: lib/clLog_impl.cc:113-147, clSNR_impl.cc:98-116,
+    // clComplexToMag_impl.cc:138-148, clComplexToArg_impl.cc:136-151, clMagPhaseToComplex_impl.cc:170-191,
+    // clQuadratureDemod_impl.cc:118-146)
+    const int G = OCLTYPE_GPU, S = OCLDEVICESELECTOR_SPECIFIC;
+    std::vector<float> fa(n, 100.0f), fb(n, 10.0f), fo(n), fo2(n);
+    std::vector<gr_complex> ca(n + 1), co(n);
+    for (size_t i = 0; i <= n; i++) ca[i] = gr_complex(3.0f, 4.0f);
+    auto near = [](float a, float b) { return std::fabs(a - b) <= 1e-5f * std::max(1.0f, std::fabs(b)); };
+    {
+        gr_vector_const_void_star in = {fa.data()}; gr_vector_void_star out = {fo.data()};
+        auto b = clLog::make(G, S, 0, g_dev, 10.0f, 0.0f);
+        double t = time_calls([&] { b->testOpenCL((int)n, in, out); });
+        report("clLog 10*log10(100)", n, t, near(fo[0], 20.0f) && near(fo[n - 1], 20.0f));
+    }
+    {
+        gr_vector_const_void_star in = {fa.data(), fb.data()}; gr_vector_void_star out = {fo.data()};
+        auto b = clSNR::make(G, S, 0, g_dev, 10.0f, 0.0f);
+        double t = time_calls([&] { b->testOpenCL((int)n, in, out); });
+        report("clSNR |10*log10(100/10)|", n, t, near(fo[0], 10.0f) && near(fo[n - 1], 10.0f));
+    }
+    {
+        gr_vector_const_void_star in = {ca.data()}; gr_vector_void_star out = {fo.data()};
+        auto b = clComplexToMag::make(G, S, 0, g_dev);
+        double t = time_calls([&] { b->testOpenCL((int)n, in, out); });
+        report("clComplexToMag |(3,4)|", n, t, near(fo[0], 5.0f) && near(fo[n - 1], 5.0f));
+        auto a = clComplexToArg::make(G, S, 0, g_dev);
+        t = time_calls([&] { a->testOpenCL((int)n, in, out); });
+        report("clComplexToArg arg(3,4)", n, t, near(fo[0], atan2f(4.0f, 3.0f)) && near(fo[n - 1], atan2f(4.0f, 3.0f)));
+        gr_vector_void_star out2 = {fo.data(), fo2.data()};
+        auto mp = clComplexToMagPhase::make(G, S, 0, g_dev);
+        t = time_calls([&] { mp->testOpenCL((int)n, in, out2); });
+        report("clComplexToMagPhase (3,4)", n, t, near(fo[n - 1], 5.0f) && near(fo2[n - 1], atan2f(4.0f, 3.0f)));
+    }
+    {
+        std::vector<float> mag(n, 2.0f), ph(n, (float)M_PI_2);
+        gr_vector_const_void_star in = {mag.data(), ph.data()}; gr_vector_void_star out = {co.data()};
+        auto b = clMagPhaseToComplex::make(G, S, 0, g_dev);
+        double t = time_calls([&] { b->testOpenCL((int)n, in, out); });
+        report("clMagPhaseToComplex (2, pi/2)", n, t, close_to(co[0], gr_complex(0.0f, 2.0f), 1e-5f) && close_to(co[n - 1], gr_complex(0.0f, 2.0f), 1e-5f));
+    }
+    {
+        for (size_t i = 0; i <= n; i++) ca[i] = gr_complex((float)cos(0.1 * (double)i), (float)sin(0.1 * (double)i));
+        gr_vector_const_void_star in = {ca.data()}; gr_vector_void_star out = {fo.data()};
+        auto b = clQuadratureDemod::make(2.0f, G, S, 0, g_dev);  // history 2: n outputs read n+1 inputs
+        double t = time_calls([&] { b->testOpenCL((int)n, in, out); });
+        report("clQuadratureDemod gain 2, 0.1 rad/sample", n, t, std::fabs(fo[0] - 0.2f) < 1e-4f && std::fabs(fo[n - 1] - 0.2f) < 1e-4f && b->history() == 2);
+    }
+}
+
+static void test_xcorr(int fft_size, size_t n)
+{
+    // impulse at 0 against impulses delayed by d: |IFFT(X0 conj Xs)| = N at lag -d, which the half swap moves to N/2 - d
+    const int nframes = (int)std::max<size_t>(1, n / fft_size), d1 = 5, d2 = 100 % fft_size;
+    std::vector<gr_complex> x0((size_t)nframes * fft_size), x1(x0.size()), x2(x0.size());
+    std::vector<float> y1(x0.size()), y2(x0.size());
+    for (int f = 0; f < nframes; f++) {
+        x0[(size_t)f * fft_size] = 1.0f;
+        x1[(size_t)f * fft_size + d1] = 1.0f;
+        x2[(size_t)f * fft_size + d2] = 1.0f;
+    }
+    gr_vector_const_void_star in = {x0.data(), x1.data(), x2.data()};
+    gr_vector_void_star out = {y1.data(), y2.data()};
+    auto b = clxcorrelate_fft_vcf::make(fft_size, 3, OCLTYPE_GPU, OCLDEVICESELECTOR_SPECIFIC, 0, g_dev, 2);
+    double t = time_calls([&] { b->work_test(nframes, in, out); });
+    bool ok = true;
+    const size_t last = (size_t)(nframes - 1) * fft_size;
+    for (int k = 0; k < fft_size; k++) {
+        const float e1 = (k == fft_size / 2 - d1) ? (float)fft_size : 0.0f, e2 = (k == (fft_size / 2 - d2 + fft_size) % fft_size) ? (float)fft_size : 0.0f;
+        ok = ok && std::fabs(y1[last + k] - e1) < 1e-3f * fft_size && std::fabs(y2[k] - e2) < 1e-3f * fft_size;
+    }
+    char name[64];
+    snprintf(name, sizeof name, "clxcorrelate_fft_vcf N=%d, 3 inputs", fft_size);
+    report(name, (size_t)nframes * fft_size, t, ok);
+}
+
 int main(int argc, char **argv)
 {
     size_t n = 8192;  // the reference's default block size
@@ -212,6 +289,8 @@ int main(int argc, char **argv)
             test_filter(ntaps, std::max<size_t>(n, 32768));
             test_pfb();
             test_xengine(16, 256, 256);
+            test_elem(n);
+            test_xcorr(std::min(fft_size, 4096), std::max<size_t>(n, fft_size));
         }
     } catch (const std::exception &e) {
         std::cerr << "error: " << e.what() << std::endl;

@@ -145,5 +145,41 @@ protected:
     clXEngine() : gr::block("clXEngine") {}
 };
 
+// ---- remaining elementwise family; make() signatures of include/clenabled/cl<Name>.h:49 ----
+#define MI355_DECLARE_SYNC_BLOCK(NAME, ...)                                                                          \
+    class NAME : virtual public gr::sync_block {                                                                      \
+    public:                                                                                                           \
+        typedef std::shared_ptr<NAME> sptr;                                                                           \
+        static sptr make(__VA_ARGS__);                                                                                \
+        virtual int testOpenCL(int noutput_items, gr_vector_const_void_star &input_items,                            \
+                               gr_vector_void_star &output_items) = 0;                                                \
+    protected:                                                                                                        \
+        NAME() : gr::sync_block(#NAME) {}                                                                             \
+    }
+MI355_DECLARE_SYNC_BLOCK(clLog, int openCLPlatformType, int devSelector, int platformId, int devId, float nValue, float kValue,
+                         int setDebug = 0);
+MI355_DECLARE_SYNC_BLOCK(clSNR, int openCLPlatformType, int devSelector, int platformId, int devId, float nValue, float kValue,
+                         int setDebug = 0);
+MI355_DECLARE_SYNC_BLOCK(clComplexToMag, int openCLPlatformType, int devSelector, int platformId, int devId, int setDebug = 0);
+MI355_DECLARE_SYNC_BLOCK(clComplexToArg, int openCLPlatformType, int devSelector, int platformId, int devId, int setDebug = 0);
+MI355_DECLARE_SYNC_BLOCK(clComplexToMagPhase, int openCLPlatformType, int devSelector, int platformId, int devId, int setDebug = 0);
+MI355_DECLARE_SYNC_BLOCK(clMagPhaseToComplex, int openCLPlatformType, int devSelector, int platformId, int devId, int setDebug = 0);
+MI355_DECLARE_SYNC_BLOCK(clQuadratureDemod, float gain, int openCLPlatformType, int devSelector, int platformId, int devId,
+                         int setDebug = 0);
+#undef MI355_DECLARE_SYNC_BLOCK
+
+// ---- frequency-domain cross-correlator, include/clenabled/clxcorrelate_fft_vcf.h:50 ----
+// io: num_inputs vectors of fftSize complex in (input 0 = reference), num_inputs-1 vectors of fftSize float out
+class clxcorrelate_fft_vcf : virtual public gr::sync_block {
+public:
+    typedef std::shared_ptr<clxcorrelate_fft_vcf> sptr;
+    // input_type 1 = the inputs are spectra, 2 = time series (forward FFT first)
+    static sptr make(int fftSize, int num_inputs, int openCLPlatformType, int devSelector, int platformId, int devId,
+                     int input_type = 1);
+    virtual int work_test(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &output_items) = 0;
+protected:
+    clxcorrelate_fft_vcf() : gr::sync_block("clxcorrelate_fft_vcf") {}
+};
+
 }  // namespace clenabled
 }  // namespace gr

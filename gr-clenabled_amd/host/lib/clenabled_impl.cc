@@ -346,7 +346,82 @@ public:
         return nframes;
     }
 };
+
+// remaining elementwise family: one implementation over mi355_elem_* (kind selects the block)
+template <class Base>
+class elem_impl_t : public Base, public MI355Base {
+    mi355_elem *d_h = nullptr;
+    int d_nin, d_nout;
+public:
+    elem_impl_t(const char *name, int kind, int nin, int nout, float p0, float p1, int openCLPlatformType, int devSelector,
+                int platformId, int devId, bool setDebug)
+        : gr::sync_block(name), MI355Base(openCLPlatformType, devSelector, platformId, devId, setDebug), d_nin(nin), d_nout(nout)
+    {
+        chk(mi355_elem_create(d_ctx, kind, p0, p1, &d_h), "mi355_elem_create");
+        this->set_history((unsigned)mi355_elem_history(d_h));  // clQuadratureDemod: 2 (lib/clQuadratureDemod_impl.cc:81)
+    }
+    ~elem_impl_t() override { mi355_elem_destroy(d_h); }
+    int work(int noutput_items, gr_vector_const_void_star &in, gr_vector_void_star &out) override
+    {
+        chk(mi355_elem_work(d_h, (size_t)noutput_items, in[0], d_nin > 1 ? in[1] : nullptr, out[0], d_nout > 1 ? out[1] : nullptr),
+            "mi355_elem_work");
+        return noutput_items;
+    }
+    int testOpenCL(int noutput_items, gr_vector_const_void_star &in, gr_vector_void_star &out) override
+    {
+        return work(noutput_items, in, out);
+    }
+};
+
+class clxcorrelate_fft_vcf_impl : public clxcorrelate_fft_vcf, public MI355Base {
+    mi355_xcorr_fft *d_h = nullptr;
+public:
+    clxcorrelate_fft_vcf_impl(int fftSize, int num_inputs, int openCLPlatformType, int devSelector, int platformId, int devId,
+                              int input_type)
+        : gr::sync_block("clxcorrelate_fft_vcf"), MI355Base(openCLPlatformType, devSelector, platformId, devId, false)
+    {
+        chk(mi355_xcorr_fft_create(d_ctx, fftSize, num_inputs, input_type, &d_h), "mi355_xcorr_fft_create");
+    }
+    ~clxcorrelate_fft_vcf_impl() override { mi355_xcorr_fft_destroy(d_h); }
+    int work(int noutput_items, gr_vector_const_void_star &in, gr_vector_void_star &out) override
+    {
+        chk(mi355_xcorr_fft_work(d_h, noutput_items, in.data(), out.data()), "mi355_xcorr_fft_work");  // vectors (:1058-1143)
+        return noutput_items;
+    }
+    int work_test(int noutput_items, gr_vector_const_void_star &in, gr_vector_void_star &out) override
+    {
+        return work(noutput_items, in, out);  // lib/clxcorrelate_fft_vcf_impl.cc:982-1056 is the same data path
+    }
+};
 }  // namespace
+
+#define MI355_ELEM_MAKE(NAME, KIND, NIN, NOUT, P0, P1, ...)                                                              \
+    {                                                                                                                     \
+        return sptr(new elem_impl_t<NAME>(#NAME, KIND, NIN, NOUT, P0, P1, openCLPlatformType, devSelector, platformId, devId, \
+                                          setDebug == 1));                                                                \
+    }
+clLog::sptr clLog::make(int openCLPlatformType, int devSelector, int platformId, int devId, float nValue, float kValue, int setDebug)
+MI355_ELEM_MAKE(clLog, MI355_ELEM_LOG10, 1, 1, nValue, kValue)
+clSNR::sptr clSNR::make(int openCLPlatformType, int devSelector, int platformId, int devId, float nValue, float kValue, int setDebug)
+MI355_ELEM_MAKE(clSNR, MI355_ELEM_SNR, 2, 1, nValue, kValue)
+clComplexToMag::sptr clComplexToMag::make(int openCLPlatformType, int devSelector, int platformId, int devId, int setDebug)
+MI355_ELEM_MAKE(clComplexToMag, MI355_ELEM_C2MAG, 1, 1, 0.f, 0.f)
+clComplexToArg::sptr clComplexToArg::make(int openCLPlatformType, int devSelector, int platformId, int devId, int setDebug)
+MI355_ELEM_MAKE(clComplexToArg, MI355_ELEM_C2ARG, 1, 1, 0.f, 0.f)
+clComplexToMagPhase::sptr clComplexToMagPhase::make(int openCLPlatformType, int devSelector, int platformId, int devId, int setDebug)
+MI355_ELEM_MAKE(clComplexToMagPhase, MI355_ELEM_C2MAGPHASE, 1, 2, 0.f, 0.f)
+clMagPhaseToComplex::sptr clMagPhaseToComplex::make(int openCLPlatformType, int devSelector, int platformId, int devId, int setDebug)
+MI355_ELEM_MAKE(clMagPhaseToComplex, MI355_ELEM_MAGPHASE2C, 2, 1, 0.f, 0.f)
+clQuadratureDemod::sptr clQuadratureDemod::make(float gain, int openCLPlatformType, int devSelector, int platformId, int devId,
+                                                int setDebug)
+MI355_ELEM_MAKE(clQuadratureDemod, MI355_ELEM_QUADDEMOD, 1, 1, gain, 0.f)
+#undef MI355_ELEM_MAKE
+
+clxcorrelate_fft_vcf::sptr clxcorrelate_fft_vcf::make(int fftSize, int num_inputs, int openCLPlatformType, int devSelector,
+                                                      int platformId, int devId, int input_type)
+{
+    return sptr(new clxcorrelate_fft_vcf_impl(fftSize, num_inputs, openCLPlatformType, devSelector, platformId, devId, input_type));
+}
 
 clMathOp::sptr clMathOp::make(int idataType, int openCLPlatformType, int devSelector, int platformId, int devId, int operatorType,
                               int setDebug)

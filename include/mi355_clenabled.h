@@ -79,6 +79,7 @@ typedef struct mi355_filter  mi355_filter;
 typedef struct mi355_pfb     mi355_pfb;
 typedef struct mi355_xengine mi355_xengine;
 typedef struct mi355_elem    mi355_elem;
+typedef struct mi355_xcorr_fft mi355_xcorr_fft;
 
 /* ---------------------------------------------------------------------------
  * Runtime: replaces GRCLBase::InitOpenCL / cleanup (lib/GRCLBase.cpp:17-369,
@@ -237,6 +238,24 @@ int mi355_elem_destroy(mi355_elem *h);
 int mi355_elem_history(const mi355_elem *h);
 int mi355_elem_work(mi355_elem *h, size_t n, const void *in0, const void *in1, void *out0, void *out1);
 int mi355_elem_work_dev(mi355_elem *h, size_t n, const void *in0, const void *in1, void *out0, void *out1, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Frequency-domain cross-correlator, replaces clxcorrelate_fft_vcf:
+ *   make(fftSize, num_inputs, openCLPlatformType, devSelector, platformId, devId, input_type)
+ *                                                  include/clenabled/clxcorrelate_fft_vcf.h:50
+ *   work(): lib/clxcorrelate_fft_vcf_impl.cc:1058-1143.
+ * Input 0 is the reference signal.  For every frame (vector of fft_size complex items) and every other
+ * input s = 1..num_inputs-1:
+ *     out[s-1][frame] = halfswap( | IFFT_unscaled( X0 * conj(Xs) ) | )        (float, fft_size items)
+ * where X = the input itself (input_type 1, spectra) or its forward FFT (input_type 2, time series) and
+ * halfswap exchanges the two halves of the vector (:1133-1140).  inputs[] holds num_inputs pointers to
+ * [nframes][fft_size] complex, outputs[] num_inputs-1 pointers to [nframes][fft_size] float.
+ * fft_size: power of two 16..4096, num_inputs 2..32, otherwise MI355_ERR_UNSUPPORTED.
+ * ------------------------------------------------------------------------------------------------ */
+int mi355_xcorr_fft_create(mi355_ctx *ctx, int fft_size, int num_inputs, int input_type, mi355_xcorr_fft **out);
+int mi355_xcorr_fft_destroy(mi355_xcorr_fft *h);
+int mi355_xcorr_fft_work(mi355_xcorr_fft *h, int nframes, const void *const *inputs, void *const *outputs);
+int mi355_xcorr_fft_work_dev(mi355_xcorr_fft *h, int nframes, const void *const *d_inputs, void *const *d_outputs, void *stream);
 
 #ifdef __cplusplus
 }

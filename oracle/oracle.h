@@ -96,6 +96,10 @@ int oracle_xengine_gather(int dtype, int ninputs, int nchan, int npol, int nfram
 /* ---- remaining elementwise blocks; kind = MI355_ELEM_* code ---- */
 int oracle_elem(int kind, float p0, float p1, size_t n, const void *in0, const void *in1, void *out0, void *out1);
 
+/* ---- frequency-domain cross-correlator: inputs[num_inputs] of [nframes][n], outputs[num_inputs-1] ---- */
+int oracle_xcorr_fft(int n, int num_inputs, int input_type, int nframes, const ocplx *const *inputs, float *const *outputs,
+                     int use_f64);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,7 @@ def lib():
         L.oracle_fft_c2c_f32.argtypes = [i, i, vp, vp]
         L.oracle_fft_c2c_f64.argtypes = [i, i, vp, vp]
         L.oracle_fft_block.argtypes = [i, i, vp, i, i, i, vp, vp, i]
+        L.oracle_xcorr_fft.argtypes = [i, i, i, i, vp, vp, i]
         L.oracle_fft_filter_new.argtypes = [i, vp, i]
         L.oracle_fft_filter_new.restype = vp
         L.oracle_fft_filter_free.argtypes = [vp]
@@ -253,3 +254,16 @@ def elem(kind, n, ins, p0=1.0, p1=0.0):
     if rc:
         raise ValueError("oracle_elem rc=%d" % rc)
     return tuple(outs)
+
+
+def xcorr_fft(n, input_type, inputs, use_f64=False):
+    """clxcorrelate_fft_vcf: inputs = list of [nframes*n] complex64 (input 0 = reference); returns num_inputs-1 float32 arrays."""
+    ins = [_c(x, np.complex64) for x in inputs]
+    nframes = ins[0].size // n
+    outs = [np.empty(nframes * n, np.float32) for _ in ins[1:]]
+    ip = (C.c_void_p * len(ins))(*[x.ctypes.data for x in ins])
+    op = (C.c_void_p * len(outs))(*[x.ctypes.data for x in outs])
+    rc = lib().oracle_xcorr_fft(n, len(ins), input_type, nframes, ip, op, 1 if use_f64 else 0)
+    if rc:
+        raise ValueError("oracle_xcorr_fft rc=%d" % rc)
+    return outs

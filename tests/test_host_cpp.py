@@ -14,7 +14,9 @@ HOSTLIB = os.path.join(ROOT, "gr-clenabled_amd", "libgnuradio-clenabled-mi355.so
 def test_host_library_exports_the_block_factories():
     assert os.path.exists(HOSTLIB), "run __graft_entry__.build()"
     syms = subprocess.run(["nm", "-DC", HOSTLIB], capture_output=True, text=True, check=True).stdout
-    for cls in ("clMathOp", "clMathConst", "clFFT", "clFilter", "clComplexFilter", "clPolyphaseChannelizer", "clXEngine"):
+    for cls in ("clMathOp", "clMathConst", "clFFT", "clFilter", "clComplexFilter", "clPolyphaseChannelizer", "clXEngine", "clLog",
+                "clSNR", "clComplexToMag", "clComplexToArg", "clComplexToMagPhase", "clMagPhaseToComplex", "clQuadratureDemod",
+                "clxcorrelate_fft_vcf"):
         assert "gr::clenabled::%s::make(" % cls in syms, cls
 
 
@@ -30,7 +32,7 @@ def test_cli_runs_every_block_and_checks_known_answers(gpu):
     r = subprocess.run([CLI, "--iterations=20"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if "MSPS" in l]
-    assert len(lines) == 7 and all(l.rstrip().endswith("ok") for l in lines), r.stdout
+    assert len(lines) == 15 and all(l.rstrip().endswith("ok") for l in lines), r.stdout
     r = subprocess.run([CLI, "--iterations=5", "--fft-only", "--fft-size=2048", "2048"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "clFFT forward N=2048" in r.stdout  # the reference's FFTValidationTest size
 

@@ -2,7 +2,7 @@
 import re, subprocess, sys
 src = sys.argv[1]
 pat = sys.argv[2] if len(sys.argv) > 2 else ""
-cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Iinclude", "-Igr-clenabled_amd/csrc", "-c", src,
+cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-slp-vectorize", "-Iinclude", "-Igr-clenabled_amd/csrc", "-c", src,
        "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = {}
