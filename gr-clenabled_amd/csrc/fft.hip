@@ -31,11 +31,11 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 // (nontemporal) loads, branch free: a thread whose frame does not exist (ragged last group) reads
 // frame 0 of the group instead and the value is discarded.  in_xor is 0 or N/2, a multiple of B0
 // (R0 >= 2), so it only permutes the r*B0 term.
-template <int N, bool REAL>
+template <int N, bool REAL, class G>
 __device__ __forceinline__ void load_group(c32 (&v)[16], const void *__restrict__ in, int grp, int tid, int nframes, int in_xor)
 {
     using P = Plan<N>;
-    constexpr int TH = Geo<N>::TH, PTS = Geo<N>::PTS, F = Geo<N>::F, R0 = P::radix(0), B0 = N / R0;
+    constexpr int TH = G::TH, PTS = G::PTS, F = G::F, R0 = P::radix(0), B0 = N / R0;
     const int frames_left = nframes - grp * F;
 #pragma unroll
     for (int q = 0; q < 16 / R0; q++) {
@@ -56,14 +56,14 @@ __device__ __forceinline__ void load_group(c32 (&v)[16], const void *__restrict_
     }
 }
 
-template <int N, int SIGN, bool REAL, bool PF>
-__global__ __launch_bounds__(Geo<N>::TH, (PF ? Geo<N>::WPE : (N <= 4096 ? 3 : 1))) void k_fft(const void *__restrict__ in, c32 *__restrict__ out,
+template <int N, int SIGN, bool REAL, bool PF, class G>
+__global__ __launch_bounds__(G::TH, (PF ? G::WPE : (N <= 4096 ? 3 : 1))) void k_fft(const void *__restrict__ in, c32 *__restrict__ out,
                                                                  const float *__restrict__ window,
                                                                  const c32 *__restrict__ twtab, int nframes, int ngroups,
                                                                  int shift)
 {
     using P = Plan<N>;
-    constexpr int TH = Geo<N>::TH, PTS = Geo<N>::PTS, F = Geo<N>::F, NP = P::NP;
+    constexpr int TH = G::TH, PTS = G::PTS, F = G::F, NP = P::NP;
     __shared__ c32 lds[NP > 1 ? PTS : 1];
     const int tid0 = threadIdx.x;
     const int in_xor = (SIGN > 0 && shift) ? (N >> 1) : 0;   // reverse: halves swapped on load (:548-553)
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(Geo<N>::TH, (PF ? Geo<N>::WPE : (N <= 4096 ? 3 : 1)
 
     // ---- per-thread constants: inter-pass twiddles and window values --------------
     TwRegs<N> tw;
-    load_twiddles<N, false>(tw, tid0, twtab);
+    load_twiddles<N, false, G>(tw, tid0, twtab);
     constexpr int R0 = P::radix(0), B0 = N / R0;
     float win[16];  // the handle always carries a window (all ones when the block has none)
 #pragma unroll
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(Geo<N>::TH, (PF ? Geo<N>::WPE : (N <= 4096 ? 3 : 1)
     // Software pipeline over the persistent loop: the loads of the NEXT frame group are issued
     // before the current group is transformed, so every workgroup always has 32 KiB in flight.
     c32 cur[16];
-    if ((int)blockIdx.x < ngroups) load_group<N, REAL>(cur, in, blockIdx.x, tid0, nframes, in_xor);
+    if ((int)blockIdx.x < ngroups) load_group<N, REAL, G>(cur, in, blockIdx.x, tid0, nframes, in_xor);
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         // Opaque per-iteration copy of the thread id: address arithmetic is recomputed
         // (a few dozen integer ops) rather than hoisted into ~60 loop-carried registers.
@@ -94,15 +94,15 @@ __global__ __launch_bounds__(Geo<N>::TH, (PF ? Geo<N>::WPE : (N <= 4096 ? 3 : 1)
         c32 nxt[16];
         if constexpr (PF) {
             const int gnext = grp + gridDim.x;
-            if (gnext < ngroups) load_group<N, REAL>(nxt, in, gnext, tid, nframes, in_xor);
+            if (gnext < ngroups) load_group<N, REAL, G>(nxt, in, gnext, tid, nframes, in_xor);
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the transform
         } else if (grp != (int)blockIdx.x) {
-            load_group<N, REAL>(cur, in, grp, tid, nframes, in_xor);
+            load_group<N, REAL, G>(cur, in, grp, tid, nframes, in_xor);
         }
         c32 v[16];
 #pragma unroll
         for (int s = 0; s < 16; s++) v[s] = scale(cur[s], win[s]);
-        transform_regs<N, SIGN, false>(v, tw, lds, tid);
+        transform_regs<N, SIGN, false, G>(v, tw, lds, tid);
         // registers -> global (streaming stores), unit stride across lanes, fftshift fused.
         // out_xor is 0 or N/2, a multiple of BL, so it only permutes the s*BL term.
         {
@@ -131,28 +131,28 @@ __global__ __launch_bounds__(Geo<N>::TH, (PF ? Geo<N>::WPE : (N <= 4096 ? 3 : 1)
     }
 }
 
-template <int N>
-int launch_n(mi355_ctx *ctx, int sign, const void *in, void *out, const float *window, const void *tw, int nframes, int shift,
+template <int N, class G>
+int launch_g(mi355_ctx *ctx, int sign, const void *in, void *out, const float *window, const void *tw, int nframes, int shift,
              int real_in, hipStream_t st)
 {
-    constexpr int F = Geo<N>::F, TH = Geo<N>::TH;
+    constexpr int F = G::F, TH = G::TH, WAVES = TH / 64;
     int ngroups = (nframes + F - 1) / F;
     int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
     // MI355_FFT_PREFETCH=1 selects the register-prefetch variant (2 workgroups/CU); measured equal to the
     // plain variant at 3 workgroups/CU on MI355X, so it is off by default.
     static const bool pf = getenv("MI355_FFT_PREFETCH") ? atoi(getenv("MI355_FFT_PREFETCH")) != 0 : false;
-    (void)cus;
-    int grid = (N <= 4096) ? mi355_balanced_grid(ctx, ngroups, 2, pf ? 2 : 3, 0.015) : mi355_balanced_grid(ctx, ngroups, 1, 1);
+    // resident waves per CU are what matters: 8..12 (2..3 workgroups of 4 waves, or 8..12 single-wave workgroups)
+    int grid = (N <= 4096) ? mi355_balanced_grid(ctx, ngroups, 8 / WAVES, (pf ? 8 : 12) / WAVES, 0.015) : mi355_balanced_grid(ctx, ngroups, 1, 1);
     if (const char *e = getenv("MI355_FFT_WG_PER_CU")) {
         if (atoi(e) > 0) grid = ngroups < cus * atoi(e) ? ngroups : cus * atoi(e);
     }
 #define LAUNCH_FFT(SG, RL)                                                                                              \
     do {                                                                                                                     \
         if (pf)                                                                                                              \
-            hipLaunchKernelGGL((k_fft<N, SG, RL, true>), dim3(grid), dim3(TH), 0, st, in, (c32 *)out, window, (const c32 *)tw, \
+            hipLaunchKernelGGL((k_fft<N, SG, RL, true, G>), dim3(grid), dim3(TH), 0, st, in, (c32 *)out, window, (const c32 *)tw, \
                                nframes, ngroups, shift);                                                                     \
         else                                                                                                                 \
-            hipLaunchKernelGGL((k_fft<N, SG, RL, false>), dim3(grid), dim3(TH), 0, st, in, (c32 *)out, window,                \
+            hipLaunchKernelGGL((k_fft<N, SG, RL, false, G>), dim3(grid), dim3(TH), 0, st, in, (c32 *)out, window,                \
                                (const c32 *)tw, nframes, ngroups, shift);                                                    \
     } while (0)
     if (sign < 0) { if (real_in) LAUNCH_FFT(-1, true); else LAUNCH_FFT(-1, false); }
@@ -160,6 +160,18 @@ int launch_n(mi355_ctx *ctx, int sign, const void *in, void *out, const float *w
 #undef LAUNCH_FFT
     MI355_HIP(hipGetLastError());
     return MI355_OK;
+}
+
+template <int N>
+int launch_n(mi355_ctx *ctx, int sign, const void *in, void *out, const float *window, const void *tw, int nframes, int shift,
+             int real_in, hipStream_t st)
+{
+    if constexpr (N >= 16 && N <= 1024) {
+        // MI355_FFT_WAVE_GEO=1: one-wave workgroups (no workgroup barriers); measured slower for N >= 256, off by default
+        static const bool wave = getenv("MI355_FFT_WAVE_GEO") ? atoi(getenv("MI355_FFT_WAVE_GEO")) != 0 : false;
+        if (wave) return launch_g<N, GeoW<N>>(ctx, sign, in, out, window, tw, nframes, shift, real_in, st);
+    }
+    return launch_g<N, Geo<N>>(ctx, sign, in, out, window, tw, nframes, shift, real_in, st);
 }
 
 int launch_fft(mi355_ctx *ctx, int n, int sign, const void *in, void *out, const float *window, const void *tw, int nframes,

@@ -138,6 +138,15 @@ template <int N> struct Geo {
     static constexpr int F = PTS / N;                       // frames per iteration
     static constexpr int WPE = (N <= 4096) ? 2 : 1;         // min waves per SIMD asked of the register allocator
 };
+// single-wave geometry for N <= 1024: a frame's N/16 threads sit inside one wave, so a one-wave workgroup needs no
+// workgroup barrier at all (the barriers below degenerate to waitcnts) and the waves of a CU run fully decoupled
+template <int N> struct GeoW {
+    static_assert(N <= 1024, "a frame must fit one wave");
+    static constexpr int TH = 64;
+    static constexpr int PTS = TH * 16;
+    static constexpr int F = PTS / N;
+    static constexpr int WPE = 2;
+};
 
 // LDS slot swizzle (8-byte slots): XOR the low four slot bits with the next four.
 // Makes the three access patterns of the 16-point-per-thread passes conflict free
@@ -169,19 +178,19 @@ constexpr int kTwPerPass = 12;
 template <int N> struct TwRegs { c32 w[Plan<N>::NP > 1 ? Plan<N>::NP - 1 : 1][kTwPerPass]; };
 
 // twtab[k] = exp(sign * 2*pi*i*k/N), k < N (generated in double on the host)
-template <int N, bool REV, int P = 1>
+template <int N, bool REV, class G = Geo<N>, int P = 1>
 __device__ __forceinline__ void load_twiddles(TwRegs<N> &tw, int tid, const c32 *__restrict__ twtab)
 {
     using PL = Plan<N, REV>;
     if constexpr (P < PL::NP) {
-        constexpr int TH = Geo<N>::TH, R = PL::radix(P), NS = PL::ns(P), B = N / R, S = tw_slots<R>();
+        constexpr int TH = G::TH, R = PL::radix(P), NS = PL::ns(P), B = N / R, S = tw_slots<R>();
 #pragma unroll
         for (int q = 0; q < 16 / R; q++) {
             const int j = (tid + TH * q) % B, k = j % NS;
 #pragma unroll
             for (int i = 0; i < S; i++) tw.w[P - 1][q * S + i] = twtab[(tw_power<R>(i) * k * (N / (NS * R))) & (N - 1)];
         }
-        load_twiddles<N, REV, P + 1>(tw, tid, twtab);
+        load_twiddles<N, REV, G, P + 1>(tw, tid, twtab);
     }
 }
 
@@ -212,12 +221,12 @@ template <int R> __device__ __forceinline__ void apply_twiddles(c32 *v, const c3
 // Out: v[q*RL + s]  = X[fr][j + orev<RL>(s)*BL]  (RL = last radix,  fr = g/BL, j = g%BL)
 // `lds` holds PTS slots and is used in place; the caller must __syncthreads() before
 // reusing it for another transform.
-template <int N, int SIGN, bool REV, int P = 0>
+template <int N, int SIGN, bool REV, class G = Geo<N>, int P = 0>
 __device__ __forceinline__ void transform_regs(c32 (&v)[16], const TwRegs<N> &tw, c32 *lds, int tid)
 {
     using PL = Plan<N, REV>;
     if constexpr (P < PL::NP) {
-        constexpr int TH = Geo<N>::TH, NP = PL::NP, R = PL::radix(P), NS = PL::ns(P), B = N / R;
+        constexpr int TH = G::TH, NP = PL::NP, R = PL::radix(P), NS = PL::ns(P), B = N / R;
         if constexpr (P > 0) {
             __syncthreads();  // previous pass' LDS writes are visible
 #pragma unroll
@@ -242,7 +251,7 @@ __device__ __forceinline__ void transform_regs(c32 (&v)[16], const TwRegs<N> &tw
                 for (int s = 0; s < R; s++) lds[lds_at<NS>(raw, rs, orev<R>(s) * NS)] = v[q * R + s];
             }
         }
-        transform_regs<N, SIGN, REV, P + 1>(v, tw, lds, tid);
+        transform_regs<N, SIGN, REV, G, P + 1>(v, tw, lds, tid);
     }
 }
 

@@ -19,6 +19,8 @@
 // Everything else (oversampled R != M, M not a power of two such as the reference
 // flowgraph's M=3, very long arms) takes the generic two-kernel path.
 #include <cmath>
+#include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -190,6 +192,126 @@ __global__ __launch_bounds__(256, (PfbGeo<M, PMAX>::WPE)) void k_pfb(const c32 *
 }
 
 // ------------------------------------------------------------------------------------
+// M == 64: one wave per workgroup, lane = arm, no LDS staging and no workgroup barrier.
+// The wave owns a contiguous run of output steps and keeps its arm windows (PMAX + 16 input
+// rows, one sample per lane and row) in a register ring across iterations: every input row is
+// loaded from HBM exactly once, 512 B per wave instruction, straight into the ring slot whose
+// row has just been retired -- so the loads for the next 16 steps are in flight while the
+// current 16 are computed.  Buffer loads with hardware range checking supply the zeros before
+// and after the stream.  Branch outputs go through 8 KiB of wave-private LDS into the
+// 16-points-per-thread layout and the 64-point backward DFT runs there (GeoW: all exchanges
+// stay inside the wave).
+// ------------------------------------------------------------------------------------
+template <int PMAX, bool IDENT>
+__global__ __launch_bounds__(64, 2) void k_pfb64(const c32 *__restrict__ in, c32 *__restrict__ out, const float *__restrict__ taps_pad,
+                                                 const c32 *__restrict__ tw_inv, const int *__restrict__ ch_map, int nmap, int K,
+                                                 long long n_in, int nsteps, int groups_per_wave)
+{
+    constexpr int M = 64, U = 16, RS = PMAX + U;                // ring slots = rows resident per lane
+    constexpr int PERIOD = RS / (RS % 16 == 0 ? 16 : 8);  // = RS / gcd(RS, U): iterations until the ring mapping repeats
+    static_assert((U * PERIOD) % RS == 0, "ring period");
+    using G = GeoW<M>;
+    using PL = Plan<M, false>;
+    __shared__ c32 lds[G::PTS];
+    const int lane0 = threadIdx.x;
+    float hrev[PMAX];
+#pragma unroll
+    for (int pp = 0; pp < PMAX; pp++) hrev[pp] = taps_pad[lane0 + (PMAX - 1 - pp) * M];
+    TwRegs<M> tw;
+    load_twiddles<M, false, G>(tw, lane0, tw_inv);
+
+    const int ngroups = (nsteps + U - 1) / U;
+    const int g_begin = blockIdx.x * groups_per_wave;
+    int g_end = g_begin + groups_per_wave;
+    if (g_end > ngroups) g_end = ngroups;
+    if (g_begin >= g_end) return;
+
+    // raw buffer over the readable input; offsets are 32-bit (the launcher guarantees n_in * 8 < 4 GiB - 64 KiB),
+    // and a row before the start of the stream wraps to an out-of-range offset, i.e. reads as zero
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)(unsigned)(n_in * 8), 0x00020000);
+    const unsigned lane_off = (unsigned)((M - 1 - lane0) * 8);
+    // sample index of ring row 0 of the first iteration: X[w] = in[n0 + w*M + (M-1-lane)]
+    const long long n0 = (long long)g_begin * U * M + K - (long long)PMAX * M;
+    auto load_row = [&](long long row) -> f2v {  // row = absolute row index relative to n0
+        const unsigned off = (unsigned)((n0 + row * M) * 8) + lane_off;
+        return __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
+    };
+    f2v ring[RS];
+#pragma unroll
+    for (int w = 0; w < RS; w++) ring[w] = load_row(w);
+
+    auto iteration = [&](auto phase_tag, int grp) {
+        constexpr int PH = decltype(phase_tag)::value;
+        const long long row0 = (long long)(grp - g_begin) * U;  // ring row 0 of this iteration
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));  // LDS addresses are recomputed per iteration instead of living in ~50 registers
+        // ---- phase 1: two steps at a time; their rows are retired and refilled right after ----
+#pragma unroll
+        for (int u = 0; u < U; u += 2) {
+            f2v a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+#pragma unroll
+            for (int pp = 0; pp < PMAX; pp++) {
+                const f2v hh = {hrev[pp], hrev[pp]};  // one register per tap; the packed FMA broadcasts it (op_sel)
+                a0 = __builtin_elementwise_fma(ring[(U * PH + u + pp) % RS], hh, a0);      // fma like the reference (:163)
+                a1 = __builtin_elementwise_fma(ring[(U * PH + u + 1 + pp) % RS], hh, a1);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // the refill below must not be hoisted above the last use of its slot
+            lds[swz(u * M + lane)] = mk(a0.x, a0.y);
+            lds[swz((u + 1) * M + lane)] = mk(a1.x, a1.y);
+            // unconditional: past the wave's range the rows are simply not used, past the stream they read as zero
+            ring[(U * PH + u) % RS] = load_row(row0 + RS + u);
+            ring[(U * PH + u + 1) % RS] = load_row(row0 + RS + u + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();  // single wave: orders the LDS writes before the reads below
+        // ---- phase 2: 64-point backward DFT of the 16 steps, wave local ----
+        c32 v[16];
+        constexpr int R0 = PL::radix(0), B0 = M / R0;
+        {
+            const int raw = (lane / B0) * M + (lane % B0);
+#pragma unroll
+            for (int r = 0; r < R0; r++) v[r] = lds[swz(raw + r * B0)];
+        }
+        __syncthreads();
+        transform_regs<M, 1, false, G>(v, tw, lds, lane);
+        constexpr int NP = PL::NP, RL = PL::radix(NP - 1), BL = M / RL;
+        const int i0 = grp * U;
+        if constexpr (IDENT) {
+#pragma unroll
+            for (int q = 0; q < 16 / RL; q++) {
+                const int g = lane + 64 * q, fr = g / BL, j = g % BL;
+                if (i0 + fr < nsteps) {
+                    c32 *__restrict__ o = out + (size_t)(i0 + fr) * M + j;
+#pragma unroll
+                    for (int t = 0; t < RL; t++) st_stream(o + orev<RL>(t) * BL, v[q * RL + t]);
+                }
+            }
+            __syncthreads();
+        } else {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 16 / RL; q++) {
+                const int g = lane + 64 * q, fr = g / BL, j = g % BL;
+#pragma unroll
+                for (int t = 0; t < RL; t++) lds[fr * M + j + orev<RL>(t) * BL] = v[q * RL + t];
+            }
+            __syncthreads();
+            const int steps = (nsteps - i0) < U ? (nsteps - i0) : U;
+            for (int e = lane; e < steps * nmap; e += 64) {
+                const int fr = e / nmap, qq = e - fr * nmap;
+                out[(size_t)i0 * nmap + e] = lds[fr * M + ch_map[qq]];
+            }
+            __syncthreads();
+        }
+    };
+    for (int grp = g_begin; grp < g_end; grp += PERIOD) {
+        iteration(std::integral_constant<int, 0>{}, grp);
+        if constexpr (PERIOD > 1) { if (grp + 1 < g_end) iteration(std::integral_constant<int, 1 % PERIOD>{}, grp + 1); }
+        if constexpr (PERIOD > 2) { if (grp + 2 < g_end) iteration(std::integral_constant<int, 2 % PERIOD>{}, grp + 2); }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // generic path: one thread per branch output, then a direct M-point DFT per mapped channel
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pfb_branches(const c32 *__restrict__ in, c32 *__restrict__ filt,
@@ -246,9 +368,35 @@ struct mi355_pfb {
 
 namespace {
 
+template <int PMAX>
+int launch_wave64(mi355_pfb *h, const void *in, void *out, hipStream_t st)
+{
+    const int ngroups = (h->nsteps + 15) / 16;
+    const int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
+    static const int wpc = getenv("MI355_PFB_WAVES_PER_CU") ? atoi(getenv("MI355_PFB_WAVES_PER_CU")) : 8;
+    long long waves = (long long)cus * (wpc > 0 ? wpc : 8);
+    if (waves > ngroups) waves = ngroups;
+    const int per = (int)((ngroups + waves - 1) / waves);
+    const int grid = (ngroups + per - 1) / per;
+    const long long n_in = (long long)h->buf_items - h->R + h->K;
+    if (h->ident)
+        hipLaunchKernelGGL((k_pfb64<PMAX, true>), dim3(grid), dim3(64), 0, st, (const c32 *)in, (c32 *)out, h->d_taps, (const c32 *)h->d_tw,
+                           h->d_map, h->nmap, h->K, n_in, h->nsteps, per);
+    else
+        hipLaunchKernelGGL((k_pfb64<PMAX, false>), dim3(grid), dim3(64), 0, st, (const c32 *)in, (c32 *)out, h->d_taps, (const c32 *)h->d_tw,
+                           h->d_map, h->nmap, h->K, n_in, h->nsteps, per);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
 template <int M, int PMAX>
 int launch_fast(mi355_pfb *h, const void *in, void *out, hipStream_t st)
 {
+    if constexpr (M == 64 && PMAX <= 32) {
+        static const bool wave = getenv("MI355_PFB_WAVE") ? atoi(getenv("MI355_PFB_WAVE")) != 0 : true;
+        const long long n_in = (long long)h->buf_items - h->R + h->K;
+        if (wave && n_in * 8 < (4ll << 30) - (64 << 10)) return launch_wave64<PMAX>(h, in, out, st);
+    }
     constexpr int T = 4096 / M;
     int ngroups = (h->nsteps + T - 1) / T;
     int grid = mi355_balanced_grid(h->ctx, ngroups, PfbGeo<M, PMAX>::WPE >= 2 ? 2 : 1, PfbGeo<M, PMAX>::WPE);
