@@ -37,6 +37,22 @@ __device__ __forceinline__ void load_group(c32 (&v)[16], const void *__restrict_
     using P = Plan<N>;
     constexpr int TH = G::TH, PTS = G::PTS, F = G::F, R0 = P::radix(0), B0 = N / R0;
     const int frames_left = nframes - grp * F;
+    if constexpr (N <= 64) {  // consecutive elements per lane; redistributed through LDS by the caller
+        (void)in_xor;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const unsigned e = (unsigned)(tid + TH * k);
+            const bool ok = (int)(e / N) < frames_left;
+            if constexpr (REAL) {
+                const float x = __builtin_nontemporal_load((const float *)in + (size_t)grp * PTS + (ok ? e : 0u));
+                v[k] = mk(ok ? x : 0.f, 0.f);
+            } else {
+                const f2v x = __builtin_nontemporal_load((const f2v *)in + (size_t)grp * PTS + (ok ? e : 0u));
+                v[k] = ok ? mk(x.x, x.y) : mk(0.f, 0.f);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 16 / R0; q++) {
         const int g = tid + TH * q, fr = g / B0;
@@ -64,7 +80,13 @@ __global__ __launch_bounds__(G::TH, (PF ? G::WPE : (N <= 4096 ? 3 : 1))) void k_
 {
     using P = Plan<N>;
     constexpr int TH = G::TH, PTS = G::PTS, F = G::F, NP = P::NP;
-    __shared__ c32 lds[NP > 1 ? PTS : 1];
+    // N <= 64: a thread's pass-0 operands are only N/16 (<= 4) consecutive elements, so loading them directly costs
+    // one 128-B line per lane and instruction.  Instead every lane moves CONSECUTIVE elements and a padded LDS image
+    // (PAD slots after every frame: conflict-free for both access patterns) redistributes them; same on the store side.
+    constexpr bool SMALL = N <= 64;
+    constexpr int PAD = (N / P::radix(0)) > 1 ? (N / P::radix(0)) : 1;
+    constexpr int LDS_SLOTS = SMALL ? PTS + (PTS / N) * PAD : (NP > 1 ? PTS : 1);
+    __shared__ c32 lds[LDS_SLOTS];
     const int tid0 = threadIdx.x;
     const int in_xor = (SIGN > 0 && shift) ? (N >> 1) : 0;   // reverse: halves swapped on load (:548-553)
     const int out_xor = (SIGN < 0 && shift) ? (N >> 1) : 0;  // forward: halves swapped on store (:594-607)
@@ -74,11 +96,15 @@ __global__ __launch_bounds__(G::TH, (PF ? G::WPE : (N <= 4096 ? 3 : 1))) void k_
     load_twiddles<N, false, G>(tw, tid0, twtab);
     constexpr int R0 = P::radix(0), B0 = N / R0;
     float win[16];  // the handle always carries a window (all ones when the block has none)
+    if constexpr (SMALL) {
+        win[0] = window[tid0 % N];  // the thread moves position tid % N of 16 different frames
+    } else {
 #pragma unroll
-    for (int q = 0; q < 16 / R0; q++) {
-        const int j = (tid0 + TH * q) % B0;
+        for (int q = 0; q < 16 / R0; q++) {
+            const int j = (tid0 + TH * q) % B0;
 #pragma unroll
-        for (int r = 0; r < R0; r++) win[q * R0 + r] = window[j + ((r * B0) ^ in_xor)];
+            for (int r = 0; r < R0; r++) win[q * R0 + r] = window[j + ((r * B0) ^ in_xor)];
+        }
     }
 
     // Software pipeline over the persistent loop: the loads of the NEXT frame group are issued
@@ -100,12 +126,54 @@ __global__ __launch_bounds__(G::TH, (PF ? G::WPE : (N <= 4096 ? 3 : 1))) void k_
             load_group<N, REAL, G>(cur, in, grp, tid, nframes, in_xor);
         }
         c32 v[16];
+        if constexpr (SMALL) {
+            // cur[k] = source element tid + TH*k of the group (position (tid % N) of its frame: one window value per thread)
+            const float wv = win[0];
+            const int pos = (tid % N) ^ in_xor, fr0 = tid / N;
 #pragma unroll
-        for (int s = 0; s < 16; s++) v[s] = scale(cur[s], win[s]);
+            for (int k = 0; k < 16; k++) {
+                const int fr = fr0 + k * (TH / N);
+                lds[fr * (N + PAD) + pos] = scale(cur[k], wv);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 16 / R0; q++) {
+                const int g = tid + TH * q, base = (g / B0) * (N + PAD) + (g % B0);
+#pragma unroll
+                for (int r = 0; r < R0; r++) v[q * R0 + r] = lds[base + r * B0];
+            }
+            __syncthreads();  // the transform reuses the LDS in its own layout
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16; s++) v[s] = scale(cur[s], win[s]);
+        }
         transform_regs<N, SIGN, false, G>(v, tw, lds, tid);
         // registers -> global (streaming stores), unit stride across lanes, fftshift fused.
         // out_xor is 0 or N/2, a multiple of BL, so it only permutes the s*BL term.
-        {
+        if constexpr (SMALL) {
+            constexpr int RL = P::radix(NP - 1), BL = N / RL;
+            if constexpr (NP > 1) __syncthreads();  // the last pass' LDS reads are done
+#pragma unroll
+            for (int q = 0; q < 16 / RL; q++) {
+                const int g = tid + TH * q, base = (g / BL) * (N + PAD) + (g % BL);
+#pragma unroll
+                for (int s = 0; s < RL; s++) lds[base + ((orev<RL>(s) * BL) ^ out_xor)] = v[q * RL + s];
+            }
+            __syncthreads();
+            f2v *__restrict__ out_g = (f2v *)out + (size_t)grp * PTS;
+            const int pos = tid % N, fr0 = tid / N;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int fr = fr0 + k * (TH / N);
+                if (fr < frames_left) {
+                    const c32 z = lds[fr * (N + PAD) + pos];
+                    f2v o;
+                    o.x = z.x;
+                    o.y = z.y;
+                    __builtin_nontemporal_store(o, out_g + tid + TH * k);
+                }
+            }
+        } else {
             constexpr int RL = P::radix(NP - 1), BL = N / RL;
             f2v *__restrict__ out_g = (f2v *)out + (size_t)grp * PTS;
 #pragma unroll
@@ -127,7 +195,7 @@ __global__ __launch_bounds__(G::TH, (PF ? G::WPE : (N <= 4096 ? 3 : 1))) void k_
 #pragma unroll
             for (int s = 0; s < 16; s++) cur[s] = nxt[s];
         }
-        if constexpr (NP > 1) __syncthreads();  // last pass' LDS reads finish before the next group's writes
+        if constexpr (NP > 1 || SMALL) __syncthreads();  // last pass' LDS reads finish before the next group's writes
     }
 }
 

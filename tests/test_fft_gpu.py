@@ -61,16 +61,28 @@ def test_golden_vectors(gpu):
     assert relerr(yr, g["fwd_real1024"]) <= TOL
 
 
-@pytest.mark.parametrize("n", [16, 256, 4096])
+@pytest.mark.parametrize("n", [2, 8, 16, 32, 64, 256, 4096])  # N <= 64 takes the LDS-redistributed load/store path
 @pytest.mark.parametrize("fwd,shift,win", [(True, True, True), (True, False, True), (False, True, True), (False, True, False),
                                            (True, True, False)])
 def test_window_shift_matrix_vs_oracle(gpu, oracle, n, fwd, shift, win):
     rng = np.random.default_rng(n + 7)
     w = oracle.window(oracle.WIN_BLACKMAN_HARRIS, n) if win else None  # GRC default window
-    x = crandn(rng, 5 * n)
+    nvec = 5 if n > 64 else 4096 // n + 3  # more than one workgroup pass, ragged
+    x = crandn(rng, nvec * n)
     y = np.empty_like(x)
-    _fft(gpu, n, gpu.CLFFT_FORWARD if fwd else gpu.CLFFT_BACKWARD, w, shift=shift).work(5, [x], [y])
+    _fft(gpu, n, gpu.CLFFT_FORWARD if fwd else gpu.CLFFT_BACKWARD, w, shift=shift).work(nvec, [x], [y])
     assert relerr(y, oracle.fft_block(n, fwd, w, shift, oracle.DTYPE_COMPLEX, x, f64=True)) <= TOL
+
+
+@pytest.mark.parametrize("n", [4, 16, 64])
+def test_real_input_small_sizes(gpu, oracle, n):
+    rng = np.random.default_rng(n + 11)
+    nvec = 4096 // n + 5
+    x = rng.standard_normal(nvec * n).astype(np.float32)
+    y = np.empty(nvec * n, np.complex64)
+    w = oracle.window(oracle.WIN_HANN, n)
+    _fft(gpu, n, gpu.CLFFT_FORWARD, w, dtype=gpu.DTYPE_FLOAT, shift=True).work(nvec, [x], [y])
+    assert relerr(y, oracle.fft_block(n, True, w, True, oracle.DTYPE_FLOAT, x, f64=True)) <= TOL
 
 
 def test_real_input_and_streams(gpu, oracle):
