@@ -199,6 +199,122 @@ __global__ __launch_bounds__(G::TH, (PF ? G::WPE : (N <= 4096 ? 3 : 1))) void k_
     }
 }
 
+// ------------------------------------------------------------------------------------
+// N = 8192 / 16384: S = N/4096 interleaved 4096-point sub-transforms per thread (decimation in time), combined by a
+// radix-S butterfly in registers.  256 threads, one frame per iteration.  Sub-frame s holds x[S*n + s], so one 16-B load
+// per lane brings the same n of two sub-frames; the sub-transforms run one after the other through the same 32 KiB of
+// LDS (3 workgroups per CU instead of the 1-2 a whole-frame LDS image allows, and two exchange passes per sub-frame
+// instead of three per frame); X[k + m*4096] = sum_s W_N^(s k) W_S^(s m) E_s[k] needs all E_s[k] of one k in one thread,
+// which the common sub-transform layout guarantees.  W_N^(s k) = W_N^(s tid) * (compile-time constant), k = tid + 256 c.
+// ------------------------------------------------------------------------------------
+__host__ __device__ constexpr float cos64(int m)
+{
+    constexpr float t[64] = {1.0f, 0.995184727f, 0.98078528f, 0.956940336f, 0.923879533f, 0.881921264f, 0.831469612f, 0.773010453f, 0.707106781f, 0.634393284f, 0.555570233f, 0.471396737f, 0.382683432f, 0.290284677f, 0.195090322f, 0.0980171403f, 0.0f, -0.0980171403f, -0.195090322f, -0.290284677f, -0.382683432f, -0.471396737f, -0.555570233f, -0.634393284f, -0.707106781f, -0.773010453f, -0.831469612f, -0.881921264f, -0.923879533f, -0.956940336f, -0.98078528f, -0.995184727f, -1.0f, -0.995184727f, -0.98078528f, -0.956940336f, -0.923879533f, -0.881921264f, -0.831469612f, -0.773010453f, -0.707106781f, -0.634393284f, -0.555570233f, -0.471396737f, -0.382683432f, -0.290284677f, -0.195090322f, -0.0980171403f, 0.0f, 0.0980171403f, 0.195090322f, 0.290284677f, 0.382683432f, 0.471396737f, 0.555570233f, 0.634393284f, 0.707106781f, 0.773010453f, 0.831469612f, 0.881921264f, 0.923879533f, 0.956940336f, 0.98078528f, 0.995184727f};
+    return t[m];
+}
+__host__ __device__ constexpr float sin64(int m)
+{
+    constexpr float t[64] = {0.0f, 0.0980171403f, 0.195090322f, 0.290284677f, 0.382683432f, 0.471396737f, 0.555570233f, 0.634393284f, 0.707106781f, 0.773010453f, 0.831469612f, 0.881921264f, 0.923879533f, 0.956940336f, 0.98078528f, 0.995184727f, 1.0f, 0.995184727f, 0.98078528f, 0.956940336f, 0.923879533f, 0.881921264f, 0.831469612f, 0.773010453f, 0.707106781f, 0.634393284f, 0.555570233f, 0.471396737f, 0.382683432f, 0.290284677f, 0.195090322f, 0.0980171403f, 0.0f, -0.0980171403f, -0.195090322f, -0.290284677f, -0.382683432f, -0.471396737f, -0.555570233f, -0.634393284f, -0.707106781f, -0.773010453f, -0.831469612f, -0.881921264f, -0.923879533f, -0.956940336f, -0.98078528f, -0.995184727f, -1.0f, -0.995184727f, -0.98078528f, -0.956940336f, -0.923879533f, -0.881921264f, -0.831469612f, -0.773010453f, -0.707106781f, -0.634393284f, -0.555570233f, -0.471396737f, -0.382683432f, -0.290284677f, -0.195090322f, -0.0980171403f};
+    return t[m];
+}
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+template <int N, int SIGN, bool REAL>
+__global__ __launch_bounds__(256, 2) void k_fft_s(const void *__restrict__ in, c32 *__restrict__ out, const float *__restrict__ window,
+                                                  const c32 *__restrict__ twN, int nframes, int shift)
+{
+    constexpr int NS = 4096, S = N / NS, BL = 256;
+    static_assert(S == 2 || S == 4, "two or four sub-transforms");
+    using G = Geo<NS>;
+    __shared__ c32 lds[NS];
+    const int tid0 = threadIdx.x;
+    TwRegs<NS> tw;
+    load_twiddles<NS, false, G>(tw, tid0, twN + N);  // the 4096-point table follows the N-point one
+    c32 wb[S - 1];
+#pragma unroll
+    for (int s = 1; s < S; s++) wb[s - 1] = twN[(s * tid0) & (N - 1)];
+    const int in_xor = (SIGN > 0 && shift) ? 8 : 0;       // reverse: halves swapped on load == n ^ 2048 == r ^ 8
+    const int m_xor = (SIGN < 0 && shift) ? (S / 2) : 0;  // forward: halves swapped on store
+
+    for (int frame = blockIdx.x; frame < nframes; frame += gridDim.x) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        c32 v[S][16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const unsigned n = (unsigned)(tid + ((r ^ in_xor) * BL));  // element n of every sub-frame
+            float w[S];
+            if constexpr (S == 2) {
+                const f2v t = *((const f2v *)window + n);
+                w[0] = t.x; w[1] = t.y;
+            } else {
+                const f4v t = *((const f4v *)window + n);
+                w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
+            }
+            if constexpr (REAL) {
+                float x[S];
+                if constexpr (S == 2) {
+                    const f2v t = __builtin_nontemporal_load((const f2v *)in + (size_t)frame * (N / 2) + n);
+                    x[0] = t.x; x[1] = t.y;
+                } else {
+                    const f4v t = __builtin_nontemporal_load((const f4v *)in + (size_t)frame * (N / 4) + n);
+                    x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
+                }
+#pragma unroll
+                for (int s = 0; s < S; s++) v[s][r] = mk(x[s] * w[s], 0.f);
+            } else {
+#pragma unroll
+                for (int h = 0; h < S / 2; h++) {
+                    const f4v t = __builtin_nontemporal_load((const f4v *)in + (size_t)frame * (N / 2) + (size_t)n * (S / 2) + h);
+                    v[2 * h][r] = mk(t.x * w[2 * h], t.y * w[2 * h]);
+                    v[2 * h + 1][r] = mk(t.z * w[2 * h + 1], t.w * w[2 * h + 1]);
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            transform_regs<NS, SIGN, false, G>(v[s], tw, lds, tid);
+            __syncthreads();  // the last pass' LDS reads are done before the next sub-transform writes
+        }
+        f2v *__restrict__ out_f = (f2v *)out + (size_t)frame * N + tid;
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            constexpr int STEP = 64 / (16 * S);  // W_N^(s * c * 256) = exp(sign 2 pi i s c / (16 S)) on the 64-point circle
+            const int c = orev<16>(t);
+            c32 a[S];
+            a[0] = v[0][t];
+#pragma unroll
+            for (int s = 1; s < S; s++) {
+                const int m = (s * c * STEP) & 63;
+                const c32 k = mk(cos64(m), SIGN < 0 ? -sin64(m) : sin64(m));
+                a[s] = cmul(v[s][t], (m == 0) ? wb[s - 1] : cmul(wb[s - 1], k));
+            }
+            if constexpr (S == 2) bfly2<SIGN>(a[0], a[1]);
+            else bfly4<SIGN>(a[0], a[1], a[2], a[3]);
+#pragma unroll
+            for (int m = 0; m < S; m++) {
+                f2v o;
+                o.x = a[m].x;
+                o.y = a[m].y;
+                __builtin_nontemporal_store(o, out_f + c * BL + ((m ^ m_xor) * NS));
+            }
+        }
+    }
+}
+
+template <int N>
+int launch_s(mi355_ctx *ctx, int sign, const void *in, void *out, const float *window, const void *tw, int nframes, int shift,
+             int real_in, hipStream_t st)
+{
+    const int grid = mi355_balanced_grid(ctx, nframes, 2, N == 8192 ? 3 : 2, 0.015);
+#define LAUNCH_S(SG, RL) hipLaunchKernelGGL((k_fft_s<N, SG, RL>), dim3(grid), dim3(256), 0, st, in, (c32 *)out, window, (const c32 *)tw, nframes, shift)
+    if (sign < 0) { if (real_in) LAUNCH_S(-1, true); else LAUNCH_S(-1, false); }
+    else          { if (real_in) LAUNCH_S(1, true);  else LAUNCH_S(1, false); }
+#undef LAUNCH_S
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
 template <int N, class G>
 int launch_g(mi355_ctx *ctx, int sign, const void *in, void *out, const float *window, const void *tw, int nframes, int shift,
              int real_in, hipStream_t st)
@@ -238,6 +354,11 @@ int launch_n(mi355_ctx *ctx, int sign, const void *in, void *out, const float *w
         // MI355_FFT_WAVE_GEO=1: one-wave workgroups (no workgroup barriers); measured slower for N >= 256, off by default
         static const bool wave = getenv("MI355_FFT_WAVE_GEO") ? atoi(getenv("MI355_FFT_WAVE_GEO")) != 0 : false;
         if (wave) return launch_g<N, GeoW<N>>(ctx, sign, in, out, window, tw, nframes, shift, real_in, st);
+    }
+    if constexpr (N == 8192 || N == 16384) {
+        // MI355_FFT_WHOLE_FRAME=1 selects the whole-frame kernel (512/1024 threads, frame image in LDS) for comparison
+        static const bool whole = getenv("MI355_FFT_WHOLE_FRAME") ? atoi(getenv("MI355_FFT_WHOLE_FRAME")) != 0 : false;
+        if (!whole) return launch_s<N>(ctx, sign, in, out, window, tw, nframes, shift, real_in, st);
     }
     return launch_g<N, Geo<N>>(ctx, sign, in, out, window, tw, nframes, shift, real_in, st);
 }
@@ -290,6 +411,13 @@ extern "C" int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, con
         double a = h->sign * 2.0 * M_PI * (double)k / (double)fft_size;
         tw[2 * k] = (float)cos(a);
         tw[2 * k + 1] = (float)sin(a);
+    }
+    if (fft_size > 4096) {  // the interleaved sub-transform kernel also needs the 4096-point table
+        for (int k = 0; k < 4096; k++) {
+            double a = h->sign * 2.0 * M_PI * (double)k / 4096.0;
+            tw.push_back((float)cos(a));
+            tw.push_back((float)sin(a));
+        }
     }
     if (hipMalloc(&h->d_tw, tw.size() * sizeof(float)) != hipSuccess) return fail(MI355_ERR_NOMEM);
     if (hipMemcpy(h->d_tw, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail(MI355_ERR_HIP);
