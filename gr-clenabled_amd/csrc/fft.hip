@@ -22,6 +22,9 @@
 #include "fft_core.cuh"
 
 using namespace fftc;
+#ifndef MI355_FFT_WPE
+#define MI355_FFT_WPE 3
+#endif
 
 namespace {
 
@@ -73,7 +76,7 @@ __device__ __forceinline__ void load_group(c32 (&v)[16], const void *__restrict_
 }
 
 template <int N, int SIGN, bool REAL, bool PF, class G>
-__global__ __launch_bounds__(G::TH, (PF ? G::WPE : (N <= 4096 ? 3 : 1))) void k_fft(const void *__restrict__ in, c32 *__restrict__ out,
+__global__ __launch_bounds__(G::TH, (PF ? G::WPE : (N <= 4096 ? MI355_FFT_WPE : 1))) void k_fft(const void *__restrict__ in, c32 *__restrict__ out,
                                                                  const float *__restrict__ window,
                                                                  const c32 *__restrict__ twtab, int nframes, int ngroups,
                                                                  int shift)

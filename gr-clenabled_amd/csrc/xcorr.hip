@@ -50,6 +50,37 @@ __device__ __forceinline__ void load_frames(c32 (&v)[16], const c32 *__restrict_
     }
 }
 
+// N <= 128 with a radix-16 first pass: the thread's operands are runs of only N/16 elements, so the lanes move
+// consecutive elements instead and a padded LDS image (stride 17*B0 slots: conflict free) redistributes them
+template <int N, class PL>
+__device__ __forceinline__ void load_frames_staged(c32 (&v)[16], const c32 *__restrict__ src, int tid, int frames_left, c32 *lds)
+{
+    constexpr int TH = Geo<N>::TH, R0 = PL::radix(0), B0 = N / R0, STR = N + B0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int e = tid + TH * k, fr = e / N;
+        const bool ok = fr < frames_left;
+        const f2v x = __builtin_nontemporal_load((const f2v *)(src + (ok ? e : 0)));
+        lds[fr * STR + (e % N)] = ok ? mk(x.x, x.y) : mk(0.f, 0.f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16 / R0; q++) {
+        const int g = tid + TH * q, base = (g / B0) * STR + (g % B0);
+#pragma unroll
+        for (int r = 0; r < R0; r++) v[q * R0 + r] = lds[base + r * B0];
+    }
+    __syncthreads();
+}
+
+// runs shorter than 8 elements (64 B) go through the staged loader
+template <int N, class PL>
+__device__ __forceinline__ void load_any(c32 (&v)[16], const c32 *__restrict__ src, int tid, int frames_left, c32 *lds)
+{
+    if constexpr (N / PL::radix(0) < 8) load_frames_staged<N, PL>(v, src, tid, frames_left, lds);
+    else load_frames<N, PL>(v, src, tid, frames_left);
+}
+
 template <int N, bool TIME>
 __global__ __launch_bounds__(Geo<N>::TH, Geo<N>::WPE) void k_xcorr(XcArgs a, const c32 *__restrict__ tw_fwd,
                                                                   const c32 *__restrict__ tw_inv, int num_inputs, int nframes,
@@ -60,7 +91,8 @@ __global__ __launch_bounds__(Geo<N>::TH, Geo<N>::WPE) void k_xcorr(XcArgs a, con
     constexpr int TH = Geo<N>::TH, PTS = Geo<N>::PTS, F = Geo<N>::F, NP = PF::NP;
     constexpr int RL = PF::radix(NP - 1);
     static_assert(PI::radix(0) == RL, "inverse plan must start with the forward plan's last radix");
-    __shared__ c32 lds[NP > 1 ? PTS : 1];
+    constexpr bool SMALL = N <= 128;                       // short runs on the load (forward plan) and the float store side
+    __shared__ c32 lds[SMALL ? PTS + PTS / 16 : PTS];
     const int tid0 = threadIdx.x;
     TwRegs<N> twf, twi;
     if constexpr (TIME) load_twiddles<N, false>(twf, tid0, tw_fwd);
@@ -75,7 +107,7 @@ __global__ __launch_bounds__(Geo<N>::TH, Geo<N>::WPE) void k_xcorr(XcArgs a, con
         c32 R[16];
         if constexpr (TIME) {
             c32 v[16];
-            load_frames<N, PF>(v, a.in[0] + base, tid, frames_left);
+            load_any<N, PF>(v, a.in[0] + base, tid, frames_left, lds);
             transform_regs<N, -1, false>(v, twf, lds, tid);
 #pragma unroll
             for (int q = 0; q < 16 / RL; q++)
@@ -83,13 +115,13 @@ __global__ __launch_bounds__(Geo<N>::TH, Geo<N>::WPE) void k_xcorr(XcArgs a, con
                 for (int r = 0; r < RL; r++) R[q * RL + r] = v[q * RL + irev<RL>(r)];
             if constexpr (NP > 1) __syncthreads();
         } else {
-            load_frames<N, PI>(R, a.in[0] + base, tid, frames_left);
+            load_any<N, PI>(R, a.in[0] + base, tid, frames_left, lds);
         }
         for (int s = 1; s < num_inputs; s++) {
             c32 w[16];
             if constexpr (TIME) {
                 c32 v[16];
-                load_frames<N, PF>(v, a.in[s] + base, tid, frames_left);
+                load_any<N, PF>(v, a.in[s] + base, tid, frames_left, lds);
                 transform_regs<N, -1, false>(v, twf, lds, tid);
 #pragma unroll
                 for (int q = 0; q < 16 / RL; q++)
@@ -97,7 +129,7 @@ __global__ __launch_bounds__(Geo<N>::TH, Geo<N>::WPE) void k_xcorr(XcArgs a, con
                     for (int r = 0; r < RL; r++) w[q * RL + r] = cmul(R[q * RL + r], cconj(v[q * RL + irev<RL>(r)]));
                 if constexpr (NP > 1) __syncthreads();  // the forward transform's LDS reads are done
             } else {
-                load_frames<N, PI>(w, a.in[s] + base, tid, frames_left);
+                load_any<N, PI>(w, a.in[s] + base, tid, frames_left, lds);
 #pragma unroll
                 for (int i = 0; i < 16; i++) w[i] = cmul(R[i], cconj(w[i]));
             }
@@ -105,15 +137,38 @@ __global__ __launch_bounds__(Geo<N>::TH, Geo<N>::WPE) void k_xcorr(XcArgs a, con
             // ---- |.|, stored with the two halves of the vector swapped ----
             constexpr int RO = PI::radix(NP - 1), BO = N / RO;
             float *__restrict__ dst = a.out[s] + base;
+            if constexpr (SMALL) {
+                // float image in LDS (frame stride 17*BO floats: conflict free), then lane-consecutive stores
+                constexpr int STR = N + BO;
+                float *ldsf = (float *)lds;
+                if constexpr (NP > 1) __syncthreads();  // the inverse transform's LDS reads are done
 #pragma unroll
-            for (int q = 0; q < 16 / RO; q++) {
-                const int g = tid + TH * q, fr = g / BO, j = g % BO;
-                if (fr < frames_left) {
+                for (int q = 0; q < 16 / RO; q++) {
+                    const int g = tid + TH * q, fb = (g / BO) * STR + (g % BO);
 #pragma unroll
                     for (int t = 0; t < RO; t++) {
-                        const int n = j + orev<RO>(t) * BO;
                         const c32 z = w[q * RO + t];
-                        __builtin_nontemporal_store(sqrtf(fmaf(z.x, z.x, z.y * z.y)), dst + fr * N + (n ^ (N / 2)));
+                        ldsf[fb + ((orev<RO>(t) * BO) ^ (N / 2))] = sqrtf(fmaf(z.x, z.x, z.y * z.y));
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int e = tid + TH * k, fr = e / N;
+                    if (fr < frames_left) __builtin_nontemporal_store(ldsf[fr * STR + (e % N)], dst + e);
+                }
+                __syncthreads();
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16 / RO; q++) {
+                    const int g = tid + TH * q, fr = g / BO, j = g % BO;
+                    if (fr < frames_left) {
+#pragma unroll
+                        for (int t = 0; t < RO; t++) {
+                            const int n = j + orev<RO>(t) * BO;
+                            const c32 z = w[q * RO + t];
+                            __builtin_nontemporal_store(sqrtf(fmaf(z.x, z.x, z.y * z.y)), dst + fr * N + (n ^ (N / 2)));
+                        }
                     }
                 }
             }
