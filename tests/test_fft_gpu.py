@@ -61,7 +61,7 @@ def test_golden_vectors(gpu):
     assert relerr(yr, g["fwd_real1024"]) <= TOL
 
 
-@pytest.mark.parametrize("n", [2, 8, 16, 32, 64, 256, 4096])  # N <= 64 takes the LDS-redistributed load/store path
+@pytest.mark.parametrize("n", [2, 8, 16, 32, 64, 256, 4096, 8192, 16384])  # N <= 64: LDS-redistributed path; > 4096: sub-transform kernel
 @pytest.mark.parametrize("fwd,shift,win", [(True, True, True), (True, False, True), (False, True, True), (False, True, False),
                                            (True, True, False)])
 def test_window_shift_matrix_vs_oracle(gpu, oracle, n, fwd, shift, win):
@@ -74,8 +74,8 @@ def test_window_shift_matrix_vs_oracle(gpu, oracle, n, fwd, shift, win):
     assert relerr(y, oracle.fft_block(n, fwd, w, shift, oracle.DTYPE_COMPLEX, x, f64=True)) <= TOL
 
 
-@pytest.mark.parametrize("n", [4, 16, 64])
-def test_real_input_small_sizes(gpu, oracle, n):
+@pytest.mark.parametrize("n", [4, 16, 64, 8192, 16384])
+def test_real_input_small_and_large_sizes(gpu, oracle, n):
     rng = np.random.default_rng(n + 11)
     nvec = 4096 // n + 5
     x = rng.standard_normal(nvec * n).astype(np.float32)
