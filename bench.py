@@ -58,21 +58,23 @@ def barrier(world):
 
 def time_steps(fn, steps, warmup, world):
     """W untimed steps, then exactly K steps bracketed by barrier+synchronize; returns
-    (wall seconds for K steps on this rank, HIP-event seconds for the same K launches)."""
+    (wall seconds for K steps on this rank, HIP-event seconds summed over the same K launches).
+    Every launch sits between its own pair of events on the launch stream, so the event figure is
+    kernel time (what rocprofv3 --kernel-trace reports) and excludes the dispatch gaps between launches."""
     import torch
     for _ in range(warmup):
         fn()
     barrier(world)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
-    e0.record()
-    for _ in range(steps):
+    for a, b in ev:
+        a.record()
         fn()
-    e1.record()
+        b.record()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     barrier(world)
-    return wall, e0.elapsed_time(e1) * 1e-3
+    return wall, sum(a.elapsed_time(b) for a, b in ev) * 1e-3
 
 
 def max_over_ranks(x, world):
