@@ -39,8 +39,8 @@ __device__ __forceinline__ void st_stream(c32 *p, c32 v) { f2v o; o.x = v.x; o.y
 // ------------------------------------------------------------------------------------
 // fused overlap-save fast convolution
 // ------------------------------------------------------------------------------------
-template <int NF>
-__global__ __launch_bounds__(Geo<NF>::TH, Geo<NF>::WPE) void k_ols(const c32 *__restrict__ in, c32 *__restrict__ out,
+template <int NF, class G>
+__global__ __launch_bounds__(G::TH, G::WPE) void k_ols(const c32 *__restrict__ in, c32 *__restrict__ out,
                                                                    const c32 *__restrict__ Hspec,
                                                                    const c32 *__restrict__ tw_fwd,
                                                                    const c32 *__restrict__ tw_inv, int ntaps, int decim,
@@ -50,14 +50,14 @@ __global__ __launch_bounds__(Geo<NF>::TH, Geo<NF>::WPE) void k_ols(const c32 *__
 {
     using PF = Plan<NF, false>;
     using PI = Plan<NF, true>;
-    constexpr int TH = Geo<NF>::TH, PTS = Geo<NF>::PTS, F = Geo<NF>::F, NP = PF::NP;
+    constexpr int TH = G::TH, PTS = G::PTS, F = G::F, NP = PF::NP;
     __shared__ c32 lds[NP > 1 ? PTS : 1];
     const int tid0 = threadIdx.x;
     const int L = NF - (ntaps - 1);
 
     TwRegs<NF> twf, twi;
-    load_twiddles<NF, false>(twf, tid0, tw_fwd);
-    load_twiddles<NF, true>(twi, tid0, tw_inv);
+    load_twiddles<NF, false, G>(twf, tid0, tw_fwd);
+    load_twiddles<NF, true, G>(twi, tid0, tw_inv);
     // spectrum of the taps at the bins this thread holds after the forward transform
     constexpr int RL = PF::radix(NP - 1), BL = NF / RL;
     static_assert(PI::radix(0) == RL, "inverse plan must start with the forward plan's last radix");
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(Geo<NF>::TH, Geo<NF>::WPE) void k_ols(const c32 *__
                 v[q * R0 + r] = ok ? x : mk(0.f, 0.f);
             }
         }
-        transform_regs<NF, -1, false>(v, twf, lds, tid);
+        transform_regs<NF, -1, false, G>(v, twf, lds, tid);
         // ---- spectrum multiply in registers, permuted into the inverse plan's input order ----
         c32 w[16];
 #pragma unroll
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(Geo<NF>::TH, Geo<NF>::WPE) void k_ols(const c32 *__
             for (int r = 0; r < RL; r++) w[q * RL + r] = cmul(v[q * RL + irev<RL>(r)], Hreg[q * RL + irev<RL>(r)]);
         }
         if constexpr (NP > 1) __syncthreads();  // forward transform's LDS reads are done
-        transform_regs<NF, 1, true>(w, twi, lds, tid);
+        transform_regs<NF, 1, true, G>(w, twi, lds, tid);
         // ---- store the valid part (n >= ntaps-1), decimated ---------------------------------
         constexpr int RO = PI::radix(NP - 1), BO = NF / RO;
         c32 *__restrict__ out_g = out + g0;  // decim == 1 fast path
@@ -338,21 +338,33 @@ int upload_taps(mi355_filter *h, const void *taps, int ntaps)
     return MI355_OK;
 }
 
-template <int NF>
-int launch_ols(mi355_filter *h, size_t nout, const void *in, void *out, hipStream_t st)
+template <int NF, class G>
+int launch_ols_g(mi355_filter *h, size_t nout, const void *in, void *out, hipStream_t st)
 {
-    constexpr int F = Geo<NF>::F, TH = Geo<NF>::TH;
+    constexpr int F = G::F, TH = G::TH, WAVES = TH / 64;
     const long long n_y = (long long)nout * h->decim;
     const long long n_in = n_y + h->ntaps - 1;
     const int L = NF - (h->ntaps - 1);
     const long long nblocks = (n_y + L - 1) / L;
     const long long ngroups = (nblocks + F - 1) / F;
     if (nblocks > 0x7fffffffLL) { mi355_set_error("work() call too large"); return MI355_ERR_INVALID_ARG; }
-    long long grid = mi355_balanced_grid(h->ctx, ngroups, 2, 3);
-    hipLaunchKernelGGL((k_ols<NF>), dim3((unsigned)grid), dim3(TH), 0, st, (const c32 *)in, (c32 *)out, (const c32 *)h->d_H,
+    long long grid = mi355_balanced_grid(h->ctx, ngroups, 8 / WAVES, 12 / WAVES);
+    hipLaunchKernelGGL((k_ols<NF, G>), dim3((unsigned)grid), dim3(TH), 0, st, (const c32 *)in, (c32 *)out, (const c32 *)h->d_H,
                        (const c32 *)h->d_twf, (const c32 *)h->d_twi, h->ntaps, h->decim, n_in, n_y, (int)nblocks, (int)ngroups);
     MI355_HIP(hipGetLastError());
     return MI355_OK;
+}
+
+template <int NF>
+int launch_ols(mi355_filter *h, size_t nout, const void *in, void *out, hipStream_t st)
+{
+    if constexpr (NF <= 1024) {
+        // one-wave workgroups (every exchange inside the wave, no workgroup barrier): +5 % at NF = 256, slower at 512/1024
+        // (measured on MI355X); MI355_FILTER_WAVE_GEO=0/1 forces either geometry
+        static const int wave = getenv("MI355_FILTER_WAVE_GEO") ? atoi(getenv("MI355_FILTER_WAVE_GEO")) : -1;
+        if (wave == 1 || (wave < 0 && NF <= 256)) return launch_ols_g<NF, GeoW<NF>>(h, nout, in, out, st);
+    }
+    return launch_ols_g<NF, Geo<NF>>(h, nout, in, out, st);
 }
 
 int launch_filter(mi355_filter *h, size_t nout, const void *in, void *out, hipStream_t st)
