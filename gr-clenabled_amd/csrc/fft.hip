@@ -387,15 +387,208 @@ struct mi355_fft {
     float *d_window;  // n floats or NULL
     void *d_tw;       // n complex: exp(sign*2*pi*i*k/n), generated in double
     HostPipe pipe;
+    // sizes that are not a power of two: chirp-z (Bluestein) over power-of-two transforms of size m
+    int m = 0;
+    void *d_pre = nullptr, *d_post = nullptr, *d_bspec = nullptr;  // window*chirp (n), chirp (n), spectrum of the conjugate chirp / m (m)
+    void *d_twm_f = nullptr, *d_twm_i = nullptr;                    // twiddle tables of the size-m forward / inverse transforms
+    float *d_ones = nullptr;                                        // all-ones window of size m
+    void *d_wa = nullptr, *d_wb = nullptr;                          // work buffers, cap_frames * m complex each
+    size_t cap_frames = 0;
 };
+
+namespace {
+
+// ---- chirp-z (Bluestein) for sizes that are not a power of two --------------------------------------------------
+//   X[k] = a[k] * sum_n (x[n] a[n]) conj(a)[k-n],  a[n] = exp(sign * i*pi*n^2/N)
+// evaluated as a circular convolution of size m = 2^ceil(log2(2N-1)) with the power-of-two kernels above:
+//   pre (window, input shift and chirp folded into one table) -> FFT_m -> x spectrum of conj(a) (pre-scaled 1/m)
+//   -> inverse FFT_m -> post (chirp, output shift).  Functional coverage, not a roofline path: ~7 passes over m-point frames.
+__global__ __launch_bounds__(256) void k_blu_pre(const void *__restrict__ in, c32 *__restrict__ A, const c32 *__restrict__ pre,
+                                                 const int *__restrict__ src, int N, int M, long long total, int real_in)
+{
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long f = e / M;
+        const int m = (int)(e - f * M);
+        c32 v = mk(0.f, 0.f);
+        if (m < N) {
+            const int i = src[m];  // original input position that lands on transform input m (reverse + shift swaps the halves)
+            const c32 x = real_in ? mk(((const float *)in)[f * N + i], 0.f) : ((const c32 *)in)[f * N + i];
+            v = cmul(x, pre[m]);
+        }
+        A[e] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_blu_mul(c32 *__restrict__ B, const c32 *__restrict__ bspec, int M, long long total)
+{
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256)
+        B[e] = cmul(B[e], bspec[e & (M - 1)]);
+}
+
+__global__ __launch_bounds__(256) void k_blu_post(const c32 *__restrict__ A, c32 *__restrict__ out, const c32 *__restrict__ post,
+                                                  int N, int M, long long total, int lo)
+{
+    // lo = 0: out[p] = X[p];  forward + shift: out[p] = X[p + len] for p < N - len, X[p - (N - len)] after (len = ceil(N/2)), lo = len
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long f = e / N;
+        const int p = (int)(e - f * N);
+        const int k = lo ? (p < N - lo ? p + lo : p - (N - lo)) : p;
+        out[e] = cmul(A[f * M + k], post[k]);
+    }
+}
+
+int launch_bluestein(mi355_fft *h, const void *in, void *out, int nframes, hipStream_t st)
+{
+    const int N = h->n, M = h->m;
+    // bound the work buffers to 2 x 128 MiB
+    size_t chunk = (128u << 20) / ((size_t)M * 8);
+    if (chunk < 1) chunk = 1;
+    if (chunk > (size_t)nframes) chunk = (size_t)nframes;
+    if (chunk > h->cap_frames) {
+        MI355_HIP(hipStreamSynchronize(st));
+        if (h->d_wa) (void)hipFree(h->d_wa);
+        if (h->d_wb) (void)hipFree(h->d_wb);
+        h->d_wa = h->d_wb = nullptr; h->cap_frames = 0;
+        MI355_HIP(hipMalloc(&h->d_wa, chunk * (size_t)M * 8));
+        MI355_HIP(hipMalloc(&h->d_wb, chunk * (size_t)M * 8));
+        h->cap_frames = chunk;
+    }
+    const int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
+    auto grid_for = [&](long long total) { long long b = (total + 255) / 256; return (unsigned)(b < (long long)cus * 16 ? b : (long long)cus * 16); };
+    const size_t isz = h->dtype == MI355_DTYPE_FLOAT ? 4 : 8;
+    const int len = (N + 1) / 2;
+    for (size_t f0 = 0; f0 < (size_t)nframes; f0 += chunk) {
+        const int nf = (int)((size_t)nframes - f0 < chunk ? (size_t)nframes - f0 : chunk);
+        const long long tm = (long long)nf * M, tn = (long long)nf * N;
+        hipLaunchKernelGGL(k_blu_pre, dim3(grid_for(tm)), dim3(256), 0, st, (const char *)in + f0 * N * isz, (c32 *)h->d_wa,
+                           (const c32 *)h->d_pre, (const int *)((const char *)h->d_post + (size_t)N * 8), N, M, tm,
+                           h->dtype == MI355_DTYPE_FLOAT ? 1 : 0);
+        int rc = launch_fft(h->ctx, M, -1, h->d_wa, h->d_wb, h->d_ones, h->d_twm_f, nf, 0, 0, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_blu_mul, dim3(grid_for(tm)), dim3(256), 0, st, (c32 *)h->d_wb, (const c32 *)h->d_bspec, M, tm);
+        rc = launch_fft(h->ctx, M, 1, h->d_wb, h->d_wa, h->d_ones, h->d_twm_i, nf, 0, 0, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_blu_post, dim3(grid_for(tn)), dim3(256), 0, st, (const c32 *)h->d_wa, (c32 *)out + f0 * N,
+                           (const c32 *)h->d_post, N, M, tn, (h->sign < 0 && h->shift) ? len : 0);
+        MI355_HIP(hipGetLastError());
+    }
+    return MI355_OK;
+}
+
+int launch_handle(mi355_fft *h, const void *in, void *out, int nvec, hipStream_t st)
+{
+    if (h->m) return launch_bluestein(h, in, out, nvec, st);
+    return launch_fft(h->ctx, h->n, h->sign, in, out, h->d_window, h->d_tw, nvec, h->shift, h->dtype == MI355_DTYPE_FLOAT, st);
+}
+
+// iterative radix-2 FFT in double (host side, used once per handle for the chirp spectrum)
+void host_fft_pow2(std::vector<double> &re, std::vector<double> &im, int sign)
+{
+    const int n = (int)re.size();
+    for (int i = 1, j = 0; i < n; i++) {
+        int bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+    }
+    for (int len = 2; len <= n; len <<= 1) {
+        for (int i = 0; i < n; i += len)
+            for (int k = 0; k < len / 2; k++) {
+                const double a = sign * 2.0 * M_PI * (double)k / (double)len, wr = cos(a), wi = sin(a);
+                const int p = i + k, q = p + len / 2;
+                const double tr = re[q] * wr - im[q] * wi, ti = re[q] * wi + im[q] * wr;
+                re[q] = re[p] - tr; im[q] = im[p] - ti;
+                re[p] += tr; im[p] += ti;
+            }
+    }
+}
+
+int upload(void **d, const void *src, size_t bytes)
+{
+    if (hipMalloc(d, bytes) != hipSuccess) return MI355_ERR_NOMEM;
+    if (hipMemcpy(*d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return MI355_ERR_HIP;
+    return MI355_OK;
+}
+
+std::vector<float> twiddle_table(int n, int sign)
+{
+    std::vector<float> tw;
+    tw.reserve(2 * (size_t)n + 8192);
+    for (int k = 0; k < n; k++) {
+        const double a = sign * 2.0 * M_PI * (double)k / (double)n;
+        tw.push_back((float)cos(a));
+        tw.push_back((float)sin(a));
+    }
+    if (n > 4096)  // the interleaved sub-transform kernel also needs the 4096-point table
+        for (int k = 0; k < 4096; k++) {
+            const double a = sign * 2.0 * M_PI * (double)k / 4096.0;
+            tw.push_back((float)cos(a));
+            tw.push_back((float)sin(a));
+        }
+    return tw;
+}
+
+// tables of the chirp-z path; window == nullptr means all ones
+int setup_bluestein(mi355_fft *h, const float *window)
+{
+    const int N = h->n;
+    int M = 1;
+    while (M < 2 * N - 1) M <<= 1;
+    h->m = M;
+    // a[n] = exp(sign * i*pi*n^2/N); n^2 reduced mod 2N in integers keeps the phase exact
+    std::vector<double> ar(N), ai(N);
+    for (int n = 0; n < N; n++) {
+        const long long q = ((long long)n * n) % (2LL * N);
+        const double ang = h->sign * M_PI * (double)q / (double)N;
+        ar[n] = cos(ang); ai[n] = sin(ang);
+    }
+    const int half = N / 2;
+    const bool rshift = h->sign > 0 && h->shift;
+    std::vector<float> pre(2 * (size_t)N), post(2 * (size_t)N);
+    std::vector<int> src(N);
+    for (int m = 0; m < N; m++) {
+        // reverse + shift: original position i lands on m = i < half ? i + (N - half) : i - half (lib/clFFT_impl.cc:477-493)
+        const int i = rshift ? (m >= N - half ? m - (N - half) : m + half) : m;
+        src[m] = i;
+        const double w = window ? (double)window[i] : 1.0;
+        pre[2 * m] = (float)(w * ar[m]); pre[2 * m + 1] = (float)(w * ai[m]);
+        post[2 * m] = (float)ar[m]; post[2 * m + 1] = (float)ai[m];
+    }
+    std::vector<double> br(M, 0.0), bi(M, 0.0);
+    for (int n = 0; n < N; n++) {
+        br[n] = ar[n]; bi[n] = -ai[n];
+        if (n) { br[M - n] = ar[n]; bi[M - n] = -ai[n]; }
+    }
+    host_fft_pow2(br, bi, -1);
+    std::vector<float> bs(2 * (size_t)M);
+    for (int k = 0; k < M; k++) { bs[2 * k] = (float)(br[k] / M); bs[2 * k + 1] = (float)(bi[k] / M); }
+    // post table is followed by the int source map (one allocation)
+    std::vector<char> post_blob((size_t)N * 8 + (size_t)N * 4);
+    memcpy(post_blob.data(), post.data(), (size_t)N * 8);
+    memcpy(post_blob.data() + (size_t)N * 8, src.data(), (size_t)N * 4);
+    int rc;
+    if ((rc = upload(&h->d_pre, pre.data(), pre.size() * 4))) return rc;
+    if ((rc = upload(&h->d_post, post_blob.data(), post_blob.size()))) return rc;
+    if ((rc = upload(&h->d_bspec, bs.data(), bs.size() * 4))) return rc;
+    std::vector<float> tf = twiddle_table(M, -1), ti = twiddle_table(M, 1), ones(M, 1.0f);
+    if ((rc = upload(&h->d_twm_f, tf.data(), tf.size() * 4))) return rc;
+    if ((rc = upload(&h->d_twm_i, ti.data(), ti.size() * 4))) return rc;
+    if ((rc = upload((void **)&h->d_ones, ones.data(), ones.size() * 4))) return rc;
+    return MI355_OK;
+}
+
+}  // namespace
 
 extern "C" int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, const float *window, int window_len, int dtype,
                                 int num_streams, int shift, mi355_fft **out)
 {
     MI355_REQUIRE(ctx && out, "NULL argument");
     *out = nullptr;
-    MI355_REQUIRE(fft_size >= 2 && fft_size <= 16384 && (fft_size & (fft_size - 1)) == 0,
-                  "fft size must be a power of two in 2..16384");
+    const bool pow2 = fft_size >= 2 && (fft_size & (fft_size - 1)) == 0;
+    if (fft_size < 2 || (pow2 && fft_size > 16384) || (!pow2 && fft_size > 8192)) {
+        mi355_set_error("fft size %d unsupported (powers of two 2..16384, any other size 3..8192)", fft_size);
+        return fft_size < 2 ? MI355_ERR_INVALID_ARG : MI355_ERR_UNSUPPORTED;
+    }
     MI355_REQUIRE(window_len == 0 || window_len == fft_size, "window not the same length as fft_size");
     MI355_REQUIRE(window_len == 0 || window != nullptr, "window is NULL");
     MI355_REQUIRE(dtype == MI355_DTYPE_COMPLEX || dtype == MI355_DTYPE_FLOAT, "clFFT dtype must be complex or float");
@@ -433,6 +626,10 @@ extern "C" int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, con
     }
     int rc = h->pipe.init(ctx);
     if (rc) return fail(rc);
+    if (!pow2) {
+        rc = setup_bluestein(h, window_len ? window : nullptr);
+        if (rc) return fail(rc);
+    }
     *out = h;
     return MI355_OK;
 }
@@ -444,6 +641,8 @@ extern "C" int mi355_fft_destroy(mi355_fft *h)
     h->pipe.release();
     if (h->d_window) (void)hipFree(h->d_window);
     if (h->d_tw) (void)hipFree(h->d_tw);
+    for (void *p : {h->d_pre, h->d_post, h->d_bspec, h->d_twm_f, h->d_twm_i, (void *)h->d_ones, h->d_wa, h->d_wb})
+        if (p) (void)hipFree(p);
     delete h;
     return MI355_OK;
 }
@@ -456,8 +655,7 @@ extern "C" int mi355_fft_work_dev(mi355_fft *h, int nvec, const void *in, void *
     MI355_REQUIRE((reinterpret_cast<uintptr_t>(in) & 7u) == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0,
                   "device buffers must be 8-byte aligned");
     MI355_HIP(hipSetDevice(h->ctx->device));
-    return launch_fft(h->ctx, h->n, h->sign, in, out, h->d_window, h->d_tw, nvec, h->shift, h->dtype == MI355_DTYPE_FLOAT,
-                      mi355_pick_stream(h->ctx, stream));
+    return launch_handle(h, in, out, nvec, mi355_pick_stream(h->ctx, stream));
 }
 
 extern "C" int mi355_fft_work(mi355_fft *h, int nvec, const void *const *in_streams, void *const *out_streams)
@@ -486,7 +684,7 @@ extern "C" int mi355_fft_work(mi355_fft *h, int nvec, const void *const *in_stre
         char *pout = (char *)out_streams[s_i];
         for (size_t ci = 0; ci < nchunks; ci++, seq++) {
             int s = (int)(seq & 1);
-            hipStream_t st = h->ctx->stream[s];
+            hipStream_t st = h->ctx->stream[h->m ? 0 : s];  // the chirp-z path shares one pair of work buffers: one stream
             if (pend_bytes[s]) {
                 MI355_HIP(hipEventSynchronize(p.done[s]));
                 memcpy(pend_dst[s], p.h_out[s], pend_bytes[s]);
@@ -496,8 +694,7 @@ extern "C" int mi355_fft_work(mi355_fft *h, int nvec, const void *const *in_stre
             size_t nf = (size_t)nvec - f0 < chunk_frames ? (size_t)nvec - f0 : chunk_frames;
             memcpy(p.h_in[s][0], pin + f0 * in_frame, nf * in_frame);
             MI355_HIP(hipMemcpyAsync(p.d_in[s][0], p.h_in[s][0], nf * in_frame, hipMemcpyHostToDevice, st));
-            rc = launch_fft(h->ctx, h->n, h->sign, p.d_in[s][0], p.d_out[s], h->d_window, h->d_tw, (int)nf, h->shift,
-                            h->dtype == MI355_DTYPE_FLOAT, st);
+            rc = launch_handle(h, p.d_in[s][0], p.d_out[s], (int)nf, st);
             if (rc) return rc;
             MI355_HIP(hipMemcpyAsync(p.h_out[s], p.d_out[s], nf * out_frame, hipMemcpyDeviceToHost, st));
             MI355_HIP(hipEventRecord(p.done[s], st));

@@ -38,10 +38,39 @@ static unsigned bitrev(unsigned v, int bits)
     return r;
 }
 
+/* direct O(N^2) DFT in double for sizes that are not a power of two (the reference leaves those to FFTW / clFFT's
+ * mixed-radix plans; the definition is the same) */
+static int dft_any(int n, int sign, const ocplx *in, ocplx *out)
+{
+    if (n < 1) return -1;
+    double *c = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+    ocplx *tmp = (ocplx *)malloc(sizeof(ocplx) * (size_t)n);
+    if (!c || !tmp) { free(c); free(tmp); return -2; }
+    double *sn = c + n;
+    for (int k = 0; k < n; k++) {
+        double a = sign * 2.0 * M_PI * (double)k / (double)n;
+        c[k] = cos(a); sn[k] = sin(a);
+    }
+    for (int k = 0; k < n; k++) {
+        double re = 0.0, im = 0.0;
+        long long idx = 0;
+        for (int i = 0; i < n; i++) {
+            re += (double)in[i].re * c[idx] - (double)in[i].im * sn[idx];
+            im += (double)in[i].re * sn[idx] + (double)in[i].im * c[idx];
+            idx += k;
+            if (idx >= n) idx -= n;
+        }
+        tmp[k].re = (float)re; tmp[k].im = (float)im;
+    }
+    memcpy(out, tmp, sizeof(ocplx) * (size_t)n);
+    free(c); free(tmp);
+    return 0;
+}
+
 int oracle_fft_c2c_f32(int n, int sign, const ocplx *in, ocplx *out)
 {
     int lg = ilog2_exact(n);
-    if (lg < 0) return -1;
+    if (lg < 0) return dft_any(n, sign, in, out);
     ocplx *w = (ocplx *)malloc(sizeof(ocplx) * (size_t)(n / 2 + 1));
     if (!w) return -2;
     for (int k = 0; k < n / 2; k++) {
@@ -77,7 +106,7 @@ int oracle_fft_c2c_f32(int n, int sign, const ocplx *in, ocplx *out)
 int oracle_fft_c2c_f64(int n, int sign, const ocplx *in, ocplx *out)
 {
     int lg = ilog2_exact(n);
-    if (lg < 0) return -1;
+    if (lg < 0) return dft_any(n, sign, in, out);
     double *re = (double *)malloc(sizeof(double) * 2 * (size_t)n);
     double *wr = (double *)malloc(sizeof(double) * (size_t)(n + 2));
     if (!re || !wr) { free(re); free(wr); return -2; }
@@ -124,7 +153,7 @@ int oracle_fft_c2c_f64(int n, int sign, const ocplx *in, ocplx *out)
 int oracle_fft_block(int n, int forward, const float *window, int shift, int dtype,
                      int nvec, const void *in, ocplx *out, int use_f64)
 {
-    if (ilog2_exact(n) < 0) return -1;
+    if (n < 1) return -1;
     if (dtype != O_DTYPE_COMPLEX && dtype != O_DTYPE_FLOAT) return -1;
     ocplx *buf = (ocplx *)malloc(sizeof(ocplx) * 2 * (size_t)n);
     if (!buf) return -2;

@@ -159,4 +159,49 @@ def test_zero_vectors_and_bad_sizes(gpu):
     e = np.empty(0, np.complex64)
     assert blk.work(0, [e], [e]) == 0
     with pytest.raises(gpu.Mi355Error):
-        _fft(gpu, 48, gpu.CLFFT_FORWARD)  # clFFT radix-3/5/7 sizes are not implemented: refused, not emulated
+        _fft(gpu, 32768, gpu.CLFFT_FORWARD)  # powers of two above 16384 are refused, not emulated
+    with pytest.raises(gpu.Mi355Error):
+        _fft(gpu, 9000, gpu.CLFFT_FORWARD)   # other sizes above 8192 too
+    with pytest.raises(gpu.Mi355Error):
+        _fft(gpu, 1, gpu.CLFFT_FORWARD)
+
+
+# sizes that are not a power of two (clFFT's radix-3/5/7 plans in the reference) run through the chirp-z path
+@pytest.mark.parametrize("n", [3, 5, 12, 48, 100, 1000, 1536, 2000, 4095, 6000, 8191])
+@pytest.mark.parametrize("fwd,shift,win", [(True, False, False), (True, True, True), (False, True, True), (False, False, False)])
+def test_sizes_that_are_not_a_power_of_two(gpu, oracle, n, fwd, shift, win):
+    rng = np.random.default_rng(n + 3)
+    nvec = 3 if n > 2048 else 7
+    w = oracle.window(oracle.WIN_HAMMING, n) if win else None
+    x = crandn(rng, nvec * n)
+    y = np.empty_like(x)
+    blk = _fft(gpu, n, gpu.CLFFT_FORWARD if fwd else gpu.CLFFT_BACKWARD, w, shift=shift)
+    assert blk.work(nvec, [x], [y]) == nvec
+    assert relerr(y, oracle.fft_block(n, fwd, w, shift, oracle.DTYPE_COMPLEX, x, f64=True)) <= TOL
+
+
+def test_chirpz_real_input_device_path_and_chunks(gpu, oracle):
+    import torch
+    n, nvec = 1200, 40
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal(nvec * n).astype(np.float32)
+    w = oracle.window(oracle.WIN_BLACKMAN, n)
+    ref = oracle.fft_block(n, True, w, True, oracle.DTYPE_FLOAT, x, f64=True)
+    blk = _fft(gpu, n, gpu.CLFFT_FORWARD, w, dtype=gpu.DTYPE_FLOAT, shift=True)
+    y = np.empty(nvec * n, np.complex64)
+    blk.work(nvec, [x], [y])
+    assert relerr(y, ref) <= TOL
+    dx = torch.from_numpy(x).cuda()
+    dy = torch.empty(nvec * n, 2, device="cuda")
+    blk.work_device(nvec, [dx], [dy])
+    torch.cuda.synchronize()
+    assert relerr(dy.cpu().numpy().view(np.complex64).reshape(-1), ref) <= TOL
+    # a call larger than one work-buffer chunk (128 MiB / (4096 * 8 B) = 4096 frames): first and last frames
+    nbig = 5000
+    xb = crandn(rng, nbig * n)
+    yb = np.empty_like(xb)
+    blk2 = _fft(gpu, n, gpu.CLFFT_FORWARD)
+    blk2.work(nbig, [xb], [yb])
+    for sl in (slice(0, 2 * n), slice((nbig - 2) * n, nbig * n)):
+        assert relerr(yb[sl], oracle.fft_block(n, True, None, False, oracle.DTYPE_COMPLEX, xb[sl], f64=True)) <= TOL
+
