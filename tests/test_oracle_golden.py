@@ -92,11 +92,11 @@ def test_fft_block_window_shift(oracle):
     out = o.fft_block(1024, True, None, False, o.DTYPE_FLOAT, g["xr1024"])
     assert relerr(out, g["fwd_real1024"]) < 2e-6
     assert o.fft_block(4096, True, None, False, o.DTYPE_COMPLEX, g["x4096"]).size == 8192
-    try:
-        o.fft(np.zeros(12, np.complex64))
-        assert False, "non power of two must be refused"
-    except ValueError:
-        pass
+    # sizes that are not a power of two: direct DFT in double, checked against numpy's mixed-radix FFT
+    rng = np.random.default_rng(12)
+    for n in (12, 45, 1000):
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+        assert relerr(o.fft(x), np.fft.fft(x.astype(np.complex128)).astype(np.complex64)) < 1e-6
 
 
 def test_fft_filter_sizes_and_outputs(oracle):
