@@ -94,6 +94,8 @@ def lib():
         "mi355_xengine_submit": (i, [vp, vp, vp]),
         "mi355_xengine_wait": (i, [vp, vp]),
         "mi355_xengine_pending": (i, [vp]),
+        "mi355_xengine_acquire": (i, [vp, pp]),
+        "mi355_xengine_submit_acquired": (i, [vp, vp]),
         "mi355_elem_create": (i, [vp, i, f, f, pp]),
         "mi355_elem_destroy": (i, [vp]),
         "mi355_elem_history": (i, [vp]),

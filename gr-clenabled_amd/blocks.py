@@ -363,6 +363,18 @@ class clXEngine(_Block):
     def pending(self):
         return self._L.mi355_xengine_pending(self._h)
 
+    def acquire(self):
+        """Zero-copy submit: the pinned frame buffer of the next free slot as a writable int8 numpy view (the
+        reference's pinned char_input / complex_input, lib/clXEngine_impl.cc:325-362); fill it, then submit_acquired()."""
+        p = C.c_void_p()
+        check(self._L.mi355_xengine_acquire(self._h, C.byref(p)), "mi355_xengine_acquire")
+        buf = (C.c_int8 * self.input_bytes()).from_address(p.value)
+        return np.frombuffer(buf, dtype=np.int8)
+
+    def submit_acquired(self, accumulator=None):
+        acc = None if accumulator is None else _hp(_host(accumulator, np.complex64))
+        check(self._L.mi355_xengine_submit_acquired(self._h, acc), "mi355_xengine_submit_acquired")
+
     def xcorrelate_device(self, input_matrix, cross_correlation, accumulate=False):
         check(self._L.mi355_xengine_xcorrelate_dev(self._h, _dp(input_matrix), _dp(cross_correlation),
                                                    1 if accumulate else 0, _torch_stream(self.device)),

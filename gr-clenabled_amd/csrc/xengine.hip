@@ -592,6 +592,7 @@ struct mi355_xengine {
         bool busy = false;
     } slot[2];
     int next_submit = 0, next_wait = 0, pending = 0;
+    bool acquired = false;  // the next slot's pinned frame buffer is handed out (zero-copy gather)
 };
 
 namespace {
@@ -785,22 +786,16 @@ int slot_prepare(mi355_xengine *h, int s)
 // At most two integrations are in flight; a third submit() is refused until wait() frees a slot.
 // accumulate != 0 adds into the slot's previous result only when used with one slot in flight
 // (pipeline integration keeps the accumulator on the host side of the block, like the reference).
-extern "C" int mi355_xengine_submit(mi355_xengine *h, const void *in_host, const void *acc_host)
+static int xe_submit_slot(mi355_xengine *h, const void *in_host /* nullptr: the slot's pinned buffer is already filled */,
+                          const void *acc_host)
 {
-    MI355_REQUIRE(h && in_host, "NULL argument");
-    std::lock_guard<std::mutex> g(h->ctx->lock);
-    MI355_HIP(hipSetDevice(h->ctx->device));
-    if (h->pending == 2) {
-        mi355_set_error("two integrations already in flight: call mi355_xengine_wait first");
-        return MI355_ERR_STATE;
-    }
     const int s = h->next_submit;
     int rc = slot_prepare(h, s);
     if (rc) return rc;
     mi355_xengine::Slot &sl = h->slot[s];
     hipStream_t st = h->ctx->stream[s];
     const size_t outb = h->out_items * 8;
-    memcpy(sl.h_in, in_host, h->in_bytes);
+    if (in_host) memcpy(sl.h_in, in_host, h->in_bytes);
     MI355_HIP(hipMemcpyAsync(sl.d_in, sl.h_in, h->in_bytes, hipMemcpyHostToDevice, st));
     if (acc_host) {
         memcpy(sl.h_out, acc_host, outb);
@@ -811,9 +806,51 @@ extern "C" int mi355_xengine_submit(mi355_xengine *h, const void *in_host, const
     MI355_HIP(hipMemcpyAsync(sl.h_out, sl.d_out, outb, hipMemcpyDeviceToHost, st));
     MI355_HIP(hipEventRecord(sl.done, st));
     sl.busy = true;
+    h->acquired = false;
     h->next_submit ^= 1;
     h->pending++;
     return MI355_OK;
+}
+
+extern "C" int mi355_xengine_submit(mi355_xengine *h, const void *in_host, const void *acc_host)
+{
+    MI355_REQUIRE(h && in_host, "NULL argument");
+    std::lock_guard<std::mutex> g(h->ctx->lock);
+    MI355_HIP(hipSetDevice(h->ctx->device));
+    if (h->pending == 2) {
+        mi355_set_error("two integrations already in flight: call mi355_xengine_wait first");
+        return MI355_ERR_STATE;
+    }
+    MI355_REQUIRE(!h->acquired, "a frame buffer is acquired: finish it with mi355_xengine_submit_acquired");
+    return xe_submit_slot(h, in_host, acc_host);
+}
+
+// Zero-copy form: hand out the pinned frame buffer of the next free slot so the block gathers its frames straight into
+// it (the reference gathers into its pinned char_input / complex_input, lib/clXEngine_impl.cc:325-362,987-1061), then
+// submit_acquired() enqueues H2D + kernels + D2H without another host copy.
+extern "C" int mi355_xengine_acquire(mi355_xengine *h, void **frame_buffer)
+{
+    MI355_REQUIRE(h && frame_buffer, "NULL argument");
+    std::lock_guard<std::mutex> g(h->ctx->lock);
+    MI355_HIP(hipSetDevice(h->ctx->device));
+    if (h->pending == 2) {
+        mi355_set_error("two integrations already in flight: call mi355_xengine_wait first");
+        return MI355_ERR_STATE;
+    }
+    int rc = slot_prepare(h, h->next_submit);
+    if (rc) return rc;
+    h->acquired = true;
+    *frame_buffer = h->slot[h->next_submit].h_in;
+    return MI355_OK;
+}
+
+extern "C" int mi355_xengine_submit_acquired(mi355_xengine *h, const void *acc_host)
+{
+    MI355_REQUIRE(h != nullptr, "NULL argument");
+    std::lock_guard<std::mutex> g(h->ctx->lock);
+    MI355_HIP(hipSetDevice(h->ctx->device));
+    MI355_REQUIRE(h->acquired, "no frame buffer acquired");
+    return xe_submit_slot(h, nullptr, acc_host);
 }
 
 // Block until the OLDEST submitted integration is complete and copy its matrix to out_host.

@@ -261,6 +261,35 @@ static void test_xcorr(int fft_size, size_t n)
     report(name, (size_t)nframes * fft_size, t, ok);
 }
 
+// End-to-end streaming rate of BASELINE config 5 through the block interface, the measurement of the reference's
+// test-clxengine (lib/test-clxengine.cc:287-332): one frame per work_test() call on every input, host buffers,
+// frames gathered into the pinned slot, H2D + correlation + D2H overlapped with the gather of the next window.
+static int xengine_e2e(int nint)
+{
+    const int N = 64, F = 1024, T = 1024;
+    auto xe = clXEngine::make(OCLTYPE_GPU, OCLDEVICESELECTOR_SPECIFIC, 0, g_dev, false, DTYPE_BYTE, 1, N, CLXCORR_TRIANGULAR_ORDER, 0, F, T, {});
+    int T_user = T;
+    g_handler_calls = 0;
+    xe->set_result_handler(on_matrix, &T_user);
+    std::vector<char> frame((size_t)F * 2);
+    for (size_t i = 0; i < frame.size(); i += 2) { frame[i] = 127; frame[i + 1] = 0; }
+    gr_vector_const_void_star in(N, frame.data());
+    gr_vector_void_star out;
+    for (int t = 0; t < T; t++) xe->work_test(1, in, out);  // warm-up window (allocates the slots)
+    auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < nint; i++)
+        for (int t = 0; t < T; t++) xe->work_test(1, in, out);
+    xe->stop();
+    std::chrono::duration<double> dt = std::chrono::steady_clock::now() - t0;
+    const double per = dt.count() / nint;
+    printf("clXEngine e2e 64 ant x 1024 ch x 1024 frames, 1 frame per work_test call: %.2f ms per integration, "
+           "%.1f MSPS total input, %.2f MSPS per stream, %.2f Gbit/s in\n",
+           per * 1e3, (double)N * F * T / per / 1e6, (double)F * T / per / 1e6, (double)N * F * T * 16 / per / 1e9);
+    bool ok = g_handler_calls == (size_t)nint + 1 && g_handler_ok;
+    printf("%s\n", ok ? "ok" : "MISMATCH");
+    return ok ? 0 : 1;
+}
+
 int main(int argc, char **argv)
 {
     size_t n = 8192;  // the reference's default block size
@@ -274,6 +303,10 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--fft-only")) only_fft = true;
         else if (!strncmp(argv[i], "--xengine-stream=", 17)) {
             try { return xengine_stream_test(argv[i] + 17); }
+            catch (const std::exception &e) { std::cerr << "error: " << e.what() << std::endl; return 2; }
+        }
+        else if (!strncmp(argv[i], "--xengine-e2e", 13)) {
+            try { return xengine_e2e(argv[i][13] == '=' ? atoi(argv[i] + 14) : 5); }
             catch (const std::exception &e) { std::cerr << "error: " << e.what() << std::endl; return 2; }
         }
         else if (!strcmp(argv[i], "--help")) {

@@ -183,8 +183,10 @@ class clXEngine_impl : public clXEngine, public MI355Base {
     int d_npol, d_num_inputs, d_num_channels, d_integration, d_pipeline_integration, d_first_channel;
     long d_in_items;
     size_t d_matrix_len, d_in_bytes;
-    // integration window being filled (the reference's pinned char_input/complex_input, :325-362)
-    std::vector<char> d_frames;
+    // integration window being filled: the pinned frame buffer of the next free slot (the reference's pinned
+    // char_input/complex_input, :325-362), acquired when a window starts -- no second host copy at submit time
+    char *d_frames = nullptr;
+    std::vector<char> d_frames_sync;  // pipeline-integration mode uses the synchronous call and a plain buffer
     std::vector<XComplex> d_result, d_accum;
     int d_tracker = 0, d_pipe_count = 0;
     long d_delivered = 0, d_frame_counter = 0;
@@ -269,7 +271,7 @@ public:
         d_in_items = (long)num_inputs * num_channels * d_npol * integration;
         d_in_bytes = mi355_xengine_input_bytes(d_h);
         d_matrix_len = mi355_xengine_output_items(d_h);
-        d_frames.resize(d_in_bytes);
+        if (d_pipeline_integration > 1) d_frames_sync.resize(d_in_bytes);
         d_result.resize(d_matrix_len);
         if (d_pipeline_integration > 1) d_accum.assign(d_matrix_len, XComplex());
         d_antenna_json = "[";  // :141-165
@@ -303,22 +305,30 @@ public:
         std::lock_guard<std::mutex> g(d_lock);
         const int remaining = d_integration - d_tracker;
         const int n = noutput_items > remaining ? remaining : noutput_items;  // :925-934
-        chk(mi355_xengine_gather(d_h, n, d_tracker, in.data(), d_frames.data()), "mi355_xengine_gather");
+        if (d_tracker == 0) {  // a new integration window starts: get the buffer it is gathered into
+            if (d_pipeline_integration > 1) d_frames = d_frames_sync.data();
+            else {
+                if (mi355_xengine_pending(d_h) == 2) collect_one();  // previous result goes out before the swap (:1070-1094)
+                void *fb = nullptr;
+                chk(mi355_xengine_acquire(d_h, &fb), "mi355_xengine_acquire");
+                d_frames = (char *)fb;
+            }
+        }
+        chk(mi355_xengine_gather(d_h, n, d_tracker, in.data(), d_frames), "mi355_xengine_gather");
         d_tracker += n;
         d_frame_counter += n;
         if (d_tracker == d_integration) {
             const long first = d_frame_counter - d_integration;
             if (d_pipeline_integration > 1) {
                 // device "+=" into the running matrix, read back every pipeline_integration windows (:785-796,1250-1285)
-                chk(mi355_xengine_xcorrelate(d_h, d_frames.data(), d_accum.data(), 1), "mi355_xengine_xcorrelate");
+                chk(mi355_xengine_xcorrelate(d_h, d_frames, d_accum.data(), 1), "mi355_xengine_xcorrelate");
                 if (++d_pipe_count >= d_pipeline_integration) {
                     deliver(d_accum.data(), first - (long)d_integration * (d_pipeline_integration - 1));
                     d_accum.assign(d_matrix_len, XComplex());
                     d_pipe_count = 0;
                 }
             } else {
-                if (mi355_xengine_pending(d_h) == 2) collect_one();  // previous result goes out before the swap (:1070-1094)
-                chk(mi355_xengine_submit(d_h, d_frames.data(), nullptr), "mi355_xengine_submit");
+                chk(mi355_xengine_submit_acquired(d_h, nullptr), "mi355_xengine_submit_acquired");
                 d_pending_first.push_back(first);
                 if (mi355_xengine_pending(d_h) == 2) collect_one();  // keep one in flight: overlap with the next window's gather
             }

@@ -213,6 +213,12 @@ int mi355_xengine_xcorrelate_dev(mi355_xengine *h, const void *in_dev, void *out
 int mi355_xengine_submit(mi355_xengine *h, const void *in_host, const void *acc_host);
 int mi355_xengine_wait(mi355_xengine *h, void *out_host);
 int mi355_xengine_pending(const mi355_xengine *h);
+/* Zero-copy form of submit(): acquire() hands out the pinned frame buffer of the next free slot (input_bytes() long, the
+ * reference's pinned char_input / complex_input, lib/clXEngine_impl.cc:325-362); the block gathers its frames straight
+ * into it (mi355_xengine_gather or its own copies) and submit_acquired() enqueues H2D + kernels + D2H.  MI355_ERR_STATE
+ * when two integrations are in flight.  Between acquire() and submit_acquired() a plain submit() is refused. */
+int mi355_xengine_acquire(mi355_xengine *h, void **frame_buffer);
+int mi355_xengine_submit_acquired(mi355_xengine *h, const void *accumulator_or_null);
 /* host gather: copy frames [0,nframes) of each input stream into time slots
  * frame0.. of a frame buffer laid out as the reference's pinned host buffer */
 int mi355_xengine_gather(const mi355_xengine *h, int nframes, int frame0, const void *const *inputs, void *frame_buffer);

@@ -192,3 +192,35 @@ def test_async_double_buffered_submit_wait(gpu, oracle):
     blk.submit(xs[1], accumulator=acc)  # pipeline integration through the async path
     blk.wait(out)
     assert np.array_equal(out, refs[0] + refs[1])
+
+
+def test_zero_copy_acquire_submit(gpu, oracle):
+    """acquire()/submit_acquired(): frames gathered straight into the pinned slot buffer; same results, same ordering
+    rules as submit()/wait()."""
+    N, F, T = 12, 16, 64
+    rng = np.random.default_rng(33)
+    xs = [rng.integers(-128, 128, size=T * N * F * 2, dtype=np.int64).astype(np.int8) for _ in range(4)]
+    refs = [oracle.xengine_ichar(N, F, 1, T, x, exact=True) for x in xs]
+    blk = _xe(gpu, gpu.DTYPE_BYTE, 1, N, F, T)
+    out = np.empty(blk.get_output_buffer_size(), np.complex64)
+    got = []
+    for i, x in enumerate(xs):
+        buf = blk.acquire()
+        assert buf.size == blk.input_bytes()
+        with pytest.raises(gpu.Mi355Error):
+            blk.submit(x)              # a plain submit is refused while a frame buffer is handed out
+        per = N * F * 2                # bytes per frame: gather frame by frame like work_processor does
+        for t in range(T):
+            buf[t * per:(t + 1) * per] = x[t * per:(t + 1) * per]
+        blk.submit_acquired()
+        if blk.pending() == 2:
+            blk.wait(out)
+            got.append(out.copy())
+    while blk.pending():
+        blk.wait(out)
+        got.append(out.copy())
+    assert len(got) == 4
+    for g, r in zip(got, refs):
+        assert np.array_equal(g, r)
+    with pytest.raises(gpu.Mi355Error):
+        blk.submit_acquired()          # nothing acquired
