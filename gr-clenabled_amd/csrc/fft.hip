@@ -654,6 +654,9 @@ extern "C" int mi355_fft_work_dev(mi355_fft *h, int nvec, const void *in, void *
     MI355_REQUIRE(in && out, "NULL buffer");
     MI355_REQUIRE((reinterpret_cast<uintptr_t>(in) & 7u) == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0,
                   "device buffers must be 8-byte aligned");
+    // the 8192/16384-point kernel reads 16 bytes per lane
+    MI355_REQUIRE(h->m != 0 || h->n <= 4096 || (reinterpret_cast<uintptr_t>(in) & 15u) == 0,
+                  "device input of an 8192/16384-point transform must be 16-byte aligned");
     MI355_HIP(hipSetDevice(h->ctx->device));
     return launch_handle(h, in, out, nvec, mi355_pick_stream(h->ctx, stream));
 }
