@@ -44,6 +44,8 @@ __global__ __launch_bounds__(G::TH, G::WPE) void k_ols(const c32 *__restrict__ i
                                                                    const c32 *__restrict__ Hspec,
                                                                    const c32 *__restrict__ tw_fwd,
                                                                    const c32 *__restrict__ tw_inv, int ntaps, int decim,
+                                                                   int L,            // new samples per block (<= NF-ntaps+1)
+                                                                   int s0,           // first stored output of a block (>= ntaps-1)
                                                                    long long n_in,   // readable input samples
                                                                    long long n_y,    // undecimated outputs wanted
                                                                    int nblocks, int ngroups)
@@ -53,7 +55,6 @@ __global__ __launch_bounds__(G::TH, G::WPE) void k_ols(const c32 *__restrict__ i
     constexpr int TH = G::TH, PTS = G::PTS, F = G::F, NP = PF::NP;
     __shared__ c32 lds[NP > 1 ? PTS : 1];
     const int tid0 = threadIdx.x;
-    const int L = NF - (ntaps - 1);
 
     TwRegs<NF> twf, twi;
     load_twiddles<NF, false, G>(twf, tid0, tw_fwd);
@@ -79,17 +80,21 @@ __global__ __launch_bounds__(G::TH, G::WPE) void k_ols(const c32 *__restrict__ i
         const long long in_left64 = n_in - g0, y_left64 = n_y - g0;
         const unsigned in_left = in_left64 > 0x7fffffffLL ? 0x7fffffffu : (unsigned)in_left64;
         const unsigned y_left = y_left64 > 0x7fffffffLL ? 0x7fffffffu : (unsigned)(y_left64 > 0 ? y_left64 : 0);
-        // ---- load: block fr of the group covers in_g[fr*L + n], n < NF; zero beyond the buffer ----
+        // ---- load: block fr of the group covers in_g[fr*L - pad + n], n < NF; zero outside the buffer.
+        // The stored outputs are n in [s0, s0+L) with s0 = ntaps-1 rounded up to 16, so that every block's STORES start on
+        // a 128-byte line; the pad = s0-(ntaps-1) samples the block reads earlier feed only outputs that are not stored
+        // (for the first block they lie before the buffer and read as zero).
         constexpr int R0 = PF::radix(0), B0 = NF / R0;
+        const int pad = s0 - (ntaps - 1);
 #pragma unroll
         for (int q = 0; q < 16 / R0; q++) {
             const int g = tid + TH * q, fr = g / B0, j = g % B0;
-            const unsigned base = (unsigned)(fr * L + j);
+            const int base = fr * L + j - pad;
 #pragma unroll
             for (int r = 0; r < R0; r++) {
-                const unsigned e = base + (unsigned)(r * B0);
-                const bool ok = e < in_left;
-                const c32 x = in_g[ok ? e : 0u];  // plain load: the ntaps-1 overlap is re-read by the next block and should stay cached
+                const int e = base + r * B0;
+                const bool ok = e >= 0 ? (unsigned)e < in_left : g0 > 0;  // e < 0 (at most pad samples) exists for every group but the first
+                const c32 x = in_g[ok ? e : 0];  // plain load: the overlap is re-read by the next block and should stay cached
                 v[q * R0 + r] = ok ? x : mk(0.f, 0.f);
             }
         }
@@ -106,19 +111,21 @@ __global__ __launch_bounds__(G::TH, G::WPE) void k_ols(const c32 *__restrict__ i
         // ---- store the valid part (n >= ntaps-1), decimated ---------------------------------
         constexpr int RO = PI::radix(NP - 1), BO = NF / RO;
         c32 *__restrict__ out_g = out + g0;  // decim == 1 fast path
+        const unsigned g_phase = (unsigned)(g0 % decim);  // uniform: one 64-bit division per group, 32-bit ones per element
+        const long long g_quot = g0 / decim;
 #pragma unroll
         for (int q = 0; q < 16 / RO; q++) {
             const int g = tid + TH * q, fr = g / BO, j = g % BO;
-            const int rel0 = fr * L + j - (ntaps - 1);
+            const int rel0 = fr * L + j - s0;
 #pragma unroll
             for (int s = 0; s < RO; s++) {
                 const int n = j + orev<RO>(s) * BO;
                 const int rel = rel0 + orev<RO>(s) * BO;  // output index relative to g0
-                if (n >= ntaps - 1 && (unsigned)rel < y_left) {
+                if (n >= s0 && n < s0 + L && (unsigned)rel < y_left) {
                     if (decim == 1) st_stream(out_g + (unsigned)rel, w[q * RO + s]);
                     else {
-                        const long long t = g0 + rel;
-                        if (t % decim == 0) out[t / decim] = w[q * RO + s];
+                        const unsigned t = g_phase + (unsigned)rel;  // (g0 + rel) mod decim == (g0 mod decim + rel) mod decim
+                        if (t % (unsigned)decim == 0) out[g_quot + t / (unsigned)decim] = w[q * RO + s];
                     }
                 }
             }
@@ -139,13 +146,15 @@ constexpr int kTdThreads = 256, kTdU = 8, kTdTile = kTdThreads * kTdU;
 __host__ __device__ inline int td_rows(int kpad)
 {
     int rows = (kTdTile + kpad + kTdU) / kTdU + 1;
+    if (rows < 260) rows = 260;  // the output transpose below needs 8 x 260 slots
     return rows + ((2 - rows) & 15);  // smallest S >= rows with S % 16 == 2
 }
 
 template <bool CTAPS>
 __global__ __launch_bounds__(kTdThreads) void k_fir_td(const c32 *__restrict__ in, c32 *__restrict__ out,
                                                        const float *__restrict__ taps_rev,  // reversed, zero padded to kpad
-                                                       int K, long long n_out, int kpad /* K rounded up to kTdU */)
+                                                       int K, long long n_out /* undecimated outputs */, int kpad /* K rounded up to kTdU */,
+                                                       int decim)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     c32 *tile = (c32 *)smem;
@@ -210,15 +219,35 @@ __global__ __launch_bounds__(kTdThreads) void k_fir_td(const c32 *__restrict__ i
 #pragma unroll
             for (int u = 0; u < kTdU; u++) win[u] = win[kTdU + u];
         }
-        // 8 consecutive outputs per thread = 64 contiguous bytes
-        const long long m0 = base + (long long)tid * kTdU;
+        // The thread holds 8 CONSECUTIVE outputs; storing them directly makes every wave instruction write 64 separate
+        // 8-byte pieces 64 bytes apart (measured: the kernel was bound by that, not by the FMAs).  Transpose through the
+        // tile (row stride 260 slots: conflict free both ways) so that lanes store consecutive samples.
+        __syncthreads();  // every wave is done reading the input tile
+        constexpr int OS = 260;
 #pragma unroll
-        for (int u = 0; u < kTdU; u++)
-            if (m0 + u < n_out) out[m0 + u] = mk(acc[u].x, acc[u].y);
+        for (int u = 0; u < kTdU; u++) tile[u * OS + tid] = mk(acc[u].x, acc[u].y);
+        __syncthreads();
+        c32 *__restrict__ out_t = out + base;
+        const long long oleft = n_out - base;
+        if (decim == 1) {
+#pragma unroll
+            for (int k = 0; k < kTdU; k++) {
+                const int o = tid + kTdThreads * k;  // output o of the tile = thread o/8, slot o%8
+                if (o < oleft) st_stream(out_t + o, tile[(o & (kTdU - 1)) * OS + (o >> 3)]);
+            }
+        } else {  // small decimations: every output is computed, every decim-th kept (cheaper than one output per thread)
+            const unsigned ph = (unsigned)(base % decim);
+            const long long q0 = base / decim;
+#pragma unroll
+            for (int k = 0; k < kTdU; k++) {
+                const int o = tid + kTdThreads * k;
+                const unsigned t = ph + (unsigned)o;
+                if (o < oleft && t % (unsigned)decim == 0) out[q0 + t / (unsigned)decim] = tile[(o & (kTdU - 1)) * OS + (o >> 3)];
+            }
+        }
     }
 }
 
-// direct form with decimation > 1: one output per thread straight from L1/L2
 template <bool CTAPS>
 __global__ __launch_bounds__(256) void k_fir_td_dec(const c32 *__restrict__ in, c32 *__restrict__ out,
                                                     const float *__restrict__ taps_rev, int K, int decim, long long n_out)
@@ -265,6 +294,18 @@ int pick_fft_size(int ntaps)
     int nf = 2;
     while (nf < 2 * ntaps) nf <<= 1;
     if (nf < 256) nf = 256;
+    // The reference size leaves between 50 % and 100 % of every block as new samples.  The kernel's rate per transformed
+    // point is nearly flat in the size (G points/s measured on MI355X below), so a larger transform whose blocks carry a
+    // larger share of new samples is faster: pick the best of the reference size and the next two.
+    auto rate = [](int n) { return n <= 256 ? 413.0 : n == 512 ? 314.0 : n == 1024 ? 295.0 : n == 2048 ? 292.0 : 230.0; };
+    const int s0 = (ntaps - 1 + 15) & ~15;
+    int best = nf;
+    double best_score = 0.0;
+    for (int c = nf; c <= 4096 && c <= 4 * nf; c <<= 1) {
+        const double score = rate(c) * (double)((c - s0) & ~15) / (double)c;
+        if (score > best_score * 1.02) { best_score = score; best = c; }
+    }
+    nf = best;
     if (const char *e = getenv("MI355_FILTER_FFT")) {
         int v = atoi(e);
         if (v >= 2 * ntaps && v >= 64 && v <= 4096 && (v & (v - 1)) == 0) nf = v;
@@ -344,13 +385,18 @@ int launch_ols_g(mi355_filter *h, size_t nout, const void *in, void *out, hipStr
     constexpr int F = G::F, TH = G::TH, WAVES = TH / 64;
     const long long n_y = (long long)nout * h->decim;
     const long long n_in = n_y + h->ntaps - 1;
-    const int L = NF - (h->ntaps - 1);
+    // any block length <= NF-ntaps+1 is a valid overlap-save schedule; a multiple of 16 keeps every block's loads
+    // and stores on 128-byte boundaries (ntaps = 3: 39 % -> 70 % of HBM peak)
+    static const bool align_stores = getenv("MI355_OLS_ALIGN") ? atoi(getenv("MI355_OLS_ALIGN")) != 0 : true;
+    const int s0 = align_stores ? ((h->ntaps - 1 + 15) & ~15) : h->ntaps - 1;  // first stored output of a block (see the kernel)
+    int L = NF - s0;
+    if (L > 16 && !getenv("MI355_OLS_RAGGED_L")) L &= ~15;
     const long long nblocks = (n_y + L - 1) / L;
     const long long ngroups = (nblocks + F - 1) / F;
     if (nblocks > 0x7fffffffLL) { mi355_set_error("work() call too large"); return MI355_ERR_INVALID_ARG; }
     long long grid = mi355_balanced_grid(h->ctx, ngroups, 8 / WAVES, 12 / WAVES);
     hipLaunchKernelGGL((k_ols<NF, G>), dim3((unsigned)grid), dim3(TH), 0, st, (const c32 *)in, (c32 *)out, (const c32 *)h->d_H,
-                       (const c32 *)h->d_twf, (const c32 *)h->d_twi, h->ntaps, h->decim, n_in, n_y, (int)nblocks, (int)ngroups);
+                       (const c32 *)h->d_twf, (const c32 *)h->d_twi, h->ntaps, h->decim, L, s0, n_in, n_y, (int)nblocks, (int)ngroups);
     MI355_HIP(hipGetLastError());
     return MI355_OK;
 }
@@ -384,11 +430,14 @@ int launch_filter(mi355_filter *h, size_t nout, const void *in, void *out, hipSt
         return MI355_ERR_STATE;
     }
     int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
-    if (h->decim == 1) {
-        const int kpad = (h->ntaps + kTdU - 1) / kTdU * kTdU;
+    const int kpad0 = (h->ntaps + kTdU - 1) / kTdU * kTdU;
+    // the register-tiled kernel computes every undecimated output: worth it up to a decimation of 8
+    if (h->decim == 1 || (h->decim <= 8 && (size_t)td_rows(kpad0) * kTdU * sizeof(c32) <= 160 * 1024)) {
+        const int kpad = kpad0;
         const size_t smem = (size_t)td_rows(kpad) * kTdU * sizeof(c32);
         if (smem > 160 * 1024) { mi355_set_error("time-domain mode supports up to ~18000 taps"); return MI355_ERR_UNSUPPORTED; }
-        long long ntiles = ((long long)nout + kTdTile - 1) / kTdTile;
+        const long long n_y = (long long)nout * h->decim;  // undecimated outputs
+        long long ntiles = (n_y + kTdTile - 1) / kTdTile;
         int per_cu = (int)((160 * 1024) / smem);
         if (per_cu > 8) per_cu = 8;
         if (per_cu < 1) per_cu = 1;
@@ -397,12 +446,12 @@ int launch_filter(mi355_filter *h, size_t nout, const void *in, void *out, hipSt
             if (smem > 64 * 1024)
                 MI355_HIP(hipFuncSetAttribute((const void *)k_fir_td<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             hipLaunchKernelGGL((k_fir_td<true>), dim3((unsigned)grid), dim3(kTdThreads), smem, st, (const c32 *)in, (c32 *)out,
-                               h->d_taps_rev, h->ntaps, (long long)nout, kpad);
+                               h->d_taps_rev, h->ntaps, n_y, kpad, h->decim);
         } else {
             if (smem > 64 * 1024)
                 MI355_HIP(hipFuncSetAttribute((const void *)k_fir_td<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             hipLaunchKernelGGL((k_fir_td<false>), dim3((unsigned)grid), dim3(kTdThreads), smem, st, (const c32 *)in, (c32 *)out,
-                               h->d_taps_rev, h->ntaps, (long long)nout, kpad);
+                               h->d_taps_rev, h->ntaps, n_y, kpad, h->decim);
         }
     } else {
         long long blocks = ((long long)nout + 255) / 256;
