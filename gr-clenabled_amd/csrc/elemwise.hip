@@ -4,7 +4,7 @@
 // lib/clComplexToArg_impl.cc:136-151, lib/clComplexToMagPhase_impl.cc:150-164,
 // lib/clMagPhaseToComplex_impl.cc:170-191, lib/clQuadratureDemod_impl.cc:118-146.
 // The reference evaluates atan2 / sin / cos in DOUBLE on purpose (README.md:112-114,147-153: float trig
-// broke downstream decoding); the same is done here.  All kernels stream with 8/16 B per lane.
+// broke downstream decoding); the same is done here.  Four items per thread through 16-byte streaming accesses.
 #include <cmath>
 
 #include "common.h"
@@ -14,40 +14,88 @@ namespace {
 struct c32 { float x, y; };
 constexpr int kT = 256;
 
+// one item: a0/a1 = first input (complex: re, im; float: value in a0), b0 = second input or, for QUADDEMOD, b0/b1 = the
+// NEXT complex item; r0/r1 = outputs (complex result in r0,r1; two float outputs in r0,r1)
+template <int KIND>
+__device__ __forceinline__ void elem_one(float a0, float a1, float b0, float b1, float p0, float p1, float &r0, float &r1)
+{
+    r1 = 0.f;
+    if constexpr (KIND == MI355_ELEM_LOG10) {
+        r0 = p0 * log10f(a0) + p1;  // log2To10Factor * log2(a) + k, lib/clLog_impl.cc:138-147 (n*log10(a)+k, :200-214)
+    } else if constexpr (KIND == MI355_ELEM_SNR) {
+        r0 = fabsf(p0 * log10f(a0 / b0) + p1);  // lib/clSNR_impl.cc:110-112
+    } else if constexpr (KIND == MI355_ELEM_C2MAG) {
+        r0 = sqrtf(a1 * a1 + a0 * a0);  // :144-148
+    } else if constexpr (KIND == MI355_ELEM_C2ARG) {
+        r0 = (float)atan2((double)a1, (double)a0);  // :145-147
+    } else if constexpr (KIND == MI355_ELEM_C2MAGPHASE) {
+        r0 = sqrtf(a1 * a1 + a0 * a0);               // :157
+        r1 = (float)atan2((double)a1, (double)a0);   // :159
+    } else if constexpr (KIND == MI355_ELEM_MAGPHASE2C) {
+        double s, c;  // :175-180
+        sincos((double)b0, &s, &c);
+        r0 = (float)((double)a0 * c);
+        r1 = (float)((double)a0 * s);
+    } else {  // QUADDEMOD: gain * atan2 of a[i+1] * conj(a[i]) in double, lib/clQuadratureDemod_impl.cc:125-141
+        const double ar = b0, ai = b1, br = a0, bi = -1.0 * (double)a1;
+        const double re = ar * br - ai * bi, im = ar * bi + ai * br;
+        r0 = (float)((double)p0 * atan2(im, re));
+    }
+}
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+
 template <int KIND>
 __global__ __launch_bounds__(kT) void k_elem(const void *__restrict__ in0, const void *__restrict__ in1, void *__restrict__ out0,
-                                             void *__restrict__ out1, size_t n, float p0, float p1)
+                                             void *__restrict__ out1, size_t n, float p0, float p1, int vec_ok)
 {
-    for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += (size_t)gridDim.x * kT) {
-        if constexpr (KIND == MI355_ELEM_LOG10) {
-            // log2To10Factor * log2(a) + k, lib/clLog_impl.cc:138-147 (n*log10(a)+k, :200-214)
-            ((float *)out0)[i] = p0 * log10f(((const float *)in0)[i]) + p1;
-        } else if constexpr (KIND == MI355_ELEM_SNR) {
-            const float t = ((const float *)in0)[i] / ((const float *)in1)[i];
-            ((float *)out0)[i] = fabsf(p0 * log10f(t) + p1);  // lib/clSNR_impl.cc:110-112
-        } else if constexpr (KIND == MI355_ELEM_C2MAG) {
-            const c32 a = ((const c32 *)in0)[i];
-            ((float *)out0)[i] = sqrtf(a.y * a.y + a.x * a.x);  // :144-148
-        } else if constexpr (KIND == MI355_ELEM_C2ARG) {
-            const c32 a = ((const c32 *)in0)[i];
-            ((float *)out0)[i] = (float)atan2((double)a.y, (double)a.x);  // :145-147
-        } else if constexpr (KIND == MI355_ELEM_C2MAGPHASE) {
-            const c32 a = ((const c32 *)in0)[i];
-            ((float *)out0)[i] = sqrtf(a.y * a.y + a.x * a.x);            // :157
-            ((float *)out1)[i] = (float)atan2((double)a.y, (double)a.x);  // :159
-        } else if constexpr (KIND == MI355_ELEM_MAGPHASE2C) {
-            const double mag = (double)((const float *)in0)[i], ph = (double)((const float *)in1)[i];  // :175-180
-            double s, c;
-            sincos(ph, &s, &c);
-            c32 r;
-            r.x = (float)(mag * c);
-            r.y = (float)(mag * s);
-            ((c32 *)out0)[i] = r;
-        } else {  // QUADDEMOD: gain * atan2 of a[i+1] * conj(a[i]) in double, lib/clQuadratureDemod_impl.cc:125-141
-            const c32 a1 = ((const c32 *)in0)[i + 1], a0 = ((const c32 *)in0)[i];
-            const double ar = a1.x, ai = a1.y, br = a0.x, bi = -1.0 * (double)a0.y;
-            const double re = ar * br - ai * bi, im = ar * bi + ai * br;
-            ((float *)out0)[i] = (float)((double)p0 * atan2(im, re));
+    constexpr bool CIN = KIND == MI355_ELEM_C2MAG || KIND == MI355_ELEM_C2ARG || KIND == MI355_ELEM_C2MAGPHASE || KIND == MI355_ELEM_QUADDEMOD;
+    constexpr bool TWO_IN = KIND == MI355_ELEM_SNR || KIND == MI355_ELEM_MAGPHASE2C;
+    constexpr bool COUT = KIND == MI355_ELEM_MAGPHASE2C, TWO_OUT = KIND == MI355_ELEM_C2MAGPHASE;
+    // 4 items per thread through 16-byte streaming accesses (the pointers are 16-byte aligned when vec_ok)
+    const size_t n4 = vec_ok ? n / 4 : 0;
+    for (size_t q = (size_t)blockIdx.x * kT + threadIdx.x; q < n4; q += (size_t)gridDim.x * kT) {
+        float a0[4], a1[4] = {0.f, 0.f, 0.f, 0.f}, b0[4] = {0.f, 0.f, 0.f, 0.f}, b1[4] = {0.f, 0.f, 0.f, 0.f}, r0[4], r1[4];
+        if constexpr (CIN) {
+            const f4v u = __builtin_nontemporal_load((const f4v *)in0 + 2 * q), v = __builtin_nontemporal_load((const f4v *)in0 + 2 * q + 1);
+            a0[0] = u.x; a1[0] = u.y; a0[1] = u.z; a1[1] = u.w; a0[2] = v.x; a1[2] = v.y; a0[3] = v.z; a1[3] = v.w;
+            if constexpr (KIND == MI355_ELEM_QUADDEMOD) {
+                const float *nx = (const float *)in0 + 8 * q + 8;  // item 4q+4 (the buffer carries one item of history)
+                b0[0] = a0[1]; b1[0] = a1[1]; b0[1] = a0[2]; b1[1] = a1[2]; b0[2] = a0[3]; b1[2] = a1[3]; b0[3] = nx[0]; b1[3] = nx[1];
+            }
+        } else {
+            const f4v u = __builtin_nontemporal_load((const f4v *)in0 + q);
+            a0[0] = u.x; a0[1] = u.y; a0[2] = u.z; a0[3] = u.w;
+        }
+        if constexpr (TWO_IN) {
+            const f4v u = __builtin_nontemporal_load((const f4v *)in1 + q);
+            b0[0] = u.x; b0[1] = u.y; b0[2] = u.z; b0[3] = u.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) elem_one<KIND>(a0[k], a1[k], b0[k], b1[k], p0, p1, r0[k], r1[k]);
+        if constexpr (COUT) {
+            __builtin_nontemporal_store((f4v){r0[0], r1[0], r0[1], r1[1]}, (f4v *)out0 + 2 * q);
+            __builtin_nontemporal_store((f4v){r0[2], r1[2], r0[3], r1[3]}, (f4v *)out0 + 2 * q + 1);
+        } else {
+            __builtin_nontemporal_store((f4v){r0[0], r0[1], r0[2], r0[3]}, (f4v *)out0 + q);
+            if constexpr (TWO_OUT) __builtin_nontemporal_store((f4v){r1[0], r1[1], r1[2], r1[3]}, (f4v *)out1 + q);
+        }
+    }
+    // tail (and the whole call when a pointer is not 16-byte aligned): one item per thread
+    for (size_t i = 4 * n4 + (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += (size_t)gridDim.x * kT) {
+        float a0, a1 = 0.f, b0 = 0.f, b1 = 0.f, r0, r1;
+        if constexpr (CIN) {
+            a0 = ((const float *)in0)[2 * i]; a1 = ((const float *)in0)[2 * i + 1];
+            if constexpr (KIND == MI355_ELEM_QUADDEMOD) { b0 = ((const float *)in0)[2 * i + 2]; b1 = ((const float *)in0)[2 * i + 3]; }
+        } else {
+            a0 = ((const float *)in0)[i];
+        }
+        if constexpr (TWO_IN) b0 = ((const float *)in1)[i];
+        elem_one<KIND>(a0, a1, b0, b1, p0, p1, r0, r1);
+        if constexpr (COUT) { ((float *)out0)[2 * i] = r0; ((float *)out0)[2 * i + 1] = r1; }
+        else {
+            ((float *)out0)[i] = r0;
+            if constexpr (TWO_OUT) ((float *)out1)[i] = r1;
         }
     }
 }
@@ -84,10 +132,12 @@ namespace {
 int launch_elem(mi355_elem *h, size_t n, const void *i0, const void *i1, void *o0, void *o1, hipStream_t st)
 {
     int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
-    size_t blocks = (n + kT - 1) / kT;
+    auto al16 = [](const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    const int vec_ok = al16(i0) && al16(i1) && al16(o0) && al16(o1);
+    size_t blocks = ((vec_ok ? (n + 3) / 4 : n) + kT - 1) / kT;
     if (blocks > (size_t)cus * 16) blocks = (size_t)cus * 16;
     if (blocks < 1) blocks = 1;
-#define ELEM_CASE(K) case K: hipLaunchKernelGGL((k_elem<K>), dim3((unsigned)blocks), dim3(kT), 0, st, i0, i1, o0, o1, n, h->p0, h->p1); break
+#define ELEM_CASE(K) case K: hipLaunchKernelGGL((k_elem<K>), dim3((unsigned)blocks), dim3(kT), 0, st, i0, i1, o0, o1, n, h->p0, h->p1, vec_ok); break
     switch (h->kind) {
         ELEM_CASE(MI355_ELEM_LOG10); ELEM_CASE(MI355_ELEM_SNR); ELEM_CASE(MI355_ELEM_C2MAG); ELEM_CASE(MI355_ELEM_C2ARG);
         ELEM_CASE(MI355_ELEM_C2MAGPHASE); ELEM_CASE(MI355_ELEM_MAGPHASE2C); ELEM_CASE(MI355_ELEM_QUADDEMOD);

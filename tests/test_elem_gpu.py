@@ -67,3 +67,33 @@ def test_gpu_device_path_and_errors(gpu):
     blk = gpu.clQuadratureDemod(1.0, *GPU_ARGS)
     with pytest.raises(ValueError):
         blk.work(10, [np.zeros(10, np.complex64)], [np.empty(10, np.float32)])  # history item missing
+
+
+@pytest.mark.gpu
+def test_device_path_unaligned_pointers_and_tails(gpu, oracle):
+    """The device path moves 4 items per thread through 16-byte accesses when every pointer is 16-byte aligned and one
+    item per thread otherwise; both, plus the n % 4 tail, must give the same numbers."""
+    import torch
+    rng = np.random.default_rng(77)
+    n = 10007
+    c = crandn(rng, n + 3)
+    blk = gpu.clComplexToMagPhase(*GPU_ARGS)
+    ref_mag, ref_ph = oracle.elem(5, n, [c[:n]])
+    dc = torch.from_numpy(c.view(np.float32).reshape(-1, 2)).cuda()
+    for off in (0, 1):  # off = 1: the input starts 8 bytes into an allocation, outputs 4 bytes in
+        mag = torch.empty(n + 1, device="cuda")
+        ph = torch.empty(n + 1, device="cuda")
+        cin = torch.from_numpy(c[:n + 1].view(np.float32).reshape(-1, 2)).cuda() if off == 0 else dc
+        x = cin[off:off + n]
+        if off:
+            ref_mag, ref_ph = oracle.elem(5, n, [c[off:off + n]])
+        blk.work_device(n, [x], [mag[off:off + n], ph[off:off + n]])
+        torch.cuda.synchronize()
+        assert relerr(mag[off:off + n].cpu().numpy(), ref_mag) <= 1e-5
+        assert relerr(ph[off:off + n].cpu().numpy(), ref_ph) <= 1e-5
+    q = gpu.clQuadratureDemod(0.7, *GPU_ARGS)
+    (ref_q,) = oracle.elem(7, n, [c[:n + 1]], p0=0.7)
+    out = torch.empty(n, device="cuda")
+    q.work_device(n, [dc[:n + 1]], [out])
+    torch.cuda.synchronize()
+    assert relerr(out.cpu().numpy(), ref_q) <= 1e-5
