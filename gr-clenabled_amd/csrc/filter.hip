@@ -331,10 +331,9 @@ int upload_taps(mi355_filter *h, const void *taps, int ntaps)
     int nf = 0;
     if (!h->use_time) {
         nf = pick_fft_size(ntaps);
-        if (nf > 4096) {
-            mi355_set_error("fast-convolution mode supports up to 2048 taps (got %d)", ntaps);
-            return MI355_ERR_UNSUPPORTED;
-        }
+        // more than 2048 taps do not fit the fused kernel's largest transform: such a filter runs in the direct form
+        // (same y, lib/fft_filter.cc and lib/fir_filter.cc agree to rounding); fftsize() then reports 0
+        if (nf > 4096) nf = 0;
     }
     MI355_HIP(hipSetDevice(h->ctx->device));
     free_dev(h);
@@ -416,7 +415,7 @@ int launch_ols(mi355_filter *h, size_t nout, const void *in, void *out, hipStrea
 int launch_filter(mi355_filter *h, size_t nout, const void *in, void *out, hipStream_t st)
 {
     if (nout == 0) return MI355_OK;
-    if (!h->use_time) {
+    if (!h->use_time && h->nf) {
         switch (h->nf) {
         case 64: return launch_ols<64>(h, nout, in, out, st);
         case 128: return launch_ols<128>(h, nout, in, out, st);

@@ -45,7 +45,7 @@ def test_golden_complex_taps(gpu, use_time):
 
 
 @pytest.mark.parametrize("use_time", [False, True])
-@pytest.mark.parametrize("ntaps", [1, 2, 8, 9, 64, 65, 128, 129, 300, 1000, 2048])
+@pytest.mark.parametrize("ntaps", [1, 2, 3, 8, 9, 17, 30, 64, 65, 100, 128, 129, 300, 600, 1000, 2048, 2049, 3000])  # > 2048: direct form in both modes
 def test_vs_oracle_fir_various_lengths(gpu, oracle, ntaps, use_time):
     rng = np.random.default_rng(ntaps)
     taps = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
@@ -149,6 +149,23 @@ def test_device_path_full_size_two_kernels_agree(gpu, oracle):
         xs = x[o0:o0 + 5000 + 64].cpu().numpy().view(np.complex64).reshape(-1)
         ys = yf[o0:o0 + 5000].cpu().numpy().view(np.complex64).reshape(-1)
         assert relerr(ys, oracle.fir_ccf(taps, xs, 5000)) <= TOL
+
+
+@pytest.mark.parametrize("use_time", [False, True])
+@pytest.mark.parametrize("decim", [2, 4, 7, 8, 9, 16])
+def test_decimations_both_modes(gpu, oracle, decim, use_time):
+    """decimation <= 8 runs in the tiled direct-form kernel, larger ones one output per thread; the FFT mode decimates on
+    the store.  y[m] = (h * x)[m * decim]."""
+    rng = np.random.default_rng(decim)
+    ntaps = 77
+    taps = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    nout = 3001
+    xh = crandn(rng, nout * decim + ntaps - 1)
+    blk = gpu.clFilter(*GPU_ARGS, decim, taps, 1, 0, use_time)
+    y = np.empty(nout, np.complex64)
+    assert blk.work(nout, [xh], [y]) == nout
+    full = oracle.fir_ccf(taps, xh, nout * decim)
+    assert relerr(y, full[::decim][:nout]) <= TOL
 
 
 def test_zero_outputs_and_bad_args(gpu):
