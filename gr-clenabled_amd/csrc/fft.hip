@@ -76,7 +76,7 @@ __device__ __forceinline__ void load_group(c32 (&v)[16], const void *__restrict_
 }
 
 template <int N, int SIGN, bool REAL, bool PF, class G>
-__global__ __launch_bounds__(G::TH, (PF ? G::WPE : (N <= 4096 ? MI355_FFT_WPE : 1))) void k_fft(const void *__restrict__ in, c32 *__restrict__ out,
+__global__ __launch_bounds__(G::TH, (N <= 4096 ? MI355_FFT_WPE : 1)) void k_fft(const void *__restrict__ in, c32 *__restrict__ out,
                                                                  const float *__restrict__ window,
                                                                  const c32 *__restrict__ twtab, int nframes, int ngroups,
                                                                  int shift)
@@ -329,7 +329,7 @@ int launch_g(mi355_ctx *ctx, int sign, const void *in, void *out, const float *w
     // plain variant at 3 workgroups/CU on MI355X, so it is off by default.
     static const bool pf = getenv("MI355_FFT_PREFETCH") ? atoi(getenv("MI355_FFT_PREFETCH")) != 0 : false;
     // resident waves per CU are what matters: 8..12 (2..3 workgroups of 4 waves, or 8..12 single-wave workgroups)
-    int grid = (N <= 4096) ? mi355_balanced_grid(ctx, ngroups, 8 / WAVES, (pf ? 8 : 12) / WAVES, 0.015) : mi355_balanced_grid(ctx, ngroups, 1, 1);
+    int grid = (N <= 4096) ? mi355_balanced_grid(ctx, ngroups, 8 / WAVES, 12 / WAVES, 0.015) : mi355_balanced_grid(ctx, ngroups, 1, 1);
     if (const char *e = getenv("MI355_FFT_WG_PER_CU")) {
         if (atoi(e) > 0) grid = ngroups < cus * atoi(e) ? ngroups : cus * atoi(e);
     }
@@ -437,9 +437,115 @@ __global__ __launch_bounds__(256) void k_blu_post(const c32 *__restrict__ A, c32
     }
 }
 
+// Fused chirp-z for m <= 4096 (N <= 2048): one kernel per call, HBM traffic = the frame read once and written once.
+// Same structure as the overlap-save filter (filter.hip): forward FFT_m, spectrum multiply in registers, inverse FFT_m
+// through the reversed radix plan.  The chirp tables are read from L2 at the positions a thread holds (coalesced).
+template <int M, bool REAL>
+__global__ __launch_bounds__(Geo<M>::TH, Geo<M>::WPE) void k_chirpz(const void *__restrict__ in, c32 *__restrict__ out,
+                                                                   const c32 *__restrict__ pre, const int *__restrict__ src,
+                                                                   const c32 *__restrict__ post, const c32 *__restrict__ bspec,
+                                                                   const c32 *__restrict__ tw_fwd, const c32 *__restrict__ tw_inv,
+                                                                   int N, int nframes, int ngroups, int lo)
+{
+    using G = Geo<M>;
+    using PF = Plan<M, false>;
+    using PI = Plan<M, true>;
+    constexpr int TH = G::TH, PTS = G::PTS, F = G::F, NP = PF::NP;
+    constexpr int RL = PF::radix(NP - 1), BL = M / RL;
+    static_assert(PI::radix(0) == RL, "inverse plan must start with the forward plan's last radix");
+    __shared__ c32 lds[NP > 1 ? PTS : 1];
+    const int tid0 = threadIdx.x;
+    TwRegs<M> twf, twi;
+    load_twiddles<M, false, G>(twf, tid0, tw_fwd);
+    load_twiddles<M, true, G>(twi, tid0, tw_inv);
+    c32 Breg[16];  // spectrum of the conjugate chirp (pre-scaled 1/m) at the bins this thread holds after the forward transform
+#pragma unroll
+    for (int q = 0; q < 16 / RL; q++) {
+        const int j = (tid0 + TH * q) % BL;
+#pragma unroll
+        for (int t = 0; t < RL; t++) Breg[q * RL + t] = bspec[j + orev<RL>(t) * BL];
+    }
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int frames_left = nframes - grp * F;
+        const size_t fbase = (size_t)grp * F;
+        c32 v[16];
+        constexpr int R0 = PF::radix(0), B0 = M / R0;
+#pragma unroll
+        for (int q = 0; q < 16 / R0; q++) {
+            const int g = tid + TH * q, fr = g / B0, j = g % B0;
+#pragma unroll
+            for (int r = 0; r < R0; r++) {
+                const int m = j + r * B0;  // transform input position
+                const bool ok = m < N && fr < frames_left;
+                c32 x = mk(0.f, 0.f);
+                if (ok) {
+                    const int i = src[m];
+                    if constexpr (REAL) x = mk(((const float *)in)[(fbase + fr) * N + i], 0.f);
+                    else x = ((const c32 *)in)[(fbase + fr) * N + i];
+                    x = cmul(x, pre[m]);
+                }
+                v[q * R0 + r] = x;
+            }
+        }
+        transform_regs<M, -1, false, G>(v, twf, lds, tid);
+        c32 w[16];
+#pragma unroll
+        for (int q = 0; q < 16 / RL; q++)
+#pragma unroll
+            for (int r = 0; r < RL; r++) w[q * RL + r] = cmul(v[q * RL + irev<RL>(r)], Breg[q * RL + irev<RL>(r)]);
+        if constexpr (NP > 1) __syncthreads();
+        transform_regs<M, 1, true, G>(w, twi, lds, tid);
+        constexpr int RO = PI::radix(NP - 1), BO = M / RO;
+#pragma unroll
+        for (int q = 0; q < 16 / RO; q++) {
+            const int g = tid + TH * q, fr = g / BO, j = g % BO;
+#pragma unroll
+            for (int t = 0; t < RO; t++) {
+                const int k = j + orev<RO>(t) * BO;
+                if (k < N && fr < frames_left) {
+                    // forward + shift: X[k] goes to position k - lo (k >= lo) or k + N - lo  (lo = ceil(N/2); lo = 0: identity)
+                    const int p = lo ? (k >= lo ? k - lo : k + (N - lo)) : k;
+                    out[(fbase + fr) * N + p] = cmul(w[q * RO + t], post[k]);
+                }
+            }
+        }
+        if constexpr (NP > 1) __syncthreads();
+    }
+}
+
+template <int M>
+int launch_chirpz_m(mi355_fft *h, const void *in, void *out, int nframes, hipStream_t st)
+{
+    constexpr int F = Geo<M>::F, TH = Geo<M>::TH;
+    const int ngroups = (nframes + F - 1) / F;
+    const int grid = mi355_balanced_grid(h->ctx, ngroups, 2, 3);
+    const int lo = (h->sign < 0 && h->shift) ? (h->n + 1) / 2 : 0;
+    const int *src = (const int *)((const char *)h->d_post + (size_t)h->n * 8);
+    if (h->dtype == MI355_DTYPE_FLOAT)
+        hipLaunchKernelGGL((k_chirpz<M, true>), dim3(grid), dim3(TH), 0, st, in, (c32 *)out, (const c32 *)h->d_pre, src, (const c32 *)h->d_post,
+                           (const c32 *)h->d_bspec, (const c32 *)h->d_twm_f, (const c32 *)h->d_twm_i, h->n, nframes, ngroups, lo);
+    else
+        hipLaunchKernelGGL((k_chirpz<M, false>), dim3(grid), dim3(TH), 0, st, in, (c32 *)out, (const c32 *)h->d_pre, src, (const c32 *)h->d_post,
+                           (const c32 *)h->d_bspec, (const c32 *)h->d_twm_f, (const c32 *)h->d_twm_i, h->n, nframes, ngroups, lo);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
 int launch_bluestein(mi355_fft *h, const void *in, void *out, int nframes, hipStream_t st)
 {
     const int N = h->n, M = h->m;
+    static const bool fused = getenv("MI355_CHIRPZ_FUSED") ? atoi(getenv("MI355_CHIRPZ_FUSED")) != 0 : true;
+    if (fused) {
+        switch (M) {
+        case 256: return launch_chirpz_m<256>(h, in, out, nframes, st);
+        case 512: return launch_chirpz_m<512>(h, in, out, nframes, st);
+        case 1024: return launch_chirpz_m<1024>(h, in, out, nframes, st);
+        case 2048: return launch_chirpz_m<2048>(h, in, out, nframes, st);
+        case 4096: return launch_chirpz_m<4096>(h, in, out, nframes, st);
+        }
+    }
     // bound the work buffers to 2 x 128 MiB
     size_t chunk = (128u << 20) / ((size_t)M * 8);
     if (chunk < 1) chunk = 1;
@@ -532,7 +638,7 @@ std::vector<float> twiddle_table(int n, int sign)
 int setup_bluestein(mi355_fft *h, const float *window)
 {
     const int N = h->n;
-    int M = 1;
+    int M = 256;  // at least 256: the fused kernel's smallest instantiation (more zero padding is harmless)
     while (M < 2 * N - 1) M <<= 1;
     h->m = M;
     // a[n] = exp(sign * i*pi*n^2/N); n^2 reduced mod 2N in integers keeps the phase exact
