@@ -318,6 +318,89 @@ int launch_s(mi355_ctx *ctx, int sign, const void *in, void *out, const float *w
     return MI355_OK;
 }
 
+// ------------------------------------------------------------------------------------
+// N = 32768 / 65536: two kernels through an N-point workspace (decimation in time, S = N/4096 = 8 / 16 sub-frames).
+//   k_fft_sub:      E_s = FFT_4096( x[S n + s] * w[S n + s] ), one workgroup iteration per sub-frame, written k-contiguous
+//   k_fft_combine:  X[k + 4096 m] = sum_s W_N^(s k) W_S^(s m) E_s[k]: lane = k, one radix-S butterfly per lane in registers
+// Traffic is twice the single-kernel minimum (the price of frames that do not fit a workgroup's LDS and registers).
+// ------------------------------------------------------------------------------------
+template <int SIGN, bool REAL>
+__global__ __launch_bounds__(256, 2) void k_fft_sub(const void *__restrict__ in, c32 *__restrict__ ws, const float *__restrict__ window,
+                                                    const c32 *__restrict__ tw4096, int S, int npair /* frames * S / 2 */, int in_xor)
+{
+    // one iteration = the two neighbouring sub-frames (s, s+1): their elements x[S n + s], x[S n + s + 1] are adjacent, so
+    // every lane moves 16 bytes of each line it touches instead of 8
+    constexpr int NS = 4096, BL = 256;
+    using G = Geo<NS>;
+    __shared__ c32 lds[NS];
+    const int tid0 = threadIdx.x;
+    TwRegs<NS> tw;
+    load_twiddles<NS, false, G>(tw, tid0, tw4096);
+    const int half = S / 2;
+    for (int pr = blockIdx.x; pr < npair; pr += gridDim.x) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int frame = pr / half, s = 2 * (pr - frame * half);
+        const size_t fb = (size_t)frame * NS * S;
+        c32 v[2][16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const size_t e = (size_t)(tid + ((r ^ in_xor) * BL)) * S + s;  // x[S n + s]; reverse + shift: n ^ 2048; e is even
+            const f2v w = *(const f2v *)(window + e);
+            if constexpr (REAL) {
+                const f2v x = __builtin_nontemporal_load((const f2v *)((const float *)in + fb + e));
+                v[0][r] = mk(x.x * w.x, 0.f);
+                v[1][r] = mk(x.y * w.y, 0.f);
+            } else {
+                const f4v x = __builtin_nontemporal_load((const f4v *)((const c32 *)in + fb + e));
+                v[0][r] = mk(x.x * w.x, x.y * w.x);
+                v[1][r] = mk(x.z * w.y, x.w * w.y);
+            }
+        }
+#pragma unroll
+        for (int h2 = 0; h2 < 2; h2++) {
+            transform_regs<NS, SIGN, false, G>(v[h2], tw, lds, tid);
+            f2v *__restrict__ o = (f2v *)ws + ((size_t)frame * S + s + h2) * NS + tid;
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                f2v z;
+                z.x = v[h2][t].x;
+                z.y = v[h2][t].y;
+                o[orev<16>(t) * BL] = z;  // plain store: the combine kernel reads it back from L2 / the Infinity Cache
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int S, int SIGN>
+__global__ __launch_bounds__(256) void k_fft_combine(const c32 *__restrict__ ws, c32 *__restrict__ out, const c32 *__restrict__ twN,
+                                                     long long total /* frames * 4096 */, int m_xor)
+{
+    constexpr int NS = 4096, N = NS * S;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long frame = e / NS;
+        const int k = (int)(e - frame * NS);
+        const c32 *src = ws + (size_t)frame * N + k;
+        c32 a[S];
+#pragma unroll
+        for (int s = 0; s < S; s++) a[s] = src[(size_t)s * NS];
+        c32 wsl[tw_slots<S>()];  // W_N^(p k) for the stored powers; apply_twiddles builds the others with one product
+#pragma unroll
+        for (int i = 0; i < tw_slots<S>(); i++) wsl[i] = twN[(tw_power<S>(i) * k) & (N - 1)];
+        apply_twiddles<S>(a, wsl);
+        bfly<S, SIGN>(a);  // slot t holds y[orev<S>(t)]
+        f2v *dst = (f2v *)out + (size_t)frame * N + k;
+#pragma unroll
+        for (int t = 0; t < S; t++) {
+            f2v z;
+            z.x = a[t].x;
+            z.y = a[t].y;
+            __builtin_nontemporal_store(z, dst + (size_t)((orev<S>(t) ^ m_xor) * NS));
+        }
+    }
+}
+
 template <int N, class G>
 int launch_g(mi355_ctx *ctx, int sign, const void *in, void *out, const float *window, const void *tw, int nframes, int shift,
              int real_in, hipStream_t st)
@@ -581,9 +664,49 @@ int launch_bluestein(mi355_fft *h, const void *in, void *out, int nframes, hipSt
     return MI355_OK;
 }
 
+int launch_big(mi355_fft *h, const void *in, void *out, int nframes, hipStream_t st)
+{
+    const int N = h->n, S = N / 4096;
+    size_t chunk = (256u << 20) / ((size_t)N * 8);  // workspace bounded to 256 MiB
+    if (chunk < 1) chunk = 1;
+    if (chunk > (size_t)nframes) chunk = (size_t)nframes;
+    if (chunk > h->cap_frames) {
+        MI355_HIP(hipStreamSynchronize(st));
+        if (h->d_wa) (void)hipFree(h->d_wa);
+        h->d_wa = nullptr; h->cap_frames = 0;
+        MI355_HIP(hipMalloc(&h->d_wa, chunk * (size_t)N * 8));
+        h->cap_frames = chunk;
+    }
+    const int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
+    const size_t isz = h->dtype == MI355_DTYPE_FLOAT ? 4 : 8;
+    const int in_xor = (h->sign > 0 && h->shift) ? 8 : 0, m_xor = (h->sign < 0 && h->shift) ? S / 2 : 0;
+    const c32 *tw4096 = (const c32 *)h->d_tw + N;
+    for (size_t f0 = 0; f0 < (size_t)nframes; f0 += chunk) {
+        const int nf = (int)((size_t)nframes - f0 < chunk ? (size_t)nframes - f0 : chunk);
+        const int nsub = nf * S / 2;  // pairs of sub-frames
+        const int grid = mi355_balanced_grid(h->ctx, nsub, 2, 2);
+        const void *src = (const char *)in + f0 * N * isz;
+#define SUB(SG, RL) hipLaunchKernelGGL((k_fft_sub<SG, RL>), dim3(grid), dim3(256), 0, st, src, (c32 *)h->d_wa, h->d_window, tw4096, S, nsub, in_xor)
+        if (h->sign < 0) { if (h->dtype == MI355_DTYPE_FLOAT) SUB(-1, true); else SUB(-1, false); }
+        else             { if (h->dtype == MI355_DTYPE_FLOAT) SUB(1, true);  else SUB(1, false); }
+#undef SUB
+        const long long total = (long long)nf * 4096;
+        long long blocks = (total + 255) / 256;
+        if (blocks > (long long)cus * 16) blocks = (long long)cus * 16;
+        c32 *dst = (c32 *)out + f0 * N;
+#define COMB(SS, SG) hipLaunchKernelGGL((k_fft_combine<SS, SG>), dim3((unsigned)blocks), dim3(256), 0, st, (const c32 *)h->d_wa, dst, (const c32 *)h->d_tw, total, m_xor)
+        if (S == 8) { if (h->sign < 0) COMB(8, -1); else COMB(8, 1); }
+        else        { if (h->sign < 0) COMB(16, -1); else COMB(16, 1); }
+#undef COMB
+        MI355_HIP(hipGetLastError());
+    }
+    return MI355_OK;
+}
+
 int launch_handle(mi355_fft *h, const void *in, void *out, int nvec, hipStream_t st)
 {
     if (h->m) return launch_bluestein(h, in, out, nvec, st);
+    if (h->n > 16384) return launch_big(h, in, out, nvec, st);
     return launch_fft(h->ctx, h->n, h->sign, in, out, h->d_window, h->d_tw, nvec, h->shift, h->dtype == MI355_DTYPE_FLOAT, st);
 }
 
@@ -691,8 +814,8 @@ extern "C" int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, con
     MI355_REQUIRE(ctx && out, "NULL argument");
     *out = nullptr;
     const bool pow2 = fft_size >= 2 && (fft_size & (fft_size - 1)) == 0;
-    if (fft_size < 2 || (pow2 && fft_size > 16384) || (!pow2 && fft_size > 8192)) {
-        mi355_set_error("fft size %d unsupported (powers of two 2..16384, any other size 3..8192)", fft_size);
+    if (fft_size < 2 || (pow2 && fft_size > 65536) || (!pow2 && fft_size > 8192)) {
+        mi355_set_error("fft size %d unsupported (powers of two 2..65536, any other size 3..8192)", fft_size);
         return fft_size < 2 ? MI355_ERR_INVALID_ARG : MI355_ERR_UNSUPPORTED;
     }
     MI355_REQUIRE(window_len == 0 || window_len == fft_size, "window not the same length as fft_size");
@@ -793,7 +916,7 @@ extern "C" int mi355_fft_work(mi355_fft *h, int nvec, const void *const *in_stre
         char *pout = (char *)out_streams[s_i];
         for (size_t ci = 0; ci < nchunks; ci++, seq++) {
             int s = (int)(seq & 1);
-            hipStream_t st = h->ctx->stream[h->m ? 0 : s];  // the chirp-z path shares one pair of work buffers: one stream
+            hipStream_t st = h->ctx->stream[(h->m || h->n > 16384) ? 0 : s];  // chirp-z / two-kernel paths share work buffers: one stream
             if (pend_bytes[s]) {
                 MI355_HIP(hipEventSynchronize(p.done[s]));
                 memcpy(pend_dst[s], p.h_out[s], pend_bytes[s]);

@@ -134,7 +134,7 @@ int mi355_mathconst_work_dev(mi355_mathconst *h, size_t nitems, const void *a, v
  * clFFT: per frame Y = [fftshift] FFT_N( x .* window ), unnormalised in both
  * directions.  Replaces the clFFT plan + MultiplyFloat kernel + host fftshift
  * of clFFT_impl (ctor lib/clFFT_impl.cc:65-151, processOpenCL :526-634).
- * fft_size: any power of two 2..16384 (single fused kernel), any other size 3..8192
+ * fft_size: any power of two 2..16384 (single fused kernel) and 32768 / 65536 (two kernels), any other size 3..8192
  * (chirp-z over the power-of-two kernels; the reference leaves those to clFFT's radix-3/5/7
  * plans); larger sizes return MI355_ERR_UNSUPPORTED.  The shift of an odd-sized frame follows
  * clFFT_impl::testCPU (len = ceil(N/2), :503-507).  window: NULL/0 or exactly fft_size floats

@@ -159,7 +159,7 @@ def test_zero_vectors_and_bad_sizes(gpu):
     e = np.empty(0, np.complex64)
     assert blk.work(0, [e], [e]) == 0
     with pytest.raises(gpu.Mi355Error):
-        _fft(gpu, 32768, gpu.CLFFT_FORWARD)  # powers of two above 16384 are refused, not emulated
+        _fft(gpu, 131072, gpu.CLFFT_FORWARD)  # powers of two above 65536 are refused, not emulated
     with pytest.raises(gpu.Mi355Error):
         _fft(gpu, 9000, gpu.CLFFT_FORWARD)   # other sizes above 8192 too
     with pytest.raises(gpu.Mi355Error):
@@ -205,3 +205,30 @@ def test_chirpz_real_input_device_path_and_chunks(gpu, oracle):
     for sl in (slice(0, 2 * n), slice((nbig - 2) * n, nbig * n)):
         assert relerr(yb[sl], oracle.fft_block(n, True, None, False, oracle.DTYPE_COMPLEX, xb[sl], f64=True)) <= TOL
 
+
+
+# 32768 / 65536: two kernels through a workspace (sub-transforms + radix-8/16 combine)
+@pytest.mark.parametrize("n", [32768, 65536])
+@pytest.mark.parametrize("fwd,shift,win", [(True, False, False), (True, True, True), (False, True, True), (False, False, False)])
+def test_two_kernel_sizes(gpu, oracle, n, fwd, shift, win):
+    rng = np.random.default_rng(n + 5)
+    nvec = 3
+    w = oracle.window(oracle.WIN_BLACKMAN_HARRIS, n) if win else None
+    x = crandn(rng, nvec * n)
+    y = np.empty_like(x)
+    blk = _fft(gpu, n, gpu.CLFFT_FORWARD if fwd else gpu.CLFFT_BACKWARD, w, shift=shift)
+    assert blk.work(nvec, [x], [y]) == nvec
+    assert relerr(y, oracle.fft_block(n, fwd, w, shift, oracle.DTYPE_COMPLEX, x, f64=True)) <= TOL
+
+
+def test_two_kernel_real_input_and_tone(gpu, oracle):
+    n = 32768
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal(2 * n).astype(np.float32)
+    y = np.empty(2 * n, np.complex64)
+    _fft(gpu, n, gpu.CLFFT_FORWARD, dtype=gpu.DTYPE_FLOAT, shift=True).work(2, [x], [y])
+    assert relerr(y, oracle.fft_block(n, True, None, True, oracle.DTYPE_FLOAT, x, f64=True)) <= TOL
+    t = np.exp(2j * np.pi * 12345 * np.arange(65536) / 65536).astype(np.complex64)  # one bin
+    z = np.empty_like(t)
+    _fft(gpu, 65536, gpu.CLFFT_FORWARD).work(1, [t], [z])
+    assert abs(z[12345] - 65536) < 1.0 and np.abs(np.delete(z, 12345)).max() < 1.0
