@@ -905,6 +905,19 @@ extern "C" int mi355_fft_work(mi355_fft *h, int nvec, const void *const *in_stre
     int rc = h->pipe.ensure(1, &inb, first * out_frame);
     if (rc) return rc;
     HostPipe &p = h->pipe;
+    if ((size_t)nvec <= chunk_frames && mi355_direct_ok((size_t)nvec * out_frame)) {
+        // small call: the kernels work on the pinned staging themselves (see common.h); streams one after the other
+        hipStream_t st = h->ctx->stream[0];
+        for (int s_i = 0; s_i < h->nstreams; s_i++) {
+            MI355_REQUIRE(in_streams[s_i] && out_streams[s_i], "NULL stream buffer");
+            memcpy(p.h_in[0][0], in_streams[s_i], (size_t)nvec * in_frame);
+            rc = launch_handle(h, p.h_in[0][0], p.h_out[0], nvec, st);
+            if (rc) return rc;
+            MI355_HIP(hipStreamSynchronize(st));
+            memcpy(out_streams[s_i], p.h_out[0], (size_t)nvec * out_frame);
+        }
+        return MI355_OK;
+    }
     // all (stream, chunk) pairs run through the two staging slots back to back
     size_t nchunks = ((size_t)nvec + chunk_frames - 1) / chunk_frames;
     char *pend_dst[2] = {nullptr, nullptr};

@@ -546,6 +546,15 @@ extern "C" int mi355_filter_work(mi355_filter *h, size_t noutput_items, const vo
     HostPipe &p = h->pipe;
     const char *pin = (const char *)in;
     char *pout = (char *)out;
+    if (noutput_items <= chunk_out && mi355_direct_ok(inb)) {  // small call: the kernel works on the pinned staging itself
+        hipStream_t st = h->ctx->stream[0];
+        memcpy(p.h_in[0][0], pin, inb);
+        rc = launch_filter(h, noutput_items, p.h_in[0][0], p.h_out[0], st);
+        if (rc) return rc;
+        MI355_HIP(hipStreamSynchronize(st));
+        memcpy(pout, p.h_out[0], noutput_items * 8);
+        return MI355_OK;
+    }
     size_t nchunks = (noutput_items + chunk_out - 1) / chunk_out;
     size_t pend_off[2] = {0, 0}, pend_bytes[2] = {0, 0};
     for (size_t ci = 0; ci < nchunks; ci++) {
