@@ -153,11 +153,19 @@ template <int N> struct GeoW {
 // for ds_write_b64 (16-lane groups) and ds_read_b64 (32-lane groups).
 __host__ __device__ constexpr int swz(int s) { return s ^ ((s >> 4) & 15); }
 
-// LDS slot of logical index (raw + c) where c is a compile-time multiple of STEP
-template <int STEP> __device__ __forceinline__ int lds_at(int raw, int raw_swz, int c)
+// 256-point frames: a 32-lane read group spans two frames whose slots are 256 apart, i.e. the same banks; folding slot
+// bit 8 (the frame parity) into bit 4 separates them.  Used only inside transform_regs (writes and reads agree).
+template <int N> __host__ __device__ constexpr int swzn(int s)
 {
-    if constexpr (STEP % 256 == 0) return raw_swz + c;  // the swizzle only touches the low 8 slot bits
-    else return swz(raw + c);
+    if (N == 256) return s ^ ((s >> 4) & 31);
+    return swz(s);
+}
+
+// LDS slot of logical index (raw + c) where c is a compile-time multiple of STEP
+template <int STEP, int N = 0> __device__ __forceinline__ int lds_at(int raw, int raw_swz, int c)
+{
+    if constexpr (STEP % 256 == 0 && N != 256) return raw_swz + c;  // the swizzle only touches the low 8 slot bits
+    else return swzn<N>(raw + c);
 }
 
 // inverse of orev: slot that holds output index r
@@ -231,9 +239,9 @@ __device__ __forceinline__ void transform_regs(c32 (&v)[16], const TwRegs<N> &tw
             __syncthreads();  // previous pass' LDS writes are visible
 #pragma unroll
             for (int q = 0; q < 16 / R; q++) {
-                const int g = tid + TH * q, raw = (g / B) * N + (g % B), rs = swz(raw);
+                const int g = tid + TH * q, raw = (g / B) * N + (g % B), rs = swzn<N>(raw);
 #pragma unroll
-                for (int r = 0; r < R; r++) v[q * R + r] = lds[lds_at<B>(raw, rs, r * B)];
+                for (int r = 0; r < R; r++) v[q * R + r] = lds[lds_at<B, N>(raw, rs, r * B)];
             }
 #pragma unroll
             for (int q = 0; q < 16 / R; q++) apply_twiddles<R>(&v[q * R], &tw.w[P - 1][q * tw_slots<R>()]);
@@ -246,9 +254,9 @@ __device__ __forceinline__ void transform_regs(c32 (&v)[16], const TwRegs<N> &tw
 #pragma unroll
             for (int q = 0; q < 16 / R; q++) {
                 const int g = tid + TH * q, fr = g / B, j = g % B;
-                const int raw = fr * N + (j / NS) * NS * R + (j % NS), rs = swz(raw);
+                const int raw = fr * N + (j / NS) * NS * R + (j % NS), rs = swzn<N>(raw);
 #pragma unroll
-                for (int s = 0; s < R; s++) lds[lds_at<NS>(raw, rs, orev<R>(s) * NS)] = v[q * R + s];
+                for (int s = 0; s < R; s++) lds[lds_at<NS, N>(raw, rs, orev<R>(s) * NS)] = v[q * R + s];
             }
         }
         transform_regs<N, SIGN, REV, G, P + 1>(v, tw, lds, tid);
