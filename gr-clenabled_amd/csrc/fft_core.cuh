@@ -158,13 +158,16 @@ __host__ __device__ constexpr int swz(int s) { return s ^ ((s >> 4) & 15); }
 template <int N> __host__ __device__ constexpr int swzn(int s)
 {
     if (N == 256) return s ^ ((s >> 4) & 31);
+    // 64-point frames: 32 lanes span 2 frames (4 butterflies per thread) or 8 frames (one 16-point butterfly per thread,
+    // 4 lanes per frame); slot bits 6 and 8 folded into bit 4 keep both patterns conflict free
+    if (N == 64) return s ^ ((s >> 4) & 15) ^ ((((s >> 6) ^ (s >> 8)) & 1) << 4);
     return swz(s);
 }
 
 // LDS slot of logical index (raw + c) where c is a compile-time multiple of STEP
 template <int STEP, int N = 0> __device__ __forceinline__ int lds_at(int raw, int raw_swz, int c)
 {
-    if constexpr (STEP % 256 == 0 && N != 256) return raw_swz + c;  // the swizzle only touches the low 8 slot bits
+    if constexpr (STEP % 256 == 0 && N != 256 && N != 64) return raw_swz + c;  // the swizzle only touches the low 8 slot bits
     else return swzn<N>(raw + c);
 }
 

@@ -256,8 +256,8 @@ __global__ __launch_bounds__(64, 2) void k_pfb64(const c32 *__restrict__ in, c32
                 a1 = __builtin_elementwise_fma(ring[(U * PH + u + 1 + pp) % RS], hh, a1);
             }
             __builtin_amdgcn_sched_barrier(0);  // the refill below must not be hoisted above the last use of its slot
-            lds[swz(u * M + lane)] = mk(a0.x, a0.y);
-            lds[swz((u + 1) * M + lane)] = mk(a1.x, a1.y);
+            lds[swzn<M>(u * M + lane)] = mk(a0.x, a0.y);
+            lds[swzn<M>((u + 1) * M + lane)] = mk(a1.x, a1.y);
             // unconditional: past the wave's range the rows are simply not used, past the stream they read as zero
             ring[(U * PH + u) % RS] = load_row(row0 + RS + u);
             ring[(U * PH + u + 1) % RS] = load_row(row0 + RS + u + 1);
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(64, 2) void k_pfb64(const c32 *__restrict__ in, c32
         {
             const int raw = (lane / B0) * M + (lane % B0);
 #pragma unroll
-            for (int r = 0; r < R0; r++) v[r] = lds[swz(raw + r * B0)];
+            for (int r = 0; r < R0; r++) v[r] = lds[swzn<M>(raw + r * B0)];
         }
         __syncthreads();
         transform_regs<M, 1, false, G>(v, tw, lds, lane);
