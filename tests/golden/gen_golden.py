@@ -33,6 +33,50 @@ def firdes_low_pass64(gain, fs, cutoff, tw, atten=53.0):
     return t
 
 
+def widen_golden():
+    """Fixtures of the widened rows and of the FFT sizes added later: float64 numpy definitions only."""
+    rng = np.random.default_rng(20260928)
+    g = {}
+    # clxcorrelate_fft_vcf (lib/clxcorrelate_fft_vcf_impl.cc:1058-1143): out = halfswap(|IFFT_unscaled(X0 conj(Xs))|)
+    n, nfr = 256, 3
+    xs = [crandn(rng, n * nfr) for _ in range(3)]
+    for itype in (1, 2):
+        X = [x.reshape(nfr, n).astype(np.complex128) for x in xs]
+        if itype == 2:
+            X = [np.fft.fft(x, axis=1) for x in X]
+        for s in (1, 2):
+            r = np.fft.ifft(X[0] * np.conj(X[s]), axis=1) * n
+            g["xcorr_t%d_out%d" % (itype, s)] = np.fft.fftshift(np.abs(r), axes=1).reshape(-1).astype(np.float32)
+    for i, x in enumerate(xs):
+        g["xcorr_in%d" % i] = x
+    # elementwise family (kernels cited in include/mi355_clenabled.h)
+    m = 1000
+    a = (np.abs(rng.standard_normal(m)) + 0.05).astype(np.float32)
+    b = (np.abs(rng.standard_normal(m)) + 0.05).astype(np.float32)
+    z = crandn(rng, m + 1)
+    ph = rng.uniform(-10, 10, m).astype(np.float32)
+    z64 = z.astype(np.complex128)
+    g.update(el_a=a, el_b=b, el_z=z, el_ph=ph,
+             el_log10=(2.5 * np.log10(a.astype(np.float64)) - 3.0).astype(np.float32),
+             el_snr=np.abs(10 * np.log10(a.astype(np.float64) / b.astype(np.float64)) + 1.0).astype(np.float32),
+             el_mag=np.abs(z64[:m]).astype(np.float32), el_arg=np.angle(z64[:m]).astype(np.float32),
+             el_mp2c=(a.astype(np.float64) * np.exp(1j * ph.astype(np.float64))).astype(np.complex64),
+             el_qdemod=(0.7 * np.angle(z64[1:] * np.conj(z64[:-1]))).astype(np.float32))
+    # FFT sizes that are not a power of two (len = ceil(N/2) shift of clFFT_impl::testCPU, :503-507) and the large ones
+    for nn in (12, 1000):
+        x = crandn(rng, 2 * nn)
+        w = (0.54 - 0.46 * np.cos(2 * np.pi * np.arange(nn) / (nn - 1))).astype(np.float32)
+        X = np.fft.fft(x.reshape(2, nn).astype(np.complex128) * w, axis=1)
+        ln = (nn + 1) // 2
+        g["fftx%d" % nn], g["fftw%d" % nn] = x, w
+        g["fft_fwd_win_shift%d" % nn] = np.concatenate([X[:, ln:], X[:, :ln]], axis=1).reshape(-1).astype(np.complex64)
+    for nn in (8192,):
+        x = crandn(rng, nn)
+        g["fftx%d" % nn] = x
+        g["fft_fwd%d" % nn] = np.fft.fft(x.astype(np.complex128)).astype(np.complex64)
+    np.savez_compressed(os.path.join(HERE, "widen_golden.npz"), **g)
+
+
 def main():
     kat = {
         "_source": "reference known-answer tests and SURVEY.md section 8(c)",
@@ -186,6 +230,7 @@ def main():
                     o[:, k, p1 * 2 + p2] = np.sum(zz[:, s1, :, p1] * np.conj(zz[:, s2, :, p2]), axis=0)
     xe["p4_x"], xe["p4_y"] = pk.reshape(-1), o.reshape(-1).astype(np.complex64)
     np.savez_compressed(os.path.join(HERE, "xengine_golden.npz"), **xe)
+    widen_golden()
 
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith((".npz", ".json")))
     print("golden fixtures written, %.1f KiB" % (tot / 1024))

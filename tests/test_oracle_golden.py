@@ -194,3 +194,25 @@ def test_xengine_gather_layout(oracle):
     o.xengine_gather(o.DTYPE_BYTE, N, F, 1, 2, 0, ins[:N], fb1)
     o.xengine_gather(o.DTYPE_BYTE, N, F, 1, 2, 2, [a[2 * F * 2:] for a in ins[:N]], fb1)
     assert np.array_equal(fb1.reshape(T, N, F * 2)[:, 1, :].reshape(-1), ins[1])
+
+
+def test_widened_rows_vs_golden(oracle):
+    """Oracle restatements of the widened rows and of the later FFT sizes vs float64 numpy fixtures."""
+    g = golden("widen_golden.npz")
+    o = oracle
+    ins = [g["xcorr_in%d" % i] for i in range(3)]
+    for itype in (1, 2):
+        outs = o.xcorr_fft(256, itype, ins, use_f64=True)
+        for s in (1, 2):
+            assert relerr(outs[s - 1], g["xcorr_t%d_out%d" % (itype, s)]) < 2e-6
+    n = g["el_a"].size
+    assert relerr(o.elem(1, n, [g["el_a"]], p0=2.5, p1=-3.0)[0], g["el_log10"]) < 1e-6
+    assert relerr(o.elem(2, n, [g["el_a"], g["el_b"]], p0=10.0, p1=1.0)[0], g["el_snr"]) < 1e-5
+    assert relerr(o.elem(3, n, [g["el_z"][:n]])[0], g["el_mag"]) < 1e-6
+    assert relerr(o.elem(4, n, [g["el_z"][:n]])[0], g["el_arg"]) < 1e-6
+    assert relerr(o.elem(6, n, [g["el_a"], g["el_ph"]])[0], g["el_mp2c"]) < 1e-6
+    assert relerr(o.elem(7, n, [g["el_z"]], p0=0.7)[0], g["el_qdemod"]) < 1e-6
+    for nn in (12, 1000):
+        y = o.fft_block(nn, True, g["fftw%d" % nn], True, o.DTYPE_COMPLEX, g["fftx%d" % nn], f64=True)
+        assert relerr(y, g["fft_fwd_win_shift%d" % nn]) < 1e-6
+    assert relerr(o.fft(g["fftx8192"]), g["fft_fwd8192"]) < 2e-6
