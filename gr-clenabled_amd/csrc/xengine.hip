@@ -519,6 +519,136 @@ __global__ __launch_bounds__(WAVES * 64) void k_xe_corr_f32(const unsigned char 
 }
 
 // ------------------------------------------------------------------------------------
+// (3b) complex-float input, FUSED (rows = stations x pols <= 64): no tile round trip through HBM.
+// A workgroup owns 8 channels (64 bytes of every (t, station) row for one polarisation, 128 for two: whole or half
+// 128-byte lines; the workgroup of the other half is the neighbouring blockIdx, i.e. the same XCD's L2 in practice) and
+// one of the time ranges.  Per 16-time-step K block the 8 waves stage the 64 KiB they need through registers into LDS in
+// the MFMA operand order of section (3) (per channel: [plane][row tile][lane][4 floats]), double buffered, the global
+// loads of block k+1 in flight while block k is multiplied.  Wave w correlates channel w: all row-tile pairs, 3 x 4
+// accumulator registers per pair (120 for 64 rows) stay in AGPRs for the whole time range -- that register capacity
+// (30 KiB per channel) is what limits a workgroup to 8 channels and rules the same design out for the 2-byte samples of
+// the int8 path (8 channels = 16 bytes per row).  The partial matrices of the time ranges are summed by k_xe_reduce.
+// HBM traffic = input once + 2-3 x the (small) output.
+// ------------------------------------------------------------------------------------
+template <int NTT, int NPOL>
+__global__ __launch_bounds__(512) void k_xe_f32_fused(const v4i *__restrict__ in, c32 *__restrict__ part, XeGeo g, int tsplit)
+{
+    constexpr int CH = 8, NP = NTT * (NTT + 1) / 2, CBYTES = 2 * NTT * kTileBytes;  // per channel and K block
+    constexpr int SEGQ = CH * NPOL / 2;                 // 16-byte pieces per (t, station) segment
+    constexpr int NS = kRowTile * NTT / NPOL;           // stations covered by the row tiles
+    constexpr int ITEMS = 16 * NS * SEGQ, PER = ITEMS / 512;
+    static_assert(ITEMS % 512 == 0, "staging items must split over the workgroup");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][CH * CBYTES];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int cgrp = blockIdx.x, ts = blockIdx.y;
+    const int kb_total = (g.T + kKB32 - 1) / kKB32, kb_per = (kb_total + tsplit - 1) / tsplit;
+    const int kb0 = ts * kb_per, kb1 = (kb0 + kb_per < kb_total) ? kb0 + kb_per : kb_total;
+    const size_t row_v4 = (size_t)g.F * NPOL / 2;      // 16-byte pieces per (t, station) row of the input
+    const size_t seg0 = (size_t)cgrp * SEGQ;            // first piece of this workgroup's channels inside a row
+
+    v4f re[NP], uu[NP], ww[NP];
+#pragma unroll
+    for (int q = 0; q < NP; q++) re[q] = uu[q] = ww[q] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    v4i stage[PER];
+    auto load_block = [&](int kb) {
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int idx = tid + 512 * k, q16 = idx % SEGQ, sidx = (idx / SEGQ) % NS, t = idx / (SEGQ * NS);
+            const int tt = kb * kKB32 + t;
+            const bool ok = sidx < g.N && tt < g.T;
+            v4i piece = (v4i){0, 0, 0, 0};
+            if (ok) piece = __builtin_nontemporal_load(in + ((size_t)tt * g.N + sidx) * row_v4 + seg0 + q16);
+            stage[k] = piece;
+        }
+    };
+    auto store_block = [&](unsigned char *buf) {
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int idx = tid + 512 * k, q16 = idx % SEGQ, sidx = (idx / SEGQ) % NS, t = idx / (SEGQ * NS);
+            // (whole-vector bit cast: __builtin_bit_cast of a single vector ELEMENT reads element 0 with this compiler)
+            const v4f fv = __builtin_bit_cast(v4f, stage[k]);
+            const float v[4] = {fv.x, fv.y, fv.z, fv.w};
+#pragma unroll
+            for (int e = 0; e < 2; e++) {  // the two complex values of the piece
+                const int ce = 2 * q16 + e, c = ce / NPOL, pol = ce % NPOL, row = sidx * NPOL + pol;
+                // time step t of the K block sits in float (t%4 + rot)%4 of lane group t/4; rot depends on the channel only, so
+                // both operands of a product see the same order, and it spreads the writes of a wave over all banks
+                const int rot = (NPOL == 1) ? (c >> 1) & 3 : c & 3;
+                const int off = c * CBYTES + (row / kRowTile) * kTileBytes + (((t >> 2) * 16 + (row % kRowTile)) * 16) + (((t + rot) & 3) * 4);
+                *(float *)(buf + off) = v[2 * e];                           // I plane
+                *(float *)(buf + off + NTT * kTileBytes) = v[2 * e + 1];    // Q plane
+            }
+        }
+    };
+
+    if (kb0 < kb1) {
+        load_block(kb0);
+        store_block(lds[0]);
+    }
+    __syncthreads();
+    for (int kb = kb0; kb < kb1; kb++) {
+        const unsigned char *buf = lds[(kb - kb0) & 1];
+        if (kb + 1 < kb1) load_block(kb + 1);
+        const unsigned char *base = buf + wave * CBYTES + lane * 16;
+        v4f I[NTT], Q[NTT];
+#pragma unroll
+        for (int rt = 0; rt < NTT; rt++) {
+            I[rt] = *(const v4f *)(base + rt * kTileBytes);
+            Q[rt] = *(const v4f *)(base + (NTT + rt) * kTileBytes);
+        }
+#pragma unroll
+        for (int bi = 0; bi < NTT; bi++) {
+#pragma unroll
+            for (int bj = 0; bj <= bi; bj++) {
+                const int q = bi * (bi + 1) / 2 + bj;
+#pragma unroll
+                for (int kc = 0; kc < 4; kc++) {
+                    re[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(I[bi][kc], I[bj][kc], re[q], 0, 0, 0);
+                    uu[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(Q[bi][kc], I[bj][kc], uu[q], 0, 0, 0);
+                    re[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(Q[bi][kc], Q[bj][kc], re[q], 0, 0, 0);
+                    ww[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(I[bi][kc], Q[bj][kc], ww[q], 0, 0, 0);
+                }
+            }
+        }
+        if (kb + 1 < kb1) store_block(lds[(kb + 1 - kb0) & 1]);
+        __syncthreads();
+    }
+    // partial matrix of this time range, channel = cgrp*8 + wave
+    const int f = cgrp * CH + wave;
+    const int nb = g.N * (g.N + 1) / 2, np2 = NPOL * NPOL;
+    c32 *__restrict__ dst = part + ((size_t)ts * g.F + f) * nb * np2;
+#pragma unroll
+    for (int bi = 0; bi < NTT; bi++) {
+#pragma unroll
+        for (int bj = 0; bj <= bi; bj++) {
+            const int q = bi * (bi + 1) / 2 + bj;
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int r1 = bi * kRowTile + (lane >> 4) * 4 + reg, r2 = bj * kRowTile + (lane & 15);
+                if (r1 >= g.A || r2 >= g.A) continue;
+                const int s1 = r1 / NPOL, p1 = r1 % NPOL, s2 = r2 / NPOL, p2 = r2 % NPOL;
+                if (s1 < s2) continue;
+                c32 v;
+                v.x = re[q][reg];
+                v.y = uu[q][reg] - ww[q][reg];
+                dst[(size_t)(s1 * (s1 + 1) / 2 + s2) * np2 + p1 * NPOL + p2] = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_xe_reduce(const c32 *__restrict__ part, c32 *__restrict__ out, size_t n, int tsplit, int accumulate)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        c32 a = part[i];
+        for (int t = 1; t < tsplit; t++) { a.x += part[(size_t)t * n + i].x; a.y += part[(size_t)t * n + i].y; }
+        if (accumulate) { a.x += out[i].x; a.y += out[i].y; }
+        out[i] = a;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // complex-float input: fp32 arithmetic, 8x8 station blocks per thread, lanes along channels
 // ------------------------------------------------------------------------------------
 constexpr int kCfBlk = 4;  // rows per side of a thread's block
@@ -603,6 +733,24 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
     if (h->data_type == MI355_DTYPE_COMPLEX) {
         const bool mfma = ((size_t)g.F * g.npol * 8) % 128 == 0 && (reinterpret_cast<uintptr_t>(in) & 15u) == 0 && tiles &&
                           xe_f32_row_tiles(g.NT) != 0 && !getenv("MI355_XE_CF32_VALU");
+        // fused kernel: rows <= 64, whole groups of 8 channels; the partial matrices live in the tile workspace
+        const int tsplit = g.T >= 64 ? 2 : 1;
+        const size_t out_items = (size_t)g.F * (g.N * (g.N + 1) / 2) * g.npol * g.npol;
+        if (mfma && g.NT <= 4 && g.F % 8 == 0 && h->tile_bytes >= (size_t)tsplit * out_items * 8 && !getenv("MI355_XE_CF32_TWO_KERNELS")) {
+            const int ntt = g.NT == 3 ? 4 : g.NT;
+            dim3 grid(g.F / 8, tsplit);
+#define FUSED(NTT, NPOL) hipLaunchKernelGGL((k_xe_f32_fused<NTT, NPOL>), grid, dim3(512), 0, st, (const v4i *)in, (c32 *)tiles, g, tsplit)
+            if (g.npol == 1) { if (ntt == 1) FUSED(1, 1); else if (ntt == 2) FUSED(2, 1); else FUSED(4, 1); }
+            else             { if (ntt == 1) FUSED(1, 2); else if (ntt == 2) FUSED(2, 2); else FUSED(4, 2); }
+#undef FUSED
+            MI355_HIP(hipGetLastError());
+            size_t blocks = (out_items + 255) / 256;
+            const size_t cap = (size_t)(h->ctx->num_cus > 0 ? h->ctx->num_cus : 256) * 16;
+            if (blocks > cap) blocks = cap;
+            hipLaunchKernelGGL(k_xe_reduce, dim3((unsigned)blocks), dim3(256), 0, st, (const c32 *)tiles, (c32 *)out, out_items, tsplit, accumulate);
+            MI355_HIP(hipGetLastError());
+            return MI355_OK;
+        }
         if (mfma) {
             XeGeo gf = g;
             gf.KB = (g.T + kKB32 - 1) / kKB32;

@@ -74,7 +74,9 @@ def test_closed_form_cases(gpu):
 
 # F*npol % 16 == 0 takes the fp32 matrix-core path (row tiles 1, 2, 3->4, 4, 5->6, 8); the others the VALU kernel
 @pytest.mark.parametrize("N,F,T,npol", [(4, 8, 16, 1), (9, 5, 33, 2), (16, 32, 64, 1), (16, 16, 64, 1), (20, 16, 50, 1),
-                                        (40, 32, 33, 1), (64, 16, 100, 1), (33, 8, 130, 2), (64, 8, 40, 2), (70, 16, 20, 2)])
+                                        (40, 32, 33, 1), (64, 16, 100, 1), (33, 8, 130, 2), (64, 8, 40, 2), (70, 16, 20, 2),
+                                        # rows <= 64 and F % 8 == 0: the fused kernel (1, 2, 3->4 and 4 row tiles, both polarisation counts)
+                                        (8, 8, 20, 2), (16, 8, 70, 2), (24, 16, 130, 2), (32, 16, 64, 2), (64, 24, 1000, 1), (5, 8, 3, 1)])
 def test_complex_float_vs_oracle(gpu, oracle, N, F, T, npol):
     rng = np.random.default_rng(N + T)
     x = crandn(rng, T * N * F * npol)
