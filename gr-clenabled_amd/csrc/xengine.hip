@@ -540,7 +540,22 @@ __global__ __launch_bounds__(512) void k_xe_f32_fused(const v4i *__restrict__ in
     static_assert(ITEMS % 512 == 0, "staging items must split over the workgroup");
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][CH * CBYTES];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int cgrp = blockIdx.x, ts = blockIdx.y;
+    // For one polarisation a workgroup reads 64-byte halves of 128-byte lines; the workgroup reading the other half must sit on
+    // the same XCD (same L2) or every line crosses the fabric twice.  Workgroups are dispatched round-robin over the 8 XCDs, so
+    // the two members of a pair take linear ids with the same id % 8 (tools/ubench/sector_read.hip: 39 -> 22 us per 134 MB).
+    const int ngrp = g.F / CH;
+    int cgrp, ts;
+    {
+        const int b = blockIdx.x, total = ngrp * tsplit;
+        if (NPOL == 1 && ngrp % 2 == 0 && total % 16 == 0) {
+            const int xcd = b & 7, within = b >> 3, member = within & 1, combo = xcd + 8 * (within >> 1);
+            cgrp = 2 * (combo % (ngrp / 2)) + member;
+            ts = combo / (ngrp / 2);
+        } else {
+            cgrp = b % ngrp;
+            ts = b / ngrp;
+        }
+    }
     const int kb_total = (g.T + kKB32 - 1) / kKB32, kb_per = (kb_total + tsplit - 1) / tsplit;
     const int kb0 = ts * kb_per, kb1 = (kb0 + kb_per < kb_total) ? kb0 + kb_per : kb_total;
     const size_t row_v4 = (size_t)g.F * NPOL / 2;      // 16-byte pieces per (t, station) row of the input
@@ -550,19 +565,27 @@ __global__ __launch_bounds__(512) void k_xe_f32_fused(const v4i *__restrict__ in
 #pragma unroll
     for (int q = 0; q < NP; q++) re[q] = uu[q] = ww[q] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-    v4i stage[PER];
-    auto load_block = [&](int kb) {
+    // One register stage: the loads of K block kb+1 are in flight while block kb is multiplied.  (Measured on MI355X: the
+    // multiply loop alone runs in 178 us = 79 % MFMA-busy, the load loop alone in 152 us, together 272 us -- the loads make
+    // little progress while the matrix pipes are saturated; a second stage, i.e. two blocks of lead, changed nothing.)
+    v4i stA[PER];
+    const int t_end = (kb1 * kKB32 < g.T) ? kb1 * kKB32 : g.T;  // a block past this workgroup's time range loads nothing (zeros)
+    auto load_block = [&](int kb, v4i(&stage)[PER]) {
 #pragma unroll
         for (int k = 0; k < PER; k++) {
             const int idx = tid + 512 * k, q16 = idx % SEGQ, sidx = (idx / SEGQ) % NS, t = idx / (SEGQ * NS);
             const int tt = kb * kKB32 + t;
-            const bool ok = sidx < g.N && tt < g.T;
+            const bool ok = sidx < g.N && tt < t_end;
             v4i piece = (v4i){0, 0, 0, 0};
-            if (ok) piece = __builtin_nontemporal_load(in + ((size_t)tt * g.N + sidx) * row_v4 + seg0 + q16);
+            if (ok) {
+                const v4i *src = in + ((size_t)tt * g.N + sidx) * row_v4 + seg0 + q16;
+                // one polarisation: the other half of the line belongs to the sibling workgroup on this XCD -> keep it in L2
+                piece = (NPOL == 1) ? *src : __builtin_nontemporal_load(src);
+            }
             stage[k] = piece;
         }
     };
-    auto store_block = [&](unsigned char *buf) {
+    auto store_block = [&](unsigned char *buf, const v4i(&stage)[PER]) {
 #pragma unroll
         for (int k = 0; k < PER; k++) {
             const int idx = tid + 512 * k, q16 = idx % SEGQ, sidx = (idx / SEGQ) % NS, t = idx / (SEGQ * NS);
@@ -581,15 +604,7 @@ __global__ __launch_bounds__(512) void k_xe_f32_fused(const v4i *__restrict__ in
             }
         }
     };
-
-    if (kb0 < kb1) {
-        load_block(kb0);
-        store_block(lds[0]);
-    }
-    __syncthreads();
-    for (int kb = kb0; kb < kb1; kb++) {
-        const unsigned char *buf = lds[(kb - kb0) & 1];
-        if (kb + 1 < kb1) load_block(kb + 1);
+    auto multiply = [&](const unsigned char *buf) {
         const unsigned char *base = buf + wave * CBYTES + lane * 16;
         v4f I[NTT], Q[NTT];
 #pragma unroll
@@ -611,7 +626,15 @@ __global__ __launch_bounds__(512) void k_xe_f32_fused(const v4i *__restrict__ in
                 }
             }
         }
-        if (kb + 1 < kb1) store_block(lds[(kb + 1 - kb0) & 1]);
+    };
+
+    load_block(kb0, stA);
+    store_block(lds[0], stA);
+    __syncthreads();
+    for (int kb = kb0; kb < kb1; kb++) {
+        load_block(kb + 1, stA);  // unconditional (the block after the last one reads as zeros): no control flow in the loop body
+        multiply(lds[(kb - kb0) & 1]);
+        store_block(lds[(kb + 1 - kb0) & 1], stA);
         __syncthreads();
     }
     // partial matrix of this time range, channel = cgrp*8 + wave
@@ -738,7 +761,7 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
         const size_t out_items = (size_t)g.F * (g.N * (g.N + 1) / 2) * g.npol * g.npol;
         if (mfma && g.NT <= 4 && g.F % 8 == 0 && h->tile_bytes >= (size_t)tsplit * out_items * 8 && !getenv("MI355_XE_CF32_TWO_KERNELS")) {
             const int ntt = g.NT == 3 ? 4 : g.NT;
-            dim3 grid(g.F / 8, tsplit);
+            dim3 grid((g.F / 8) * tsplit);
 #define FUSED(NTT, NPOL) hipLaunchKernelGGL((k_xe_f32_fused<NTT, NPOL>), grid, dim3(512), 0, st, (const v4i *)in, (c32 *)tiles, g, tsplit)
             if (g.npol == 1) { if (ntt == 1) FUSED(1, 1); else if (ntt == 2) FUSED(2, 1); else FUSED(4, 1); }
             else             { if (ntt == 1) FUSED(1, 2); else if (ntt == 2) FUSED(2, 2); else FUSED(4, 2); }
