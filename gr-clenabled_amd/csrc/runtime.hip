@@ -79,6 +79,12 @@ extern "C" int mi355_ctx_create(int ocl_type, int dev_selector, int platform_id,
     c->debug = debug;
     c->num_cus = prop.multiProcessorCount;
     hipError_t e = hipSetDevice(dev);
+    // work() is a latency path (one scheduler-sized buffer per call): let the host spin on completion instead of sleeping on
+    // an interrupt.  Fails harmlessly when the device is already active in this process (e.g. under PyTorch); MI355_NO_SPIN=1 skips it.
+    if (e == hipSuccess && !getenv("MI355_NO_SPIN")) {
+        (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
+        (void)hipGetLastError();
+    }
     for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipStreamCreateWithFlags(&c->stream[i], hipStreamNonBlocking);
     if (e != hipSuccess) {
         mi355_set_error("creating the context's streams on device %d -> %s", dev, hipGetErrorString(e));
