@@ -538,9 +538,10 @@ __global__ __launch_bounds__(Geo<M>::TH, Geo<M>::WPE) void k_chirpz(const void *
     static_assert(PI::radix(0) == RL, "inverse plan must start with the forward plan's last radix");
     __shared__ c32 lds[NP > 1 ? PTS : 1];
     const int tid0 = threadIdx.x;
+    constexpr bool SHARE = (PF::L % 4) == 0;  // all-radix-16 sizes: inverse twiddles = conjugates of the forward ones
     TwRegs<M> twf, twi;
     load_twiddles<M, false, G>(twf, tid0, tw_fwd);
-    load_twiddles<M, true, G>(twi, tid0, tw_inv);
+    if constexpr (!SHARE) load_twiddles<M, true, G>(twi, tid0, tw_inv);
     c32 Breg[16];  // spectrum of the conjugate chirp (pre-scaled 1/m) at the bins this thread holds after the forward transform
 #pragma unroll
     for (int q = 0; q < 16 / RL; q++) {
@@ -579,7 +580,8 @@ __global__ __launch_bounds__(Geo<M>::TH, Geo<M>::WPE) void k_chirpz(const void *
 #pragma unroll
             for (int r = 0; r < RL; r++) w[q * RL + r] = cmul(v[q * RL + irev<RL>(r)], Breg[q * RL + irev<RL>(r)]);
         if constexpr (NP > 1) __syncthreads();
-        transform_regs<M, 1, true, G>(w, twi, lds, tid);
+        if constexpr (SHARE) transform_regs<M, 1, true, G, 0, true>(w, twf, lds, tid);
+        else transform_regs<M, 1, true, G>(w, twi, lds, tid);
         constexpr int RO = PI::radix(NP - 1), BO = M / RO;
 #pragma unroll
         for (int q = 0; q < 16 / RO; q++) {

@@ -206,7 +206,7 @@ __device__ __forceinline__ void load_twiddles(TwRegs<N> &tw, int tid, const c32 
 }
 
 // v[r] *= W^r for r = 1..R-1, W^r rebuilt from the stored powers
-template <int R> __device__ __forceinline__ void apply_twiddles(c32 *v, const c32 *w_in)
+template <int R, bool CJ = false> __device__ __forceinline__ void apply_twiddles(c32 *v, const c32 *w_in)
 {
     // Opaque copies: keeps the w[4a]*w[b] products inside the frame loop instead of
     // letting loop-invariant code motion turn them back into 15 live register pairs.
@@ -214,6 +214,7 @@ template <int R> __device__ __forceinline__ void apply_twiddles(c32 *v, const c3
 #pragma unroll
     for (int i = 0; i < tw_slots<R>(); i++) {
         w[i] = w_in[i];
+        if (CJ) w[i].y = -w[i].y;  // the stored table is the forward one; an all-radix-16 inverse plan needs its conjugate
         asm volatile("" : "+v"(w[i].x), "+v"(w[i].y));
     }
 #pragma unroll
@@ -232,7 +233,7 @@ template <int R> __device__ __forceinline__ void apply_twiddles(c32 *v, const c3
 // Out: v[q*RL + s]  = X[fr][j + orev<RL>(s)*BL]  (RL = last radix,  fr = g/BL, j = g%BL)
 // `lds` holds PTS slots and is used in place; the caller must __syncthreads() before
 // reusing it for another transform.
-template <int N, int SIGN, bool REV, class G = Geo<N>, int P = 0>
+template <int N, int SIGN, bool REV, class G = Geo<N>, int P = 0, bool CJ = false>
 __device__ __forceinline__ void transform_regs(c32 (&v)[16], const TwRegs<N> &tw, c32 *lds, int tid)
 {
     using PL = Plan<N, REV>;
@@ -247,7 +248,7 @@ __device__ __forceinline__ void transform_regs(c32 (&v)[16], const TwRegs<N> &tw
                 for (int r = 0; r < R; r++) v[q * R + r] = lds[lds_at<B, N>(raw, rs, r * B)];
             }
 #pragma unroll
-            for (int q = 0; q < 16 / R; q++) apply_twiddles<R>(&v[q * R], &tw.w[P - 1][q * tw_slots<R>()]);
+            for (int q = 0; q < 16 / R; q++) apply_twiddles<R, CJ>(&v[q * R], &tw.w[P - 1][q * tw_slots<R>()]);
             if constexpr (P < NP - 1) __syncthreads();  // everyone has read before anyone overwrites in place
         }
 #pragma unroll
@@ -262,7 +263,7 @@ __device__ __forceinline__ void transform_regs(c32 (&v)[16], const TwRegs<N> &tw
                 for (int s = 0; s < R; s++) lds[lds_at<NS, N>(raw, rs, orev<R>(s) * NS)] = v[q * R + s];
             }
         }
-        transform_regs<N, SIGN, REV, G, P + 1>(v, tw, lds, tid);
+        transform_regs<N, SIGN, REV, G, P + 1, CJ>(v, tw, lds, tid);
     }
 }
 

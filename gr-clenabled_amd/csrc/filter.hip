@@ -56,9 +56,12 @@ __global__ __launch_bounds__(G::TH, G::WPE) void k_ols(const c32 *__restrict__ i
     __shared__ c32 lds[NP > 1 ? PTS : 1];
     const int tid0 = threadIdx.x;
 
+    // all-radix-16 sizes (256, 4096): the reversed plan IS the forward plan, so the inverse twiddles are the conjugates of the
+    // forward ones at the same positions -- one register set serves both transforms
+    constexpr bool SHARE = (PF::L % 4) == 0;
     TwRegs<NF> twf, twi;
     load_twiddles<NF, false, G>(twf, tid0, tw_fwd);
-    load_twiddles<NF, true, G>(twi, tid0, tw_inv);
+    if constexpr (!SHARE) load_twiddles<NF, true, G>(twi, tid0, tw_inv);
     // spectrum of the taps at the bins this thread holds after the forward transform
     constexpr int RL = PF::radix(NP - 1), BL = NF / RL;
     static_assert(PI::radix(0) == RL, "inverse plan must start with the forward plan's last radix");
@@ -107,7 +110,8 @@ __global__ __launch_bounds__(G::TH, G::WPE) void k_ols(const c32 *__restrict__ i
             for (int r = 0; r < RL; r++) w[q * RL + r] = cmul(v[q * RL + irev<RL>(r)], Hreg[q * RL + irev<RL>(r)]);
         }
         if constexpr (NP > 1) __syncthreads();  // forward transform's LDS reads are done
-        transform_regs<NF, 1, true, G>(w, twi, lds, tid);
+        if constexpr (SHARE) transform_regs<NF, 1, true, G, 0, true>(w, twf, lds, tid);
+        else transform_regs<NF, 1, true, G>(w, twi, lds, tid);
         // ---- store the valid part (n >= ntaps-1), decimated ---------------------------------
         constexpr int RO = PI::radix(NP - 1), BO = NF / RO;
         c32 *__restrict__ out_g = out + g0;  // decim == 1 fast path
@@ -296,12 +300,12 @@ int pick_fft_size(int ntaps)
     if (nf < 256) nf = 256;
     // The reference size leaves between 50 % and 100 % of every block as new samples.  The kernel's rate per transformed
     // point is nearly flat in the size (G points/s measured on MI355X below), so a larger transform whose blocks carry a
-    // larger share of new samples is faster: pick the best of the reference size and the next two.
-    auto rate = [](int n) { return n <= 256 ? 413.0 : n == 512 ? 314.0 : n == 1024 ? 295.0 : n == 2048 ? 292.0 : 230.0; };
+    // larger share of new samples is faster: pick the best of the reference size and the next three.
+    auto rate = [](int n) { return n <= 256 ? 413.0 : n == 512 ? 314.0 : n == 1024 ? 295.0 : n == 2048 ? 292.0 : 290.0; };
     const int s0 = (ntaps - 1 + 15) & ~15;
     int best = nf;
     double best_score = 0.0;
-    for (int c = nf; c <= 4096 && c <= 4 * nf; c <<= 1) {
+    for (int c = nf; c <= 4096 && c <= 8 * nf; c <<= 1) {
         const double score = rate(c) * (double)((c - s0) & ~15) / (double)c;
         if (score > best_score * 1.02) { best_score = score; best = c; }
     }

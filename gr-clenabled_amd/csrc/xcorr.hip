@@ -94,9 +94,11 @@ __global__ __launch_bounds__(Geo<N>::TH, Geo<N>::WPE) void k_xcorr(XcArgs a, con
     constexpr bool SMALL = N <= 128;                       // short runs on the load (forward plan) and the float store side
     __shared__ c32 lds[SMALL ? PTS + PTS / 16 : PTS];
     const int tid0 = threadIdx.x;
+    // all-radix-16 sizes: the reversed plan is the forward plan, the inverse twiddles are the conjugates of the forward ones
+    constexpr bool SHARE = TIME && (PF::L % 4) == 0;
     TwRegs<N> twf, twi;
     if constexpr (TIME) load_twiddles<N, false>(twf, tid0, tw_fwd);
-    load_twiddles<N, true>(twi, tid0, tw_inv);
+    if constexpr (!SHARE) load_twiddles<N, true>(twi, tid0, tw_inv);
 
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         int tid = tid0;
@@ -133,7 +135,8 @@ __global__ __launch_bounds__(Geo<N>::TH, Geo<N>::WPE) void k_xcorr(XcArgs a, con
 #pragma unroll
                 for (int i = 0; i < 16; i++) w[i] = cmul(R[i], cconj(w[i]));
             }
-            transform_regs<N, 1, true>(w, twi, lds, tid);
+            if constexpr (SHARE) transform_regs<N, 1, true, Geo<N>, 0, true>(w, twf, lds, tid);
+            else transform_regs<N, 1, true>(w, twi, lds, tid);
             // ---- |.|, stored with the two halves of the vector swapped ----
             constexpr int RO = PI::radix(NP - 1), BO = N / RO;
             float *__restrict__ dst = a.out[s] + base;

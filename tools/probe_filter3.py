@@ -13,8 +13,8 @@ def timeit(fn, iters=8):
 n = 1 << 25
 x = torch.randn(n + 4096, 2, device="cuda"); y = torch.empty(n, 2, device="cuda")
 rng = np.random.default_rng(0)
-for ntaps in (400, 600, 800, 1000):
-    for nf in (0,):
+for ntaps in (129, 200, 300, 400, 600):
+    for nf in (0, 2048, 4096):
         if nf and nf < 2 * ntaps: continue
         if nf: os.environ["MI355_FILTER_FFT"] = str(nf)
         else: os.environ.pop("MI355_FILTER_FFT", None)
