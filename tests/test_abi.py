@@ -60,3 +60,16 @@ def test_no_gpu_means_loud_failure(pkg):
         pytest.skip("a GPU is present")
     with pytest.raises(pkg.Mi355Error):
         pkg.clMathOp(pkg.DTYPE_COMPLEX, 1, 1, 0, 0, pkg.MATHOP_MULTIPLY)
+
+
+def test_dropin_python_module_name():
+    """`import clenabled` (the reference's module name) resolves to the MI355X block classes."""
+    import subprocess
+    import sys
+    code = ("import clenabled as c; names = ['clMathOp','clMathConst','clFFT','clFilter','clComplexFilter','clPolyphaseChannelizer',"
+            "'clXEngine','clLog','clSNR','clComplexToMag','clComplexToArg','clComplexToMagPhase','clMagPhaseToComplex',"
+            "'clQuadratureDemod','clxcorrelate_fft_vcf','CLFFT_FORWARD','DTYPE_COMPLEX','MATHOP_MULTIPLY'];"
+            "missing = [n for n in names if not hasattr(c, n)]; assert not missing, missing; print('ok')")
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "gr-clenabled_amd", "python"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
