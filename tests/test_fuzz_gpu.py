@@ -1,0 +1,100 @@
+"""Seeded random sweeps of block parameters against the oracle (GPU).  Every draw is deterministic; the point is to cross
+kernel-selection boundaries (transform sizes, staged / direct host paths, fused / two-kernel X-engine, wave / staged PFB)
+at sizes nobody picked by hand."""
+import numpy as np
+import pytest
+
+from conftest import GPU_ARGS, crandn, relerr
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def test_fuzz_fft(gpu, oracle):
+    rng = np.random.default_rng(1001)
+    sizes = [int(2 ** rng.integers(1, 15)) for _ in range(10)] + [int(rng.integers(3, 2400)) for _ in range(10)] + [int(rng.integers(2049, 8192)) for _ in range(3)]
+    for n in sizes:
+        fwd, shift, win, real = (bool(rng.integers(0, 2)) for _ in range(4))
+        real = real and fwd
+        nvec = int(rng.integers(1, max(2, min(40, 60000 // n))))
+        w = (rng.random(n).astype(np.float32) + 0.1) if win else None
+        x = rng.standard_normal(nvec * n).astype(np.float32) if real else crandn(rng, nvec * n)
+        y = np.empty(nvec * n, np.complex64)
+        blk = gpu.clFFT(n, gpu.CLFFT_FORWARD if fwd else gpu.CLFFT_BACKWARD, w if win else [], gpu.DTYPE_FLOAT if real else gpu.DTYPE_COMPLEX,
+                        *GPU_ARGS, 0, 1, shift)
+        blk.work(nvec, [x], [y])
+        ref = oracle.fft_block(n, fwd, w, shift, oracle.DTYPE_FLOAT if real else oracle.DTYPE_COMPLEX, x, f64=True)
+        assert relerr(y, ref) <= TOL, (n, fwd, shift, win, real, nvec)
+
+
+def test_fuzz_filters(gpu, oracle):
+    rng = np.random.default_rng(1002)
+    for _ in range(24):
+        ntaps = int(rng.choice([rng.integers(1, 40), rng.integers(40, 300), rng.integers(300, 2600)]))
+        decim = int(rng.choice([1, 1, 2, 3, 5, 8, 11]))
+        use_time, ctaps = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        nout = int(rng.integers(1, 6000))
+        xh = crandn(rng, nout * decim + ntaps - 1)
+        y = np.empty(nout, np.complex64)
+        if ctaps:
+            taps = (crandn(rng, ntaps) / np.sqrt(ntaps)).astype(np.complex64)
+            blk = gpu.clComplexFilter(*GPU_ARGS, decim, taps, 1, 0, use_time=use_time)
+            full = oracle.fir_ccc(taps, xh, nout * decim)
+        else:
+            taps = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+            blk = gpu.clFilter(*GPU_ARGS, decim, taps, 1, 0, use_time)
+            full = oracle.fir_ccf(taps, xh, nout * decim)
+        assert blk.work(nout, [xh], [y]) == nout
+        assert relerr(y, full[::decim][:nout]) <= TOL, (ntaps, decim, use_time, ctaps, nout)
+
+
+def test_fuzz_pfb(gpu, oracle):
+    rng = np.random.default_rng(1003)
+    for _ in range(16):
+        M = int(rng.choice([2, 3, 4, 8, 12, 16, 32, 64, 64, 64, 128, 256]))
+        R = M if rng.integers(0, 3) else int(rng.integers(1, M + 1))
+        per_arm = int(rng.integers(1, 70))
+        ntaps = max(1, per_arm * M - int(rng.integers(0, M)))
+        steps = int(rng.integers(1, 200))
+        while (steps * R) % M:  # buf_items must be a multiple of the channel count
+            steps += 1
+        buf = steps * R
+        nmap = int(rng.integers(1, M + 1))
+        chmap = rng.integers(0, M, size=nmap).tolist() if rng.integers(0, 2) else list(range(M))
+        taps = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+        blk = gpu.clPolyphaseChannelizer(*GPU_ARGS, taps, buf, M, R, chmap)
+        x = crandn(rng, blk.ninput())
+        y = np.empty(blk.noutput(), np.complex64)
+        blk.general_work(buf, None, [x], [y])
+        ref = oracle.pfb(taps, buf, M, R, chmap, x, f64=True)
+        assert relerr(y, ref) <= TOL, (M, R, ntaps, buf, len(chmap))
+
+
+def test_fuzz_xengine(gpu, oracle):
+    rng = np.random.default_rng(1004)
+    for _ in range(18):
+        kind = int(rng.integers(0, 3))  # 0 IChar, 1 complex float, 2 packed 4-bit
+        npol = 2 if kind == 2 else int(rng.integers(1, 3))
+        N = int(rng.integers(2, 70 if npol == 1 else 40))
+        F = int(rng.choice([1, 2, 5, 8, 16, 24, 32, 64]))
+        if kind != 1 and (F * (2 * npol if kind == 0 else 2)) % 4:
+            F += 1  # integer inputs: a (t, station) row must be a whole number of 4-byte units (documented constraint)
+        T = int(rng.integers(1, 300))
+        if kind == 0:
+            x = rng.integers(-128, 128, size=T * N * F * npol * 2, dtype=np.int64).astype(np.int8)
+            blk = gpu.clXEngine(*GPU_ARGS, False, gpu.DTYPE_BYTE, npol, N, 1, 0, F, T, [])
+            out = np.empty(blk.get_output_buffer_size(), np.complex64)
+            blk.xcorrelate(x, out)
+            assert np.array_equal(out, oracle.xengine_ichar(N, F, npol, T, x, exact=True)), (N, F, T, npol)
+        elif kind == 1:
+            x = crandn(rng, T * N * F * npol)
+            blk = gpu.clXEngine(*GPU_ARGS, False, gpu.DTYPE_COMPLEX, npol, N, 1, 0, F, T, [])
+            out = np.empty(blk.get_output_buffer_size(), np.complex64)
+            blk.xcorrelate(x, out)
+            assert relerr(out, oracle.xengine_cf32(N, F, npol, T, x)) <= TOL, (N, F, T, npol)
+        else:
+            x = rng.integers(0, 256, size=T * N * F * 2, dtype=np.int64).astype(np.uint8)
+            blk = gpu.clXEngine(*GPU_ARGS, False, gpu.DTYPE_PACKEDXY, 2, N, 1, 0, F, T, [])
+            out = np.empty(blk.get_output_buffer_size(), np.complex64)
+            blk.xcorrelate(x, out)
+            assert relerr(out, oracle.xengine_packed4(N, F, T, x)) <= TOL, (N, F, T)
