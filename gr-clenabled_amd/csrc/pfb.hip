@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, (PfbGeo<M, PMAX>::WPE)) void k_pfb(const c32 *
 }
 
 // ------------------------------------------------------------------------------------
-// M == 64: one wave per workgroup, lane = arm, no LDS staging and no workgroup barrier.
+// M == 64 / 128 / 256: one thread per arm (M/64 waves per workgroup), no LDS staging; for M == 64 no workgroup barrier.
 // The wave owns a contiguous run of output steps and keeps its arm windows (PMAX + 16 input
 // rows, one sample per lane and row) in a register ring across iterations: every input row is
 // loaded from HBM exactly once, 512 B per wave instruction, straight into the ring slot whose
@@ -202,15 +202,20 @@ __global__ __launch_bounds__(256, (PfbGeo<M, PMAX>::WPE)) void k_pfb(const c32 *
 // 16-points-per-thread layout and the 64-point backward DFT runs there (GeoW: all exchanges
 // stay inside the wave).
 // ------------------------------------------------------------------------------------
-template <int PMAX, bool IDENT>
-__global__ __launch_bounds__(64, 2) void k_pfb64(const c32 *__restrict__ in, c32 *__restrict__ out, const float *__restrict__ taps_pad,
+// one thread per arm: M threads (M/64 waves) per workgroup, 16 steps per iteration
+template <int M> struct GeoArm {
+    static constexpr int TH = M, PTS = M * 16, F = 16, WPE = 2;
+};
+
+template <int M, int PMAX, bool IDENT>
+__global__ __launch_bounds__(M, 2) void k_pfbw(const c32 *__restrict__ in, c32 *__restrict__ out, const float *__restrict__ taps_pad,
                                                  const c32 *__restrict__ tw_inv, const int *__restrict__ ch_map, int nmap, int K,
                                                  long long n_in, int nsteps, int groups_per_wave)
 {
-    constexpr int M = 64, U = 16, RS = PMAX + U;                // ring slots = rows resident per lane
+    constexpr int U = 16, RS = PMAX + U;                        // ring slots = rows resident per lane
     constexpr int PERIOD = RS / (RS % 16 == 0 ? 16 : 8);  // = RS / gcd(RS, U): iterations until the ring mapping repeats
     static_assert((U * PERIOD) % RS == 0, "ring period");
-    using G = GeoW<M>;
+    using G = GeoArm<M>;
     using PL = Plan<M, false>;
     __shared__ c32 lds[G::PTS];
     const int lane0 = threadIdx.x;
@@ -263,8 +268,8 @@ __global__ __launch_bounds__(64, 2) void k_pfb64(const c32 *__restrict__ in, c32
             ring[(U * PH + u + 1) % RS] = load_row(row0 + RS + u + 1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();  // single wave: orders the LDS writes before the reads below
-        // ---- phase 2: 64-point backward DFT of the 16 steps, wave local ----
+        __syncthreads();  // orders the LDS writes before the reads below (a plain waitcnt when M = 64: single wave)
+        // ---- phase 2: M-point backward DFT of the 16 steps ----
         c32 v[16];
         constexpr int R0 = PL::radix(0), B0 = M / R0;
         {
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(64, 2) void k_pfb64(const c32 *__restrict__ in, c32
         if constexpr (IDENT) {
 #pragma unroll
             for (int q = 0; q < 16 / RL; q++) {
-                const int g = lane + 64 * q, fr = g / BL, j = g % BL;
+                const int g = lane + M * q, fr = g / BL, j = g % BL;
                 if (i0 + fr < nsteps) {
                     c32 *__restrict__ o = out + (size_t)(i0 + fr) * M + j;
 #pragma unroll
@@ -291,13 +296,13 @@ __global__ __launch_bounds__(64, 2) void k_pfb64(const c32 *__restrict__ in, c32
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < 16 / RL; q++) {
-                const int g = lane + 64 * q, fr = g / BL, j = g % BL;
+                const int g = lane + M * q, fr = g / BL, j = g % BL;
 #pragma unroll
                 for (int t = 0; t < RL; t++) lds[fr * M + j + orev<RL>(t) * BL] = v[q * RL + t];
             }
             __syncthreads();
             const int steps = (nsteps - i0) < U ? (nsteps - i0) : U;
-            for (int e = lane; e < steps * nmap; e += 64) {
+            for (int e = lane; e < steps * nmap; e += M) {
                 const int fr = e / nmap, qq = e - fr * nmap;
                 out[(size_t)i0 * nmap + e] = lds[fr * M + ch_map[qq]];
             }
@@ -368,22 +373,22 @@ struct mi355_pfb {
 
 namespace {
 
-template <int PMAX>
-int launch_wave64(mi355_pfb *h, const void *in, void *out, hipStream_t st)
+template <int M, int PMAX>
+int launch_wave(mi355_pfb *h, const void *in, void *out, hipStream_t st)
 {
     const int ngroups = (h->nsteps + 15) / 16;
     const int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
     static const int wpc = getenv("MI355_PFB_WAVES_PER_CU") ? atoi(getenv("MI355_PFB_WAVES_PER_CU")) : 8;
-    long long waves = (long long)cus * (wpc > 0 ? wpc : 8);
-    if (waves > ngroups) waves = ngroups;
-    const int per = (int)((ngroups + waves - 1) / waves);
+    long long wgs = (long long)cus * (wpc > 0 ? wpc : 8) / (M / 64);  // 8 waves per CU
+    if (wgs > ngroups) wgs = ngroups;
+    const int per = (int)((ngroups + wgs - 1) / wgs);
     const int grid = (ngroups + per - 1) / per;
     const long long n_in = (long long)h->buf_items - h->R + h->K;
     if (h->ident)
-        hipLaunchKernelGGL((k_pfb64<PMAX, true>), dim3(grid), dim3(64), 0, st, (const c32 *)in, (c32 *)out, h->d_taps, (const c32 *)h->d_tw,
+        hipLaunchKernelGGL((k_pfbw<M, PMAX, true>), dim3(grid), dim3(M), 0, st, (const c32 *)in, (c32 *)out, h->d_taps, (const c32 *)h->d_tw,
                            h->d_map, h->nmap, h->K, n_in, h->nsteps, per);
     else
-        hipLaunchKernelGGL((k_pfb64<PMAX, false>), dim3(grid), dim3(64), 0, st, (const c32 *)in, (c32 *)out, h->d_taps, (const c32 *)h->d_tw,
+        hipLaunchKernelGGL((k_pfbw<M, PMAX, false>), dim3(grid), dim3(M), 0, st, (const c32 *)in, (c32 *)out, h->d_taps, (const c32 *)h->d_tw,
                            h->d_map, h->nmap, h->K, n_in, h->nsteps, per);
     MI355_HIP(hipGetLastError());
     return MI355_OK;
@@ -392,10 +397,10 @@ int launch_wave64(mi355_pfb *h, const void *in, void *out, hipStream_t st)
 template <int M, int PMAX>
 int launch_fast(mi355_pfb *h, const void *in, void *out, hipStream_t st)
 {
-    if constexpr (M == 64 && PMAX <= 32) {
+    if constexpr ((M == 64 || M == 128 || M == 256) && PMAX <= 32) {
         static const bool wave = getenv("MI355_PFB_WAVE") ? atoi(getenv("MI355_PFB_WAVE")) != 0 : true;
         const long long n_in = (long long)h->buf_items - h->R + h->K;
-        if (wave && n_in * 8 < (4ll << 30) - (64 << 10)) return launch_wave64<PMAX>(h, in, out, st);
+        if (wave && n_in * 8 < (4ll << 30) - (64 << 10)) return launch_wave<M, PMAX>(h, in, out, st);
     }
     constexpr int T = 4096 / M;
     int ngroups = (h->nsteps + T - 1) / T;
