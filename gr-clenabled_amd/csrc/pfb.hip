@@ -317,6 +317,126 @@ __global__ __launch_bounds__(M, 2) void k_pfbw(const c32 *__restrict__ in, c32 *
 }
 
 // ------------------------------------------------------------------------------------
+// M == 32 (written for 8 / 16 / 32): the same ring kernel with 64/M independent time streams per wave (lane = (stream, arm)); every
+// stream owns a contiguous run of steps, so each lane still advances 16 rows per iteration and loads every row once.
+// One iteration transforms 16 steps of every stream (1024/M frames of M points, single-wave geometry).
+// ------------------------------------------------------------------------------------
+template <int M, int PMAX, bool IDENT>
+__global__ __launch_bounds__(64, 2) void k_pfbs(const c32 *__restrict__ in, c32 *__restrict__ out, const float *__restrict__ taps_pad,
+                                                const c32 *__restrict__ tw_inv, const int *__restrict__ ch_map, int nmap, int K,
+                                                long long n_in, int nsteps, int groups_per_stream)
+{
+    constexpr int U = 16, RS = PMAX + U, SEG = 64 / M;
+    constexpr int PERIOD = RS / (RS % 16 == 0 ? 16 : 8);
+    static_assert((U * PERIOD) % RS == 0 && PERIOD <= 3, "ring period");
+    using G = GeoW<M>;
+    using PL = Plan<M, false>;
+    constexpr int NP = PL::NP;
+    __shared__ c32 lds[G::PTS];
+    const int lane0 = threadIdx.x, arm0 = lane0 % M, sg0 = lane0 / M;
+    float hrev[PMAX];
+#pragma unroll
+    for (int pp = 0; pp < PMAX; pp++) hrev[pp] = taps_pad[arm0 + (PMAX - 1 - pp) * M];
+    TwRegs<M> tw;
+    load_twiddles<M, false, G>(tw, lane0, tw_inv);
+
+    const int ngroups = (nsteps + U - 1) / U;
+    const int stream0 = blockIdx.x * SEG;                       // first stream of this wave
+    const int g_begin = (stream0 + sg0) * groups_per_stream;    // this lane's stream
+    if (stream0 * groups_per_stream >= ngroups) return;
+
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)(unsigned)(n_in * 8), 0x00020000);
+    const unsigned lane_off = (unsigned)((M - 1 - arm0) * 8);
+    const long long n0 = (long long)g_begin * U * M + K - (long long)PMAX * M;
+    auto load_row = [&](long long row) -> f2v {
+        const long long n = n0 + row * M;
+        // streams past the end of the data would wrap the 32-bit offset back into range: clamp them out explicitly
+        const unsigned off = (n * 8 >= (4ll << 30)) ? 0xfffffff8u : (unsigned)(n * 8) + lane_off;
+        return __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
+    };
+    f2v ring[RS];
+#pragma unroll
+    for (int w = 0; w < RS; w++) ring[w] = load_row(w);
+
+    auto iteration = [&](auto phase_tag, int it) {
+        constexpr int PH = decltype(phase_tag)::value;
+        const long long row0 = (long long)it * U;
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int arm = lane % M, sg = lane / M;
+#pragma unroll
+        for (int u = 0; u < U; u += 2) {
+            f2v a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+#pragma unroll
+            for (int pp = 0; pp < PMAX; pp++) {
+                const f2v hh = {hrev[pp], hrev[pp]};
+                a0 = __builtin_elementwise_fma(ring[(U * PH + u + pp) % RS], hh, a0);
+                a1 = __builtin_elementwise_fma(ring[(U * PH + u + 1 + pp) % RS], hh, a1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            lds[swzn<M>((sg * U + u) * M + arm)] = mk(a0.x, a0.y);
+            lds[swzn<M>((sg * U + u + 1) * M + arm)] = mk(a1.x, a1.y);
+            ring[(U * PH + u) % RS] = load_row(row0 + RS + u);
+            ring[(U * PH + u + 1) % RS] = load_row(row0 + RS + u + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        c32 v[16];
+        constexpr int R0 = PL::radix(0), B0 = M / R0;
+#pragma unroll
+        for (int q = 0; q < 16 / R0; q++) {
+            const int g = lane + 64 * q, raw = (g / B0) * M + (g % B0);
+#pragma unroll
+            for (int r = 0; r < R0; r++) v[q * R0 + r] = lds[swzn<M>(raw + r * B0)];
+        }
+        __syncthreads();
+        transform_regs<M, 1, false, G>(v, tw, lds, lane);
+        constexpr int RL = PL::radix(NP - 1), BL = M / RL;
+        // frame fr of the iteration = step fr%16 of stream fr/16
+        auto first_step = [&](int fr, bool &ok) {
+            const int gb = (stream0 + fr / U) * groups_per_stream, grp = gb + it;
+            ok = it < groups_per_stream && grp < ngroups;
+            return grp * U + (fr % U);
+        };
+        if constexpr (IDENT) {
+#pragma unroll
+            for (int q = 0; q < 16 / RL; q++) {
+                const int g = lane + 64 * q, fr = g / BL, j = g % BL;
+                bool ok;
+                const int step = first_step(fr, ok);
+                if (ok && step < nsteps) {
+                    c32 *__restrict__ o = out + (size_t)step * M + j;
+#pragma unroll
+                    for (int t = 0; t < RL; t++) st_stream(o + orev<RL>(t) * BL, v[q * RL + t]);
+                }
+            }
+            __syncthreads();
+        } else {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 16 / RL; q++) {
+                const int g = lane + 64 * q, fr = g / BL, j = g % BL;
+#pragma unroll
+                for (int t = 0; t < RL; t++) lds[fr * M + j + orev<RL>(t) * BL] = v[q * RL + t];
+            }
+            __syncthreads();
+            for (int e = lane; e < SEG * U * nmap; e += 64) {
+                const int fr = e / nmap, qq = e - fr * nmap;
+                bool ok;
+                const int step = first_step(fr, ok);
+                if (ok && step < nsteps) out[(size_t)step * nmap + qq] = lds[fr * M + ch_map[qq]];
+            }
+            __syncthreads();
+        }
+    };
+    for (int it = 0; it < groups_per_stream; it += PERIOD) {
+        iteration(std::integral_constant<int, 0>{}, it);
+        if constexpr (PERIOD > 1) { if (it + 1 < groups_per_stream) iteration(std::integral_constant<int, 1 % PERIOD>{}, it + 1); }
+        if constexpr (PERIOD > 2) { if (it + 2 < groups_per_stream) iteration(std::integral_constant<int, 2 % PERIOD>{}, it + 2); }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // generic path: one thread per branch output, then a direct M-point DFT per mapped channel
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pfb_branches(const c32 *__restrict__ in, c32 *__restrict__ filt,
@@ -395,8 +515,36 @@ int launch_wave(mi355_pfb *h, const void *in, void *out, hipStream_t st)
 }
 
 template <int M, int PMAX>
+int launch_streams(mi355_pfb *h, const void *in, void *out, hipStream_t st)
+{
+    constexpr int SEG = 64 / M;
+    const int ngroups = (h->nsteps + 15) / 16;
+    const int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
+    long long streams = (long long)cus * 8 * SEG;  // 8 waves per CU, SEG streams per wave
+    if (streams > ngroups) streams = ngroups;
+    const int gps = (int)((ngroups + streams - 1) / streams);
+    const int nstreams = (ngroups + gps - 1) / gps;
+    const int grid = (nstreams + SEG - 1) / SEG;
+    const long long n_in = (long long)h->buf_items - h->R + h->K;
+    if (h->ident)
+        hipLaunchKernelGGL((k_pfbs<M, PMAX, true>), dim3(grid), dim3(64), 0, st, (const c32 *)in, (c32 *)out, h->d_taps, (const c32 *)h->d_tw,
+                           h->d_map, h->nmap, h->K, n_in, h->nsteps, gps);
+    else
+        hipLaunchKernelGGL((k_pfbs<M, PMAX, false>), dim3(grid), dim3(64), 0, st, (const c32 *)in, (c32 *)out, h->d_taps, (const c32 *)h->d_tw,
+                           h->d_map, h->nmap, h->K, n_in, h->nsteps, gps);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+template <int M, int PMAX>
 int launch_fast(mi355_pfb *h, const void *in, void *out, hipStream_t st)
 {
+    // measured: 32 channels gain 6-11 % over the staged kernel; 8 and 16 channels (64-128 byte rows, gathered stores) lose 15 %
+    if constexpr (M == 32 && PMAX <= 32) {
+        static const bool wave = getenv("MI355_PFB_WAVE") ? atoi(getenv("MI355_PFB_WAVE")) != 0 : true;
+        const long long n_in = (long long)h->buf_items - h->R + h->K;
+        if (wave && n_in * 8 < (4ll << 30) - (64 << 10)) return launch_streams<M, PMAX>(h, in, out, st);
+    }
     if constexpr ((M == 64 || M == 128 || M == 256) && PMAX <= 32) {
         static const bool wave = getenv("MI355_PFB_WAVE") ? atoi(getenv("MI355_PFB_WAVE")) != 0 : true;
         const long long n_in = (long long)h->buf_items - h->R + h->K;
