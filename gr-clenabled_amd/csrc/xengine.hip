@@ -61,6 +61,7 @@ struct XeGeo {
     int A, NT, KB;         // rows = N*npol, row tiles, K blocks of 64 time steps
     int mode;              // 0 = IChar, 1 = packed 4-bit
     int f0, Fs;            // channel slab handled by this launch: [f0, f0 + Fs); the tile workspace holds one slab
+    int Fout;              // channels of the caller's matrices (F - 1 when one zero channel pads the rows to 4-byte units)
 };
 
 __device__ __forceinline__ size_t tile_off(const XeGeo &g, int f, int kb, int plane, int rt)
@@ -287,6 +288,7 @@ __global__ __launch_bounds__(256) void k_xe_corr(const unsigned char *__restrict
             const int s1 = r1 / g.npol, p1 = r1 - s1 * g.npol, s2 = r2 / g.npol, p2 = r2 - s2 * g.npol;
             if (s1 < s2) continue;
             const int k = s1 * (s1 + 1) / 2 + s2;
+            if (f + g.f0 >= g.Fout) continue;  // the padding channel has no output
             const size_t o = ((size_t)(f + g.f0) * nb + k) * np2 + p1 * g.npol + p2;
             // same expression as the oracle's exact path: (double)S * kd * kd, rounded once
             const double kd = scale2;  // 1/127 or 1/7
@@ -365,6 +367,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_xe_corr_lds(const unsigned char 
             const int s1 = r1 / g.npol, p1 = r1 - s1 * g.npol, s2 = r2 / g.npol, p2 = r2 - s2 * g.npol;
             if (s1 < s2) continue;
             const int k = s1 * (s1 + 1) / 2 + s2;
+            if (f + g.f0 >= g.Fout) continue;  // the padding channel has no output
             const size_t o = ((size_t)(f + g.f0) * nb + k) * np2 + p1 * g.npol + p2;
             const double kd = scale2;
             c32 v;
@@ -740,19 +743,45 @@ struct mi355_xengine {
     // 1234-1299): submit() returns once the integration is enqueued, wait() hands back the oldest result.
     struct Slot {
         void *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
-        unsigned char *d_tiles = nullptr;
+        unsigned char *d_tiles = nullptr, *d_pad = nullptr;
         hipEvent_t done = nullptr;
         bool busy = false;
     } slot[2];
     int next_submit = 0, next_wait = 0, pending = 0;
     bool acquired = false;  // the next slot's pinned frame buffer is handed out (zero-copy gather)
+    int pad = 0;            // one zero channel appended on the device (odd channel count of 2-byte samples)
+    size_t pad_bytes = 0;
+    unsigned char *d_pad = nullptr;
 };
 
 namespace {
 
-int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipStream_t st, unsigned char *tiles)
+// rows of (t, station) with an odd number of 2-byte channels: copy into rows padded by one zero channel (4-byte units)
+__global__ __launch_bounds__(256) void k_xe_pad_rows(const unsigned short *__restrict__ in, unsigned short *__restrict__ out, size_t rows,
+                                                     int src_units, int dst_units)
+{
+    const size_t total = rows * (size_t)dst_units;
+    for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u < total; u += (size_t)gridDim.x * 256) {
+        const size_t row = u / dst_units;
+        const int c = (int)(u - row * dst_units);
+        out[u] = c < src_units ? in[row * src_units + c] : (unsigned short)0;
+    }
+}
+
+int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipStream_t st, unsigned char *tiles, unsigned char *padbuf)
 {
     const XeGeo &g = h->g;
+    if (h->pad) {
+        const size_t rows = (size_t)g.T * g.N;
+        const int dst_units = g.F, src_units = g.Fout;  // 2-byte units per row (IChar one polarisation / packed: 2 bytes per channel)
+        size_t blocks = (rows * dst_units + 255) / 256;
+        const size_t cap = (size_t)(h->ctx->num_cus > 0 ? h->ctx->num_cus : 256) * 16;
+        if (blocks > cap) blocks = cap;
+        hipLaunchKernelGGL(k_xe_pad_rows, dim3((unsigned)blocks), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)padbuf, rows,
+                           src_units, dst_units);
+        MI355_HIP(hipGetLastError());
+        in = padbuf;
+    }
     if (h->data_type == MI355_DTYPE_COMPLEX) {
         const bool mfma = ((size_t)g.F * g.npol * 8) % 128 == 0 && (reinterpret_cast<uintptr_t>(in) & 15u) == 0 && tiles &&
                           xe_f32_row_tiles(g.NT) != 0 && !getenv("MI355_XE_CF32_VALU");
@@ -862,8 +891,10 @@ extern "C" int mi355_xengine_destroy(mi355_xengine *h)
         if (sl.h_in) (void)hipHostFree(sl.h_in);
         if (sl.h_out) (void)hipHostFree(sl.h_out);
         if (sl.d_tiles && sl.d_tiles != h->d_tiles) (void)hipFree(sl.d_tiles);
+        if (sl.d_pad && sl.d_pad != h->d_pad) (void)hipFree(sl.d_pad);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
+    if (h->d_pad) (void)hipFree(h->d_pad);
     delete h;
     return MI355_OK;
 }
@@ -880,21 +911,19 @@ extern "C" int mi355_xengine_create(mi355_ctx *ctx, int data_type, int npol, int
     MI355_REQUIRE(num_inputs >= 2, "Please specify at least 2 inputs to correlate.");  // :106-109
     MI355_REQUIRE(num_channels >= 1 && integration >= 1, "num_channels and integration must be positive");
     MI355_REQUIRE(integration <= 65536, "integration above 65536 frames would overflow the int32 accumulators");
-    if (data_type != MI355_DTYPE_COMPLEX) {
-        // the corner turn consumes 4-byte units of the input rows
-        MI355_REQUIRE(((size_t)num_channels * (data_type == MI355_DTYPE_BYTE ? npol * 2 : 2)) % 4 == 0,
-                      "num_channels * bytes per channel must be a multiple of 4");
-    }
+    // the corner turn consumes 4-byte units of the input rows: an odd count of 2-byte channels gets one zero channel on the device
+    const int pad = (data_type != MI355_DTYPE_COMPLEX && ((size_t)num_channels * (data_type == MI355_DTYPE_BYTE ? npol * 2 : 2)) % 4 != 0) ? 1 : 0;
     mi355_xengine *h = new (std::nothrow) mi355_xengine();
     if (!h) return MI355_ERR_NOMEM;
     h->ctx = ctx; h->data_type = data_type;
     XeGeo &g = h->g;
-    g.N = num_inputs; g.F = num_channels; g.npol = npol; g.T = integration;
+    g.N = num_inputs; g.F = num_channels + pad; g.Fout = num_channels; g.npol = npol; g.T = integration;
+    h->pad = pad;
     g.A = g.N * npol; g.NT = (g.A + kRowTile - 1) / kRowTile; g.KB = (g.T + kKBlock - 1) / kKBlock;
     g.mode = (data_type == MI355_DTYPE_PACKEDXY) ? 1 : 0;
-    const size_t items = (size_t)g.N * g.F * npol * g.T;
+    const size_t items = (size_t)g.N * g.Fout * npol * g.T;
     h->in_bytes = items * mi355_dtype_size(data_type);  // frame_size_times_integration_bytes, :198
-    h->out_items = (size_t)g.F * ((size_t)g.N * (g.N + 1) / 2) * npol * npol;
+    h->out_items = (size_t)g.Fout * ((size_t)g.N * (g.N + 1) / 2) * npol * npol;
     g.f0 = 0; g.Fs = g.F;
     // slab size: bound the tile workspace to 4 GiB
     {
@@ -917,6 +946,10 @@ extern "C" int mi355_xengine_create(mi355_ctx *ctx, int data_type, int npol, int
         return MI355_ERR_NOMEM;
     }
     if (h->tile_bytes && hipMemset(h->d_tiles, 0, h->tile_bytes) != hipSuccess) { mi355_xengine_destroy(h); return MI355_ERR_HIP; }
+    if (pad) {
+        h->pad_bytes = (size_t)g.T * g.N * g.F * 2;
+        if (hipMalloc((void **)&h->d_pad, h->pad_bytes) != hipSuccess) { mi355_xengine_destroy(h); return MI355_ERR_NOMEM; }
+    }
     *out = h;
     return MI355_OK;
 }
@@ -930,7 +963,7 @@ extern "C" int mi355_xengine_xcorrelate_dev(mi355_xengine *h, const void *in_dev
     MI355_REQUIRE((reinterpret_cast<uintptr_t>(in_dev) & 3u) == 0 && (reinterpret_cast<uintptr_t>(out_dev) & 7u) == 0,
                   "device buffers must be 4-byte (input) / 8-byte (output) aligned");
     MI355_HIP(hipSetDevice(h->ctx->device));
-    return launch_xe(h, in_dev, out_dev, accumulate, mi355_pick_stream(h->ctx, stream), h->d_tiles);
+    return launch_xe(h, in_dev, out_dev, accumulate, mi355_pick_stream(h->ctx, stream), h->d_tiles, h->d_pad);
 }
 
 namespace {
@@ -944,6 +977,10 @@ int slot_prepare(mi355_xengine *h, int s)
     MI355_HIP(hipHostMalloc(&sl.h_in, h->in_bytes, hipHostMallocDefault));
     MI355_HIP(hipHostMalloc(&sl.h_out, outb, hipHostMallocDefault));
     MI355_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    if (h->pad) {
+        if (s == 0) sl.d_pad = h->d_pad;
+        else MI355_HIP(hipMalloc((void **)&sl.d_pad, h->pad_bytes));
+    }
     if (s == 0 || h->tile_bytes == 0) sl.d_tiles = h->d_tiles;
     else {
         MI355_HIP(hipMalloc((void **)&sl.d_tiles, h->tile_bytes));
@@ -972,7 +1009,7 @@ static int xe_submit_slot(mi355_xengine *h, const void *in_host /* nullptr: the 
         memcpy(sl.h_out, acc_host, outb);
         MI355_HIP(hipMemcpyAsync(sl.d_out, sl.h_out, outb, hipMemcpyHostToDevice, st));
     }
-    rc = launch_xe(h, sl.d_in, sl.d_out, acc_host != nullptr, st, sl.d_tiles);
+    rc = launch_xe(h, sl.d_in, sl.d_out, acc_host != nullptr, st, sl.d_tiles, sl.d_pad);
     if (rc) return rc;
     MI355_HIP(hipMemcpyAsync(sl.h_out, sl.d_out, outb, hipMemcpyDeviceToHost, st));
     MI355_HIP(hipEventRecord(sl.done, st));
@@ -1063,19 +1100,19 @@ extern "C" int mi355_xengine_gather(const mi355_xengine *h, int nframes, int fra
     const XeGeo &g = h->g;
     MI355_REQUIRE(nframes >= 0 && frame0 >= 0 && frame0 + nframes <= g.T, "frames outside the integration window");
     const size_t esz = mi355_dtype_size(h->data_type);
-    const size_t frame_bytes = (size_t)g.F * g.N * g.npol * esz;
+    const size_t frame_bytes = (size_t)g.Fout * g.N * g.npol * esz;
     char *dst = (char *)frame_buffer;
     for (int b = 0; b < nframes; b++) {
         char *fb = dst + frame_bytes * (size_t)(frame0 + b);
         for (int i = 0; i < g.N; i++) {
             if (g.npol == 1 || h->data_type == MI355_DTYPE_PACKEDXY) {
-                const size_t row = (size_t)g.F * g.npol * esz;
+                const size_t row = (size_t)g.Fout * g.npol * esz;
                 memcpy(fb + (size_t)i * row, (const char *)inputs[i] + (size_t)b * row, row);
             } else {
-                const char *x = (const char *)inputs[i] + (size_t)b * g.F * esz;
-                const char *y = (const char *)inputs[i + g.N] + (size_t)b * g.F * esz;
-                char *row = fb + (size_t)i * g.F * 2 * esz;
-                for (int c = 0; c < g.F; c++) {
+                const char *x = (const char *)inputs[i] + (size_t)b * g.Fout * esz;
+                const char *y = (const char *)inputs[i + g.N] + (size_t)b * g.Fout * esz;
+                char *row = fb + (size_t)i * g.Fout * 2 * esz;
+                for (int c = 0; c < g.Fout; c++) {
                     memcpy(row + (size_t)c * 2 * esz, x + (size_t)c * esz, esz);
                     memcpy(row + (size_t)c * 2 * esz + esz, y + (size_t)c * esz, esz);
                 }

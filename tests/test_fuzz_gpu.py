@@ -77,8 +77,6 @@ def test_fuzz_xengine(gpu, oracle):
         npol = 2 if kind == 2 else int(rng.integers(1, 3))
         N = int(rng.integers(2, 70 if npol == 1 else 40))
         F = int(rng.choice([1, 2, 5, 8, 16, 24, 32, 64]))
-        if kind != 1 and (F * (2 * npol if kind == 0 else 2)) % 4:
-            F += 1  # integer inputs: a (t, station) row must be a whole number of 4-byte units (documented constraint)
         T = int(rng.integers(1, 300))
         if kind == 0:
             x = rng.integers(-128, 128, size=T * N * F * npol * 2, dtype=np.int64).astype(np.int8)

@@ -35,7 +35,7 @@ def test_golden_exact_integer_sums(gpu):
     assert relerr(out, g["p4_y"]) <= TOL  # includes the code-8 -> 0 LUT quirk (lib/clXEngine_impl.cc:833)
 
 
-@pytest.mark.parametrize("N,F,T,npol", [(2, 2, 1, 1), (3, 6, 5, 1), (16, 8, 64, 1), (17, 4, 65, 1), (33, 10, 130, 2),
+@pytest.mark.parametrize("N,F,T,npol", [(2, 2, 1, 1), (3, 6, 5, 1), (16, 8, 64, 1), (17, 4, 65, 1), (33, 10, 130, 2), (5, 1, 9, 1), (12, 7, 70, 1),
                                         (64, 16, 256, 1), (64, 4, 128, 2), (40, 6, 200, 2), (100, 2, 70, 1)])
 def test_ichar_bit_exact_vs_oracle(gpu, oracle, N, F, T, npol):
     rng = np.random.default_rng(N * 1000 + T)
@@ -89,7 +89,7 @@ def test_complex_float_vs_oracle(gpu, oracle, N, F, T, npol):
     assert relerr(out, ref + ref) <= TOL
 
 
-@pytest.mark.parametrize("N,F,T", [(2, 2, 3), (5, 6, 70), (16, 8, 64)])
+@pytest.mark.parametrize("N,F,T", [(2, 2, 3), (5, 6, 70), (16, 8, 64), (6, 5, 40), (3, 1, 2)])  # odd channel counts: padded on the device
 def test_packed4_vs_oracle(gpu, oracle, N, F, T):
     rng = np.random.default_rng(N * 7 + T)
     x = rng.integers(0, 256, size=T * N * F * 2, dtype=np.int64).astype(np.uint8)
