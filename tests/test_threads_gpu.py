@@ -1,0 +1,60 @@
+"""GNU Radio runs every block's work() on its own thread: several blocks of one process work concurrently on the same GPU."""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import GPU_ARGS, crandn, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def test_blocks_work_concurrently_from_threads(gpu, oracle):
+    rng = np.random.default_rng(0)
+    errs = []
+
+    def run_fft():
+        x = crandn(rng, 8 * 4096)
+        y = np.empty_like(x)
+        blk = gpu.clFFT(4096, gpu.CLFFT_FORWARD, [], gpu.DTYPE_COMPLEX, *GPU_ARGS)
+        ref = oracle.fft_block(4096, True, None, False, oracle.DTYPE_COMPLEX, x, f64=True)
+        for _ in range(100):
+            blk.work(8, [x], [y])
+            if relerr(y, ref) > 1e-5:
+                errs.append("fft")
+
+    def run_filter():
+        taps = oracle.firdes_low_pass(1.0, 10e6, 1e6, 372000.0)
+        x = crandn(rng, 32768 + 64)
+        y = np.empty(32768, np.complex64)
+        blk = gpu.clFilter(*GPU_ARGS, 1, taps)
+        ref = oracle.fir_ccf(taps, x, 32768)
+        for _ in range(100):
+            blk.work(32768, [x], [y])
+            if relerr(y, ref) > 1e-5:
+                errs.append("filter")
+
+    def run_math():
+        a = crandn(rng, 8192)
+        c = np.empty_like(a)
+        blk = gpu.clMathOp(gpu.DTYPE_COMPLEX, *GPU_ARGS, gpu.MATHOP_MULTIPLY)
+        for _ in range(200):
+            blk.work(8192, [a, a], [c])
+            if not np.allclose(c, a * a, rtol=1e-6):
+                errs.append("math")
+
+    def run_xe():
+        N, F, T = 8, 16, 64
+        x = np.random.default_rng(5).integers(-128, 128, size=T * N * F * 2, dtype=np.int64).astype(np.int8)
+        blk = gpu.clXEngine(*GPU_ARGS, False, gpu.DTYPE_BYTE, 1, N, 1, 0, F, T, [])
+        out = np.empty(blk.get_output_buffer_size(), np.complex64)
+        ref = oracle.xengine_ichar(N, F, 1, T, x, exact=True)
+        for _ in range(100):
+            blk.xcorrelate(x, out)
+            if not np.array_equal(out, ref):
+                errs.append("xengine")
+
+    ts = [threading.Thread(target=f) for f in (run_fft, run_filter, run_math, run_xe, run_fft, run_math)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs[:5]
