@@ -533,14 +533,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_xe_corr_f32(const unsigned char 
 // the int8 path (8 channels = 16 bytes per row).  The partial matrices of the time ranges are summed by k_xe_reduce.
 // HBM traffic = input once + 2-3 x the (small) output.
 // ------------------------------------------------------------------------------------
-template <int NTT, int NPOL>
-__global__ __launch_bounds__(512) void k_xe_f32_fused(const v4i *__restrict__ in, c32 *__restrict__ part, XeGeo g, int tsplit)
+template <int NTT, int NPOL, int CH>
+__global__ __launch_bounds__(CH * 64) void k_xe_f32_fused(const v4i *__restrict__ in, c32 *__restrict__ part, XeGeo g, int tsplit)
 {
-    constexpr int CH = 8, NP = NTT * (NTT + 1) / 2, CBYTES = 2 * NTT * kTileBytes;  // per channel and K block
+    constexpr int NTHR = CH * 64, NP = NTT * (NTT + 1) / 2, CBYTES = 2 * NTT * kTileBytes;  // per channel and K block
     constexpr int SEGQ = CH * NPOL / 2;                 // 16-byte pieces per (t, station) segment
     constexpr int NS = kRowTile * NTT / NPOL;           // stations covered by the row tiles
-    constexpr int ITEMS = 16 * NS * SEGQ, PER = ITEMS / 512;
-    static_assert(ITEMS % 512 == 0, "staging items must split over the workgroup");
+    constexpr int ITEMS = 16 * NS * SEGQ, PER = ITEMS / NTHR;
+    static_assert(ITEMS % NTHR == 0, "staging items must split over the workgroup");
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][CH * CBYTES];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // For one polarisation a workgroup reads 64-byte halves of 128-byte lines; the workgroup reading the other half must sit on
@@ -550,10 +550,11 @@ __global__ __launch_bounds__(512) void k_xe_f32_fused(const v4i *__restrict__ in
     int cgrp, ts;
     {
         const int b = blockIdx.x, total = ngrp * tsplit;
-        if (NPOL == 1 && ngrp % 2 == 0 && total % 16 == 0) {
-            const int xcd = b & 7, within = b >> 3, member = within & 1, combo = xcd + 8 * (within >> 1);
-            cgrp = 2 * (combo % (ngrp / 2)) + member;
-            ts = combo / (ngrp / 2);
+        constexpr int SH = 128 / (CH * NPOL * 8) > 0 ? 128 / (CH * NPOL * 8) : 1;  // workgroups sharing one 128-byte line
+        if (SH > 1 && ngrp % SH == 0 && total % (8 * SH) == 0) {
+            const int xcd = b & 7, within = b >> 3, member = within % SH, combo = xcd + 8 * (within / SH);
+            cgrp = SH * (combo % (ngrp / SH)) + member;
+            ts = combo / (ngrp / SH);
         } else {
             cgrp = b % ngrp;
             ts = b / ngrp;
@@ -576,14 +577,14 @@ __global__ __launch_bounds__(512) void k_xe_f32_fused(const v4i *__restrict__ in
     auto load_block = [&](int kb, v4i(&stage)[PER]) {
 #pragma unroll
         for (int k = 0; k < PER; k++) {
-            const int idx = tid + 512 * k, q16 = idx % SEGQ, sidx = (idx / SEGQ) % NS, t = idx / (SEGQ * NS);
+            const int idx = tid + NTHR * k, q16 = idx % SEGQ, sidx = (idx / SEGQ) % NS, t = idx / (SEGQ * NS);
             const int tt = kb * kKB32 + t;
             const bool ok = sidx < g.N && tt < t_end;
             v4i piece = (v4i){0, 0, 0, 0};
             if (ok) {
                 const v4i *src = in + ((size_t)tt * g.N + sidx) * row_v4 + seg0 + q16;
                 // one polarisation: the other half of the line belongs to the sibling workgroup on this XCD -> keep it in L2
-                piece = (NPOL == 1) ? *src : __builtin_nontemporal_load(src);
+                piece = (CH * NPOL * 8 < 128) ? *src : __builtin_nontemporal_load(src);
             }
             stage[k] = piece;
         }
@@ -591,7 +592,7 @@ __global__ __launch_bounds__(512) void k_xe_f32_fused(const v4i *__restrict__ in
     auto store_block = [&](unsigned char *buf, const v4i(&stage)[PER]) {
 #pragma unroll
         for (int k = 0; k < PER; k++) {
-            const int idx = tid + 512 * k, q16 = idx % SEGQ, sidx = (idx / SEGQ) % NS, t = idx / (SEGQ * NS);
+            const int idx = tid + NTHR * k, q16 = idx % SEGQ, sidx = (idx / SEGQ) % NS, t = idx / (SEGQ * NS);
             // (whole-vector bit cast: __builtin_bit_cast of a single vector ELEMENT reads element 0 with this compiler)
             const v4f fv = __builtin_bit_cast(v4f, stage[k]);
             const float v[4] = {fv.x, fv.y, fv.z, fv.w};
@@ -790,10 +791,15 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
         const size_t out_items = (size_t)g.F * (g.N * (g.N + 1) / 2) * g.npol * g.npol;
         if (mfma && g.NT <= 4 && g.F % 8 == 0 && h->tile_bytes >= (size_t)tsplit * out_items * 8 && !getenv("MI355_XE_CF32_TWO_KERNELS")) {
             const int ntt = g.NT == 3 ? 4 : g.NT;
-            dim3 grid((g.F / 8) * tsplit);
-#define FUSED(NTT, NPOL) hipLaunchKernelGGL((k_xe_f32_fused<NTT, NPOL>), grid, dim3(512), 0, st, (const v4i *)in, (c32 *)tiles, g, tsplit)
-            if (g.npol == 1) { if (ntt == 1) FUSED(1, 1); else if (ntt == 2) FUSED(2, 1); else FUSED(4, 1); }
-            else             { if (ntt == 1) FUSED(1, 2); else if (ntt == 2) FUSED(2, 2); else FUSED(4, 2); }
+            // 4 channels per workgroup: two independent workgroups per CU whose load / multiply phases interleave
+            static const int chw = getenv("MI355_XE_CF32_CH") ? atoi(getenv("MI355_XE_CF32_CH")) : 4;
+            const int ch = (chw == 8) ? 8 : 4;
+            dim3 grid((g.F / ch) * tsplit);
+#define FUSED(NTT, NPOL, CHN) hipLaunchKernelGGL((k_xe_f32_fused<NTT, NPOL, CHN>), grid, dim3(CHN * 64), 0, st, (const v4i *)in, (c32 *)tiles, g, tsplit)
+#define FUSED_CH(NTT, NPOL) do { if (ch == 8) FUSED(NTT, NPOL, 8); else FUSED(NTT, NPOL, 4); } while (0)
+            if (g.npol == 1) { if (ntt == 1) FUSED_CH(1, 1); else if (ntt == 2) FUSED_CH(2, 1); else FUSED_CH(4, 1); }
+            else             { if (ntt == 1) FUSED_CH(1, 2); else if (ntt == 2) FUSED_CH(2, 2); else FUSED_CH(4, 2); }
+#undef FUSED_CH
 #undef FUSED
             MI355_HIP(hipGetLastError());
             size_t blocks = (out_items + 255) / 256;
