@@ -474,7 +474,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_xe_corr_f32(const unsigned char 
         __syncthreads();
         const unsigned char *pI = buf + lane * 16, *pQ = pI + NTT * kTileBytes;
         // operands of pair q+1 are read from LDS before the MFMAs of pair q are issued
-        v4f op[2][4];
+        // three real products per element instead of four (see k_xe_f32_fused): k1 = (I1+Q1) I2, k2 = I1 (I2+Q2), k3 = Q1 (I2-Q2)
+        v4f op[2][4];  // I1, Q1, I2, Q2 of the pair
         auto fetch = [&](int q, v4f(&o)[4]) {
             o[0] = *(const v4f *)(pI + bi[q] * kTileBytes);
             o[1] = *(const v4f *)(pQ + bi[q] * kTileBytes);
@@ -487,13 +488,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_xe_corr_f32(const unsigned char 
             if (q + 1 < PPW) fetch(q + 1, op[(q + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the MFMAs (the scheduler sinks it otherwise)
             const v4f(&o)[4] = op[q & 1];
+            const v4f s1 = o[0] + o[1], s2 = o[2] + o[3], d2 = o[2] - o[3];
 #pragma unroll
             for (int kc = 0; kc < 4; kc++) {
-                // dependent-accumulator latency is 40 cycles vs 32 issue: never two MFMAs into re[] back to back
-                re[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(o[0][kc], o[2][kc], re[q], 0, 0, 0);
-                uu[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(o[1][kc], o[2][kc], uu[q], 0, 0, 0);
-                re[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(o[1][kc], o[3][kc], re[q], 0, 0, 0);
-                ww[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(o[0][kc], o[3][kc], ww[q], 0, 0, 0);
+                re[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(s1[kc], o[2][kc], re[q], 0, 0, 0);   // k1
+                uu[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(o[0][kc], s2[kc], uu[q], 0, 0, 0);   // k2
+                ww[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(o[1][kc], d2[kc], ww[q], 0, 0, 0);   // k3
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -513,8 +513,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_xe_corr_f32(const unsigned char 
             if (s1 < s2) continue;
             const size_t o = ((size_t)f * nb + (s1 * (s1 + 1) / 2 + s2)) * np2 + p1 * g.npol + p2;
             c32 v;
-            v.x = re[q][reg];
-            v.y = uu[q][reg] - ww[q][reg];
+            v.x = re[q][reg] - ww[q][reg];  // k1 - k3
+            v.y = re[q][reg] - uu[q][reg];  // k1 - k2
             if (accumulate) { v.x += out[o].x; v.y += out[o].y; }
             out[o] = v;
         }
@@ -616,6 +616,15 @@ __global__ __launch_bounds__(CH * 64) void k_xe_f32_fused(const v4i *__restrict_
             I[rt] = *(const v4f *)(base + rt * kTileBytes);
             Q[rt] = *(const v4f *)(base + (NTT + rt) * kTileBytes);
         }
+        // x1 conj(x2) = (I1 I2 + Q1 Q2) + i (Q1 I2 - I1 Q2) with THREE real products per element instead of four:
+        //   k1 = (I1 + Q1) I2,  k2 = I1 (I2 + Q2),  k3 = Q1 (I2 - Q2)   =>   re = k1 - k3,  im = k1 - k2   (epilogue)
+        // S = I + Q and D = I - Q are formed in registers from the operand vectors (8 packed adds per K block).
+        v4f S[NTT], D[NTT];
+#pragma unroll
+        for (int rt = 0; rt < NTT; rt++) {
+            S[rt] = I[rt] + Q[rt];
+            D[rt] = I[rt] - Q[rt];
+        }
 #pragma unroll
         for (int bi = 0; bi < NTT; bi++) {
 #pragma unroll
@@ -623,10 +632,9 @@ __global__ __launch_bounds__(CH * 64) void k_xe_f32_fused(const v4i *__restrict_
                 const int q = bi * (bi + 1) / 2 + bj;
 #pragma unroll
                 for (int kc = 0; kc < 4; kc++) {
-                    re[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(I[bi][kc], I[bj][kc], re[q], 0, 0, 0);
-                    uu[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(Q[bi][kc], I[bj][kc], uu[q], 0, 0, 0);
-                    re[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(Q[bi][kc], Q[bj][kc], re[q], 0, 0, 0);
-                    ww[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(I[bi][kc], Q[bj][kc], ww[q], 0, 0, 0);
+                    re[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(S[bi][kc], I[bj][kc], re[q], 0, 0, 0);  // k1 = (I1+Q1) I2
+                    uu[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(I[bi][kc], S[bj][kc], uu[q], 0, 0, 0);  // k2 = I1 (I2+Q2)
+                    ww[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(Q[bi][kc], D[bj][kc], ww[q], 0, 0, 0);  // k3 = Q1 (I2-Q2)
                 }
             }
         }
@@ -657,8 +665,9 @@ __global__ __launch_bounds__(CH * 64) void k_xe_f32_fused(const v4i *__restrict_
                 const int s1 = r1 / NPOL, p1 = r1 % NPOL, s2 = r2 / NPOL, p2 = r2 % NPOL;
                 if (s1 < s2) continue;
                 c32 v;
-                v.x = re[q][reg];
-                v.y = uu[q][reg] - ww[q][reg];
+                // k1 - k3 = I1 I2 + Q1 Q2 ;  k1 - k2 = Q1 I2 - I1 Q2
+                v.x = re[q][reg] - ww[q][reg];
+                v.y = re[q][reg] - uu[q][reg];
                 dst[(size_t)(s1 * (s1 + 1) / 2 + s2) * np2 + p1 * NPOL + p2] = v;
             }
         }
