@@ -155,7 +155,7 @@ __host__ __device__ inline int td_rows(int kpad)
 }
 
 template <bool CTAPS>
-__global__ __launch_bounds__(kTdThreads) void k_fir_td(const c32 *__restrict__ in, c32 *__restrict__ out,
+__global__ __launch_bounds__(kTdThreads, 4) void k_fir_td(const c32 *__restrict__ in, c32 *__restrict__ out,
                                                        const float *__restrict__ taps_rev,  // reversed, zero padded to kpad
                                                        int K, long long n_out /* undecimated outputs */, int kpad /* K rounded up to kTdU */,
                                                        int decim)
@@ -173,7 +173,8 @@ __global__ __launch_bounds__(kTdThreads) void k_fir_td(const c32 *__restrict__ i
         const long long left64 = n_in - base;
         const unsigned left = left64 > 0x7fffffffLL ? 0x7fffffffu : (unsigned)left64;
         __syncthreads();
-        // fill in batches of 8 loads per thread so the loads are all in flight before the LDS writes
+        // fill in batches of 8 loads per thread so the loads are all in flight before the LDS writes.  (Fetching the next
+        // tile into registers during the FMAs was measured too: the 18 extra registers cost the fourth wave per SIMD, -6 %.)
         for (int i0 = tid; i0 < span; i0 += 8 * kTdThreads) {
             c32 st[8];
 #pragma unroll
@@ -190,39 +191,61 @@ __global__ __launch_bounds__(kTdThreads) void k_fir_td(const c32 *__restrict__ i
             }
         }
         __syncthreads();
-        // (re, im) pairs as explicit 2-vectors -> v_pk_fma_f32: two FMAs per lane per instruction
-        f2v acc[kTdU], win[2 * kTdU];
+        // (re, im) pairs as explicit 2-vectors -> v_pk_fma_f32: two FMAs per lane per instruction.  The 16-sample window lives
+        // in three rotating 8-sample register blocks: a step multiplies blocks (cur, next) while the LDS reads of the block
+        // after them and the scalar loads of the next 8 taps are in flight, so no step waits on its own loads, and the
+        // rotation (unrolled by three) costs no register moves.
+        constexpr int TF = CTAPS ? 2 : 1;
+        f2v acc[kTdU], b0[kTdU], b1[kTdU], b2[kTdU];
+        float h0[TF * kTdU], h1[TF * kTdU];
         const f2v *tl2 = (const f2v *)tile;
+        const int nblk = kpad / kTdU;
 #pragma unroll
         for (int u = 0; u < kTdU; u++) {
             acc[u] = (f2v){0.f, 0.f};
-            win[u] = tl2[u * S + tid];  // x[tid*8 + u]
+            b0[u] = tl2[u * S + tid];      // x[tid*8 + u]
+            b1[u] = tl2[u * S + tid + 1];  // x[tid*8 + 8 + u]
         }
-        for (int k0 = 0; k0 < kpad; k0 += kTdU) {
-            const int row = tid + (k0 >> 3) + 1;
 #pragma unroll
-            for (int u = 0; u < kTdU; u++) win[kTdU + u] = tl2[u * S + row];  // x[tid*8 + k0 + 8 + u]
+        for (int i = 0; i < TF * kTdU; i++) h0[i] = taps_rev[i];  // uniform -> scalar loads
+        auto step = [&](const f2v (&cur)[kTdU], const f2v (&nxt)[kTdU], f2v (&pre)[kTdU], const float (&hc)[TF * kTdU],
+                        float (&hn)[TF * kTdU], int blk) {
+            int row = tid + blk + 2;  // the block after `nxt` (one row past the last one used exists in the tile: td_rows)
+            asm volatile("" : "+v"(row));  // one set of reads per step: keeps the compiler from pairing the reads of two steps (deeper, 180 VGPRs)
+#pragma unroll
+            for (int u = 0; u < kTdU; u++) pre[u] = tl2[u * S + row];
+#pragma unroll
+            for (int i = 0; i < TF * kTdU; i++) hn[i] = taps_rev[TF * kTdU * (blk + 1) + i];  // padded by one block (set_taps)
 #pragma unroll
             for (int i = 0; i < kTdU; i++) {
-                if constexpr (CTAPS) {
-                    const float hr = taps_rev[2 * (k0 + i)], hi = taps_rev[2 * (k0 + i) + 1];  // uniform -> scalar loads
-                    const f2v hrr = {hr, hr}, hii = {-hi, hi};
 #pragma unroll
-                    for (int u = 0; u < kTdU; u++) {
-                        const f2v x = win[i + u];
-                        acc[u] = __builtin_elementwise_fma(x, hrr, acc[u]);                    // (hr*x.x, hr*x.y)
-                        acc[u] = __builtin_elementwise_fma((f2v){x.y, x.x}, hii, acc[u]);       // (-hi*x.y, hi*x.x)
+                for (int u = 0; u < kTdU; u++) {
+                    const f2v x = (i + u < kTdU) ? cur[(i + u) & (kTdU - 1)] : nxt[(i + u) & (kTdU - 1)];
+                    if constexpr (CTAPS) {
+                        const float hr = hc[2 * i], hi = hc[2 * i + 1];
+                        acc[u] = __builtin_elementwise_fma(x, (f2v){hr, hr}, acc[u]);                   // (hr*x.x, hr*x.y)
+                        acc[u] = __builtin_elementwise_fma((f2v){x.y, x.x}, (f2v){-hi, hi}, acc[u]);  // (-hi*x.y, hi*x.x)
+                    } else {
+                        acc[u] = __builtin_elementwise_fma(x, (f2v){hc[i], hc[i]}, acc[u]);
                     }
-                } else {
-                    const float h = taps_rev[k0 + i];
-                    const f2v hh = {h, h};
-#pragma unroll
-                    for (int u = 0; u < kTdU; u++) acc[u] = __builtin_elementwise_fma(win[i + u], hh, acc[u]);
                 }
             }
-#pragma unroll
-            for (int u = 0; u < kTdU; u++) win[u] = win[kTdU + u];
+        };
+        int blk = 0;
+        for (; blk + 6 <= nblk; blk += 6) {
+            step(b0, b1, b2, h0, h1, blk);
+            step(b1, b2, b0, h1, h0, blk + 1);
+            step(b2, b0, b1, h0, h1, blk + 2);
+            step(b0, b1, b2, h1, h0, blk + 3);
+            step(b1, b2, b0, h0, h1, blk + 4);
+            step(b2, b0, b1, h1, h0, blk + 5);
         }
+        // up to five blocks left, same rotation
+        if (blk < nblk) { step(b0, b1, b2, h0, h1, blk); blk++;
+            if (blk < nblk) { step(b1, b2, b0, h1, h0, blk); blk++;
+                if (blk < nblk) { step(b2, b0, b1, h0, h1, blk); blk++;
+                    if (blk < nblk) { step(b0, b1, b2, h1, h0, blk); blk++;
+                        if (blk < nblk) { step(b1, b2, b0, h0, h1, blk); blk++; } } } } }
         // The thread holds 8 CONSECUTIVE outputs; storing them directly makes every wave instruction write 64 separate
         // 8-byte pieces 64 bytes apart (measured: the kernel was bound by that, not by the FMAs).  Transpose through the
         // tile (row stride 260 slots: conflict free both ways) so that lanes store consecutive samples.
@@ -346,7 +369,7 @@ int upload_taps(mi355_filter *h, const void *taps, int ntaps)
     h->taps_host.assign((const float *)taps, (const float *)taps + (size_t)per * ntaps);
     // reversed taps for the direct form (lib/fir_filter.cc:187-189 reverses them too)
     const int kpad = (ntaps + kTdU - 1) / kTdU * kTdU;
-    std::vector<float> rev((size_t)per * kpad, 0.0f);  // zero padded: the kernel loops to kpad without a bound test
+    std::vector<float> rev((size_t)per * (kpad + kTdU), 0.0f);  // zero padded: the kernel loops to kpad without a bound test and prefetches one block of taps past it
     for (int k = 0; k < ntaps; k++)
         for (int c = 0; c < per; c++) rev[(size_t)per * k + c] = h->taps_host[(size_t)per * (ntaps - 1 - k) + c];
     MI355_HIP(hipMalloc((void **)&h->d_taps_rev, rev.size() * sizeof(float)));
@@ -441,21 +464,21 @@ int launch_filter(mi355_filter *h, size_t nout, const void *in, void *out, hipSt
         if (smem > 160 * 1024) { mi355_set_error("time-domain mode supports up to ~18000 taps"); return MI355_ERR_UNSUPPORTED; }
         const long long n_y = (long long)nout * h->decim;  // undecimated outputs
         long long ntiles = (n_y + kTdTile - 1) / kTdTile;
-        int per_cu = (int)((160 * 1024) / smem);
-        if (per_cu > 8) per_cu = 8;
-        if (per_cu < 1) per_cu = 1;
+        // grid-stride workgroups, several rounds of them: measured, 12-16 per CU beat exactly the resident number by 8 %
+        // (workgroups that finish early are replaced at once, which evens out the barrier phases)
+        int per_cu = 16;
+        if (const char *e = getenv("MI355_TD_WG_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
         long long grid = ntiles < (long long)cus * per_cu ? ntiles : (long long)cus * per_cu;
-        if (h->complex_taps) {
-            if (smem > 64 * 1024)
-                MI355_HIP(hipFuncSetAttribute((const void *)k_fir_td<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            hipLaunchKernelGGL((k_fir_td<true>), dim3((unsigned)grid), dim3(kTdThreads), smem, st, (const c32 *)in, (c32 *)out,
-                               h->d_taps_rev, h->ntaps, n_y, kpad, h->decim);
-        } else {
-            if (smem > 64 * 1024)
-                MI355_HIP(hipFuncSetAttribute((const void *)k_fir_td<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            hipLaunchKernelGGL((k_fir_td<false>), dim3((unsigned)grid), dim3(kTdThreads), smem, st, (const c32 *)in, (c32 *)out,
-                               h->d_taps_rev, h->ntaps, n_y, kpad, h->decim);
-        }
+#define LAUNCH_TD(CT)                                                                                                        \
+    do {                                                                                                                     \
+        if (smem > 64 * 1024)                                                                                                \
+            MI355_HIP(hipFuncSetAttribute((const void *)k_fir_td<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL((k_fir_td<CT>), dim3((unsigned)grid), dim3(kTdThreads), smem, st, (const c32 *)in, (c32 *)out,     \
+                           h->d_taps_rev, h->ntaps, n_y, kpad, h->decim);                                                   \
+    } while (0)
+        if (h->complex_taps) LAUNCH_TD(true);
+        else LAUNCH_TD(false);
+#undef LAUNCH_TD
     } else {
         long long blocks = ((long long)nout + 255) / 256;
         long long grid = blocks < (long long)cus * 8 ? blocks : (long long)cus * 8;
