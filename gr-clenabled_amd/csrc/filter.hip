@@ -33,6 +33,7 @@ using namespace fftc;
 namespace {
 
 typedef float f2v __attribute__((ext_vector_type(2)));
+typedef unsigned int u2g __attribute__((vector_size(8)));  // operand type of the raw buffer builtins
 
 __device__ __forceinline__ void st_stream(c32 *p, c32 v) { f2v o; o.x = v.x; o.y = v.y; __builtin_nontemporal_store(o, (f2v *)p); }
 
@@ -73,6 +74,19 @@ __global__ __launch_bounds__(G::TH, G::WPE) void k_ols(const c32 *__restrict__ i
         for (int s = 0; s < RL; s++) Hreg[q * RL + s] = Hspec[j + orev<RL>(s) * BL];
     }
 
+    // bit k set: register k of the inverse transform's output lies outside the store window [s0, s0+L) of its block
+    constexpr int RO = PI::radix(NP - 1), BO = NF / RO;
+    int inval0 = 0;
+#pragma unroll
+    for (int q = 0; q < 16 / RO; q++) {
+        const int j = (tid0 + TH * q) % BO;
+#pragma unroll
+        for (int s = 0; s < RO; s++) {
+            const int n = j + orev<RO>(s) * BO;
+            if (!(n >= s0 && n < s0 + L)) inval0 |= 1 << (q * RO + s);
+        }
+    }
+
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         c32 v[16];
         int tid = tid0;
@@ -89,16 +103,33 @@ __global__ __launch_bounds__(G::TH, G::WPE) void k_ols(const c32 *__restrict__ i
         // (for the first block they lie before the buffer and read as zero).
         constexpr int R0 = PF::radix(0), B0 = NF / R0;
         const int pad = s0 - (ntaps - 1);
+        if (g0 > 0) {
+            // every group but the first: one raw buffer over [in_g - pad, end of input) -- all offsets are non-negative, the
+            // hardware range check supplies the zeros past the end, and the loads carry no compare / select / branch
+            const long long left_b = (in_left64 + pad) * 8;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(in_g - pad), 0, left_b > 0x7ffffff8LL ? 0x7ffffff8 : (int)left_b, 0x00020000);
 #pragma unroll
-        for (int q = 0; q < 16 / R0; q++) {
-            const int g = tid + TH * q, fr = g / B0, j = g % B0;
-            const int base = fr * L + j - pad;
+            for (int q = 0; q < 16 / R0; q++) {
+                const int g = tid + TH * q, fr = g / B0, j = g % B0;
+                const unsigned off = (unsigned)(fr * L + j) * 8u;
 #pragma unroll
-            for (int r = 0; r < R0; r++) {
-                const int e = base + r * B0;
-                const bool ok = e >= 0 ? (unsigned)e < in_left : g0 > 0;  // e < 0 (at most pad samples) exists for every group but the first
-                const c32 x = in_g[ok ? e : 0];  // plain load: the overlap is re-read by the next block and should stay cached
-                v[q * R0 + r] = ok ? x : mk(0.f, 0.f);
+                for (int r = 0; r < R0; r++) {
+                    const f2v x = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(rs, off + (unsigned)(r * B0 * 8), 0, 0));
+                    v[q * R0 + r] = mk(x.x, x.y);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16 / R0; q++) {
+                const int g = tid + TH * q, fr = g / B0, j = g % B0;
+                const int base = fr * L + j - pad;
+#pragma unroll
+                for (int r = 0; r < R0; r++) {
+                    const int e = base + r * B0;
+                    const bool ok = e >= 0 && (unsigned)e < in_left;  // the pad samples before the buffer read as zero
+                    const c32 x = in_g[ok ? e : 0];
+                    v[q * R0 + r] = ok ? x : mk(0.f, 0.f);
+                }
             }
         }
         transform_regs<NF, -1, false, G>(v, twf, lds, tid);
@@ -113,21 +144,39 @@ __global__ __launch_bounds__(G::TH, G::WPE) void k_ols(const c32 *__restrict__ i
         if constexpr (SHARE) transform_regs<NF, 1, true, G, 0, true>(w, twf, lds, tid);
         else transform_regs<NF, 1, true, G>(w, twi, lds, tid);
         // ---- store the valid part (n >= ntaps-1), decimated ---------------------------------
-        constexpr int RO = PI::radix(NP - 1), BO = NF / RO;
-        c32 *__restrict__ out_g = out + g0;  // decim == 1 fast path
-        const unsigned g_phase = (unsigned)(g0 % decim);  // uniform: one 64-bit division per group, 32-bit ones per element
-        const long long g_quot = g0 / decim;
+        if (decim == 1) {
+            // raw buffer over this group's outputs: a lane whose sample lies outside the block's store window [s0, s0+L)
+            // gets the offset 0xffffffff, so the range check drops its store like it drops the ones past n_y -- two integer
+            // operations per store instead of three compares, a mask update and a branch
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)(out + g0), 0, (int)(y_left > 0x0ffffffeu ? 0x7ffffff0u : y_left * 8u), 0x00020000);
+            int inval = inval0;
+            asm volatile("" : "+v"(inval));  // one register, bits extracted per store (not 16 hoisted selects)
 #pragma unroll
-        for (int q = 0; q < 16 / RO; q++) {
-            const int g = tid + TH * q, fr = g / BO, j = g % BO;
-            const int rel0 = fr * L + j - s0;
+            for (int q = 0; q < 16 / RO; q++) {
+                const int g = tid + TH * q, fr = g / BO, j = g % BO;
+                const unsigned off0 = (unsigned)(fr * L + j - s0) * 8u;
 #pragma unroll
-            for (int s = 0; s < RO; s++) {
-                const int n = j + orev<RO>(s) * BO;
-                const int rel = rel0 + orev<RO>(s) * BO;  // output index relative to g0
-                if (n >= s0 && n < s0 + L && (unsigned)rel < y_left) {
-                    if (decim == 1) st_stream(out_g + (unsigned)rel, w[q * RO + s]);
-                    else {
+                for (int s = 0; s < RO; s++) {
+                    const int k = q * RO + s;
+                    const unsigned off = (off0 + (unsigned)(orev<RO>(s) * BO * 8)) | (unsigned)__builtin_amdgcn_sbfe(inval, k, 1);
+                    f2v o;
+                    o.x = w[k].x;
+                    o.y = w[k].y;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2g, o), ro, off, 0, 2 /* nt */);
+                }
+            }
+        } else {
+            const unsigned g_phase = (unsigned)(g0 % decim);  // uniform: one 64-bit division per group, 32-bit ones per element
+            const long long g_quot = g0 / decim;
+#pragma unroll
+            for (int q = 0; q < 16 / RO; q++) {
+                const int g = tid + TH * q, fr = g / BO, j = g % BO;
+                const int rel0 = fr * L + j - s0;
+#pragma unroll
+                for (int s = 0; s < RO; s++) {
+                    const int n = j + orev<RO>(s) * BO;
+                    const int rel = rel0 + orev<RO>(s) * BO;  // output index relative to g0
+                    if (n >= s0 && n < s0 + L && (unsigned)rel < y_left) {
                         const unsigned t = g_phase + (unsigned)rel;  // (g0 + rel) mod decim == (g0 mod decim + rel) mod decim
                         if (t % (unsigned)decim == 0) out[g_quot + t / (unsigned)decim] = w[q * RO + s];
                     }
