@@ -66,6 +66,49 @@ template <int TSPLIT, bool PIN> void run(const v4i *in, int *out)
     printf("tsplit=%d pinned=%d grid=%3d: %7.1f us\n", TSPLIT, (int)PIN, grid, ms / 20 * 1e3);
 }
 
+
+// half-line variant: workgroup = (32-channel half of a line, pair), 512 threads, 8 pieces per thread and K block of 32 steps
+template <bool PIN>
+__global__ __launch_bounds__(512) void kh(const v4i *__restrict__ in, int *__restrict__ out, int T, int N, int F)
+{
+    const int nlines = F / 64, npair = 10, per_line = 2 * npair;
+    int line, within;
+    if (PIN) { const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3; line = xcd + 8 * (w / per_line); within = w % per_line; }
+    else { line = blockIdx.x / per_line; within = blockIdx.x % per_line; }
+    if (line >= nlines) return;
+    const int half = within & 1, pair = within >> 1;
+    int bi = 0;
+    while ((bi + 1) * (bi + 2) / 2 <= pair) bi++;
+    const int bj = pair - bi * (bi + 1) / 2;
+    const int tid = threadIdx.x, o = tid & 3, sl = (tid >> 2) & 31, to = tid >> 7;
+    const int station = ((sl >> 4) ? bj : bi) * 16 + (sl & 15);
+    const bool loads = !(bi == bj && (sl >> 4));
+    const size_t row_v4 = (size_t)F * 2 / 16, tstr = (size_t)N * row_v4;
+    const v4i *src = in + ((size_t)(to * 8) * N + station) * row_v4 + (size_t)line * 8 + half * 4 + o;
+    v4i acc = (v4i){0, 0, 0, 0};
+    if (loads)
+        for (int tb = 0; tb < T; tb += 32) {
+            v4i v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = src[(size_t)(tb + i) * tstr];
+#pragma unroll
+            for (int i = 0; i < 8; i++) acc += v[i];
+        }
+    const int s = acc.x + acc.y + acc.z + acc.w;
+    if (s == 0x12345678) out[blockIdx.x] = s;
+}
+template <bool PIN> void runh(const v4i *in, int *out)
+{
+    const int T = 1024, N = 64, F = 1024, grid = (F / 64) * 20;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((kh<PIN>), dim3(grid), dim3(512), 0, 0, in, out, T, N, F);
+    hipEventRecord(a);
+    for (int i = 0; i < 20; i++) hipLaunchKernelGGL((kh<PIN>), dim3(grid), dim3(512), 0, 0, in, out, T, N, F);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    printf("half lines, 512 threads, pinned=%d grid=%3d: %7.1f us\n", (int)PIN, grid, ms / 20 * 1e3);
+}
+
 int main()
 {
     v4i *in; int *out;
@@ -73,5 +116,6 @@ int main()
     CK(hipMalloc(&in, bytes)); CK(hipMalloc(&out, 1 << 20));
     CK(hipMemset(in, 1, bytes));
     run<1, true>(in, out); run<1, false>(in, out); run<2, true>(in, out); run<2, false>(in, out); run<4, true>(in, out);
+    runh<true>(in, out); runh<false>(in, out);
     return 0;
 }
