@@ -164,11 +164,15 @@ template <int N> __host__ __device__ constexpr int swzn(int s)
     return swz(s);
 }
 
-// LDS slot of logical index (raw + c) where c is a compile-time multiple of STEP
+// LDS slot of logical index (raw + c) where c is a compile-time multiple of STEP whose bits are disjoint from raw's (every
+// caller: c selects a digit of the index that raw leaves zero).  All swizzles above are XOR-linear in the slot bits, so
+// swz(raw + c) = swz(raw) ^ swz(c): one v_xor with a literal per access instead of re-deriving the swizzle (8-9 integer
+// operations each, a third of the vector instructions of the transform kernels before this).
 template <int STEP, int N = 0> __device__ __forceinline__ int lds_at(int raw, int raw_swz, int c)
 {
-    if constexpr (STEP % 256 == 0 && N != 256 && N != 64) return raw_swz + c;  // the swizzle only touches the low 8 slot bits
-    else return swzn<N>(raw + c);
+    (void)raw;
+    if constexpr (STEP % 256 == 0 && N != 256 && N != 64) return raw_swz + c;  // the swizzle only touches the low 8 slot bits: c folds into the DS offset field
+    else return raw_swz ^ swzn<N>(c);
 }
 
 // inverse of orev: slot that holds output index r

@@ -148,15 +148,15 @@ __global__ __launch_bounds__(256, (PfbGeo<M, PMAX>::WPE)) void k_pfb(const c32 *
         __syncthreads();  // every wave is done with the staged input: reuse LDS for the transform
         // ---- phase 2: branch outputs -> transform layout (R == M: no rotation) ---------------
 #pragma unroll
-        for (int u = 0; u < U; u++) lds[swz((sg * U + u) * M + jb)] = mk(acc[u].x, acc[u].y);
+        for (int u = 0; u < U; u++) lds[swz(sg * U * M + jb) ^ swz(u * M)] = mk(acc[u].x, acc[u].y);  // linear swizzle, disjoint bits
         __syncthreads();
         c32 v[16];
         constexpr int R0 = PL::radix(0), B0 = M / R0;
 #pragma unroll
         for (int q = 0; q < 16 / R0; q++) {
-            const int g = tid + TH * q, raw = (g / B0) * M + (g % B0);
+            const int g = tid + TH * q, raw_swz = swz((g / B0) * M + (g % B0));
 #pragma unroll
-            for (int r = 0; r < R0; r++) v[q * R0 + r] = lds[swz(raw + r * B0)];
+            for (int r = 0; r < R0; r++) v[q * R0 + r] = lds[raw_swz ^ swz(r * B0)];
         }
         if constexpr (NP > 1) __syncthreads();  // pass 0 writes LDS in place
         transform_regs<M, 1, false>(v, tw, lds, tid);
@@ -250,6 +250,7 @@ __global__ __launch_bounds__(M, 2) void k_pfbw(const c32 *__restrict__ in, c32 *
         const long long row0 = (long long)(grp - g_begin) * U;  // ring row 0 of this iteration
         int lane = lane0;
         asm volatile("" : "+v"(lane));  // LDS addresses are recomputed per iteration instead of living in ~50 registers
+        const int lane_swz = swzn<M>(lane);
         // ---- phase 1: two steps at a time; their rows are retired and refilled right after ----
 #pragma unroll
         for (int u = 0; u < U; u += 2) {
@@ -261,8 +262,8 @@ __global__ __launch_bounds__(M, 2) void k_pfbw(const c32 *__restrict__ in, c32 *
                 a1 = __builtin_elementwise_fma(ring[(U * PH + u + 1 + pp) % RS], hh, a1);
             }
             __builtin_amdgcn_sched_barrier(0);  // the refill below must not be hoisted above the last use of its slot
-            lds[swzn<M>(u * M + lane)] = mk(a0.x, a0.y);
-            lds[swzn<M>((u + 1) * M + lane)] = mk(a1.x, a1.y);
+            lds[lane_swz ^ swzn<M>(u * M)] = mk(a0.x, a0.y);  // swizzles are XOR-linear: swz(u*M + lane) = swz(lane) ^ swz(u*M)
+            lds[lane_swz ^ swzn<M>((u + 1) * M)] = mk(a1.x, a1.y);
             // unconditional: past the wave's range the rows are simply not used, past the stream they read as zero
             ring[(U * PH + u) % RS] = load_row(row0 + RS + u);
             ring[(U * PH + u + 1) % RS] = load_row(row0 + RS + u + 1);
@@ -273,9 +274,9 @@ __global__ __launch_bounds__(M, 2) void k_pfbw(const c32 *__restrict__ in, c32 *
         c32 v[16];
         constexpr int R0 = PL::radix(0), B0 = M / R0;
         {
-            const int raw = (lane / B0) * M + (lane % B0);
+            const int raw_swz = swzn<M>((lane / B0) * M + (lane % B0));
 #pragma unroll
-            for (int r = 0; r < R0; r++) v[r] = lds[swzn<M>(raw + r * B0)];
+            for (int r = 0; r < R0; r++) v[r] = lds[raw_swz ^ swzn<M>(r * B0)];
         }
         __syncthreads();
         transform_regs<M, 1, false, G>(v, tw, lds, lane);
@@ -364,6 +365,7 @@ __global__ __launch_bounds__(64, 2) void k_pfbs(const c32 *__restrict__ in, c32 
         int lane = lane0;
         asm volatile("" : "+v"(lane));
         const int arm = lane % M, sg = lane / M;
+        const int arm_swz = swzn<M>(sg * U * M + arm);
 #pragma unroll
         for (int u = 0; u < U; u += 2) {
             f2v a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
@@ -374,8 +376,8 @@ __global__ __launch_bounds__(64, 2) void k_pfbs(const c32 *__restrict__ in, c32 
                 a1 = __builtin_elementwise_fma(ring[(U * PH + u + 1 + pp) % RS], hh, a1);
             }
             __builtin_amdgcn_sched_barrier(0);
-            lds[swzn<M>((sg * U + u) * M + arm)] = mk(a0.x, a0.y);
-            lds[swzn<M>((sg * U + u + 1) * M + arm)] = mk(a1.x, a1.y);
+            lds[arm_swz ^ swzn<M>(u * M)] = mk(a0.x, a0.y);  // swz(sg*U*M + u*M + arm) = swz(sg*U*M + arm) ^ swz(u*M): disjoint bits, linear swizzle
+            lds[arm_swz ^ swzn<M>((u + 1) * M)] = mk(a1.x, a1.y);
             ring[(U * PH + u) % RS] = load_row(row0 + RS + u);
             ring[(U * PH + u + 1) % RS] = load_row(row0 + RS + u + 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -385,9 +387,9 @@ __global__ __launch_bounds__(64, 2) void k_pfbs(const c32 *__restrict__ in, c32 
         constexpr int R0 = PL::radix(0), B0 = M / R0;
 #pragma unroll
         for (int q = 0; q < 16 / R0; q++) {
-            const int g = lane + 64 * q, raw = (g / B0) * M + (g % B0);
+            const int g = lane + 64 * q, raw_swz = swzn<M>((g / B0) * M + (g % B0));
 #pragma unroll
-            for (int r = 0; r < R0; r++) v[q * R0 + r] = lds[swzn<M>(raw + r * B0)];
+            for (int r = 0; r < R0; r++) v[q * R0 + r] = lds[raw_swz ^ swzn<M>(r * B0)];
         }
         __syncthreads();
         transform_regs<M, 1, false, G>(v, tw, lds, lane);

@@ -12,7 +12,7 @@ def timeit(fn, iters=10):
     t.record(); torch.cuda.synchronize()
     return s.elapsed_time(t) / iters * 1e-3
 buf = 1 << 26
-for M in (8, 16, 32):
+for M in (8, 16, 32, 64, 128, 256):
     for per_arm in (8, 16, 32):
         taps = np.random.default_rng(1).standard_normal(M * per_arm).astype(np.float32)
         blk = pkg.clPolyphaseChannelizer(1, 2, 0, 0, taps, buf, M, M, list(range(M)))
