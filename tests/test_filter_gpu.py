@@ -45,7 +45,7 @@ def test_golden_complex_taps(gpu, use_time):
 
 
 @pytest.mark.parametrize("use_time", [False, True])
-@pytest.mark.parametrize("ntaps", [1, 2, 3, 8, 9, 17, 30, 64, 65, 100, 128, 129, 300, 600, 1000, 2048, 2049, 3000])  # > 2048: direct form in both modes
+@pytest.mark.parametrize("ntaps", [1, 2, 3, 8, 9, 17, 30, 64, 65, 100, 128, 129, 300, 600, 1000, 2048, 2049, 3000, 4096, 4097, 6001, 9000])  # > 2048: partitioned into <= 2048-tap segments in FFT mode
 def test_vs_oracle_fir_various_lengths(gpu, oracle, ntaps, use_time):
     rng = np.random.default_rng(ntaps)
     taps = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
@@ -56,6 +56,31 @@ def test_vs_oracle_fir_various_lengths(gpu, oracle, ntaps, use_time):
     y = np.empty(n, np.complex64)
     blk.work(n, [xh], [y])
     assert relerr(y, oracle.fir_ccf(taps, xh, n)) <= TOL
+
+
+@pytest.mark.parametrize("decim", [1, 3])
+def test_long_filter_partitioned_streaming(gpu, oracle, decim):
+    """5000 taps = three segments of the NF = 4096 kernel accumulating into y; two consecutive calls with history equal one
+    call and the oracle, with and without decimation, through the device-resident path as well."""
+    import torch
+    rng = np.random.default_rng(50 + decim)
+    ntaps = 5000
+    taps = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    n = 7000
+    x = crandn(rng, 2 * n * decim + ntaps - 1)
+    blk = gpu.clFilter(*GPU_ARGS, decim, taps)
+    assert blk.fftsize() == 4096
+    ya, yb, yw = (np.empty(m, np.complex64) for m in (n, n, 2 * n))
+    blk.work(n, [x[:n * decim + ntaps - 1]], [ya])
+    blk.work(n, [x[n * decim:]], [yb])
+    blk.work(2 * n, [x], [yw])
+    assert relerr(np.concatenate([ya, yb]), yw) <= 2e-6  # same samples, block boundaries at different places
+    ref = oracle.fir_ccf(taps, x, 2 * n * decim)[::decim][:2 * n]
+    assert relerr(yw, ref) <= TOL
+    xd = torch.from_numpy(x.view(np.float32).reshape(-1, 2)).cuda()
+    yd = torch.empty(2 * n, 2, device="cuda")
+    blk.work_device(2 * n, [xd], [yd])
+    assert relerr(yd.cpu().numpy().view(np.complex64).reshape(-1), ref) <= TOL
 
 
 def test_reference_fft_sizes_and_stateful_oracle(gpu, oracle):
