@@ -61,23 +61,24 @@ def barrier(world):
 
 def time_steps(fn, steps, warmup, world):
     """W untimed steps, then exactly K steps bracketed by barrier+synchronize; returns
-    (wall seconds for K steps on this rank, HIP-event seconds summed over the same K launches).
-    Every launch sits between its own pair of events on the launch stream, so the event figure is
-    kernel time (what rocprofv3 --kernel-trace reports) and excludes the dispatch gaps between launches."""
+    (wall seconds for K steps on this rank, HIP-event seconds over the same K launches).
+    ONE pair of events on the launch stream brackets the K back-to-back launches: the event figure / K is the average
+    launch duration (what rocprofv3 --kernel-trace reports, plus the ~1 us hand-over between consecutive kernels).
+    Events between the launches were measured to cost 7 % of the rate (each is a barrier packet the next kernel waits on)."""
     import torch
     for _ in range(warmup):
         fn()
     barrier(world)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    for a, b in ev:
-        a.record()
+    a.record()
+    for _ in range(steps):
         fn()
-        b.record()
+    b.record()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     barrier(world)
-    return wall, sum(a.elapsed_time(b) for a, b in ev) * 1e-3
+    return wall, a.elapsed_time(b) * 1e-3
 
 
 def max_over_ranks(x, world):
