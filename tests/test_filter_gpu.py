@@ -83,6 +83,20 @@ def test_long_filter_partitioned_streaming(gpu, oracle, decim):
     assert relerr(yd.cpu().numpy().view(np.complex64).reshape(-1), ref) <= TOL
 
 
+def test_long_complex_filter_partitioned(gpu, oracle):
+    """clComplexFilter, 4500 complex taps in the fast-convolution mode = three accumulating segments; tiny and ragged calls."""
+    rng = np.random.default_rng(77)
+    ntaps = 4500
+    taps = ((rng.standard_normal(ntaps) + 1j * rng.standard_normal(ntaps)) / np.sqrt(2 * ntaps)).astype(np.complex64)
+    blk = gpu.clComplexFilter(*GPU_ARGS, 1, taps, 1, 0, use_time=False)
+    assert blk.fftsize() == 4096
+    for n in (1, 17, 2049, 6000):
+        x = crandn(rng, n + ntaps - 1)
+        y = np.empty(n, np.complex64)
+        assert blk.work(n, [x], [y]) == n
+        assert relerr(y, oracle.fir_ccc(taps, x, n)) <= TOL, n
+
+
 def test_reference_fft_sizes_and_stateful_oracle(gpu, oracle):
     """The fused overlap-save kernel equals the reference's stateful overlap-add
     (lib/fft_filter.cc:133-175) run over the same stream from a zero tail."""
