@@ -412,7 +412,10 @@ int launch_g(mi355_ctx *ctx, int sign, const void *in, void *out, const float *w
     // plain variant at 3 workgroups/CU on MI355X, so it is off by default.
     static const bool pf = getenv("MI355_FFT_PREFETCH") ? atoi(getenv("MI355_FFT_PREFETCH")) != 0 : false;
     // resident waves per CU are what matters: 8..12 (2..3 workgroups of 4 waves, or 8..12 single-wave workgroups)
-    int grid = (N <= 4096) ? mi355_balanced_grid(ctx, ngroups, 8 / WAVES, 12 / WAVES, 0.015) : mi355_balanced_grid(ctx, ngroups, 1, 1);
+    // N <= 4096: 3 workgroups per CU are resident, but 8-16 per CU (each still loops over >= 4 frame groups with its
+    // twiddles and window in registers) measured 3-6 % faster at every size: workgroups that finish early are replaced at
+    // once, so slow CUs / HBM channels do not hold a fixed share of the work
+    int grid = (N <= 4096) ? mi355_balanced_grid(ctx, ngroups, 32 / WAVES, 64 / WAVES, 0.015) : mi355_balanced_grid(ctx, ngroups, 1, 1);
     if (const char *e = getenv("MI355_FFT_WG_PER_CU")) {
         if (atoi(e) > 0) grid = ngroups < cus * atoi(e) ? ngroups : cus * atoi(e);
     }
