@@ -135,7 +135,7 @@ int launch_elem(mi355_elem *h, size_t n, const void *i0, const void *i1, void *o
     auto al16 = [](const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     const int vec_ok = al16(i0) && al16(i1) && al16(o0) && al16(o1);
     size_t blocks = ((vec_ok ? (n + 3) / 4 : n) + kT - 1) / kT;
-    if (blocks > (size_t)cus * 16) blocks = (size_t)cus * 16;
+    if (blocks > (size_t)cus * 128) blocks = (size_t)cus * 128;  // many short grid-stride blocks: see mathop.hip
     if (blocks < 1) blocks = 1;
 #define ELEM_CASE(K) case K: hipLaunchKernelGGL((k_elem<K>), dim3((unsigned)blocks), dim3(kT), 0, st, i0, i1, o0, o1, n, h->p0, h->p1, vec_ok); break
     switch (h->kind) {

@@ -3,9 +3,10 @@
 // lib/clMathConst_impl.cc:100-225,311-361.
 //
 // HBM-bound streaming kernels: 16 B per lane per access (two gr_complex), four
-// independent accesses in flight per lane, grid capped at 8 blocks per CU and
+// independent accesses in flight per lane, grid capped at 128 blocks per CU and
 // grid-strided.  Algorithmic traffic: 24 B/item (clMathOp, complex),
 // 16 B/item (clMathConst, complex).
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -136,7 +137,8 @@ inline int grid_for(const mi355_ctx *ctx, size_t nvec)
 {
     size_t per_block = (size_t)kThreads * kUnroll;
     size_t blocks = (nvec + per_block - 1) / per_block;
-    size_t cap = (size_t)(ctx->num_cus > 0 ? ctx->num_cus : 256) * 8;
+    static const int per_cu = getenv("MI355_MATH_WG_PER_CU") && atoi(getenv("MI355_MATH_WG_PER_CU")) > 0 ? atoi(getenv("MI355_MATH_WG_PER_CU")) : 128;  // measured: 8 per CU 6.0 TB/s, 32 6.45, 128 6.6 (grid-stride blocks that finish early are replaced at once)
+    size_t cap = (size_t)(ctx->num_cus > 0 ? ctx->num_cus : 256) * per_cu;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
