@@ -796,7 +796,8 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
         const bool mfma = ((size_t)g.F * g.npol * 8) % 128 == 0 && (reinterpret_cast<uintptr_t>(in) & 15u) == 0 && tiles &&
                           xe_f32_row_tiles(g.NT) != 0 && !getenv("MI355_XE_CF32_VALU");
         // fused kernel: rows <= 64, whole groups of 8 channels; the partial matrices live in the tile workspace
-        const int tsplit = g.T >= 64 ? 2 : 1;
+        static const int ts_env = getenv("MI355_XE_CF32_TSPLIT") ? atoi(getenv("MI355_XE_CF32_TSPLIT")) : 0;
+        const int tsplit = (ts_env > 0 && g.T % (16 * ts_env) == 0) ? ts_env : (g.T >= 64 ? 2 : 1);
         const size_t out_items = (size_t)g.F * (g.N * (g.N + 1) / 2) * g.npol * g.npol;
         if (mfma && g.NT <= 4 && g.F % 8 == 0 && h->tile_bytes >= (size_t)tsplit * out_items * 8 && !getenv("MI355_XE_CF32_TWO_KERNELS")) {
             const int ntt = g.NT == 3 ? 4 : g.NT;
