@@ -554,7 +554,8 @@ int launch_fast(mi355_pfb *h, const void *in, void *out, hipStream_t st)
     }
     constexpr int T = 4096 / M;
     int ngroups = (h->nsteps + T - 1) / T;
-    int grid = mi355_balanced_grid(h->ctx, ngroups, PfbGeo<M, PMAX>::WPE >= 2 ? 2 : 1, PfbGeo<M, PMAX>::WPE);
+    // many short grid-stride workgroups (measured at 8 and 16 channels: 2 per CU 250 GS/s, 8 per CU 280, 32 per CU 302)
+    int grid = mi355_balanced_grid(h->ctx, ngroups, 16, 32);
     long long n_in = (long long)h->buf_items - h->R + h->K;
     if (h->ident)
         hipLaunchKernelGGL((k_pfb<M, PMAX, true>), dim3(grid), dim3(256), 0, st, (const c32 *)in, (c32 *)out, h->d_taps,
