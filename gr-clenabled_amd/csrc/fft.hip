@@ -336,17 +336,24 @@ __global__ __launch_bounds__(256, 2) void k_fft_sub(const void *__restrict__ in,
     const int tid0 = threadIdx.x;
     TwRegs<NS> tw;
     load_twiddles<NS, false, G>(tw, tid0, tw4096);
-    const int half = S / 2;
-    for (int pr = blockIdx.x; pr < npair; pr += gridDim.x) {
+    // The S/2 pair iterations of one frame each touch EVERY 128-byte line of the frame (16 bytes of every S*8), so they must
+    // share an L2: workgroup id % 8 is the XCD, and frame f is given to XCD f % 8, whose workgroups walk its pairs together
+    // (the grid is a multiple of 8).  Unmapped, every XCD fetched every frame from HBM: 111 -> 1xx GS/s at N = 32768.
+    const int half = S / 2, nframes = npair / half;
+    const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
+    for (int q = blockIdx.x >> 3;; q += per_xcd) {
+        const int frame = (q / half) * 8 + xcd, s = 2 * (q % half);
+        if (q / half >= (nframes + 7) / 8) break;
+        if (frame >= nframes) continue;
         int tid = tid0;
         asm volatile("" : "+v"(tid));
-        const int frame = pr / half, s = 2 * (pr - frame * half);
         const size_t fb = (size_t)frame * NS * S;
         c32 v[2][16];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const size_t e = (size_t)(tid + ((r ^ in_xor) * BL)) * S + s;  // x[S n + s]; reverse + shift: n ^ 2048; e is even
-            const f2v w = *(const f2v *)(window + e);
+            const int n = tid + ((r ^ in_xor) * BL);  // reverse + shift: n ^ 2048
+            const size_t e = (size_t)n * S + s;       // x[S n + s]; e is even
+            const f2v w = *((const f2v *)window + (size_t)(s >> 1) * NS + n);  // pair-major window (see the plan)
             if constexpr (REAL) {
                 const f2v x = __builtin_nontemporal_load((const f2v *)((const float *)in + fb + e));
                 v[0][r] = mk(x.x * w.x, 0.f);
@@ -689,7 +696,7 @@ int launch_big(mi355_fft *h, const void *in, void *out, int nframes, hipStream_t
     for (size_t f0 = 0; f0 < (size_t)nframes; f0 += chunk) {
         const int nf = (int)((size_t)nframes - f0 < chunk ? (size_t)nframes - f0 : chunk);
         const int nsub = nf * S / 2;  // pairs of sub-frames
-        const int grid = mi355_balanced_grid(h->ctx, nsub, 2, 2);
+        const int grid = (mi355_balanced_grid(h->ctx, nsub, 2, 2) + 7) & ~7;  // whole octets: workgroup id % 8 = XCD (see k_fft_sub)
         const void *src = (const char *)in + f0 * N * isz;
 #define SUB(SG, RL) hipLaunchKernelGGL((k_fft_sub<SG, RL>), dim3(grid), dim3(256), 0, st, src, (c32 *)h->d_wa, h->d_window, tw4096, S, nsub, in_xor)
         if (h->sign < 0) { if (h->dtype == MI355_DTYPE_FLOAT) SUB(-1, true); else SUB(-1, false); }
@@ -854,6 +861,18 @@ extern "C" int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, con
     {
         std::vector<float> w(fft_size, 1.0f);  // no window == all ones: the kernel has a single code path
         if (window_len) memcpy(w.data(), window, sizeof(float) * (size_t)fft_size);
+        if (pow2 && fft_size > 16384) {
+            // two-kernel sizes: k_fft_sub reads the window values of the sub-frame pair (s, s+1) for every n -- stored
+            // pair-major, [s/2][n][2], they are one contiguous 8-byte load per lane instead of 8 bytes out of every S*4
+            const int S = fft_size / 4096;
+            std::vector<float> p((size_t)fft_size);
+            for (int sp = 0; sp < S / 2; sp++)
+                for (int n = 0; n < 4096; n++) {
+                    p[((size_t)sp * 4096 + n) * 2] = w[(size_t)n * S + 2 * sp];
+                    p[((size_t)sp * 4096 + n) * 2 + 1] = w[(size_t)n * S + 2 * sp + 1];
+                }
+            w.swap(p);
+        }
         if (hipMalloc((void **)&h->d_window, sizeof(float) * (size_t)fft_size) != hipSuccess) return fail(MI355_ERR_NOMEM);
         if (hipMemcpy(h->d_window, w.data(), sizeof(float) * (size_t)fft_size, hipMemcpyHostToDevice) != hipSuccess)
             return fail(MI355_ERR_HIP);
