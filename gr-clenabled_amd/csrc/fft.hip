@@ -231,11 +231,14 @@ __global__ __launch_bounds__(256, 2) void k_fft_s(const void *__restrict__ in, c
     using G = Geo<NS>;
     __shared__ c32 lds[NS];
     const int tid0 = threadIdx.x;
+    constexpr bool RELOAD = S == 4;  // 16384: 128 data registers -- the twiddles are re-read (L1/L2) per frame instead of spilling
     TwRegs<NS> tw;
-    load_twiddles<NS, false, G>(tw, tid0, twN + N);  // the 4096-point table follows the N-point one
     c32 wb[S - 1];
+    if constexpr (!RELOAD) {
+        load_twiddles<NS, false, G>(tw, tid0, twN + N);  // the 4096-point table follows the N-point one
 #pragma unroll
-    for (int s = 1; s < S; s++) wb[s - 1] = twN[(s * tid0) & (N - 1)];
+        for (int s = 1; s < S; s++) wb[s - 1] = twN[(s * tid0) & (N - 1)];
+    }
     const int in_xor = (SIGN > 0 && shift) ? 8 : 0;       // reverse: halves swapped on load == n ^ 2048 == r ^ 8
     const int m_xor = (SIGN < 0 && shift) ? (S / 2) : 0;  // forward: halves swapped on store
 
@@ -274,10 +277,15 @@ __global__ __launch_bounds__(256, 2) void k_fft_s(const void *__restrict__ in, c
                 }
             }
         }
+        if constexpr (RELOAD) load_twiddles<NS, false, G>(tw, tid, twN + N);
 #pragma unroll
         for (int s = 0; s < S; s++) {
             transform_regs<NS, SIGN, false, G>(v[s], tw, lds, tid);
             __syncthreads();  // the last pass' LDS reads are done before the next sub-transform writes
+        }
+        if constexpr (RELOAD) {
+#pragma unroll
+            for (int s = 1; s < S; s++) wb[s - 1] = twN[(s * tid) & (N - 1)];
         }
         f2v *__restrict__ out_f = (f2v *)out + (size_t)frame * N + tid;
 #pragma unroll
