@@ -181,10 +181,10 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank):
     out["clFilter_fft_65taps"] = rate(lambda: flt.work_device(nf, [a], [c]), nf, 16)
     out["clFilter_fft_65taps"]["fft_size"] = flt.fftsize()
     fir = pkg.clFilter(*args, 1, taps65, 1, 0, True)
-    # direct form: 2 packed FMAs x 2 = 4 flop per tap and sample -> compute bound well before HBM (157 TFLOP/s fp32 vector peak)
+    # direct form: 4 flop per tap and sample on the fp32 matrix cores -> compute bound well before HBM (157 TFLOP/s fp32 peak, vector or matrix)
     out["clFilter_fir_65taps"] = rate(lambda: fir.work_device(nf, [a], [c]), nf, 16,
-                                      lambda dt: {"TFLOPs": round(4.0 * 65 * nf / dt / 1e12, 1), "valu_frac_f32_157TF": round(4.0 * 65 * nf / dt / 157e12, 3),
-                                                  "bound": "valu"})
+                                      lambda dt: {"TFLOPs": round(4.0 * 65 * nf / dt / 1e12, 1), "mfma_frac_f32_157TF": round(4.0 * 65 * nf / dt / 157e12, 3),
+                                                  "bound": "mfma"})
     ct = (taps65 * np.exp(1j * np.pi * np.arange(65) / 8)).astype(np.complex64)
     cfl = pkg.clComplexFilter(*args, 1, ct, 1, 0, use_time=False)
     out["clComplexFilter_fft_65ctaps"] = rate(lambda: cfl.work_device(nf, [a], [c]), nf, 16)

@@ -331,6 +331,121 @@ __global__ __launch_bounds__(kTdThreads, 4) void k_fir_td(const c32 *__restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------
+// direct-form FIR on the fp32 matrix cores (real taps, decimation 1).
+//   y[base + 16 i + j] = sum_k' xin[base + 16 i + k'] * hrev[k' - j]      (xin = history-prefixed input, hrev = reversed taps)
+// is a matrix product D[i][j] = sum_k' A[i][k'] B[k'][j] with A a window matrix of the input (row i starts 16 samples after
+// row i-1) and B the Toeplitz matrix of the taps (zero outside [0, K)); k' runs over K + 15 values, four per
+// v_mfma_f32_16x16x4_f32 (exact fp32 fused multiply-adds, the same peak as the packed vector FMAs but issued off the vector
+// ALU, which is what limits k_fir_td).  Real and imaginary parts are two real products with the same B.
+// A wave owns 4 blocks of 256 consecutive outputs (8 independent accumulators: no dependent MFMA back to back); the
+// workgroup's 4096 + 4*KK input samples sit in LDS as separate re / im planes addressed n + n/16 (the pad makes the 16 rows
+// of an A operand, 16 floats apart, fall into different banks); the tap table is read from LDS too (one word per lane and
+// step).  The D layout (row = 4*(lane/16) + reg, col = lane%16) puts 16 consecutive outputs on 16 consecutive lanes: every
+// store instruction writes four whole 128-byte lines straight from the accumulators -- no output transpose.
+// The next tile's samples are fetched into registers while the current one is multiplied.
+// ------------------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr int kMfTile = 4096, kMfThreads = 256, kMfPre = 18;  // prefetch registers: up to 18 * 256 = 4608 samples of span
+
+__host__ __device__ inline int mf_pad(int n) { return n + (n >> 4); }
+
+template <bool CTAPS>
+__global__ __launch_bounds__(kMfThreads, 2) void k_fir_mfma(const c32 *__restrict__ in, c32 *__restrict__ out,
+                                                            const float *__restrict__ hb,  // hb[m + 15] = hrev[m], zeros around: 4*KK + 16 floats (complex taps: a second table with the imaginary parts follows)
+                                                            int K, int KK, long long n_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int span = kMfTile + 4 * KK;          // samples the tile's outputs read (K + 15 rounded up to the MFMA step)
+    const int nq = (span + kMfThreads - 1) / kMfThreads;  // loads per thread and tile (<= kMfPre, the launcher checks)
+    const int plane = mf_pad(nq * kMfThreads + 16) + 1;    // whole rounds of the fill, and one MFMA step of over-read
+    float *xr = (float *)smem, *xi = xr + plane, *tb = xi + plane;
+    const int tlen = 4 * KK + 24;  // table slots in LDS (one step of over-read included)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    for (int i = tid; i < tlen; i += kMfThreads) {
+        tb[i] = i < 4 * KK + 16 ? hb[i] : 0.f;
+        if constexpr (CTAPS) tb[tlen + i] = i < 4 * KK + 16 ? hb[4 * KK + 16 + i] : 0.f;
+    }
+    const long long ntiles = (n_out + kMfTile - 1) / kMfTile, n_in = n_out + K - 1;
+
+    f2v pre[kMfPre];
+    auto fetch = [&](long long tl) {
+        const long long base = tl * kMfTile, left = n_in - base;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(in + base), 0, left * 8 > 0x7ffffff8LL ? 0x7ffffff8 : (int)(left * 8), 0x00020000);
+#pragma unroll
+        for (int q = 0; q < kMfPre; q++) {
+            const int i = tid + q * kMfThreads;
+            if (q < nq) pre[q] = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(rs, (unsigned)i * 8u, 0, 0));  // past the span: unused slots
+        }
+    };
+    if ((long long)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (long long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        __syncthreads();  // the previous tile's operand reads are done (first pass: the tap table is in place)
+#pragma unroll
+        for (int q = 0; q < kMfPre; q++) {
+            const int i = tid + q * kMfThreads;
+            if (q < nq) { xr[mf_pad(i)] = pre[q].x; xi[mf_pad(i)] = pre[q].y; }
+        }
+        if (tl + gridDim.x < ntiles) fetch(tl + gridDim.x);
+        __syncthreads();
+        v4f dr[4], di[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) dr[b] = di[b] = (v4f){0.f, 0.f, 0.f, 0.f};
+        // operands of step kk: A[row c][k' = 4 kk + g] of block b = sample n + 256 b, n = wave*1024 + 16 c + g + 4 kk, at padded
+        // slot n + n/16 + 272 b (256 b is a multiple of 16); B = tb[4 kk + g - c + 15].  The operands of the next step are read
+        // before the current step's eight MFMAs are issued.
+        int n = wave * 1024 + 16 * c + g;
+        const float *tbl = tb + (g - c + 15);
+        float ar[4], ai[4], bv, bw = 0.f;  // bw: imaginary part of the tap (complex taps)
+        {
+            const int a = n + (n >> 4);
+            bv = tbl[0];
+            if constexpr (CTAPS) bw = tbl[tlen];
+#pragma unroll
+            for (int b = 0; b < 4; b++) { ar[b] = xr[a + 272 * b]; ai[b] = xi[a + 272 * b]; }
+        }
+        for (int kk = 0; kk < KK; kk++) {
+            n += 4;
+            const int a = n + (n >> 4);  // one step past the last one stays inside the planes (sized for it)
+            float nr[4], ni[4], nw = 0.f;
+            const float nb = tbl[4 * kk + 4];
+            if constexpr (CTAPS) nw = tbl[tlen + 4 * kk + 4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) { nr[b] = xr[a + 272 * b]; ni[b] = xi[a + 272 * b]; }
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                dr[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[b], bv, dr[b], 0, 0, 0);
+                di[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[b], bv, di[b], 0, 0, 0);
+            }
+            if constexpr (CTAPS) {  // (xr + j xi)(hr + j hi): re -= xi hi, im += xr hi
+                const float mw = -bw;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    dr[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[b], mw, dr[b], 0, 0, 0);
+                    di[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[b], bw, di[b], 0, 0, 0);
+                }
+            }
+            bv = nb;
+            bw = nw;
+#pragma unroll
+            for (int b = 0; b < 4; b++) { ar[b] = nr[b]; ai[b] = ni[b]; }
+        }
+        // D[row = 4 g + reg][col = c] = y[base + 64 g + 16 reg + c]
+        const long long obase = tl * kMfTile + wave * 1024, oleft = n_out - obase;
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)(out + obase), 0, oleft <= 0 ? 0 : (oleft * 8 > 0x7ffffff8LL ? 0x7ffffff8 : (int)(oleft * 8)), 0x00020000);
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                f2v o;
+                o.x = dr[b][r];
+                o.y = di[b][r];
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2g, o), ro, (unsigned)(b * 256 + 64 * g + 16 * r + c) * 8u, 0, 2 /* nt */);
+            }
+        }
+    }
+}
+
 template <bool CTAPS>
 __global__ __launch_bounds__(256) void k_fir_td_dec(const c32 *__restrict__ in, c32 *__restrict__ out,
                                                     const float *__restrict__ taps_rev, int K, int decim, long long n_out)
@@ -363,6 +478,8 @@ struct mi355_filter {
     int nseg = 1, seg_len = 0, seg_first = 0;  // partitioned fast convolution of a long filter: segments, taps per segment, taps of segment 0
     std::vector<float> taps_host;  // ntaps floats or 2*ntaps floats
     float *d_taps_rev = nullptr;
+    float *d_hb = nullptr;  // matrix-core direct form: zero-padded reversed taps (real taps only)
+    int mf_kk = 0;          // MFMA steps per output block, 0 = kernel not applicable
     void *d_H = nullptr, *d_twf = nullptr, *d_twi = nullptr;
     HostPipe pipe;
     std::mutex lock;
@@ -403,6 +520,8 @@ void free_dev(mi355_filter *h)
 {
     (void)hipSetDevice(h->ctx->device);
     if (h->d_taps_rev) (void)hipFree(h->d_taps_rev);
+    if (h->d_hb) (void)hipFree(h->d_hb);
+    h->d_hb = nullptr;
     if (h->d_H) (void)hipFree(h->d_H);
     if (h->d_twf) (void)hipFree(h->d_twf);
     if (h->d_twi) (void)hipFree(h->d_twi);
@@ -444,6 +563,21 @@ int upload_taps(mi355_filter *h, const void *taps, int ntaps)
         for (int c = 0; c < per; c++) rev[(size_t)per * k + c] = h->taps_host[(size_t)per * (ntaps - 1 - k) + c];
     MI355_HIP(hipMalloc((void **)&h->d_taps_rev, rev.size() * sizeof(float)));
     MI355_HIP(hipMemcpy(h->d_taps_rev, rev.data(), rev.size() * sizeof(float), hipMemcpyHostToDevice));
+    h->mf_kk = 0;
+    {
+        const int kk = (ntaps + 15 + 3) / 4;
+        // the tile's input span must fit the prefetch registers (<= 497 taps).  Longer filters were tried with an in-place fill:
+        // no faster than the vector kernel (one workgroup per CU at that LDS size), and the extra path cost the short ones 15 %
+        if (kMfTile + 4 * kk <= kMfPre * kMfThreads) {
+            const size_t tl = (size_t)4 * kk + 16;
+            std::vector<float> hb(tl * per, 0.0f);  // [real parts | imaginary parts]
+            for (int m = 0; m < ntaps; m++)
+                for (int cpt = 0; cpt < per; cpt++) hb[cpt * tl + m + 15] = h->taps_host[(size_t)per * (ntaps - 1 - m) + cpt];
+            MI355_HIP(hipMalloc((void **)&h->d_hb, hb.size() * sizeof(float)));
+            MI355_HIP(hipMemcpy(h->d_hb, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice));
+            h->mf_kk = kk;
+        }
+    }
     if (nf) {
         // H[k] = sum_n (h[n]/NF) exp(-2 pi i k n / NF), evaluated in double (lib/fft_filter.cc:52-66)
         std::vector<float> H(2 * (size_t)nf * nseg), twf(2 * (size_t)nf), twi(2 * (size_t)nf);
@@ -538,6 +672,27 @@ int launch_filter(mi355_filter *h, size_t nout, const void *in, void *out, hipSt
         return MI355_ERR_STATE;
     }
     int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
+    static const bool mf_on = !getenv("MI355_FIR_MFMA") || atoi(getenv("MI355_FIR_MFMA")) != 0;
+    if (mf_on && h->decim == 1 && h->mf_kk && h->ntaps >= 16) {  // fewer taps: the vector kernel's short loop wins (9 taps: 350 vs 330 GS/s)
+        const int span = kMfTile + 4 * h->mf_kk;
+        const int nq = (span + kMfThreads - 1) / kMfThreads;
+        const size_t smem = ((size_t)2 * (mf_pad(nq * kMfThreads + 16) + 1) + (size_t)(h->complex_taps ? 2 : 1) * (4 * h->mf_kk + 24)) * sizeof(float);
+        const long long ntiles = ((long long)nout + kMfTile - 1) / kMfTile;
+        static const int per_cu = getenv("MI355_TD_WG_PER_CU") && atoi(getenv("MI355_TD_WG_PER_CU")) > 0 ? atoi(getenv("MI355_TD_WG_PER_CU")) : 16;
+        const long long grid = ntiles < (long long)cus * per_cu ? ntiles : (long long)cus * per_cu;
+        if (smem > 64 * 1024) {
+            if (h->complex_taps) MI355_HIP(hipFuncSetAttribute((const void *)k_fir_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            else MI355_HIP(hipFuncSetAttribute((const void *)k_fir_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        }
+        if (h->complex_taps)
+            hipLaunchKernelGGL(k_fir_mfma<true>, dim3((unsigned)grid), dim3(kMfThreads), smem, st, (const c32 *)in, (c32 *)out, h->d_hb, h->ntaps,
+                               h->mf_kk, (long long)nout);
+        else
+            hipLaunchKernelGGL(k_fir_mfma<false>, dim3((unsigned)grid), dim3(kMfThreads), smem, st, (const c32 *)in, (c32 *)out, h->d_hb, h->ntaps,
+                               h->mf_kk, (long long)nout);
+        MI355_HIP(hipGetLastError());
+        return MI355_OK;
+    }
     const int kpad0 = (h->ntaps + kTdU - 1) / kTdU * kTdU;
     // the register-tiled kernel computes every undecimated output: worth it up to a decimation of 8
     if (h->decim == 1 || (h->decim <= 8 && (size_t)td_rows(kpad0) * kTdU * sizeof(c32) <= 160 * 1024)) {
