@@ -350,10 +350,10 @@ constexpr int kMfTile = 4096, kMfThreads = 256, kMfPre = 18;  // prefetch regist
 
 __host__ __device__ inline int mf_pad(int n) { return n + (n >> 4); }
 
-template <bool CTAPS>
+template <bool CTAPS, bool DEC>
 __global__ __launch_bounds__(kMfThreads, 2) void k_fir_mfma(const c32 *__restrict__ in, c32 *__restrict__ out,
                                                             const float *__restrict__ hb,  // hb[m + 15] = hrev[m], zeros around: 4*KK + 16 floats (complex taps: a second table with the imaginary parts follows)
-                                                            int K, int KK, long long n_out)
+                                                            int K, int KK, long long n_out /* undecimated outputs */, int decim)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int span = kMfTile + 4 * KK;          // samples the tile's outputs read (K + 15 rounded up to the MFMA step)
@@ -432,15 +432,29 @@ __global__ __launch_bounds__(kMfThreads, 2) void k_fir_mfma(const c32 *__restric
         }
         // D[row = 4 g + reg][col = c] = y[base + 64 g + 16 reg + c]
         const long long obase = tl * kMfTile + wave * 1024, oleft = n_out - obase;
-        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)(out + obase), 0, oleft <= 0 ? 0 : (oleft * 8 > 0x7ffffff8LL ? 0x7ffffff8 : (int)(oleft * 8)), 0x00020000);
+        if constexpr (!DEC) {
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)(out + obase), 0, oleft <= 0 ? 0 : (oleft * 8 > 0x7ffffff8LL ? 0x7ffffff8 : (int)(oleft * 8)), 0x00020000);
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
+            for (int b = 0; b < 4; b++) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                f2v o;
-                o.x = dr[b][r];
-                o.y = di[b][r];
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2g, o), ro, (unsigned)(b * 256 + 64 * g + 16 * r + c) * 8u, 0, 2 /* nt */);
+                for (int r = 0; r < 4; r++) {
+                    f2v o;
+                    o.x = dr[b][r];
+                    o.y = di[b][r];
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2g, o), ro, (unsigned)(b * 256 + 64 * g + 16 * r + c) * 8u, 0, 2 /* nt */);
+                }
+            }
+        } else {  // small decimations: every output is computed, every decim-th kept (the matrix cores have the headroom)
+            const unsigned ph = (unsigned)(obase % decim);
+            const long long q0 = obase / decim;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int o = b * 256 + 64 * g + 16 * r + c;
+                    const unsigned t = ph + (unsigned)o;
+                    if (o < oleft && t % (unsigned)decim == 0) out[q0 + t / (unsigned)decim] = mk(dr[b][r], di[b][r]);
+                }
             }
         }
     }
@@ -673,23 +687,26 @@ int launch_filter(mi355_filter *h, size_t nout, const void *in, void *out, hipSt
     }
     int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
     static const bool mf_on = !getenv("MI355_FIR_MFMA") || atoi(getenv("MI355_FIR_MFMA")) != 0;
-    if (mf_on && h->decim == 1 && h->mf_kk && h->ntaps >= 16) {  // fewer taps: the vector kernel's short loop wins (9 taps: 350 vs 330 GS/s)
+    // decimations 2-8 keep every decim-th output of the same product; that variant needs more registers (2 workgroups per CU)
+    // and only pays from ~100 taps (129 taps, decimation 2: 137 -> 148 GS/s; 65 taps: equal)
+    if (mf_on && h->mf_kk && ((h->decim == 1 && h->ntaps >= 16) || (h->decim >= 2 && h->decim <= 8 && h->ntaps >= 96))) {  // fewer taps: the vector kernel's short loop wins (9 taps: 350 vs 330 GS/s)
         const int span = kMfTile + 4 * h->mf_kk;
         const int nq = (span + kMfThreads - 1) / kMfThreads;
         const size_t smem = ((size_t)2 * (mf_pad(nq * kMfThreads + 16) + 1) + (size_t)(h->complex_taps ? 2 : 1) * (4 * h->mf_kk + 24)) * sizeof(float);
-        const long long ntiles = ((long long)nout + kMfTile - 1) / kMfTile;
+        const long long n_y = (long long)nout * h->decim;  // undecimated outputs
+        const long long ntiles = (n_y + kMfTile - 1) / kMfTile;
         static const int per_cu = getenv("MI355_TD_WG_PER_CU") && atoi(getenv("MI355_TD_WG_PER_CU")) > 0 ? atoi(getenv("MI355_TD_WG_PER_CU")) : 16;
         const long long grid = ntiles < (long long)cus * per_cu ? ntiles : (long long)cus * per_cu;
-        if (smem > 64 * 1024) {
-            if (h->complex_taps) MI355_HIP(hipFuncSetAttribute((const void *)k_fir_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            else MI355_HIP(hipFuncSetAttribute((const void *)k_fir_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        }
-        if (h->complex_taps)
-            hipLaunchKernelGGL(k_fir_mfma<true>, dim3((unsigned)grid), dim3(kMfThreads), smem, st, (const c32 *)in, (c32 *)out, h->d_hb, h->ntaps,
-                               h->mf_kk, (long long)nout);
-        else
-            hipLaunchKernelGGL(k_fir_mfma<false>, dim3((unsigned)grid), dim3(kMfThreads), smem, st, (const c32 *)in, (c32 *)out, h->d_hb, h->ntaps,
-                               h->mf_kk, (long long)nout);
+#define LAUNCH_MF(CT, DC)                                                                                                     \
+    do {                                                                                                                      \
+        if (smem > 64 * 1024)                                                                                                 \
+            MI355_HIP(hipFuncSetAttribute((const void *)k_fir_mfma<CT, DC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL((k_fir_mfma<CT, DC>), dim3((unsigned)grid), dim3(kMfThreads), smem, st, (const c32 *)in, (c32 *)out, h->d_hb, \
+                           h->ntaps, h->mf_kk, n_y, h->decim);                                                                \
+    } while (0)
+        if (h->complex_taps) { if (h->decim == 1) LAUNCH_MF(true, false); else LAUNCH_MF(true, true); }
+        else                 { if (h->decim == 1) LAUNCH_MF(false, false); else LAUNCH_MF(false, true); }
+#undef LAUNCH_MF
         MI355_HIP(hipGetLastError());
         return MI355_OK;
     }
