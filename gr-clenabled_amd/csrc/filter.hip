@@ -339,16 +339,17 @@ __global__ __launch_bounds__(kTdThreads, 4) void k_fir_td(const c32 *__restrict_
 // v_mfma_f32_16x16x4_f32 (exact fp32 fused multiply-adds, the same peak as the packed vector FMAs but issued off the vector
 // ALU, which is what limits k_fir_td).  Real and imaginary parts are two real products with the same B.
 // A wave owns 4 blocks of 256 consecutive outputs (8 independent accumulators: no dependent MFMA back to back); the
-// workgroup's 4096 + 4*KK input samples sit in LDS as separate re / im planes addressed n + n/16 (the pad makes the 16 rows
+// workgroup's 4096 + 4*KK input samples sit in LDS as separate re / im planes addressed n + 2*(n/16) (the pad makes the 16 rows
 // of an A operand, 16 floats apart, fall into different banks); the tap table is read from LDS too (one word per lane and
 // step).  The D layout (row = 4*(lane/16) + reg, col = lane%16) puts 16 consecutive outputs on 16 consecutive lanes: every
 // store instruction writes four whole 128-byte lines straight from the accumulators -- no output transpose.
-// The next tile's samples are fetched into registers while the current one is multiplied.
+// The next tile's samples are fetched into registers while the current one is multiplied.  (One-wave workgroups without any
+// workgroup barrier were measured too: 3-5 % slower -- three waves per SIMD and more halo re-reads.)
 // ------------------------------------------------------------------------------------
 typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int kMfTile = 4096, kMfThreads = 256, kMfPre = 18;  // prefetch registers: up to 18 * 256 = 4608 samples of span
 
-__host__ __device__ inline int mf_pad(int n) { return n + (n >> 4); }
+__host__ __device__ inline int mf_pad(int n) { return n + ((n >> 4) << 1); }  // 16 samples -> 18 slots: rows 18 apart, the two row groups of a half-wave on even / odd banks (stride 17 left 48 % of the LDS cycles in conflicts)
 
 template <bool CTAPS, bool DEC>
 __global__ __launch_bounds__(kMfThreads, 2) void k_fir_mfma(const c32 *__restrict__ in, c32 *__restrict__ out,
@@ -392,26 +393,26 @@ __global__ __launch_bounds__(kMfThreads, 2) void k_fir_mfma(const c32 *__restric
 #pragma unroll
         for (int b = 0; b < 4; b++) dr[b] = di[b] = (v4f){0.f, 0.f, 0.f, 0.f};
         // operands of step kk: A[row c][k' = 4 kk + g] of block b = sample n + 256 b, n = wave*1024 + 16 c + g + 4 kk, at padded
-        // slot n + n/16 + 272 b (256 b is a multiple of 16); B = tb[4 kk + g - c + 15].  The operands of the next step are read
+        // slot n + 2*(n/16) + 288 b (256 b is a multiple of 16); B = tb[4 kk + g - c + 15].  The operands of the next step are read
         // before the current step's eight MFMAs are issued.
         int n = wave * 1024 + 16 * c + g;
         const float *tbl = tb + (g - c + 15);
         float ar[4], ai[4], bv, bw = 0.f;  // bw: imaginary part of the tap (complex taps)
         {
-            const int a = n + (n >> 4);
+            const int a = mf_pad(n);
             bv = tbl[0];
             if constexpr (CTAPS) bw = tbl[tlen];
 #pragma unroll
-            for (int b = 0; b < 4; b++) { ar[b] = xr[a + 272 * b]; ai[b] = xi[a + 272 * b]; }
+            for (int b = 0; b < 4; b++) { ar[b] = xr[a + 288 * b]; ai[b] = xi[a + 288 * b]; }
         }
         for (int kk = 0; kk < KK; kk++) {
             n += 4;
-            const int a = n + (n >> 4);  // one step past the last one stays inside the planes (sized for it)
+            const int a = mf_pad(n);  // one step past the last one stays inside the planes (sized for it)
             float nr[4], ni[4], nw = 0.f;
             const float nb = tbl[4 * kk + 4];
             if constexpr (CTAPS) nw = tbl[tlen + 4 * kk + 4];
 #pragma unroll
-            for (int b = 0; b < 4; b++) { nr[b] = xr[a + 272 * b]; ni[b] = xi[a + 272 * b]; }
+            for (int b = 0; b < 4; b++) { nr[b] = xr[a + 288 * b]; ni[b] = xi[a + 288 * b]; }
 #pragma unroll
             for (int b = 0; b < 4; b++) {
                 dr[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[b], bv, dr[b], 0, 0, 0);
