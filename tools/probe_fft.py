@@ -16,7 +16,7 @@ tot = 1 << 26
 x = torch.randn(tot, 2, device="cuda"); y = torch.empty_like(x)
 for n in sizes:
     nvec = tot // n
-    if n & (n - 1): nvec = min(nvec, (1 << 22) // n)  # chirp-z sizes: smaller batch
+    if n & (n - 1): nvec = min(nvec, (int(os.environ.get("PROBE_CZ_LOG2", "22")) and (1 << int(os.environ.get("PROBE_CZ_LOG2", "22")))) // n)  # chirp-z sizes: smaller batch
     w = np.blackman(n).astype(np.float32)
     blk = pkg.clFFT(n, pkg.CLFFT_FORWARD, w, pkg.DTYPE_COMPLEX, 1, 2, 0, 0, 0, 1, True)
     dt = timeit(lambda: blk.work_device(nvec, [x], [y]))
