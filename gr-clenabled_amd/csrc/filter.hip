@@ -195,6 +195,114 @@ __global__ __launch_bounds__(G::TH, G::WPE) void k_ols(const c32 *__restrict__ i
 }
 
 // ------------------------------------------------------------------------------------
+// partitioned fast convolution of a long filter (more than 2048 taps) in ONE pass: per output block the P segment spectra
+// are applied to P forward transforms of the correspondingly delayed input blocks and SUMMED in the frequency domain, then
+// one inverse transform: y_blk = IFFT( sum_p FFT(x delayed by the taps before segment p) * H_p ).  P + 1 transforms per
+// block instead of the 2 P of P separate passes, the input is read from HBM once (the P spans of a block overlap with the
+// spans of the neighbouring blocks: L2) and y is written once, never re-read.  NF = 4096; the segment spectra are read
+// from L2 per block (16 values per thread and segment) instead of living in registers.
+// ------------------------------------------------------------------------------------
+template <class G>
+__global__ __launch_bounds__(G::TH, 2) void k_ols_part(const c32 *__restrict__ in, c32 *__restrict__ out, const c32 *__restrict__ Hspec,  // [nseg][NF]
+                                                      const c32 *__restrict__ tw_fwd, int ktot, int nseg, int seg_len, int seg_first,
+                                                      int decim, int L, int s0, long long n_y, int ngroups)
+{
+    constexpr int NF = 4096;
+    using PF = Plan<NF, false>;
+    using PI = Plan<NF, true>;
+    constexpr int TH = G::TH, PTS = G::PTS, F = G::F, NP = PF::NP;
+    static_assert((PF::L % 4) == 0, "all-radix-16 size: one twiddle set serves both directions");
+    __shared__ c32 lds[PTS];
+    const int tid0 = threadIdx.x;
+    TwRegs<NF> twf;
+    load_twiddles<NF, false, G>(twf, tid0, tw_fwd);
+    constexpr int RL = PF::radix(NP - 1), BL = NF / RL, R0 = PF::radix(0), B0 = NF / R0, RO = PI::radix(NP - 1), BO = NF / RO;
+
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const long long g0 = (long long)grp * F * L;
+        const long long y_left64 = n_y - g0;
+        const unsigned y_left = y_left64 > 0x7fffffffLL ? 0x7fffffffu : (unsigned)(y_left64 > 0 ? y_left64 : 0);
+        c32 w[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) w[k] = mk(0.f, 0.f);
+        for (int sg = 0; sg < nseg; sg++) {
+            // segment sg: tp taps, applied to the input delayed by the taps before it = the buffer read `shift` samples later
+            const int tp = sg == 0 ? seg_first : seg_len;
+            const long long shift = sg == 0 ? (long long)ktot - seg_first : (long long)(nseg - 1 - sg) * seg_len;
+            const int pad = s0 - (tp - 1);
+            const c32 *__restrict__ in_g = in + shift + g0;
+            const long long in_left64 = n_y + tp - 1 - g0;
+            const unsigned in_left = in_left64 > 0x7fffffffLL ? 0x7fffffffu : (unsigned)(in_left64 > 0 ? in_left64 : 0);
+            c32 v[16];
+            if (g0 > 0 || shift >= pad) {  // the pad samples in front of the block exist in the buffer
+                const long long left_b = (in_left64 + pad) * 8;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(in_g - pad), 0, left_b <= 0 ? 0 : (left_b > 0x7ffffff8LL ? 0x7ffffff8 : (int)left_b), 0x00020000);
+#pragma unroll
+                for (int q = 0; q < 16 / R0; q++) {
+                    const int g = tid + TH * q, fr = g / B0, j = g % B0;
+                    const unsigned off = (unsigned)(fr * L + j) * 8u;
+#pragma unroll
+                    for (int r = 0; r < R0; r++) {
+                        const f2v x = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(rs, off + (unsigned)(r * B0 * 8), 0, 0));
+                        v[q * R0 + r] = mk(x.x, x.y);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16 / R0; q++) {
+                    const int g = tid + TH * q, fr = g / B0, j = g % B0;
+                    const int base = fr * L + j - pad;
+#pragma unroll
+                    for (int r = 0; r < R0; r++) {
+                        const int e = base + r * B0;
+                        const bool ok = e >= 0 && (unsigned)e < in_left;  // in front of the buffer: feeds only outputs that are not stored
+                        const c32 x = in_g[ok ? e : 0];
+                        v[q * R0 + r] = ok ? x : mk(0.f, 0.f);
+                    }
+                }
+            }
+            transform_regs<NF, -1, false, G>(v, twf, lds, tid);
+            const c32 *__restrict__ Hs = Hspec + (size_t)sg * NF;
+#pragma unroll
+            for (int q = 0; q < 16 / RL; q++) {
+                const int j = (tid + TH * q) % BL;
+#pragma unroll
+                for (int r = 0; r < RL; r++) {
+                    const int src = q * RL + irev<RL>(r);
+                    const c32 t = cmul(v[src], Hs[j + orev<RL>(irev<RL>(r)) * BL]);
+                    w[q * RL + r].x += t.x;
+                    w[q * RL + r].y += t.y;
+                }
+            }
+            __syncthreads();  // this transform's LDS reads are done before the next one (or the inverse) writes
+        }
+        transform_regs<NF, 1, true, G, 0, true>(w, twf, lds, tid);
+        const unsigned g_phase = (unsigned)(g0 % decim);
+        const long long g_quot = g0 / decim;
+#pragma unroll
+        for (int q = 0; q < 16 / RO; q++) {
+            const int g = tid + TH * q, fr = g / BO, j = g % BO;
+            const int rel0 = fr * L + j - s0;
+#pragma unroll
+            for (int s = 0; s < RO; s++) {
+                const int n = j + orev<RO>(s) * BO;
+                const int rel = rel0 + orev<RO>(s) * BO;
+                if (n >= s0 && n < s0 + L && (unsigned)rel < y_left) {
+                    if (decim == 1) st_stream(out + g0 + (unsigned)rel, w[q * RO + s]);
+                    else {
+                        const unsigned t = g_phase + (unsigned)rel;
+                        if (t % (unsigned)decim == 0) out[g_quot + t / (unsigned)decim] = w[q * RO + s];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // direct-form FIR, decimation 1.  256 threads x 8 CONSECUTIVE outputs; the thread
 // slides an 8+8 register window over its inputs, so U+K-1 LDS reads feed U*K FMAs.
 // The tile is stored transposed in LDS -- sample n at slot (n%8)*S + n/8 with
@@ -633,6 +741,20 @@ int launch_ols_g(mi355_filter *h, size_t nout, const void *in, void *out, hipStr
     constexpr int F = G::F, TH = G::TH, WAVES = TH / 64;
     const long long n_y = (long long)nout * h->decim;
     static const bool align_stores = getenv("MI355_OLS_ALIGN") ? atoi(getenv("MI355_OLS_ALIGN")) != 0 : true;
+    static const bool one_pass = !getenv("MI355_OLS_PART_ONE_PASS") || atoi(getenv("MI355_OLS_PART_ONE_PASS")) != 0;
+    if constexpr (NF == 4096) {
+        if (h->nseg > 1 && one_pass) {
+            const int s0 = (h->seg_len - 1 + 15) & ~15;
+            const int L = (NF - s0) & ~15;
+            const long long nblocks = (n_y + L - 1) / L, ngroups = (nblocks + F - 1) / F;
+            if (nblocks > 0x7fffffffLL) { mi355_set_error("work() call too large"); return MI355_ERR_INVALID_ARG; }
+            long long grid = mi355_balanced_grid(h->ctx, ngroups, 2, 2);
+            hipLaunchKernelGGL((k_ols_part<G>), dim3((unsigned)grid), dim3(TH), 0, st, (const c32 *)in, (c32 *)out, (const c32 *)h->d_H,
+                               (const c32 *)h->d_twf, h->ntaps, h->nseg, h->seg_len, h->seg_first, h->decim, L, s0, n_y, (int)ngroups);
+            MI355_HIP(hipGetLastError());
+            return MI355_OK;
+        }
+    }
     for (int sgm = 0; sgm < h->nseg; sgm++) {
         // segment sgm of a partitioned filter (nseg == 1: the whole filter): its taps, and where its input starts --
         // in_p[i] = in[i + (segments after this one) * seg_len], see upload_taps
