@@ -50,7 +50,8 @@ __global__ __launch_bounds__(G::TH, G::WPE) void k_ols(const c32 *__restrict__ i
                                                                    long long n_in,   // readable input samples
                                                                    long long n_y,    // undecimated outputs wanted
                                                                    int nblocks, int ngroups,
-                                                                   int accumulate)   // y += instead of y = (later segments of a partitioned long filter)
+                                                                   int accumulate,   // y += instead of y = (later segments of a partitioned long filter)
+                                                                   int xcd_map)
 {
     using PF = Plan<NF, false>;
     using PI = Plan<NF, true>;
@@ -88,7 +89,14 @@ __global__ __launch_bounds__(G::TH, G::WPE) void k_ols(const c32 *__restrict__ i
         }
     }
 
-    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    // Consecutive groups overlap by ntaps-1 input samples.  Workgroup id % 8 is the XCD: each XCD gets a contiguous run of
+    // groups and its workgroups walk it side by side, so the overlap is re-read from that XCD's L2 instead of crossing the
+    // fabric again (long filters read every sample twice).  Falls back to the plain stride when the grid is not whole octets.
+    const bool xmap = (gridDim.x & 7) == 0 && xcd_map;
+    const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3, chunk = (ngroups + 7) >> 3;
+    for (int q = xmap ? (int)(blockIdx.x >> 3) : (int)blockIdx.x; q < (xmap ? chunk : ngroups); q += xmap ? per_xcd : (int)gridDim.x) {
+        const int grp = xmap ? xcd * chunk + q : q;
+        if (grp >= ngroups) break;
         c32 v[16];
         int tid = tid0;
         asm volatile("" : "+v"(tid));  // keep address arithmetic inside the loop (see fft.hip)
@@ -741,6 +749,7 @@ int launch_ols_g(mi355_filter *h, size_t nout, const void *in, void *out, hipStr
     constexpr int F = G::F, TH = G::TH, WAVES = TH / 64;
     const long long n_y = (long long)nout * h->decim;
     static const bool align_stores = getenv("MI355_OLS_ALIGN") ? atoi(getenv("MI355_OLS_ALIGN")) != 0 : true;
+    static const int xcd_map = getenv("MI355_OLS_XCD_MAP") ? atoi(getenv("MI355_OLS_XCD_MAP")) : 1;
     static const bool one_pass = !getenv("MI355_OLS_PART_ONE_PASS") || atoi(getenv("MI355_OLS_PART_ONE_PASS")) != 0;
     if constexpr (NF == 4096) {
         if (h->nseg > 1 && one_pass) {
@@ -774,7 +783,7 @@ int launch_ols_g(mi355_filter *h, size_t nout, const void *in, void *out, hipStr
         long long grid = WAVES == 1 ? mi355_balanced_grid(h->ctx, ngroups, 32, 48) : mi355_balanced_grid(h->ctx, ngroups, 8 / WAVES, 12 / WAVES);
         hipLaunchKernelGGL((k_ols<NF, G>), dim3((unsigned)grid), dim3(TH), 0, st, (const c32 *)in + shift, (c32 *)out,
                            (const c32 *)h->d_H + (size_t)sgm * NF, (const c32 *)h->d_twf, (const c32 *)h->d_twi, tn, h->decim, L, s0, n_in, n_y,
-                           (int)nblocks, (int)ngroups, sgm > 0 ? 1 : 0);
+                           (int)nblocks, (int)ngroups, sgm > 0 ? 1 : 0, xcd_map);
         MI355_HIP(hipGetLastError());
     }
     return MI355_OK;
