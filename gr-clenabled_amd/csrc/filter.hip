@@ -226,7 +226,12 @@ __global__ __launch_bounds__(G::TH, 2) void k_ols_part(const c32 *__restrict__ i
     load_twiddles<NF, false, G>(twf, tid0, tw_fwd);
     constexpr int RL = PF::radix(NP - 1), BL = NF / RL, R0 = PF::radix(0), B0 = NF / R0, RO = PI::radix(NP - 1), BO = NF / RO;
 
-    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    // XCD-contiguous group mapping as in k_ols: here the P input spans of a block overlap the neighbouring blocks' almost entirely
+    const bool xmap = (gridDim.x & 7) == 0;
+    const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3, chunk = (ngroups + 7) >> 3;
+    for (int q = xmap ? (int)(blockIdx.x >> 3) : (int)blockIdx.x; q < (xmap ? chunk : ngroups); q += xmap ? per_xcd : (int)gridDim.x) {
+        const int grp = xmap ? xcd * chunk + q : q;
+        if (grp >= ngroups) break;
         int tid = tid0;
         asm volatile("" : "+v"(tid));
         const long long g0 = (long long)grp * F * L;
