@@ -158,7 +158,7 @@ int mi355_fft_work_dev(mi355_fft *h, int nvec, const void *in, void *out, void *
  * use_time = 0 : fused overlap-save fast convolution (FFT -> xH -> IFFT in LDS); the transform size is chosen
  *                for throughput (>= the reference's 2*2^ceil(log2 ntaps), lib/fft_filter.cc:72-97); a filter longer
  *                than 2048 taps is partitioned into ceil(ntaps/2048) segments whose spectra are applied to delayed
- *                input blocks and summed before ONE inverse transform per block (same y; 10-20x the direct form's rate)
+ *                input blocks and summed before ONE inverse transform per block (same y; 10-25x the direct form's rate)
  * use_time = 1 : direct-form tap dot product
  * complex_taps = 1 : taps is ntaps gr_complex (clComplexFilter), else floats.
  * ------------------------------------------------------------------------- */

@@ -11,7 +11,7 @@ def timeit(fn, iters=8):
     for _ in range(iters): fn()
     t.record(); torch.cuda.synchronize()
     return s.elapsed_time(t) / iters * 1e-3
-n = 1 << 25
+n = 1 << int(os.environ.get("PROBE_LOG2", "25"))
 x = torch.randn(n + 4096, 2, device="cuda"); y = torch.empty(n, 2, device="cuda")
 rng = np.random.default_rng(0)
 for ntaps in (3, 17, 65, 129, 300, 1000, 2000):

@@ -10,11 +10,11 @@ def timeit(fn, iters=8):
     for _ in range(iters): fn()
     t.record(); torch.cuda.synchronize()
     return s.elapsed_time(t) / iters * 1e-3
-n = 1 << 25
+n = 1 << int(os.environ.get("PROBE_LOG2", "25"))
 x = torch.randn(n + 4096, 2, device="cuda"); y = torch.empty(n, 2, device="cuda")
 rng = np.random.default_rng(0)
-for ntaps in (129, 200, 300, 400, 600):
-    for nf in (0, 2048, 4096):
+for ntaps in (33, 65, 100, 129, 200, 300, 600, 1000):
+    for nf in (0, 256, 512, 1024, 2048, 4096):
         if nf and nf < 2 * ntaps: continue
         if nf: os.environ["MI355_FILTER_FFT"] = str(nf)
         else: os.environ.pop("MI355_FILTER_FFT", None)

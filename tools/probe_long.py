@@ -11,7 +11,7 @@ def timeit(fn, iters=4):
     for _ in range(iters): fn()
     t.record(); torch.cuda.synchronize()
     return s.elapsed_time(t) / iters * 1e-3
-n = 1 << 25
+n = 1 << int(os.environ.get("PROBE_LOG2", "25"))
 x = torch.randn(n + 20000, 2, device="cuda"); y = torch.empty(n, 2, device="cuda")
 rng = np.random.default_rng(0)
 for ntaps in (2048, 2049, 3000, 4096, 6000, 8192, 16384):
