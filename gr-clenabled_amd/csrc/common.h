@@ -92,6 +92,12 @@ static inline bool mi355_direct_ok(size_t max_buffer_bytes)
     return !off && max_buffer_bytes <= kDirectBytes;
 }
 
+// Staging copy of the host path (caller's pageable buffer <-> pinned staging).  One thread moves ~13 GB/s, which bounded the
+// large host calls at 1.8 GS/s (PCIe would carry 3x that): copies of 2 MiB and more are split over a small persistent pool
+// (MI355_COPY_THREADS, default 4 helpers; 0 = plain memcpy).  If the pool is busy with another block's copy the caller just
+// copies alone.
+void mi355_copy(void *dst, const void *src, size_t bytes);
+
 struct HostPipe {
     static constexpr int MAXIN = 2;
     mi355_ctx *ctx = nullptr;

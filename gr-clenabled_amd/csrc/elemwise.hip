@@ -218,21 +218,21 @@ extern "C" int mi355_elem_work(mi355_elem *h, size_t n, const void *in0, const v
     const void *ins[2] = {in0, in1};
     void *outs[2] = {out0, out1};
     if (mi355_direct_ok(items * 8)) {  // small call: the kernel works on the pinned staging itself (common.h)
-        for (int i = 0; i < h->sh.nin; i++) memcpy(h->h_in[i], ins[i], items * h->sh.in_sz[i]);
+        for (int i = 0; i < h->sh.nin; i++) mi355_copy(h->h_in[i], ins[i], items * h->sh.in_sz[i]);
         int rc = launch_elem(h, n, h->h_in[0], h->h_in[1], h->h_out[0], h->h_out[1], st);
         if (rc) return rc;
         MI355_HIP(hipStreamSynchronize(st));
-        for (int i = 0; i < h->sh.nout; i++) memcpy(outs[i], h->h_out[i], n * h->sh.out_sz[i]);
+        for (int i = 0; i < h->sh.nout; i++) mi355_copy(outs[i], h->h_out[i], n * h->sh.out_sz[i]);
         return MI355_OK;
     }
     for (int i = 0; i < h->sh.nin; i++) {
-        memcpy(h->h_in[i], ins[i], items * h->sh.in_sz[i]);
+        mi355_copy(h->h_in[i], ins[i], items * h->sh.in_sz[i]);
         MI355_HIP(hipMemcpyAsync(h->d_in[i], h->h_in[i], items * h->sh.in_sz[i], hipMemcpyHostToDevice, st));
     }
     int rc = launch_elem(h, n, h->d_in[0], h->d_in[1], h->d_out[0], h->d_out[1], st);
     if (rc) return rc;
     for (int i = 0; i < h->sh.nout; i++) MI355_HIP(hipMemcpyAsync(h->h_out[i], h->d_out[i], n * h->sh.out_sz[i], hipMemcpyDeviceToHost, st));
     MI355_HIP(hipStreamSynchronize(st));
-    for (int i = 0; i < h->sh.nout; i++) memcpy(outs[i], h->h_out[i], n * h->sh.out_sz[i]);
+    for (int i = 0; i < h->sh.nout; i++) mi355_copy(outs[i], h->h_out[i], n * h->sh.out_sz[i]);
     return MI355_OK;
 }

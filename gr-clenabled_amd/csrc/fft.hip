@@ -942,11 +942,11 @@ extern "C" int mi355_fft_work(mi355_fft *h, int nvec, const void *const *in_stre
         hipStream_t st = h->ctx->stream[0];
         for (int s_i = 0; s_i < h->nstreams; s_i++) {
             MI355_REQUIRE(in_streams[s_i] && out_streams[s_i], "NULL stream buffer");
-            memcpy(p.h_in[0][0], in_streams[s_i], (size_t)nvec * in_frame);
+            mi355_copy(p.h_in[0][0], in_streams[s_i], (size_t)nvec * in_frame);
             rc = launch_handle(h, p.h_in[0][0], p.h_out[0], nvec, st);
             if (rc) return rc;
             MI355_HIP(hipStreamSynchronize(st));
-            memcpy(out_streams[s_i], p.h_out[0], (size_t)nvec * out_frame);
+            mi355_copy(out_streams[s_i], p.h_out[0], (size_t)nvec * out_frame);
         }
         return MI355_OK;
     }
@@ -964,12 +964,12 @@ extern "C" int mi355_fft_work(mi355_fft *h, int nvec, const void *const *in_stre
             hipStream_t st = h->ctx->stream[(h->m || h->n > 16384) ? 0 : s];  // chirp-z / two-kernel paths share work buffers: one stream
             if (pend_bytes[s]) {
                 MI355_HIP(hipEventSynchronize(p.done[s]));
-                memcpy(pend_dst[s], p.h_out[s], pend_bytes[s]);
+                mi355_copy(pend_dst[s], p.h_out[s], pend_bytes[s]);
                 pend_bytes[s] = 0;
             }
             size_t f0 = ci * chunk_frames;
             size_t nf = (size_t)nvec - f0 < chunk_frames ? (size_t)nvec - f0 : chunk_frames;
-            memcpy(p.h_in[s][0], pin + f0 * in_frame, nf * in_frame);
+            mi355_copy(p.h_in[s][0], pin + f0 * in_frame, nf * in_frame);
             MI355_HIP(hipMemcpyAsync(p.d_in[s][0], p.h_in[s][0], nf * in_frame, hipMemcpyHostToDevice, st));
             rc = launch_handle(h, p.d_in[s][0], p.d_out[s], (int)nf, st);
             if (rc) return rc;
@@ -983,7 +983,7 @@ extern "C" int mi355_fft_work(mi355_fft *h, int nvec, const void *const *in_stre
         int s = (int)((seq + q) & 1);
         if (pend_bytes[s]) {
             MI355_HIP(hipEventSynchronize(p.done[s]));
-            memcpy(pend_dst[s], p.h_out[s], pend_bytes[s]);
+            mi355_copy(pend_dst[s], p.h_out[s], pend_bytes[s]);
             pend_bytes[s] = 0;
         }
     }

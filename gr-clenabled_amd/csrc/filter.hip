@@ -968,11 +968,11 @@ extern "C" int mi355_filter_work(mi355_filter *h, size_t noutput_items, const vo
     char *pout = (char *)out;
     if (noutput_items <= chunk_out && mi355_direct_ok(inb)) {  // small call: the kernel works on the pinned staging itself
         hipStream_t st = h->ctx->stream[0];
-        memcpy(p.h_in[0][0], pin, inb);
+        mi355_copy(p.h_in[0][0], pin, inb);
         rc = launch_filter(h, noutput_items, p.h_in[0][0], p.h_out[0], st);
         if (rc) return rc;
         MI355_HIP(hipStreamSynchronize(st));
-        memcpy(pout, p.h_out[0], noutput_items * 8);
+        mi355_copy(pout, p.h_out[0], noutput_items * 8);
         return MI355_OK;
     }
     size_t nchunks = (noutput_items + chunk_out - 1) / chunk_out;
@@ -982,13 +982,13 @@ extern "C" int mi355_filter_work(mi355_filter *h, size_t noutput_items, const vo
         hipStream_t st = h->ctx->stream[s];
         if (pend_bytes[s]) {
             MI355_HIP(hipEventSynchronize(p.done[s]));
-            memcpy(pout + pend_off[s], p.h_out[s], pend_bytes[s]);
+            mi355_copy(pout + pend_off[s], p.h_out[s], pend_bytes[s]);
             pend_bytes[s] = 0;
         }
         size_t o0 = ci * chunk_out;
         size_t no = noutput_items - o0 < chunk_out ? noutput_items - o0 : chunk_out;
         size_t in_bytes = (no * h->decim + hist) * 8;
-        memcpy(p.h_in[s][0], pin + o0 * h->decim * 8, in_bytes);
+        mi355_copy(p.h_in[s][0], pin + o0 * h->decim * 8, in_bytes);
         MI355_HIP(hipMemcpyAsync(p.d_in[s][0], p.h_in[s][0], in_bytes, hipMemcpyHostToDevice, st));
         rc = launch_filter(h, no, p.d_in[s][0], p.d_out[s], st);
         if (rc) return rc;
@@ -1000,7 +1000,7 @@ extern "C" int mi355_filter_work(mi355_filter *h, size_t noutput_items, const vo
         int s = (int)((nchunks + q) & 1);
         if (pend_bytes[s]) {
             MI355_HIP(hipEventSynchronize(p.done[s]));
-            memcpy(pout + pend_off[s], p.h_out[s], pend_bytes[s]);
+            mi355_copy(pout + pend_off[s], p.h_out[s], pend_bytes[s]);
             pend_bytes[s] = 0;
         }
     }

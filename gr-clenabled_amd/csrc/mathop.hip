@@ -313,12 +313,12 @@ extern "C" int mi355_mathop_work(mi355_mathop *h, size_t nitems, const void *a, 
         // itself.  One launch + one synchronisation instead of three copy submissions + a launch + a synchronisation.
         const size_t bytes = nitems * h->isize;
         hipStream_t st = h->ctx->stream[0];
-        memcpy(p.h_in[0][0], pa, bytes);
-        memcpy(p.h_in[0][1], pb, bytes);
+        mi355_copy(p.h_in[0][0], pa, bytes);
+        mi355_copy(p.h_in[0][1], pb, bytes);
         rc = dispatch2(h, nitems, p.h_in[0][0], p.h_in[0][1], p.h_out[0], st);
         if (rc) return rc;
         MI355_HIP(hipStreamSynchronize(st));
-        memcpy(pc, p.h_out[0], bytes);
+        mi355_copy(pc, p.h_out[0], bytes);
         return MI355_OK;
     }
     size_t nchunks = (nitems + chunk_items - 1) / chunk_items;
@@ -328,14 +328,14 @@ extern "C" int mi355_mathop_work(mi355_mathop *h, size_t nitems, const void *a, 
         hipStream_t st = h->ctx->stream[s];
         if (pend_bytes[s]) {  // slot busy with chunk ci-2: drain it
             MI355_HIP(hipEventSynchronize(p.done[s]));
-            memcpy(pc + pend_off[s], p.h_out[s], pend_bytes[s]);
+            mi355_copy(pc + pend_off[s], p.h_out[s], pend_bytes[s]);
             pend_bytes[s] = 0;
         }
         size_t off_items = ci * chunk_items;
         size_t n = nitems - off_items < chunk_items ? nitems - off_items : chunk_items;
         size_t bytes = n * h->isize, off = off_items * h->isize;
-        memcpy(p.h_in[s][0], pa + off, bytes);
-        memcpy(p.h_in[s][1], pb + off, bytes);
+        mi355_copy(p.h_in[s][0], pa + off, bytes);
+        mi355_copy(p.h_in[s][1], pb + off, bytes);
         MI355_HIP(hipMemcpyAsync(p.d_in[s][0], p.h_in[s][0], bytes, hipMemcpyHostToDevice, st));
         MI355_HIP(hipMemcpyAsync(p.d_in[s][1], p.h_in[s][1], bytes, hipMemcpyHostToDevice, st));
         rc = dispatch2(h, n, p.d_in[s][0], p.d_in[s][1], p.d_out[s], st);
@@ -348,7 +348,7 @@ extern "C" int mi355_mathop_work(mi355_mathop *h, size_t nitems, const void *a, 
         int s = (int)((nchunks + q) & 1);  // older slot first
         if (pend_bytes[s]) {
             MI355_HIP(hipEventSynchronize(p.done[s]));
-            memcpy(pc + pend_off[s], p.h_out[s], pend_bytes[s]);
+            mi355_copy(pc + pend_off[s], p.h_out[s], pend_bytes[s]);
             pend_bytes[s] = 0;
         }
     }
@@ -432,11 +432,11 @@ extern "C" int mi355_mathconst_work(mi355_mathconst *h, size_t nitems, const voi
     if (mi355_direct_ok(nitems * h->isize)) {  // small call: the kernel works on the pinned staging itself (see common.h)
         const size_t bytes = nitems * h->isize;
         hipStream_t st = h->ctx->stream[0];
-        memcpy(p.h_in[0][0], pa, bytes);
+        mi355_copy(p.h_in[0][0], pa, bytes);
         rc = dispatch1(h, nitems, p.h_in[0][0], p.h_out[0], k, st);
         if (rc) return rc;
         MI355_HIP(hipStreamSynchronize(st));
-        if (h->op != MI355_OP_EMPTY) memcpy(pc, p.h_out[0], bytes);
+        if (h->op != MI355_OP_EMPTY) mi355_copy(pc, p.h_out[0], bytes);
         return MI355_OK;
     }
     size_t nchunks = (nitems + chunk_items - 1) / chunk_items;
@@ -446,13 +446,13 @@ extern "C" int mi355_mathconst_work(mi355_mathconst *h, size_t nitems, const voi
         hipStream_t st = h->ctx->stream[s];
         if (pend_bytes[s]) {
             MI355_HIP(hipEventSynchronize(p.done[s]));
-            if (h->op != MI355_OP_EMPTY) memcpy(pc + pend_off[s], p.h_out[s], pend_bytes[s]);
+            if (h->op != MI355_OP_EMPTY) mi355_copy(pc + pend_off[s], p.h_out[s], pend_bytes[s]);
             pend_bytes[s] = 0;
         }
         size_t off_items = ci * chunk_items;
         size_t n = nitems - off_items < chunk_items ? nitems - off_items : chunk_items;
         size_t bytes = n * h->isize, off = off_items * h->isize;
-        memcpy(p.h_in[s][0], pa + off, bytes);
+        mi355_copy(p.h_in[s][0], pa + off, bytes);
         MI355_HIP(hipMemcpyAsync(p.d_in[s][0], p.h_in[s][0], bytes, hipMemcpyHostToDevice, st));
         rc = dispatch1(h, n, p.d_in[s][0], p.d_out[s], k, st);
         if (rc) return rc;
@@ -464,7 +464,7 @@ extern "C" int mi355_mathconst_work(mi355_mathconst *h, size_t nitems, const voi
         int s = (int)((nchunks + q) & 1);
         if (pend_bytes[s]) {
             MI355_HIP(hipEventSynchronize(p.done[s]));
-            if (h->op != MI355_OP_EMPTY) memcpy(pc + pend_off[s], p.h_out[s], pend_bytes[s]);
+            if (h->op != MI355_OP_EMPTY) mi355_copy(pc + pend_off[s], p.h_out[s], pend_bytes[s]);
             pend_bytes[s] = 0;
         }
     }

@@ -704,12 +704,12 @@ extern "C" int mi355_pfb_work(mi355_pfb *h, const void *in, void *out)
     if (rc) return rc;
     HostPipe &p = h->pipe;
     hipStream_t st = h->ctx->stream[0];
-    memcpy(p.h_in[0][0], in, inb);
+    mi355_copy(p.h_in[0][0], in, inb);
     if (mi355_direct_ok(inb > outb ? inb : outb)) {  // small call: the kernel works on the pinned staging itself (common.h)
         rc = launch_pfb(h, p.h_in[0][0], p.h_out[0], st);
         if (rc) return rc;
         MI355_HIP(hipStreamSynchronize(st));
-        memcpy(out, p.h_out[0], outb);
+        mi355_copy(out, p.h_out[0], outb);
         return MI355_OK;
     }
     MI355_HIP(hipMemcpyAsync(p.d_in[0][0], p.h_in[0][0], inb, hipMemcpyHostToDevice, st));
@@ -717,6 +717,6 @@ extern "C" int mi355_pfb_work(mi355_pfb *h, const void *in, void *out)
     if (rc) return rc;
     MI355_HIP(hipMemcpyAsync(p.h_out[0], p.d_out[0], outb, hipMemcpyDeviceToHost, st));
     MI355_HIP(hipStreamSynchronize(st));
-    memcpy(out, p.h_out[0], outb);
+    mi355_copy(out, p.h_out[0], outb);
     return MI355_OK;
 }

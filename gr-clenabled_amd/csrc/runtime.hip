@@ -211,3 +211,89 @@ void HostPipe::release()
     }
     cap_in[0] = cap_in[1] = cap_out = 0;
 }
+
+// ---------------------------------------------------------------------------
+// parallel staging copy (see common.h)
+// ---------------------------------------------------------------------------
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <thread>
+
+namespace {
+struct CopyPool {
+    std::mutex use;                  // one job at a time
+    std::mutex m;
+    std::condition_variable cv, done_cv;
+    std::vector<std::thread> workers;
+    char *dst = nullptr;
+    const char *src = nullptr;
+    size_t part = 0, bytes = 0;
+    unsigned long long job = 0;      // generation counter
+    int pending = 0;
+    bool stop = false;
+
+    explicit CopyPool(int n)
+    {
+        for (int i = 0; i < n; i++)
+            workers.emplace_back([this, i] {
+                unsigned long long seen = 0;
+                for (;;) {
+                    std::unique_lock<std::mutex> lk(m);
+                    cv.wait(lk, [&] { return stop || job != seen; });
+                    if (stop) return;
+                    seen = job;
+                    const size_t off = (size_t)(i + 1) * part;  // part 0 is the caller's
+                    const size_t len = off < bytes ? (bytes - off < part ? bytes - off : part) : 0;
+                    char *d = dst + off;
+                    const char *s2 = src + off;
+                    lk.unlock();
+                    if (len) memcpy(d, s2, len);
+                    lk.lock();
+                    if (--pending == 0) done_cv.notify_one();
+                }
+            });
+    }
+    ~CopyPool()
+    {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        cv.notify_all();
+        for (auto &t : workers) t.join();
+    }
+    void copy(void *d, const void *s2, size_t n)
+    {
+        const int parts = (int)workers.size() + 1;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            dst = (char *)d; src = (const char *)s2; bytes = n;
+            part = ((n + parts - 1) / parts + 4095) & ~(size_t)4095;
+            pending = (int)workers.size();
+            job++;
+        }
+        cv.notify_all();
+        memcpy(d, s2, part < n ? part : n);
+        std::unique_lock<std::mutex> lk(m);
+        done_cv.wait(lk, [&] { return pending == 0; });
+    }
+};
+CopyPool *copy_pool()
+{
+    static CopyPool *pool = [] {
+        const char *e = getenv("MI355_COPY_THREADS");
+        const int n = e ? atoi(e) : 4;
+        return n > 0 ? new CopyPool(n > 16 ? 16 : n) : (CopyPool *)nullptr;  // lives until process exit
+    }();
+    return pool;
+}
+}  // namespace
+
+void mi355_copy(void *dst, const void *src, size_t bytes)
+{
+    CopyPool *p = bytes >= (2u << 20) ? copy_pool() : nullptr;
+    if (p && p->use.try_lock()) {
+        p->copy(dst, src, bytes);
+        p->use.unlock();
+    } else {
+        memcpy(dst, src, bytes);
+    }
+}

@@ -1019,10 +1019,10 @@ static int xe_submit_slot(mi355_xengine *h, const void *in_host /* nullptr: the 
     mi355_xengine::Slot &sl = h->slot[s];
     hipStream_t st = h->ctx->stream[s];
     const size_t outb = h->out_items * 8;
-    if (in_host) memcpy(sl.h_in, in_host, h->in_bytes);
+    if (in_host) mi355_copy(sl.h_in, in_host, h->in_bytes);
     MI355_HIP(hipMemcpyAsync(sl.d_in, sl.h_in, h->in_bytes, hipMemcpyHostToDevice, st));
     if (acc_host) {
-        memcpy(sl.h_out, acc_host, outb);
+        mi355_copy(sl.h_out, acc_host, outb);
         MI355_HIP(hipMemcpyAsync(sl.d_out, sl.h_out, outb, hipMemcpyHostToDevice, st));
     }
     rc = launch_xe(h, sl.d_in, sl.d_out, acc_host != nullptr, st, sl.d_tiles, sl.d_pad);
@@ -1089,7 +1089,7 @@ extern "C" int mi355_xengine_wait(mi355_xengine *h, void *out_host)
     }
     mi355_xengine::Slot &sl = h->slot[h->next_wait];
     MI355_HIP(hipEventSynchronize(sl.done));
-    memcpy(out_host, sl.h_out, h->out_items * 8);
+    mi355_copy(out_host, sl.h_out, h->out_items * 8);
     sl.busy = false;
     h->next_wait ^= 1;
     h->pending--;
