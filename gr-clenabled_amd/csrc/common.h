@@ -97,6 +97,8 @@ static inline bool mi355_direct_ok(size_t max_buffer_bytes)
 // (MI355_COPY_THREADS, default 4 helpers; 0 = plain memcpy).  If the pool is busy with another block's copy the caller just
 // copies alone.
 void mi355_copy(void *dst, const void *src, size_t bytes);
+// runs fn(arg, part, parts) for part = 0..parts-1 on the pool (part 0 on the caller); false = pool busy or disabled, nothing was run
+bool mi355_parallel(void (*fn)(void *, int part, int parts), void *arg);
 
 struct HostPipe {
     static constexpr int MAXIN = 2;

@@ -213,7 +213,7 @@ void HostPipe::release()
 }
 
 // ---------------------------------------------------------------------------
-// parallel staging copy (see common.h)
+// small persistent helper pool for host-side data movement (see common.h): staging copies and the X-engine frame gather
 // ---------------------------------------------------------------------------
 #include <atomic>
 #include <condition_variable>
@@ -221,19 +221,18 @@ void HostPipe::release()
 #include <thread>
 
 namespace {
-struct CopyPool {
+struct JobPool {
     std::mutex use;                  // one job at a time
     std::mutex m;
     std::condition_variable cv, done_cv;
     std::vector<std::thread> workers;
-    char *dst = nullptr;
-    const char *src = nullptr;
-    size_t part = 0, bytes = 0;
+    void (*fn)(void *, int, int) = nullptr;
+    void *arg = nullptr;
     unsigned long long job = 0;      // generation counter
     int pending = 0;
     bool stop = false;
 
-    explicit CopyPool(int n)
+    explicit JobPool(int n)
     {
         for (int i = 0; i < n; i++)
             workers.emplace_back([this, i] {
@@ -243,57 +242,67 @@ struct CopyPool {
                     cv.wait(lk, [&] { return stop || job != seen; });
                     if (stop) return;
                     seen = job;
-                    const size_t off = (size_t)(i + 1) * part;  // part 0 is the caller's
-                    const size_t len = off < bytes ? (bytes - off < part ? bytes - off : part) : 0;
-                    char *d = dst + off;
-                    const char *s2 = src + off;
+                    void (*f)(void *, int, int) = fn;
+                    void *a = arg;
+                    const int parts = (int)workers.size() + 1;
                     lk.unlock();
-                    if (len) memcpy(d, s2, len);
+                    f(a, i + 1, parts);  // part 0 is the caller's
                     lk.lock();
                     if (--pending == 0) done_cv.notify_one();
                 }
             });
     }
-    ~CopyPool()
+    ~JobPool()
     {
         { std::lock_guard<std::mutex> lk(m); stop = true; }
         cv.notify_all();
         for (auto &t : workers) t.join();
     }
-    void copy(void *d, const void *s2, size_t n)
+    void run(void (*f)(void *, int, int), void *a)
     {
-        const int parts = (int)workers.size() + 1;
         {
             std::lock_guard<std::mutex> lk(m);
-            dst = (char *)d; src = (const char *)s2; bytes = n;
-            part = ((n + parts - 1) / parts + 4095) & ~(size_t)4095;
+            fn = f; arg = a;
             pending = (int)workers.size();
             job++;
         }
         cv.notify_all();
-        memcpy(d, s2, part < n ? part : n);
+        f(a, 0, (int)workers.size() + 1);
         std::unique_lock<std::mutex> lk(m);
         done_cv.wait(lk, [&] { return pending == 0; });
     }
 };
-CopyPool *copy_pool()
+JobPool *job_pool()
 {
-    static CopyPool *pool = [] {
+    static JobPool *pool = [] {
         const char *e = getenv("MI355_COPY_THREADS");
         const int n = e ? atoi(e) : 4;
-        return n > 0 ? new CopyPool(n > 16 ? 16 : n) : (CopyPool *)nullptr;  // lives until process exit
+        return n > 0 ? new JobPool(n > 16 ? 16 : n) : (JobPool *)nullptr;  // lives until process exit
     }();
     return pool;
 }
+struct CopyJob { char *dst; const char *src; size_t bytes; };
+void copy_part(void *a, int part, int parts)
+{
+    const CopyJob *j = (const CopyJob *)a;
+    const size_t per = ((j->bytes + parts - 1) / parts + 4095) & ~(size_t)4095, off = (size_t)part * per;
+    if (off < j->bytes) memcpy(j->dst + off, j->src + off, j->bytes - off < per ? j->bytes - off : per);
+}
 }  // namespace
+
+bool mi355_parallel(void (*fn)(void *, int, int), void *arg)
+{
+    JobPool *p = job_pool();
+    if (p && p->use.try_lock()) {
+        p->run(fn, arg);
+        p->use.unlock();
+        return true;
+    }
+    return false;
+}
 
 void mi355_copy(void *dst, const void *src, size_t bytes)
 {
-    CopyPool *p = bytes >= (2u << 20) ? copy_pool() : nullptr;
-    if (p && p->use.try_lock()) {
-        p->copy(dst, src, bytes);
-        p->use.unlock();
-    } else {
-        memcpy(dst, src, bytes);
-    }
+    CopyJob j = {(char *)dst, (const char *)src, bytes};
+    if (bytes < (2u << 20) || !mi355_parallel(copy_part, &j)) memcpy(dst, src, bytes);
 }

@@ -1117,23 +1117,31 @@ extern "C" int mi355_xengine_gather(const mi355_xengine *h, int nframes, int fra
     MI355_REQUIRE(nframes >= 0 && frame0 >= 0 && frame0 + nframes <= g.T, "frames outside the integration window");
     const size_t esz = mi355_dtype_size(h->data_type);
     const size_t frame_bytes = (size_t)g.Fout * g.N * g.npol * esz;
-    char *dst = (char *)frame_buffer;
-    for (int b = 0; b < nframes; b++) {
-        char *fb = dst + frame_bytes * (size_t)(frame0 + b);
-        for (int i = 0; i < g.N; i++) {
-            if (g.npol == 1 || h->data_type == MI355_DTYPE_PACKEDXY) {
-                const size_t row = (size_t)g.Fout * g.npol * esz;
-                memcpy(fb + (size_t)i * row, (const char *)inputs[i] + (size_t)b * row, row);
-            } else {
-                const char *x = (const char *)inputs[i] + (size_t)b * g.Fout * esz;
-                const char *y = (const char *)inputs[i + g.N] + (size_t)b * g.Fout * esz;
-                char *row = fb + (size_t)i * g.Fout * 2 * esz;
-                for (int c = 0; c < g.Fout; c++) {
-                    memcpy(row + (size_t)c * 2 * esz, x + (size_t)c * esz, esz);
-                    memcpy(row + (size_t)c * 2 * esz + esz, y + (size_t)c * esz, esz);
+    struct Job { const mi355_xengine *h; int nframes, frame0; const void *const *inputs; char *dst; size_t esz, frame_bytes; } job =
+        {h, nframes, frame0, inputs, (char *)frame_buffer, esz, frame_bytes};
+    auto part = [](void *a, int p, int parts) {
+        const Job &j = *(const Job *)a;
+        const XeGeo &g = j.h->g;
+        const int per = (j.nframes + parts - 1) / parts, b0 = p * per, b1 = b0 + per < j.nframes ? b0 + per : j.nframes;
+        for (int b = b0; b < b1; b++) {
+            char *fb = j.dst + j.frame_bytes * (size_t)(j.frame0 + b);
+            for (int i = 0; i < g.N; i++) {
+                if (g.npol == 1 || j.h->data_type == MI355_DTYPE_PACKEDXY) {
+                    const size_t row = (size_t)g.Fout * g.npol * j.esz;
+                    memcpy(fb + (size_t)i * row, (const char *)j.inputs[i] + (size_t)b * row, row);
+                } else {
+                    const char *x = (const char *)j.inputs[i] + (size_t)b * g.Fout * j.esz;
+                    const char *y = (const char *)j.inputs[i + g.N] + (size_t)b * g.Fout * j.esz;
+                    char *row = fb + (size_t)i * g.Fout * 2 * j.esz;
+                    for (int c = 0; c < g.Fout; c++) {
+                        memcpy(row + (size_t)c * 2 * j.esz, x + (size_t)c * j.esz, j.esz);
+                        memcpy(row + (size_t)c * 2 * j.esz + j.esz, y + (size_t)c * j.esz, j.esz);
+                    }
                 }
             }
         }
-    }
+    };
+    // many frames per call (a GNU Radio work() call carries hundreds): split them over the helper pool; a single frame stays here
+    if (!(nframes >= 8 && frame_bytes * (size_t)nframes >= (2u << 20) && mi355_parallel(part, &job))) part(&job, 0, 1);
     return MI355_OK;
 }
