@@ -188,6 +188,17 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank):
     ct = (taps65 * np.exp(1j * np.pi * np.arange(65) / 8)).astype(np.complex64)
     cfl = pkg.clComplexFilter(*args, 1, ct, 1, 0, use_time=False)
     out["clComplexFilter_fft_65ctaps"] = rate(lambda: cfl.work_device(nf, [a], [c]), nf, 16)
+    # a long filter (3000 taps): partitioned fast convolution, two segments summed in the frequency domain per block
+    rng3 = np.random.default_rng(3000)
+    taps3000 = (rng3.standard_normal(3000) / np.sqrt(3000.0)).astype(np.float32)
+    nl = n - 3000
+    lfl = pkg.clFilter(*args, 1, taps3000, 1, 0, False)
+    out["clFilter_fft_3000taps"] = rate(lambda: lfl.work_device(nl, [a], [c]), nl, 16)
+    # other transform sizes of the headline block: one smaller, one two-kernel size
+    for fn_ in (1024, 32768):
+        fb = pkg.clFFT(fn_, pkg.CLFFT_FORWARD, np.blackman(fn_).astype(np.float32), pkg.DTYPE_COMPLEX, *args, 0, 1, True)
+        nv = n // fn_
+        out["clFFT_%d" % fn_] = rate(lambda: fb.work_device(nv, [a], [c]), nv * fn_, 16)
     # BASELINE configs[3]: polyphase channelizer 64 ch x 32 taps/arm; streaming buffer and the 65536-item call
     for buf, key in (((1 << 26) - (1 << 16), "clPolyphaseChannelizer_64x32_stream"), (65536, "clPolyphaseChannelizer_64x32_buf65536")):
         pfb = pkg.clPolyphaseChannelizer(*args, taps2048, buf, 64, 64, list(range(64)))
