@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "common.h"
+#include "xengine_fused.h"
 
 namespace {
 
@@ -851,6 +852,13 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
     // than one pass (108-190 us vs 81 us: twice the launches at a fraction of the parallelism and no
     // visible cache benefit), so slabs are only used to bound the workspace (4 GiB) for huge problems.
     const size_t row_bytes = (g.mode == 0) ? (size_t)g.F * g.npol * 2 : (size_t)g.F * 2;
+    // IChar with at most 64 rows and whole 128-byte lines per row: corner turn and correlation fused in one pass
+    // (xengine_fused.hip); the tile workspace then only holds the int32 partial sums of the time ranges.
+    if (g.mode == 0 && (reinterpret_cast<uintptr_t>(in) & 15u) == 0) {
+        const XeFusedPlan fp = mi355_xe_fused_plan(g.N, g.F, g.Fout, g.npol, g.T, h->ctx->num_cus);
+        if (fp.ok && (fp.part_bytes == 0 || (tiles && fp.part_bytes <= h->tile_bytes)))
+            return mi355_xe_fused_launch(fp, in, out, tiles, g.N, g.F, g.Fout, g.T, 0.007874015748031496063, accumulate, st);
+    }
     const bool fast_turn = row_bytes % 128 == 0 && (reinterpret_cast<uintptr_t>(in) & 15u) == 0 && !getenv("MI355_XE_SLOW_TURN");
     const int cpl = (g.mode == 1) ? 64 : 64 / g.npol;              // channels per 128-byte input line
     const int align = fast_turn ? cpl : 2;                          // slab boundaries: whole lines / whole 4-byte units

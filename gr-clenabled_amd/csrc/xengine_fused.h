@@ -1,0 +1,21 @@
+// Fused int8 (IChar) X-engine path: corner turn in LDS + MFMA correlation in one pass (xengine_fused.hip).
+#pragma once
+#include <cstddef>
+
+#include "common.h"
+
+struct XeFusedPlan {
+    bool ok = false;     // geometry supported by the fused kernels
+    int npol = 1, ntt = 0;
+    int units = 0;       // 32-byte column slices of an input row
+    int tsplit = 1;      // time ranges (partial sums are combined by the reduce kernel when > 1)
+    size_t part_bytes = 0;  // int32 partial-sum workspace needed (0 when tsplit == 1)
+};
+
+// stations N, channels F (F * npol * 2 bytes per (t, station) row), integration T
+XeFusedPlan mi355_xe_fused_plan(int N, int F, int Fout, int npol, int T, int num_cus);
+
+// in: [t][station][chan][pol]{I,Q} int8 (16-byte aligned), out: [chan][baseline][pol^2] complex float.
+// part: workspace of plan.part_bytes (unused when tsplit == 1).  kd: 1/127.
+int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void *part, int N, int F, int Fout, int T, double kd,
+                          int accumulate, hipStream_t st);

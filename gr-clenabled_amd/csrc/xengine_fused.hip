@@ -1,0 +1,339 @@
+// clXEngine, IChar (int8 I/Q) input: corner turn AND correlation in one pass over the input.
+// Reference behaviour: lib/clXEngine_impl.cc:708-817 (CharToComplex + XCorrelate kernels), :859-867 (IChar scale);
+// input layout [t][station][chan][pol]{I,Q} (:766-767,987-1061), output [chan][baseline][pol^2] (:786-808).
+//
+// Why this shape (measured on MI355X, tools/ubench/slice_read.hip): a workgroup can hold the int32 accumulators of at most
+// ~16 channels (84 registers per channel and lane), i.e. a 32-byte column slice of every (t, station) row; the four
+// workgroups that share a 128-byte line sit on one XCD (blockIdx % 8) and run the same time range, so HBM sees every line
+// once (24.8 us for the 134 MB of BASELINE config 5; 16-byte slices 40 us, 8-byte slices 75 us: the L2 request rate, not the
+// byte count, is the limit).  16 channels per workgroup x 256 CUs = 4 x the channels -> the integration is split into 4
+// time ranges whose exact int32 partial sums are combined afterwards (k_xe_i8_reduce).
+//
+// Workgroup = 8 waves.  Raw input goes global -> LDS by DMA (global_load_lds_dwordx4, no staging registers) into a ring of
+// four 16-time-step stages; two stages (32 steps = one K block of v_mfma_i32_16x16x32_i8) are consumed while two are in
+// flight.  Wave w owns the w-th 4-byte unit of the slice (one polarisation: channels 2w, 2w+1; two: channel w, X and Y):
+// it reads its unit of 8 consecutive time steps per lane straight from the raw image (ds_read_b32; 4-way bank conflicts are
+// inherent in reading one dword of 16-byte pieces, the stage halves are skewed by 16 B to keep it at 4), byte-transposes
+// in registers (v_perm_b32) into MFMA operands and accumulates all row-tile pairs of its channels.
+//   re  += I_a I_b^T + Q_a Q_b^T
+//   im' += Q_a I_b^T + I_a (~Q_b)^T      (~q = -q - 1 is exact for every int8, -128 included, unlike -q)
+//   im   = im' + sum_t I_a(t)             (row sums via v_sad_u8 on the operand bytes)
+// so a channel needs 2 accumulators per tile pair (80 registers for 64 rows) + 4 row-sum registers.
+#include "xengine_fused.h"
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+struct c32 { float x, y; };
+
+constexpr int kStageT = 16, kRing = 4, kChunk = 1024, kWaves = 8, kThreads = kWaves * 64;
+
+struct FuArgs {
+    const unsigned char *in;
+    v4i *part;
+    c32 *out;
+    int N, F, Fout, T;
+    int nlines, tsplit, steps;  // 128-byte lines per input row; time ranges; K blocks (32 time steps) per time range
+    int pinned, accumulate;
+    double kd;
+};
+
+__device__ __forceinline__ unsigned perm(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+
+// 4 dwords (bytes b0..b3 of four consecutive time steps) -> out[j] = byte j of each input dword
+__device__ __forceinline__ void transpose4x4(unsigned i0, unsigned i1, unsigned i2, unsigned i3, unsigned (&out)[4])
+{
+    const unsigned t0 = perm(i1, i0, 0x05010400u), t1 = perm(i1, i0, 0x07030602u);
+    const unsigned t2 = perm(i3, i2, 0x05010400u), t3 = perm(i3, i2, 0x07030602u);
+    out[0] = perm(t2, t0, 0x05040100u);
+    out[1] = perm(t2, t0, 0x07060302u);
+    out[2] = perm(t3, t1, 0x05040100u);
+    out[3] = perm(t3, t1, 0x07060302u);
+}
+
+__device__ __forceinline__ long pack64(unsigned lo, unsigned hi) { return (long)(((unsigned long)hi << 32) | (unsigned long)lo); }
+
+// one LDS-DMA piece: every lane fetches 16 bytes from its own global address; they land at lds_dst + lane * 16
+__device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+template <int NPOL, int NTT>
+__global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
+{
+    constexpr int NSH = (NTT * 16 / NPOL > 32) ? 2 : 1;     // 32-station halves of a time step
+    constexpr int STAGE = kStageT * NSH * kChunk + 16;       // + the 16-byte skew of the second half of the stage
+    constexpr int CPW = 2 / NPOL;                            // channels per wave
+    constexpr int NP = NTT * (NTT + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ---- which slice / time range: the 4 workgroups of a 128-byte line on one XCD, same time range
+    int slice, q;
+    {
+        const int b = blockIdx.x;
+        if (a.pinned) {
+            const int xcd = b & 7, within = b >> 3, sector = within & 3, combo = xcd + 8 * (within >> 2);
+            slice = (combo % a.nlines) * 4 + sector;
+            q = combo / a.nlines;
+        } else {
+            slice = b % (a.nlines * 4);
+            q = b / (a.nlines * 4);
+        }
+    }
+    const size_t row_bytes = (size_t)a.nlines * 128;
+    const int t_base = q * a.steps * 32;
+    const unsigned lds0 = (unsigned)(size_t)lds;
+
+    // ---- DMA of one 16-step stage: chunk = (time step, station half) = 32 stations x 32 B, 2 * NSH chunks per wave
+    const unsigned char *src_lane = a.in + (size_t)(lane >> 1) * row_bytes + (size_t)slice * 32 + (lane & 1) * 16;
+    auto issue_stage = [&](int sigma) {
+        const int slot = sigma & (kRing - 1), t0 = t_base + sigma * kStageT;
+#pragma unroll
+        for (int k = 0; k < 2 * NSH; k++) {
+            const int idx = wave + kWaves * k, t16 = idx / NSH, sh = idx % NSH;
+            const int s = sh * 32 + (lane >> 1);
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + slot * STAGE + idx * kChunk + (t16 >> 3) * 16);
+            if (s < a.N) dma16(src_lane + ((size_t)(t0 + t16) * a.N + sh * 32) * row_bytes, dst);
+        }
+    };
+
+    v4i re[CPW][NP], im[CPW][NP];
+    unsigned rs[CPW][NTT];  // biased row sums of I (v_sad_u8 of the bytes xor 0x80)
+#pragma unroll
+    for (int c = 0; c < CPW; c++) {
+#pragma unroll
+        for (int p = 0; p < NP; p++) re[c][p] = im[c][p] = (v4i){0, 0, 0, 0};
+#pragma unroll
+        for (int rt = 0; rt < NTT; rt++) rs[c][rt] = 0u;
+    }
+
+    const int r = lane & 15, g = lane >> 4;
+    const int hpiece = wave >> 2, dq = wave & 3;
+    const int lane_base = (g >> 1) * STAGE + (g & 1) * (8 * NSH * kChunk + 16) + hpiece * 16 + dq * 4 + ((NPOL == 1) ? r : (r >> 1)) * 32;
+    const bool odd_pol = (r & 1) != 0;
+
+    issue_stage(0);
+    issue_stage(1);
+    for (int j = 0; j < a.steps; j++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // stages 2j, 2j+1 complete for every wave; everybody finished reading the slots of step j-1
+        if (j + 1 < a.steps) {
+            issue_stage(2 * j + 2);
+            issue_stage(2 * j + 3);
+        }
+        const unsigned char *base = lds + ((2 * j) & (kRing - 1)) * STAGE + lane_base;
+        long I[CPW][NTT], Q[CPW][NTT];
+#pragma unroll
+        for (int rt = 0; rt < NTT; rt++) {
+            const int tile_imm = (NPOL == 1) ? (rt >> 1) * kChunk + (rt & 1) * 512 : rt * 256;
+            unsigned raw[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) raw[i] = *(const unsigned *)(base + i * NSH * kChunk + tile_imm);
+            unsigned o0[4], o1[4];
+            transpose4x4(raw[0], raw[1], raw[2], raw[3], o0);
+            transpose4x4(raw[4], raw[5], raw[6], raw[7], o1);
+            if constexpr (NPOL == 1) {
+                // unit bytes: I(2w) Q(2w) I(2w+1) Q(2w+1); row = station
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    I[c][rt] = pack64(o0[2 * c], o1[2 * c]);
+                    Q[c][rt] = pack64(o0[2 * c + 1], o1[2 * c + 1]);
+                }
+            } else {
+                // unit bytes: XI XQ YI YQ of channel w; rows 2s (X), 2s+1 (Y): even / odd lanes of a station pair
+                I[0][rt] = odd_pol ? pack64(o0[2], o1[2]) : pack64(o0[0], o1[0]);
+                Q[0][rt] = odd_pol ? pack64(o0[3], o1[3]) : pack64(o0[1], o1[1]);
+            }
+#pragma unroll
+            for (int c = 0; c < CPW; c++) {
+                const unsigned lo = (unsigned)(unsigned long)I[c][rt], hi = (unsigned)((unsigned long)I[c][rt] >> 32);
+                rs[c][rt] = __builtin_amdgcn_sad_u8(lo ^ 0x80808080u, 0u, rs[c][rt]);
+                rs[c][rt] = __builtin_amdgcn_sad_u8(hi ^ 0x80808080u, 0u, rs[c][rt]);
+            }
+        }
+        // two sweeps over the pairs so that consecutive MFMAs never touch the same accumulator
+#pragma unroll
+        for (int c = 0; c < CPW; c++) {
+#pragma unroll
+            for (int bi = 0; bi < NTT; bi++)
+#pragma unroll
+                for (int bj = 0; bj <= bi; bj++) {
+                    const int p = bi * (bi + 1) / 2 + bj;
+                    re[c][p] = __builtin_amdgcn_mfma_i32_16x16x32_i8(I[c][bi], I[c][bj], re[c][p], 0, 0, 0);
+                    im[c][p] = __builtin_amdgcn_mfma_i32_16x16x32_i8(Q[c][bi], I[c][bj], im[c][p], 0, 0, 0);
+                }
+#pragma unroll
+            for (int bi = 0; bi < NTT; bi++)
+#pragma unroll
+                for (int bj = 0; bj <= bi; bj++) {
+                    const int p = bi * (bi + 1) / 2 + bj;
+                    re[c][p] = __builtin_amdgcn_mfma_i32_16x16x32_i8(Q[c][bi], Q[c][bj], re[c][p], 0, 0, 0);
+                    im[c][p] = __builtin_amdgcn_mfma_i32_16x16x32_i8(I[c][bi], ~Q[c][bj], im[c][p], 0, 0, 0);
+                }
+        }
+    }
+
+    // ---- epilogue.  Row sums: lane (r, g) summed its 8 bytes of every step; total over the four g; remove the bias.
+    const int nb = a.N * (a.N + 1) / 2, np2 = NPOL * NPOL, A = a.N * NPOL;
+#pragma unroll
+    for (int c = 0; c < CPW; c++) {
+        const int f = slice * (16 / NPOL) + ((NPOL == 1) ? 2 * wave + c : wave);
+        int rsum[NTT];
+#pragma unroll
+        for (int rt = 0; rt < NTT; rt++) {
+            int v = (int)rs[c][rt] - 128 * 8 * a.steps;
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            rsum[rt] = v;  // every lane: sum_t I of row (rt, lane % 16)
+        }
+#pragma unroll
+        for (int bi = 0; bi < NTT; bi++) {
+            int corr[4];  // row sums of the rows this lane holds in the C layout: row = 4 * (lane / 16) + reg
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) corr[reg] = __shfl(rsum[bi], 4 * g + reg);
+#pragma unroll
+            for (int bj = 0; bj <= bi; bj++) {
+                const int p = bi * (bi + 1) / 2 + bj;
+                v4i vre = re[c][p], vim = im[c][p];
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) vim[reg] += corr[reg];
+                if (a.tsplit > 1) {
+                    v4i *dst = a.part + ((((size_t)q * a.F + f) * NP + p) * 2) * 64 + lane;
+                    __builtin_nontemporal_store(vre, dst);
+                    __builtin_nontemporal_store(vim, dst + 64);
+                } else {
+                    if (f >= a.Fout) continue;
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) {
+                        const int r1 = bi * 16 + 4 * g + reg, r2 = bj * 16 + r;
+                        if (r1 >= A || r2 >= A) continue;
+                        const int s1 = r1 / NPOL, p1 = r1 % NPOL, s2 = r2 / NPOL, p2 = r2 % NPOL;
+                        if (s1 < s2) continue;
+                        const size_t o = ((size_t)f * nb + (s1 * (s1 + 1) / 2 + s2)) * np2 + p1 * NPOL + p2;
+                        // int32 wrap-around can only have happened for re == +2^31 (every sample -128 over 65536 frames)
+                        const double dre = (vre[reg] == (int)0x80000000) ? 2147483648.0 : (double)vre[reg];
+                        c32 v;
+                        v.x = (float)(dre * a.kd * a.kd);  // the oracle's expression: (double)S * kd * kd, rounded once
+                        v.y = (float)((double)vim[reg] * a.kd * a.kd);
+                        if (a.accumulate) { v.x += a.out[o].x; v.y += a.out[o].y; }
+                        a.out[o] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// sum of the time ranges' partial matrices (exact, int64), scale, scatter into the reference's output order
+template <int NPOL>
+__global__ __launch_bounds__(256) void k_xe_i8_reduce(const v4i *__restrict__ part, c32 *__restrict__ out, int N, int F, int Fout, int NP,
+                                                      int tsplit, double kd, int accumulate)
+{
+    const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    const size_t item = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (f, p)
+    if (item >= (size_t)Fout * NP) return;
+    const int f = (int)(item / NP), p = (int)(item % NP);
+    int bi = 0;
+    while ((bi + 1) * (bi + 2) / 2 <= p) bi++;
+    const int bj = p - bi * (bi + 1) / 2;
+    long sre[4] = {0, 0, 0, 0}, sim[4] = {0, 0, 0, 0};
+    for (int q = 0; q < tsplit; q++) {
+        const v4i *src = part + ((((size_t)q * F + f) * NP + p) * 2) * 64 + lane;
+        const v4i a = __builtin_nontemporal_load(src), b = __builtin_nontemporal_load(src + 64);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { sre[k] += a[k]; sim[k] += b[k]; }
+    }
+    const int nb = N * (N + 1) / 2, np2 = NPOL * NPOL, A = N * NPOL;
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+        const int r1 = bi * 16 + 4 * g + reg, r2 = bj * 16 + r;
+        if (r1 >= A || r2 >= A) continue;
+        const int s1 = r1 / NPOL, p1 = r1 % NPOL, s2 = r2 / NPOL, p2 = r2 % NPOL;
+        if (s1 < s2) continue;
+        const size_t o = ((size_t)f * nb + (s1 * (s1 + 1) / 2 + s2)) * np2 + p1 * NPOL + p2;
+        c32 v;
+        v.x = (float)((double)sre[reg] * kd * kd);
+        v.y = (float)((double)sim[reg] * kd * kd);
+        if (accumulate) { v.x += out[o].x; v.y += out[o].y; }
+        out[o] = v;
+    }
+}
+
+template <int NPOL, int NTT> int launch_fused(const XeFusedPlan &p, const FuArgs &a, hipStream_t st)
+{
+    constexpr int NSH = (NTT * 16 / NPOL > 32) ? 2 : 1;
+    constexpr int lds_bytes = kRing * (kStageT * NSH * kChunk + 16);
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+        MI355_HIP(hipFuncSetAttribute((const void *)k_xe_i8_fused<NPOL, NTT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_xe_i8_fused<NPOL, NTT>), dim3(p.units * p.tsplit), dim3(kThreads), lds_bytes, st, a);
+    MI355_HIP(hipGetLastError());
+    if (p.tsplit > 1) {
+        const int NP = NTT * (NTT + 1) / 2;
+        const size_t items = (size_t)a.Fout * NP;
+        hipLaunchKernelGGL((k_xe_i8_reduce<NPOL>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, (const v4i *)a.part, a.out, a.N, a.F,
+                           a.Fout, NP, p.tsplit, a.kd, a.accumulate);
+        MI355_HIP(hipGetLastError());
+    }
+    return MI355_OK;
+}
+
+}  // namespace
+
+XeFusedPlan mi355_xe_fused_plan(int N, int F, int Fout, int npol, int T, int num_cus)
+{
+    XeFusedPlan p;
+    (void)Fout;
+    const int A = N * npol;
+    const size_t row_bytes = (size_t)F * npol * 2;
+    if (A > 64 || A < 1 || row_bytes % 128 != 0 || T % 32 != 0 || getenv("MI355_XE_NO_FUSED")) return p;
+    p.npol = npol;
+    const int nt = (A + 15) / 16;
+    p.ntt = nt <= 1 ? 1 : nt <= 2 ? 2 : 4;
+    p.units = (int)(row_bytes / 32);
+    // time split: fill the device (one workgroup per CU), whole K blocks per range
+    const int cus = num_cus > 0 ? num_cus : 256;
+    int s = 1;
+    if (const char *e = getenv("MI355_XE_TSPLIT")) s = atoi(e) > 0 ? atoi(e) : 1;
+    else
+        while (p.units * s < cus && s < 16) s *= 2;
+    while (s > 1 && (T % (32 * s) != 0)) s /= 2;
+    p.tsplit = s;
+    const int NP = p.ntt * (p.ntt + 1) / 2;
+    p.part_bytes = s > 1 ? (size_t)s * F * NP * 2 * 1024 : 0;
+    p.ok = true;
+    return p;
+}
+
+int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void *part, int N, int F, int Fout, int T, double kd, int accumulate,
+                          hipStream_t st)
+{
+    FuArgs a;
+    a.in = (const unsigned char *)in;
+    a.part = (v4i *)part;
+    a.out = (c32 *)out;
+    a.N = N; a.F = F; a.Fout = Fout; a.T = T;
+    a.nlines = p.units / 4;
+    a.tsplit = p.tsplit;
+    a.steps = T / (32 * p.tsplit);
+    a.pinned = ((a.nlines * p.tsplit) % 8 == 0) ? 1 : 0;
+    a.accumulate = accumulate;
+    a.kd = kd;
+    if (p.npol == 1) {
+        if (p.ntt == 1) return launch_fused<1, 1>(p, a, st);
+        if (p.ntt == 2) return launch_fused<1, 2>(p, a, st);
+        return launch_fused<1, 4>(p, a, st);
+    }
+    if (p.ntt == 1) return launch_fused<2, 1>(p, a, st);
+    if (p.ntt == 2) return launch_fused<2, 2>(p, a, st);
+    return launch_fused<2, 4>(p, a, st);
+}
