@@ -294,8 +294,9 @@ __global__ __launch_bounds__(256) void k_xe_corr(const unsigned char *__restrict
             // same expression as the oracle's exact path: (double)S * kd * kd, rounded once
             const double kd = scale2;  // 1/127 or 1/7
             c32 v;
-            v.x = (float)((double)re[q][reg] * kd * kd);
-            v.y = (float)((double)(uu[q][reg] - ww[q][reg]) * kd * kd);
+            // the only int32 wrap-around possible up to 65536 frames: re == +2^31 (every sample -128), which reads back as INT_MIN
+            v.x = (float)((re[q][reg] == (int)0x80000000 ? 2147483648.0 : (double)re[q][reg]) * kd * kd);
+            v.y = (float)(((double)uu[q][reg] - (double)ww[q][reg]) * kd * kd);
             if (accumulate) { v.x += out[o].x; v.y += out[o].y; }
             out[o] = v;
         }
@@ -372,8 +373,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_xe_corr_lds(const unsigned char 
             const size_t o = ((size_t)(f + g.f0) * nb + k) * np2 + p1 * g.npol + p2;
             const double kd = scale2;
             c32 v;
-            v.x = (float)((double)re[q][reg] * kd * kd);
-            v.y = (float)((double)(uu[q][reg] - ww[q][reg]) * kd * kd);
+            // the only int32 wrap-around possible up to 65536 frames: re == +2^31 (every sample -128), which reads back as INT_MIN
+            v.x = (float)((re[q][reg] == (int)0x80000000 ? 2147483648.0 : (double)re[q][reg]) * kd * kd);
+            v.y = (float)(((double)uu[q][reg] - (double)ww[q][reg]) * kd * kd);
             if (accumulate) { v.x += out[o].x; v.y += out[o].y; }
             out[o] = v;
         }
@@ -962,6 +964,10 @@ extern "C" int mi355_xengine_create(mi355_ctx *ctx, int data_type, int npol, int
         h->tile_bytes = per_chan * per;
         if (data_type == MI355_DTYPE_COMPLEX)  // fp32 tiles: 16-time-step K blocks, whole problem in one pass
             h->tile_bytes = (size_t)g.F * ((g.T + kKB32 - 1) / kKB32) * 2 * xe_f32_row_tiles(g.NT) * kTileBytes;
+        if (data_type == MI355_DTYPE_BYTE) {  // the fused path keeps the partial sums of its time ranges here
+            const XeFusedPlan fp = mi355_xe_fused_plan(g.N, g.F, g.Fout, npol, g.T, ctx->num_cus);
+            if (fp.ok && fp.part_bytes > h->tile_bytes) h->tile_bytes = fp.part_bytes;
+        }
     }
     if (hipSetDevice(ctx->device) != hipSuccess) { delete h; return MI355_ERR_HIP; }
     if (h->tile_bytes && hipMalloc((void **)&h->d_tiles, h->tile_bytes) != hipSuccess) {
@@ -984,8 +990,9 @@ extern "C" size_t mi355_xengine_output_items(const mi355_xengine *h) { return h 
 extern "C" int mi355_xengine_xcorrelate_dev(mi355_xengine *h, const void *in_dev, void *out_dev, int accumulate, void *stream)
 {
     MI355_REQUIRE(h && in_dev && out_dev, "NULL argument");
-    MI355_REQUIRE((reinterpret_cast<uintptr_t>(in_dev) & 3u) == 0 && (reinterpret_cast<uintptr_t>(out_dev) & 7u) == 0,
-                  "device buffers must be 4-byte (input) / 8-byte (output) aligned");
+    MI355_REQUIRE((reinterpret_cast<uintptr_t>(in_dev) & (h->data_type == MI355_DTYPE_COMPLEX ? 7u : 3u)) == 0 &&
+                      (reinterpret_cast<uintptr_t>(out_dev) & 7u) == 0,
+                  "device buffers must be 4-byte (int8 / packed input) or 8-byte (complex input, output) aligned");
     MI355_HIP(hipSetDevice(h->ctx->device));
     return launch_xe(h, in_dev, out_dev, accumulate, mi355_pick_stream(h->ctx, stream), h->d_tiles, h->d_pad);
 }

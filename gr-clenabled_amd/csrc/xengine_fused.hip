@@ -35,6 +35,7 @@ struct FuArgs {
     int N, F, Fout, T;
     int nlines, tsplit, steps;  // 128-byte lines per input row; time ranges; K blocks (32 time steps) per time range
     int pinned, accumulate;
+    int dbg;  // tuning aid (MI355_XE_DBG): 1 = no compute, 2 = no stores, 4 = no DMA
     double kd;
 };
 
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
             const int idx = wave + kWaves * k, t16 = idx / NSH, sh = idx % NSH;
             const int s = sh * 32 + (lane >> 1);
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + slot * STAGE + idx * kChunk + (t16 >> 3) * 16);
-            if (s < a.N) dma16(src_lane + ((size_t)(t0 + t16) * a.N + sh * 32) * row_bytes, dst);
+            if (s < a.N && !(a.dbg & 4)) dma16(src_lane + ((size_t)(t0 + t16) * a.N + sh * 32) * row_bytes, dst);
         }
     };
 
@@ -119,14 +120,28 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
     const int lane_base = (g >> 1) * STAGE + (g & 1) * (8 * NSH * kChunk + 16) + hpiece * 16 + dq * 4 + ((NPOL == 1) ? r : (r >> 1)) * 32;
     const bool odd_pol = (r & 1) != 0;
 
+    // Ring schedule: step j consumes stages 2j, 2j+1 (slots (2j) % 4, +1).  The raw bytes are pulled into registers (as MFMA
+    // operands) first, so the slots are free again after a second barrier and the DMA of step j+2 is issued BEFORE the matrix
+    // products of step j: two steps (128 KB per CU) are in flight while the wave multiplies.
+    constexpr int PER_STEP = 4 * NSH;  // DMA instructions per wave and step (every wave issues all of them: N > 32 when NSH == 2)
     issue_stage(0);
     issue_stage(1);
+    if (a.steps > 1) {
+        issue_stage(2);
+        issue_stage(3);
+    }
     for (int j = 0; j < a.steps; j++) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // stages 2j, 2j+1 complete for every wave; everybody finished reading the slots of step j-1
         if (j + 1 < a.steps) {
-            issue_stage(2 * j + 2);
-            issue_stage(2 * j + 3);
+            if constexpr (PER_STEP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();  // stages 2j, 2j+1 have landed for every wave
+        if (a.dbg & 1) {
+            __syncthreads();
+            if (j + 2 < a.steps) { issue_stage(2 * j + 4); issue_stage(2 * j + 5); }
+            continue;
         }
         const unsigned char *base = lds + ((2 * j) & (kRing - 1)) * STAGE + lane_base;
         long I[CPW][NTT], Q[CPW][NTT];
@@ -157,6 +172,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
                 rs[c][rt] = __builtin_amdgcn_sad_u8(lo ^ 0x80808080u, 0u, rs[c][rt]);
                 rs[c][rt] = __builtin_amdgcn_sad_u8(hi ^ 0x80808080u, 0u, rs[c][rt]);
             }
+        }
+        __syncthreads();  // every wave holds its operands in registers: the two slots are free
+        if (j + 2 < a.steps) {
+            issue_stage(2 * j + 4);
+            issue_stage(2 * j + 5);
         }
         // two sweeps over the pairs so that consecutive MFMAs never touch the same accumulator
 #pragma unroll
@@ -204,10 +224,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
                 v4i vre = re[c][p], vim = im[c][p];
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) vim[reg] += corr[reg];
+                if (a.dbg & 2) { if (vre[0] == 0x12345678 && vim[1] == 0x7654321) a.part[lane] = vre; continue; }
                 if (a.tsplit > 1) {
                     v4i *dst = a.part + ((((size_t)q * a.F + f) * NP + p) * 2) * 64 + lane;
-                    __builtin_nontemporal_store(vre, dst);
-                    __builtin_nontemporal_store(vim, dst + 64);
+                    if (a.dbg & 8) { dst[0] = vre; dst[64] = vim; }
+                    else { __builtin_nontemporal_store(vre, dst); __builtin_nontemporal_store(vim, dst + 64); }
                 } else {
                     if (f >= a.Fout) continue;
 #pragma unroll
@@ -234,7 +255,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
 // sum of the time ranges' partial matrices (exact, int64), scale, scatter into the reference's output order
 template <int NPOL>
 __global__ __launch_bounds__(256) void k_xe_i8_reduce(const v4i *__restrict__ part, c32 *__restrict__ out, int N, int F, int Fout, int NP,
-                                                      int tsplit, double kd, int accumulate)
+                                                      int tsplit, double kd, int accumulate, int dbg)
 {
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     const size_t item = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (f, p)
@@ -246,7 +267,7 @@ __global__ __launch_bounds__(256) void k_xe_i8_reduce(const v4i *__restrict__ pa
     long sre[4] = {0, 0, 0, 0}, sim[4] = {0, 0, 0, 0};
     for (int q = 0; q < tsplit; q++) {
         const v4i *src = part + ((((size_t)q * F + f) * NP + p) * 2) * 64 + lane;
-        const v4i a = __builtin_nontemporal_load(src), b = __builtin_nontemporal_load(src + 64);
+        const v4i a = (dbg & 16) ? src[0] : __builtin_nontemporal_load(src), b = (dbg & 16) ? src[64] : __builtin_nontemporal_load(src + 64);
 #pragma unroll
         for (int k = 0; k < 4; k++) { sre[k] += a[k]; sim[k] += b[k]; }
     }
@@ -281,7 +302,7 @@ template <int NPOL, int NTT> int launch_fused(const XeFusedPlan &p, const FuArgs
         const int NP = NTT * (NTT + 1) / 2;
         const size_t items = (size_t)a.Fout * NP;
         hipLaunchKernelGGL((k_xe_i8_reduce<NPOL>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, (const v4i *)a.part, a.out, a.N, a.F,
-                           a.Fout, NP, p.tsplit, a.kd, a.accumulate);
+                           a.Fout, NP, p.tsplit, a.kd, a.accumulate, a.dbg);
         MI355_HIP(hipGetLastError());
     }
     return MI355_OK;
@@ -328,6 +349,8 @@ int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void 
     a.pinned = ((a.nlines * p.tsplit) % 8 == 0) ? 1 : 0;
     a.accumulate = accumulate;
     a.kd = kd;
+    static const int dbg = getenv("MI355_XE_DBG") ? atoi(getenv("MI355_XE_DBG")) : 0;
+    a.dbg = dbg;
     if (p.npol == 1) {
         if (p.ntt == 1) return launch_fused<1, 1>(p, a, st);
         if (p.ntt == 2) return launch_fused<1, 2>(p, a, st);

@@ -36,7 +36,11 @@ def test_golden_exact_integer_sums(gpu):
 
 
 @pytest.mark.parametrize("N,F,T,npol", [(2, 2, 1, 1), (3, 6, 5, 1), (16, 8, 64, 1), (17, 4, 65, 1), (33, 10, 130, 2), (5, 1, 9, 1), (12, 7, 70, 1),
-                                        (64, 16, 256, 1), (64, 4, 128, 2), (40, 6, 200, 2), (100, 2, 70, 1)])
+                                        (64, 16, 256, 1), (64, 4, 128, 2), (40, 6, 200, 2), (100, 2, 70, 1),
+                                        # whole 128-byte input rows and <= 64 rows: the fused single-pass kernels (xengine_fused.hip), every
+                                        # row-tile count, one and two polarisations, direct and time-split (partial sums) forms
+                                        (64, 64, 64, 1), (20, 128, 96, 1), (5, 64, 32, 1), (33, 64, 256, 1), (48, 192, 128, 1), (64, 128, 512, 1),
+                                        (16, 32, 32, 2), (32, 64, 128, 2), (7, 96, 64, 2), (24, 32, 1024, 2)])
 def test_ichar_bit_exact_vs_oracle(gpu, oracle, N, F, T, npol):
     rng = np.random.default_rng(N * 1000 + T)
     x = rng.integers(-128, 128, size=T * N * F * npol * 2, dtype=np.int64).astype(np.int8)  # full range incl. -128
@@ -47,6 +51,33 @@ def test_ichar_bit_exact_vs_oracle(gpu, oracle, N, F, T, npol):
     assert np.array_equal(out, oracle.xengine_ichar(N, F, npol, T, x, exact=True))
     # and the reference's own float arithmetic agrees within the budget
     assert relerr(out, oracle.xengine_ichar(N, F, npol, T, x, exact=False)) <= TOL
+
+
+@pytest.mark.parametrize("tsplit", ["1", "4", None])
+def test_fused_full_range_extremes(gpu, oracle, monkeypatch, tsplit):
+    """Every sample (-128, -128) over the longest integration: re = 2 * 128^2 * 65536 = 2^31 wraps the int32 accumulator of a single
+    time range and must still come out exact; also the accumulate form on the fused path."""
+    if tsplit is None:
+        monkeypatch.delenv("MI355_XE_TSPLIT", raising=False)
+    else:
+        monkeypatch.setenv("MI355_XE_TSPLIT", tsplit)
+    N, F, T = 3, 64, 65536
+    x = np.full(T * N * F * 2, -128, np.int8)
+    blk = _xe(gpu, gpu.DTYPE_BYTE, 1, N, F, T)
+    out = np.empty(blk.get_output_buffer_size(), np.complex64)
+    blk.xcorrelate(x, out)
+    kd = 0.007874015748031496063
+    assert np.array_equal(out, np.full(out.shape, np.float32(2147483648.0 * kd * kd), np.complex64))
+    rng = np.random.default_rng(5)
+    N, F, T = 40, 64, 128
+    x = rng.integers(-128, 128, size=T * N * F * 2, dtype=np.int64).astype(np.int8)
+    blk = _xe(gpu, gpu.DTYPE_BYTE, 1, N, F, T)
+    out = np.empty(blk.get_output_buffer_size(), np.complex64)
+    blk.xcorrelate(x, out)
+    ref = oracle.xengine_ichar(N, F, 1, T, x, exact=True)
+    assert np.array_equal(out, ref)
+    blk.xcorrelate(x, out, True)
+    assert np.array_equal(out, ref + ref)
 
 
 def test_closed_form_cases(gpu):
