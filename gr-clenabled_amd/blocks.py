@@ -86,6 +86,12 @@ class _Block:
         check(self._L.mi355_ctx_synchronize(self._ctx), "mi355_ctx_synchronize")
 
 
+def _need(name, arr, items):
+    """work() contract: every buffer holds at least noutput_items items (the C ABI copies exactly that many)."""
+    if arr.size < items:
+        raise ValueError("%s holds %d items, the call needs %d" % (name, arr.size, items))
+
+
 class clMathOp(_Block):
     """clMathOp::make(idataType, openCLPlatformType, devSelector, platformId, devId,
     operatorType, setDebug=0)  -- include/clenabled/clMathOp.h:42"""
@@ -99,8 +105,12 @@ class clMathOp(_Block):
 
     def work(self, noutput_items, input_items, output_items):
         dt = _NP_OF[self.dtype]
+        if len(input_items) < 2 or len(output_items) < 1:
+            raise ValueError("clMathOp.work needs two inputs and one output")
         a, b = _host(input_items[0], dt), _host(input_items[1], dt)
         c = _host(output_items[0], dt, writable=True)
+        for name, arr in (("input 0", a), ("input 1", b), ("output", c)):
+            _need(name, arr, noutput_items)
         check(self._L.mi355_mathop_work(self._h, noutput_items, _hp(a), _hp(b), _hp(c)), "mi355_mathop_work")
         return noutput_items
 
@@ -135,6 +145,8 @@ class clMathConst(_Block):
         dt = _NP_OF[self.dtype]
         a = _host(input_items[0], dt)
         c = _host(output_items[0], dt, writable=True)
+        _need("input", a, noutput_items)
+        _need("output", c, noutput_items)
         check(self._L.mi355_mathconst_work(self._h, noutput_items, _hp(a), _hp(c)), "mi355_mathconst_work")
         return noutput_items
 
@@ -168,8 +180,13 @@ class clFFT(_Block):
 
     def work(self, noutput_items, input_items, output_items):
         dt = _NP_OF[self.dtype]
+        if len(input_items) < self.num_streams or len(output_items) < self.num_streams:
+            raise ValueError("clFFT.work needs %d input and output streams" % self.num_streams)
         ins = [_host(x, dt) for x in input_items[:self.num_streams]]
         outs = [_host(x, np.complex64, writable=True) for x in output_items[:self.num_streams]]
+        for i, (x, y) in enumerate(zip(ins, outs)):
+            _need("input %d" % i, x, noutput_items * self.fft_size)
+            _need("output %d" % i, y, noutput_items * self.fft_size)
         pi = (C.c_void_p * len(ins))(*[x.ctypes.data for x in ins])
         po = (C.c_void_p * len(outs))(*[x.ctypes.data for x in outs])
         check(self._L.mi355_fft_work(self._h, noutput_items, pi, po), "mi355_fft_work")
@@ -375,11 +392,24 @@ class clXEngine(_Block):
         acc = None if accumulator is None else _hp(_host(accumulator, np.complex64))
         check(self._L.mi355_xengine_submit_acquired(self._h, acc), "mi355_xengine_submit_acquired")
 
-    def xcorrelate_device(self, input_matrix, cross_correlation, accumulate=False):
+    def xcorrelate_device(self, input_matrix, cross_correlation, accumulate=False, stations_per_group=None):
+        """Device-resident xcorrelate.  stations_per_group: the input is the receive buffer of the multi-GPU corner turn,
+        [group][t][station in group][chan][pol] (gr-clenabled_amd/shard.py), read in place."""
+        if stations_per_group:
+            check(self._L.mi355_xengine_xcorrelate_grouped_dev(self._h, _dp(input_matrix), _dp(cross_correlation), 1 if accumulate else 0,
+                                                               int(stations_per_group), _torch_stream(self.device)),
+                  "mi355_xengine_xcorrelate_grouped_dev")
+            return self.get_output_buffer_size()
         check(self._L.mi355_xengine_xcorrelate_dev(self._h, _dp(input_matrix), _dp(cross_correlation),
                                                    1 if accumulate else 0, _torch_stream(self.device)),
               "mi355_xengine_xcorrelate_dev")
         return self.get_output_buffer_size()
+
+    def pack3d_device(self, dst, src, width_bytes, rows, nblocks, src_pitch, src_block_stride, dst_pitch, dst_block_stride):
+        """Strided device copy on this block's context (the send-side packing of the corner turn)."""
+        check(self._L.mi355_pack3d_dev(self._ctx, _dp(dst), _dp(src), int(width_bytes), int(rows), int(nblocks), int(src_pitch),
+                                       int(src_block_stride), int(dst_pitch), int(dst_block_stride), _torch_stream(self.device)),
+              "mi355_pack3d_dev")
 
     def gather(self, nframes, frame0, input_items, frame_buffer):
         """Host frame gather of work_processor (lib/clXEngine_impl.cc:987-1061)."""

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <mutex>
 #include <new>
 
@@ -91,6 +92,10 @@ static inline bool mi355_direct_ok(size_t max_buffer_bytes)
     static const bool off = getenv("MI355_NO_DIRECT") != nullptr;
     return !off && max_buffer_bytes <= kDirectBytes;
 }
+// Completion wait of such a call (one kernel of a few microseconds): poll the stream for a bounded time, then sleep on it.
+// The device's scheduling flags are left alone (a process-wide hipDeviceScheduleSpin would make every blocking wait of
+// every block in a thread-per-block flowgraph burn a core); MI355_SPIN_US sets the polling window, 0 = always sleep.
+hipError_t mi355_direct_sync(hipStream_t st);
 
 // Staging copy of the host path (caller's pageable buffer <-> pinned staging).  One thread moves ~13 GB/s, which bounded the
 // large host calls at 1.8 GS/s (PCIe would carry 3x that): copies of 2 MiB and more are split over a small persistent pool

@@ -221,7 +221,7 @@ extern "C" int mi355_elem_work(mi355_elem *h, size_t n, const void *in0, const v
         for (int i = 0; i < h->sh.nin; i++) mi355_copy(h->h_in[i], ins[i], items * h->sh.in_sz[i]);
         int rc = launch_elem(h, n, h->h_in[0], h->h_in[1], h->h_out[0], h->h_out[1], st);
         if (rc) return rc;
-        MI355_HIP(hipStreamSynchronize(st));
+        MI355_HIP(mi355_direct_sync(st));
         for (int i = 0; i < h->sh.nout; i++) mi355_copy(outs[i], h->h_out[i], n * h->sh.out_sz[i]);
         return MI355_OK;
     }

@@ -495,6 +495,12 @@ struct mi355_fft {
     float *d_ones = nullptr;                                        // all-ones window of size m
     void *d_wa = nullptr, *d_wb = nullptr;                          // work buffers, cap_frames * m complex each
     size_t cap_frames = 0;
+    // The two-kernel sizes (> 16384 points) and the unfused chirp-z path go through ONE workspace per handle.  Calls on
+    // different streams / threads are serialised on it: the lock covers the enqueue, ws_done orders the streams (the next
+    // user's stream waits for the previous user's kernels) and guards the re-allocation.
+    std::mutex ws_lock;
+    hipEvent_t ws_done = nullptr;
+    bool ws_used = false;
 };
 
 namespace {
@@ -636,6 +642,23 @@ int launch_chirpz_m(mi355_fft *h, const void *in, void *out, int nframes, hipStr
     return MI355_OK;
 }
 
+// workspace hand-over between streams: call with h->ws_lock held
+int ws_acquire(mi355_fft *h, hipStream_t st, bool realloc)
+{
+    if (!h->ws_done) MI355_HIP(hipEventCreateWithFlags(&h->ws_done, hipEventDisableTiming));
+    if (h->ws_used) {
+        if (realloc) MI355_HIP(hipEventSynchronize(h->ws_done));  // nobody may still be reading the buffers that are freed
+        else MI355_HIP(hipStreamWaitEvent(st, h->ws_done, 0));
+    }
+    return MI355_OK;
+}
+int ws_release(mi355_fft *h, hipStream_t st)
+{
+    MI355_HIP(hipEventRecord(h->ws_done, st));
+    h->ws_used = true;
+    return MI355_OK;
+}
+
 int launch_bluestein(mi355_fft *h, const void *in, void *out, int nframes, hipStream_t st)
 {
     const int N = h->n, M = h->m;
@@ -653,6 +676,11 @@ int launch_bluestein(mi355_fft *h, const void *in, void *out, int nframes, hipSt
     size_t chunk = (128u << 20) / ((size_t)M * 8);
     if (chunk < 1) chunk = 1;
     if (chunk > (size_t)nframes) chunk = (size_t)nframes;
+    std::lock_guard<std::mutex> ws_guard(h->ws_lock);
+    {
+        const int rc = ws_acquire(h, st, chunk > h->cap_frames);
+        if (rc) return rc;
+    }
     if (chunk > h->cap_frames) {
         MI355_HIP(hipStreamSynchronize(st));
         if (h->d_wa) (void)hipFree(h->d_wa);
@@ -681,7 +709,7 @@ int launch_bluestein(mi355_fft *h, const void *in, void *out, int nframes, hipSt
                            (const c32 *)h->d_post, N, M, tn, (h->sign < 0 && h->shift) ? len : 0);
         MI355_HIP(hipGetLastError());
     }
-    return MI355_OK;
+    return ws_release(h, st);
 }
 
 int launch_big(mi355_fft *h, const void *in, void *out, int nframes, hipStream_t st)
@@ -690,6 +718,11 @@ int launch_big(mi355_fft *h, const void *in, void *out, int nframes, hipStream_t
     size_t chunk = (256u << 20) / ((size_t)N * 8);  // workspace bounded to 256 MiB
     if (chunk < 1) chunk = 1;
     if (chunk > (size_t)nframes) chunk = (size_t)nframes;
+    std::lock_guard<std::mutex> ws_guard(h->ws_lock);
+    {
+        const int rc = ws_acquire(h, st, chunk > h->cap_frames);
+        if (rc) return rc;
+    }
     if (chunk > h->cap_frames) {
         MI355_HIP(hipStreamSynchronize(st));
         if (h->d_wa) (void)hipFree(h->d_wa);
@@ -720,7 +753,7 @@ int launch_big(mi355_fft *h, const void *in, void *out, int nframes, hipStream_t
 #undef COMB
         MI355_HIP(hipGetLastError());
     }
-    return MI355_OK;
+    return ws_release(h, st);
 }
 
 int launch_handle(mi355_fft *h, const void *in, void *out, int nvec, hipStream_t st)
@@ -904,6 +937,7 @@ extern "C" int mi355_fft_destroy(mi355_fft *h)
     if (h->d_tw) (void)hipFree(h->d_tw);
     for (void *p : {h->d_pre, h->d_post, h->d_bspec, h->d_twm_f, h->d_twm_i, (void *)h->d_ones, h->d_wa, h->d_wb})
         if (p) (void)hipFree(p);
+    if (h->ws_done) (void)hipEventDestroy(h->ws_done);
     delete h;
     return MI355_OK;
 }
@@ -945,7 +979,7 @@ extern "C" int mi355_fft_work(mi355_fft *h, int nvec, const void *const *in_stre
             mi355_copy(p.h_in[0][0], in_streams[s_i], (size_t)nvec * in_frame);
             rc = launch_handle(h, p.h_in[0][0], p.h_out[0], nvec, st);
             if (rc) return rc;
-            MI355_HIP(hipStreamSynchronize(st));
+            MI355_HIP(mi355_direct_sync(st));
             mi355_copy(out_streams[s_i], p.h_out[0], (size_t)nvec * out_frame);
         }
         return MI355_OK;

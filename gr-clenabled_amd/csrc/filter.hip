@@ -665,7 +665,7 @@ void free_dev(mi355_filter *h)
     h->d_H = h->d_twf = h->d_twi = nullptr;
 }
 
-int upload_taps(mi355_filter *h, const void *taps, int ntaps)
+int upload_taps_impl(mi355_filter *h, const void *taps, int ntaps)
 {
     MI355_REQUIRE(taps && ntaps >= 1, "taps must hold at least one tap");
     const int per = h->complex_taps ? 2 : 1;
@@ -748,6 +748,20 @@ int upload_taps(mi355_filter *h, const void *taps, int ntaps)
     return MI355_OK;
 }
 
+// A failure half way (out of memory while the tables are rebuilt) must not leave a handle whose sizes describe tables
+// that do not exist: the handle is marked empty and work() refuses with MI355_ERR_STATE until set_taps succeeds again.
+int upload_taps(mi355_filter *h, const void *taps, int ntaps)
+{
+    const int rc = upload_taps_impl(h, taps, ntaps);
+    if (rc != MI355_OK && rc != MI355_ERR_INVALID_ARG) {
+        free_dev(h);
+        h->ntaps = 0;
+        h->nf = 0;
+        h->mf_kk = 0;
+    }
+    return rc;
+}
+
 template <int NF, class G>
 int launch_ols_g(mi355_filter *h, size_t nout, const void *in, void *out, hipStream_t st)
 {
@@ -810,6 +824,10 @@ int launch_ols(mi355_filter *h, size_t nout, const void *in, void *out, hipStrea
 
 int launch_filter(mi355_filter *h, size_t nout, const void *in, void *out, hipStream_t st)
 {
+    if (h->ntaps < 1) {
+        mi355_set_error("the filter has no taps (the last set_taps failed)");
+        return MI355_ERR_STATE;
+    }
     if (nout == 0) return MI355_OK;
     if (!h->use_time && h->nf) {
         switch (h->nf) {
@@ -971,7 +989,7 @@ extern "C" int mi355_filter_work(mi355_filter *h, size_t noutput_items, const vo
         mi355_copy(p.h_in[0][0], pin, inb);
         rc = launch_filter(h, noutput_items, p.h_in[0][0], p.h_out[0], st);
         if (rc) return rc;
-        MI355_HIP(hipStreamSynchronize(st));
+        MI355_HIP(mi355_direct_sync(st));
         mi355_copy(pout, p.h_out[0], noutput_items * 8);
         return MI355_OK;
     }

@@ -317,7 +317,7 @@ extern "C" int mi355_mathop_work(mi355_mathop *h, size_t nitems, const void *a, 
         mi355_copy(p.h_in[0][1], pb, bytes);
         rc = dispatch2(h, nitems, p.h_in[0][0], p.h_in[0][1], p.h_out[0], st);
         if (rc) return rc;
-        MI355_HIP(hipStreamSynchronize(st));
+        MI355_HIP(mi355_direct_sync(st));
         mi355_copy(pc, p.h_out[0], bytes);
         return MI355_OK;
     }
@@ -435,7 +435,7 @@ extern "C" int mi355_mathconst_work(mi355_mathconst *h, size_t nitems, const voi
         mi355_copy(p.h_in[0][0], pa, bytes);
         rc = dispatch1(h, nitems, p.h_in[0][0], p.h_out[0], k, st);
         if (rc) return rc;
-        MI355_HIP(hipStreamSynchronize(st));
+        MI355_HIP(mi355_direct_sync(st));
         if (h->op != MI355_OP_EMPTY) mi355_copy(pc, p.h_out[0], bytes);
         return MI355_OK;
     }

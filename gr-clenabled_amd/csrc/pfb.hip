@@ -708,7 +708,7 @@ extern "C" int mi355_pfb_work(mi355_pfb *h, const void *in, void *out)
     if (mi355_direct_ok(inb > outb ? inb : outb)) {  // small call: the kernel works on the pinned staging itself (common.h)
         rc = launch_pfb(h, p.h_in[0][0], p.h_out[0], st);
         if (rc) return rc;
-        MI355_HIP(hipStreamSynchronize(st));
+        MI355_HIP(mi355_direct_sync(st));
         mi355_copy(out, p.h_out[0], outb);
         return MI355_OK;
     }

@@ -45,6 +45,20 @@ extern "C" int mi355_device_count(void)
     return n;
 }
 
+hipError_t mi355_direct_sync(hipStream_t st)
+{
+    static const int window_us = getenv("MI355_SPIN_US") ? atoi(getenv("MI355_SPIN_US")) : 200;
+    if (window_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q != hipErrorNotReady) return q;
+            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > window_us) break;
+        }
+    }
+    return hipStreamSynchronize(st);
+}
+
 extern "C" int mi355_ctx_create(int ocl_type, int dev_selector, int platform_id, int dev_id, int debug, mi355_ctx **out)
 {
     MI355_REQUIRE(out != nullptr, "out is NULL");
@@ -79,9 +93,9 @@ extern "C" int mi355_ctx_create(int ocl_type, int dev_selector, int platform_id,
     c->debug = debug;
     c->num_cus = prop.multiProcessorCount;
     hipError_t e = hipSetDevice(dev);
-    // work() is a latency path (one scheduler-sized buffer per call): let the host spin on completion instead of sleeping on
-    // an interrupt.  Fails harmlessly when the device is already active in this process (e.g. under PyTorch); MI355_NO_SPIN=1 skips it.
-    if (e == hipSuccess && !getenv("MI355_NO_SPIN")) {
+    // (The host does NOT switch the device to spin-wait scheduling: that flag is process wide.  Scheduler-sized calls poll
+    // their own stream for a bounded time instead, mi355_direct_sync; MI355_SPIN=1 restores the device-wide flag.)
+    if (e == hipSuccess && getenv("MI355_SPIN") && atoi(getenv("MI355_SPIN")) != 0) {
         (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
         (void)hipGetLastError();
     }
@@ -120,6 +134,51 @@ extern "C" int mi355_ctx_synchronize(mi355_ctx *ctx)
     MI355_REQUIRE(ctx != nullptr, "ctx is NULL");
     MI355_HIP(hipSetDevice(ctx->device));
     for (int i = 0; i < 2; i++) MI355_HIP(hipStreamSynchronize(ctx->stream[i]));
+    return MI355_OK;
+}
+
+namespace {
+// strided block copy: dst[b][r][0..width) = src[b][r][0..width) with independent row pitches and block strides
+template <typename V>
+__global__ __launch_bounds__(256) void k_pack3d(unsigned char *__restrict__ dst, const unsigned char *__restrict__ src, size_t wv, size_t rows,
+                                                size_t nblocks, size_t src_pitch, size_t src_block, size_t dst_pitch, size_t dst_block)
+{
+    const size_t total = nblocks * rows * wv;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t c = e % wv, rb = e / wv, r = rb % rows, b = rb / rows;
+        const V v = __builtin_nontemporal_load((const V *)(src + b * src_block + r * src_pitch) + c);
+        __builtin_nontemporal_store(v, (V *)(dst + b * dst_block + r * dst_pitch) + c);
+    }
+}
+}  // namespace
+
+// Device-side strided copy used around the X-engine's all-to-all corner turn (gr-clenabled_amd/shard.py): packs the channel
+// slice every peer gets into one contiguous send block, i.e. [t][station][peer][chan slice] -> [peer][t][station][chan slice].
+extern "C" int mi355_pack3d_dev(mi355_ctx *ctx, void *dst, const void *src, size_t width_bytes, size_t rows, size_t nblocks, size_t src_pitch,
+                                size_t src_block_stride, size_t dst_pitch, size_t dst_block_stride, void *stream)
+{
+    MI355_REQUIRE(ctx && dst && src, "NULL argument");
+    if (width_bytes == 0 || rows == 0 || nblocks == 0) return MI355_OK;
+    MI355_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = mi355_pick_stream(ctx, stream);
+    const uintptr_t all = reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src) | width_bytes | src_pitch | src_block_stride | dst_pitch |
+                          dst_block_stride;
+    const size_t vec = (all & 15u) == 0 ? 16 : (all & 3u) == 0 ? 4 : 1;
+    const size_t wv = width_bytes / vec, total = nblocks * rows * wv;
+    size_t blocks = (total + 255) / 256;
+    const size_t cap = (size_t)(ctx->num_cus > 0 ? ctx->num_cus : 256) * 32;
+    if (blocks > cap) blocks = cap;
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    if (vec == 16)
+        hipLaunchKernelGGL((k_pack3d<v4i_t>), dim3((unsigned)blocks), dim3(256), 0, st, (unsigned char *)dst, (const unsigned char *)src, wv, rows,
+                           nblocks, src_pitch, src_block_stride, dst_pitch, dst_block_stride);
+    else if (vec == 4)
+        hipLaunchKernelGGL((k_pack3d<int>), dim3((unsigned)blocks), dim3(256), 0, st, (unsigned char *)dst, (const unsigned char *)src, wv, rows,
+                           nblocks, src_pitch, src_block_stride, dst_pitch, dst_block_stride);
+    else
+        hipLaunchKernelGGL((k_pack3d<unsigned char>), dim3((unsigned)blocks), dim3(256), 0, st, (unsigned char *)dst, (const unsigned char *)src, wv,
+                           rows, nblocks, src_pitch, src_block_stride, dst_pitch, dst_block_stride);
+    MI355_HIP(hipGetLastError());
     return MI355_OK;
 }
 

@@ -781,7 +781,8 @@ __global__ __launch_bounds__(256) void k_xe_pad_rows(const unsigned short *__res
     }
 }
 
-int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipStream_t st, unsigned char *tiles, unsigned char *padbuf)
+int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipStream_t st, unsigned char *tiles, unsigned char *padbuf,
+              int stations_per_group = 0)
 {
     const XeGeo &g = h->g;
     if (h->pad) {
@@ -859,7 +860,11 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
     if (g.mode == 0 && (reinterpret_cast<uintptr_t>(in) & 15u) == 0) {
         const XeFusedPlan fp = mi355_xe_fused_plan(g.N, g.F, g.Fout, g.npol, g.T, h->ctx->num_cus);
         if (fp.ok && (fp.part_bytes == 0 || (tiles && fp.part_bytes <= h->tile_bytes)))
-            return mi355_xe_fused_launch(fp, in, out, tiles, g.N, g.F, g.Fout, g.T, 0.007874015748031496063, accumulate, st);
+            return mi355_xe_fused_launch(fp, in, out, tiles, g.N, g.F, g.Fout, g.T, 0.007874015748031496063, accumulate, st, stations_per_group);
+    }
+    if (stations_per_group > 0 && stations_per_group < g.N) {
+        mi355_set_error("antenna-group-major input needs the fused IChar path (<= 64 rows, whole 128-byte rows, integration %% 32 == 0)");
+        return MI355_ERR_UNSUPPORTED;
     }
     const bool fast_turn = row_bytes % 128 == 0 && (reinterpret_cast<uintptr_t>(in) & 15u) == 0 && !getenv("MI355_XE_SLOW_TURN");
     const int cpl = (g.mode == 1) ? 64 : 64 / g.npol;              // channels per 128-byte input line
@@ -986,6 +991,21 @@ extern "C" int mi355_xengine_create(mi355_ctx *ctx, int data_type, int npol, int
 
 extern "C" size_t mi355_xengine_input_bytes(const mi355_xengine *h) { return h ? h->in_bytes : 0; }
 extern "C" size_t mi355_xengine_output_items(const mi355_xengine *h) { return h ? h->out_items : 0; }
+
+// The same with the input as the blocks of an all-to-all corner turn: [group][t][station in group][chan][pol] (every group
+// = stations_per_group consecutive stations, one contiguous block per sending rank).  Only the fused IChar path reads this
+// in place; other geometries return MI355_ERR_UNSUPPORTED (re-lay the blocks out with mi355_pack3d_dev first).
+extern "C" int mi355_xengine_xcorrelate_grouped_dev(mi355_xengine *h, const void *in_dev, void *out_dev, int accumulate, int stations_per_group,
+                                                    void *stream)
+{
+    MI355_REQUIRE(h && in_dev && out_dev, "NULL argument");
+    MI355_REQUIRE(stations_per_group >= 1 && h->g.N % stations_per_group == 0, "stations_per_group must divide the number of inputs");
+    MI355_REQUIRE((reinterpret_cast<uintptr_t>(in_dev) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out_dev) & 7u) == 0,
+                  "device buffers must be 16-byte (input) / 8-byte (output) aligned");
+    MI355_REQUIRE(h->data_type == MI355_DTYPE_BYTE && !h->pad, "group-major input: IChar with an even channel count only");
+    MI355_HIP(hipSetDevice(h->ctx->device));
+    return launch_xe(h, in_dev, out_dev, accumulate, mi355_pick_stream(h->ctx, stream), h->d_tiles, h->d_pad, stations_per_group);
+}
 
 extern "C" int mi355_xengine_xcorrelate_dev(mi355_xengine *h, const void *in_dev, void *out_dev, int accumulate, void *stream)
 {

@@ -17,5 +17,7 @@ XeFusedPlan mi355_xe_fused_plan(int N, int F, int Fout, int npol, int T, int num
 
 // in: [t][station][chan][pol]{I,Q} int8 (16-byte aligned), out: [chan][baseline][pol^2] complex float.
 // part: workspace of plan.part_bytes (unused when tsplit == 1).  kd: 1/127.
+// stations_per_group (0 or N: the reference layout): the input is [group][t][station in group][chan][pol]{I,Q}, the blocks an
+// all-to-all corner turn delivers (gr-clenabled_amd/shard.py) -- read in place, no re-layout pass.
 int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void *part, int N, int F, int Fout, int T, double kd,
-                          int accumulate, hipStream_t st);
+                          int accumulate, hipStream_t st, int stations_per_group = 0);

@@ -33,6 +33,7 @@ struct FuArgs {
     v4i *part;
     c32 *out;
     int N, F, Fout, T;
+    int ng;     // stations per antenna group: input is [group][t][station in group][...] (ng == N: the reference layout)
     int nlines, tsplit, steps;  // 128-byte lines per input row; time ranges; K blocks (32 time steps) per time range
     int pinned, accumulate;
     int dbg;  // tuning aid (MI355_XE_DBG): 1 = no compute, 2 = no stores, 4 = no DMA
@@ -93,7 +94,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
     const unsigned lds0 = (unsigned)(size_t)lds;
 
     // ---- DMA of one 16-step stage: chunk = (time step, station half) = 32 stations x 32 B, 2 * NSH chunks per wave
-    const unsigned char *src_lane = a.in + (size_t)(lane >> 1) * row_bytes + (size_t)slice * 32 + (lane & 1) * 16;
+    // station s of time step t sits at ((s / ng) * T * ng + t * ng + s % ng) * row_bytes: the frames of antenna group s / ng
+    // are one contiguous block (what the all-to-all corner turn of shard.py delivers); ng == N is the reference's layout
+    const size_t t_stride = (size_t)a.ng * row_bytes;
+    const unsigned char *src_lane[NSH];
+#pragma unroll
+    for (int sh = 0; sh < NSH; sh++) {
+        const int s = sh * 32 + (lane >> 1);
+        src_lane[sh] = a.in + ((size_t)(s / a.ng) * a.T * a.ng + (size_t)(s % a.ng)) * row_bytes + (size_t)slice * 32 + (lane & 1) * 16;
+    }
     auto issue_stage = [&](int sigma) {
         const int slot = sigma & (kRing - 1), t0 = t_base + sigma * kStageT;
 #pragma unroll
@@ -101,7 +110,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
             const int idx = wave + kWaves * k, t16 = idx / NSH, sh = idx % NSH;
             const int s = sh * 32 + (lane >> 1);
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + slot * STAGE + idx * kChunk + (t16 >> 3) * 16);
-            if (s < a.N && !(a.dbg & 4)) dma16(src_lane + ((size_t)(t0 + t16) * a.N + sh * 32) * row_bytes, dst);
+            if (s < a.N && !(a.dbg & 4)) dma16(src_lane[sh] + (size_t)(t0 + t16) * t_stride, dst);
         }
     };
 
@@ -336,13 +345,14 @@ XeFusedPlan mi355_xe_fused_plan(int N, int F, int Fout, int npol, int T, int num
 }
 
 int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void *part, int N, int F, int Fout, int T, double kd, int accumulate,
-                          hipStream_t st)
+                          hipStream_t st, int stations_per_group)
 {
     FuArgs a;
     a.in = (const unsigned char *)in;
     a.part = (v4i *)part;
     a.out = (c32 *)out;
     a.N = N; a.F = F; a.Fout = Fout; a.T = T;
+    a.ng = (stations_per_group > 0 && stations_per_group < N) ? stations_per_group : N;
     a.nlines = p.units / 4;
     a.tsplit = p.tsplit;
     a.steps = T / (32 * p.tsplit);

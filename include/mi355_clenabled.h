@@ -104,6 +104,11 @@ int mi355_malloc(mi355_ctx *ctx, size_t bytes, void **dptr);
 int mi355_free(mi355_ctx *ctx, void *dptr);
 int mi355_memcpy_h2d(mi355_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int mi355_memcpy_d2h(mi355_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+/* Device-side strided block copy, dst[b][r][0..width) = src[b][r][0..width) for b < nblocks, r < rows, with independent
+ * row pitches and block strides (bytes).  Used to pack the per-peer channel slices of the X-engine's all-to-all corner
+ * turn (the reference has no multi-device path). */
+int mi355_pack3d_dev(mi355_ctx *ctx, void *dst_dev, const void *src_dev, size_t width_bytes, size_t rows, size_t nblocks,
+                     size_t src_pitch, size_t src_block_stride, size_t dst_pitch, size_t dst_block_stride, void *stream);
 
 /* ---------------------------------------------------------------------------
  * clMathOp: c = a (op) b.  Replaces clMathOp_impl::processOpenCL
@@ -208,6 +213,12 @@ size_t mi355_xengine_output_items(const mi355_xengine *h);
 /* accumulate=0: out = V ; accumulate=1: out += V (pipeline integration) */
 int mi355_xengine_xcorrelate(mi355_xengine *h, const void *in_host, void *out_host, int accumulate);
 int mi355_xengine_xcorrelate_dev(mi355_xengine *h, const void *in_dev, void *out_dev, int accumulate, void *stream);
+/* Multi-GPU form (no counterpart in the reference, which runs one X-engine on one device): the input is the
+ * receive buffer of the all-to-all corner turn, [group][t][station in group][chan][pol], stations_per_group stations per
+ * sending rank; it is read in place.  IChar geometries of the fused path only (<= 64 rows, rows of whole 128-byte lines,
+ * integration % 32 == 0), otherwise MI355_ERR_UNSUPPORTED. */
+int mi355_xengine_xcorrelate_grouped_dev(mi355_xengine *h, const void *in_dev, void *out_dev, int accumulate,
+                                         int stations_per_group, void *stream);
 /* Double-buffered asynchronous form of the host path: replaces the reference's pinned double
  * buffers + worker thread (lib/clXEngine_impl.cc:304-382 start(), :1234-1299 runThread()).
  * submit() copies the integration window into a pinned slot and enqueues H2D + kernels + D2H on that
