@@ -9,9 +9,15 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
   beyond the 256 MiB Infinity Cache) per GPU.  Independent block instances shard one
   per GPU with no data-path collective -> "scaling": "weak".
 Rank 0 prints ONE JSON line.  `value` = samples all ranks processed / max-over-ranks
-time.  `roofline` prices the FFT kernel against HBM (16 algorithmic bytes per complex
+time over EXACTLY K steps.  `sustained` repeats the same launch back to back for >= 2 s
+(median / min of the per-launch time over batches: clocks under a long load, not a 4 ms
+burst).  `roofline` prices the FFT kernel against HBM (16 algorithmic bytes per complex
 sample); `cpu_baseline` times the oracle's restatement of the reference's
-CPU path (clFFT_impl::testCPU) on one host core over a bounded sample.
+CPU path (clFFT_impl::testCPU) on ONE host core and on ALL of them (threads over frames)
+over a bounded sample, with the host's CPU model and core counts.  `blocks` carries the
+other hot-path blocks (device resident), the host-pointer work() calls (`*_hostpath`,
+PCIe inclusive, never `value`), BASELINE config 1 as SURVEY 8d states it, and the
+sharded X-engine (all-to-all corner turn overlapped with the correlation).
 """
 import argparse
 import json
@@ -98,22 +104,118 @@ def lowpass_taps(gain, fs, cutoff, tw, atten=53.0):
     return (t * (gain / t.sum())).astype(np.float32)
 
 
-def cpu_baseline_fft(o, window, budget_s=12.0):
-    """Oracle restatement of clFFT_impl::testCPU (window, float FFT, shift) on ONE core."""
+def host_cpu():
+    """CPU model string, logical and physical core counts of the box the baseline runs on."""
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                k, _, v = ln.partition(":")
+                k, v = k.strip(), v.strip()
+                if k == "model name" and model == "unknown":
+                    model = v
+                elif k == "physical id":
+                    pid = v
+                elif k == "core id":
+                    cid = v
+                elif not ln.strip():
+                    if cid is not None:
+                        phys.add((pid, cid))
+                    pid = cid = None
+    except OSError:
+        pass
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None  # a container may hold fewer CPUs than it can see
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = fh.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp_:
+                q, per = float(fq.read()), float(fp_.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota:
+        usable = max(1, min(usable, int(quota + 0.5)))
+    return {"cpu_model": model, "cores_total": os.cpu_count() or 1, "cores_physical": len(phys) or None, "cores_usable": usable,
+            "cgroup_cpu_quota": quota}
+
+
+def cpu_baseline_fft(o, window, budget_s=8.0, budget_all_s=4.0):
+    """Oracle restatement of clFFT_impl::testCPU (window, float FFT, shift): ONE core (the reference's default, nthreads = 1,
+    include/clenabled/clFilter.h:53), then all usable cores with the frames split over threads (ctypes releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
     rng = np.random.default_rng(1234)
     probe = 64
     x = (rng.standard_normal(probe * FFT_N) + 1j * rng.standard_normal(probe * FFT_N)).astype(np.complex64)
+    L = o.lib()
+
+    def run(xin, yout):  # the C entry itself with caller-owned buffers: no allocation (and no page faults) inside the timed loops
+        rc = L.oracle_fft_block(FFT_N, 1, window.ctypes.data, 1, o.DTYPE_COMPLEX, probe, xin.ctypes.data, yout.ctypes.data, 0)
+        assert rc == 0
+
+    y = np.empty_like(x)
+    run(x, y)
+    assert np.array_equal(y, o.fft_block(FFT_N, True, window, True, o.DTYPE_COMPLEX, x))
     t0 = time.perf_counter()
-    o.fft_block(FFT_N, True, window, True, o.DTYPE_COMPLEX, x)
-    per_frame = (time.perf_counter() - t0) / probe
-    frames = int(max(probe, min(200000, budget_s / per_frame)))
-    reps = max(1, frames // probe)
+    run(x, y)
+    per_call = time.perf_counter() - t0
+    reps = max(1, int(budget_s / per_call))
     t0 = time.perf_counter()
     for _ in range(reps):
-        o.fft_block(FFT_N, True, window, True, o.DTYPE_COMPLEX, x)
+        run(x, y)
     dt = time.perf_counter() - t0
-    return {"value": round(reps * probe * FFT_N / dt / 1e6, 2), "unit": "MSamples/s", "cores": 1, "kind": "port",
-            "sample": "%d frames of %d-pt complex FFT (window+shift), oracle fft_block f32, %.1f s" % (reps * probe, FFT_N, dt)}
+    host = host_cpu()
+    nthr = max(1, host["cores_usable"])
+    xs = [x.copy() for _ in range(nthr)]
+    ys = [np.empty_like(x) for _ in range(nthr)]
+    for k in range(nthr):
+        ys[k][:] = 0  # touch the pages
+    done = [0] * nthr
+
+    budget = [0.5]
+
+    def worker(k):  # time-bounded: every thread transforms its own 64-frame buffer until the deadline
+        stop = time.perf_counter() + budget[0]
+        while time.perf_counter() < stop:
+            run(xs[k], ys[k])
+            done[k] += probe
+
+    with ThreadPoolExecutor(nthr) as ex:
+        list(ex.map(worker, range(nthr)))  # warm-up round: threads started, clocks up
+        done[:] = [0] * nthr
+        budget[0] = budget_all_s
+        t1 = time.perf_counter()
+        list(ex.map(worker, range(nthr)))
+        dta = time.perf_counter() - t1
+    frames_all = sum(done)
+    d = {"value": round(reps * probe * FFT_N / dt / 1e6, 2), "unit": "MSamples/s", "cores": 1, "kind": "port",
+         "sample": "%d frames of %d-pt complex FFT (window+shift), oracle fft_block f32, %.1f s" % (reps * probe, FFT_N, dt),
+         "all_cores": {"value": round(frames_all * FFT_N / dta / 1e6, 2), "unit": "MSamples/s", "cores": nthr,
+                       "sample": "%d threads, %d frames in total, %.1f s (frames split over threads)" % (nthr, frames_all, dta)}}
+    d.update(host)
+    return d
+
+
+def config1_testcpu(o):
+    """BASELINE configs[0] exactly as SURVEY 8d states it: clMathOp complex multiply, 8192-sample buffers of (1.0, 0.5),
+    the reference CLI's loop -- 1 warm-up + 200 timed testCPU iterations (lib/test_clenabled.cc:1596-1650), one core."""
+    n = 8192
+    a = np.full(n, 1.0 + 0.5j, np.complex64)
+    b = a.copy()
+    c = o.mathop(o.DTYPE_COMPLEX, o.OP_MULTIPLY, a, b)
+    ok = bool(np.all(c == np.complex64(0.75 + 1.0j)))
+    t0 = time.perf_counter()
+    for _ in range(200):
+        o.mathop(o.DTYPE_COMPLEX, o.OP_MULTIPLY, a, b)
+    dt = (time.perf_counter() - t0) / 200
+    return {"us_per_call": round(dt * 1e6, 2), "MSamples_per_s": round(n / dt / 1e6, 1), "iterations": 200, "items": n,
+            "result_is_0.75+1.0j": ok, "kind": "port (oracle mathop through ctypes; the call overhead is included)"}
 
 
 def cpu_extras(o, o_taps):
@@ -146,6 +248,119 @@ def cpu_extras(o, o_taps):
     x8 = rng.integers(-127, 128, size=T * N * F * 2, dtype=np.int64).astype(np.int8)
     out["clXEngine_64ant_1024ch_1024t_ichar"] = timed(lambda: o.xengine_ichar(N, F, 1, T, x8, exact=False), N * F * T)  # kernel text restated
     return out
+
+
+def sustained(fn, samples_per_launch, min_s=2.0, batch=64):
+    """>= min_s of back-to-back launches in batches of `batch`, one event pair per batch (events between single launches cost
+    7 % of the rate): whole-leg rate, median and min of the per-launch time over the batches."""
+    import torch
+    torch.cuda.synchronize()
+    evs = []
+    t0 = time.perf_counter()
+    launches = 0
+    while True:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(batch):
+            fn()
+        b.record()
+        evs.append((a, b))
+        launches += batch
+        if len(evs) % 8 == 0:           # bound the queue depth: wait for the batch issued eight batches ago
+            evs[-8][1].synchronize()
+            if time.perf_counter() - t0 >= min_s:
+                break
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    per = sorted(a.elapsed_time(b) * 1e3 / batch for a, b in evs)  # us per launch
+    return {"seconds": round(wall, 2), "launches": launches, "MSamples_per_s": round(launches * samples_per_launch / wall / 1e6, 1),
+            "us_per_launch_median": round(per[len(per) // 2], 2), "us_per_launch_min": round(per[0], 2),
+            "us_per_launch_max": round(per[-1], 2),
+            "hbm_frac_median": round(samples_per_launch * BYTES_PER_SAMPLE / (per[len(per) // 2] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+
+
+def hostpath_blocks(pkg, o_taps, dev):
+    """Host-pointer work() calls at the reference's call sizes (what the GNU Radio scheduler hands a block): pageable numpy
+    buffers in, pageable out, PCIe both ways, blocking like the reference's enqueueReadBuffer.  Secondary, never `value`."""
+    rng = np.random.default_rng(11)
+    args = (1, 2, 0, dev)
+    out = {}
+
+    def lat(fn, iters=200, warm=20):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for _ in range(iters // 5):
+                fn()
+            ts.append((time.perf_counter() - t0) / (iters // 5))
+        ts.sort()
+        return ts[len(ts) // 2], ts[0]
+
+    def entry_(n, med, mn):
+        return {"us_per_call_median": round(med * 1e6, 1), "us_per_call_min": round(mn * 1e6, 1), "items_per_call": n,
+                "MSamples_per_s": round(n / med / 1e6, 1)}
+
+    def crandn(n):
+        return (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+
+    n = 8192
+    a, b = crandn(n), crandn(n)
+    c = np.empty_like(a)
+    mul = pkg.clMathOp(pkg.DTYPE_COMPLEX, *args, pkg.MATHOP_MULTIPLY)
+    out["clMathOp_8192_hostpath"] = entry_(n, *lat(lambda: mul.work(n, [a, b], [c])))
+    x = crandn(4096)
+    y = np.empty_like(x)
+    fft = pkg.clFFT(4096, pkg.CLFFT_FORWARD, np.blackman(4096).astype(np.float32), pkg.DTYPE_COMPLEX, *args, 0, 1, True)
+    out["clFFT_4096_1vector_hostpath"] = entry_(4096, *lat(lambda: fft.work(1, [x], [y])))
+    n = 32768
+    xf = crandn(n + 64)
+    yf = np.empty(n, np.complex64)
+    flt = pkg.clFilter(*args, 1, o_taps[0], 1, 0, False)
+    out["clFilter_fft_65taps_32768_hostpath"] = entry_(n, *lat(lambda: flt.work(n, [xf], [yf])))
+    buf = 65536
+    pfb = pkg.clPolyphaseChannelizer(*args, o_taps[1], buf, 64, 64, list(range(64)))
+    xp = crandn(pfb.ninput())
+    yp = np.empty(pfb.noutput(), np.complex64)
+    out["clPolyphaseChannelizer_64x32_buf65536_hostpath"] = entry_(buf, *lat(lambda: pfb.general_work(buf, None, [xp], [yp]), iters=100))
+    # large streaming call: pinned double-buffered chunks, H2D of chunk c+1 under the kernel / D2H of chunk c
+    n = 1 << 24
+    xl = crandn(n)
+    yl = np.empty_like(xl)
+    med, mn = lat(lambda: fft.work(n // 4096, [xl], [yl]), iters=5, warm=1)
+    out["clFFT_4096_2p24_samples_hostpath"] = entry_(n, med, mn)
+    # X-engine: whole integration windows through the double-buffered submit()/wait() pipeline (host copy into the pinned
+    # slot + H2D + correlation + D2H; the frame gather of general_work() is the C++ CLI's --xengine-e2e figure, DESIGN 7)
+    N, F, T = 64, 1024, 1024
+    xe = pkg.clXEngine(*args, False, pkg.DTYPE_BYTE, 1, N, 1, 0, F, T, [])
+    xi = rng.integers(-127, 128, size=T * N * F * 2, dtype=np.int64).astype(np.int8)
+    vis = np.empty(xe.get_output_buffer_size(), np.complex64)
+    xe.xcorrelate(xi, vis)
+    k = 6
+    t0 = time.perf_counter()
+    xe.submit(xi)
+    for _ in range(k - 1):
+        xe.submit(xi)
+        xe.wait(vis)
+    xe.wait(vis)
+    dt = (time.perf_counter() - t0) / k
+    out["clXEngine_64ant_1024ch_1024t_ichar_hostpath"] = {"us_per_integration": round(dt * 1e6, 1), "integrations": k,
+                                                          "total_input_MSamples_per_s": round(N * F * T / dt / 1e6, 1),
+                                                          "input_Gbit_per_s": round(N * F * T * 16 / dt / 1e9, 1)}
+    return out
+
+
+def gather_floats(value, world):
+    """Every rank's float, in rank order (per-GPU lines of the replica-sharded blocks)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or world == 1:
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device="cuda")
+    outs = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(outs, t)
+    return [float(o.item()) for o in outs]
 
 
 def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank):
@@ -206,6 +421,8 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank):
         xi = a[:pfb.ninput()]
         yo = c[:pfb.noutput()]
         out[key] = rate(lambda: pfb.work_device([xi], [yo]), buf, 16)
+        # BASELINE configs[3] is "8 independent instances, 1 per GPU": every rank's own rate, no collective in the data path
+        out[key]["per_gpu_MSamples_per_s"] = [round(v, 1) for v in gather_floats(out[key]["MSamples_per_s"], world)]
     # frequency-domain cross-correlator, 4 time-series inputs of 1024-point vectors (reference + 3):
     # algorithmic bytes per input sample = 8 read + 4 written per non-reference input
     xn, xin = 1024, 4
@@ -252,28 +469,40 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank):
 
 
 def sharded_xengine(pkg, dev, steps, world, rank):
-    """BASELINE configs[4] sharded the way SURVEY 8e describes: every rank ingests its antenna group, an all-to-all corner
+    """BASELINE configs[4] sharded the way SURVEY 8e describes: every rank ingests its antenna group, ONE all-to-all corner
     turn (RCCL over xGMI, gr-clenabled_amd/shard.py) hands every rank its channel slice of all antennas, then the local
-    correlation.  Runs AFTER the headline line is printed (it is the only collective in the data path) and reports on stderr."""
+    correlation.  The send blocks are packed by one strided device copy, the receive buffer is read in place by the fused
+    kernel (stations_per_group), and the exchange of integration i+1 runs on a side stream under the correlation of i."""
     import torch
     N, F, T = 64, 1024, 1024
-    Fw = F // world
+    Fw, Ng = F // world, N // world
     g = torch.Generator(device="cuda").manual_seed(4242 + rank)
     xe = pkg.clXEngine(1, 2, 0, dev, False, pkg.DTYPE_BYTE, 1, N, 1, 0, Fw, T, [])
     vis = torch.zeros(xe.get_output_buffer_size(), 2, device="cuda")
-    ctn = pkg.shard.XEngineCornerTurn(N, F, T, 1)
-    loc = torch.randint(-127, 128, ctn.local_shape(), dtype=torch.int8, device="cuda", generator=g)
+    ctn = pkg.shard.XEngineCornerTurn(N, F, T, 1, block=xe)
+    loc = [torch.randint(-127, 128, ctn.local_shape(), dtype=torch.int8, device="cuda", generator=g) for _ in range(2)]
 
-    def sharded():
-        slab = ctn.exchange(loc)
-        xe.xcorrelate_device(slab, vis)
+    def run(k):
+        h = ctn.start(loc[0], 0)
+        for i in range(k):
+            nxt = ctn.start(loc[(i + 1) & 1], (i + 1) & 1) if i + 1 < k else None
+            recv = ctn.finish(h)
+            xe.xcorrelate_device(recv, vis, stations_per_group=Ng)
+            h = nxt
 
-    wall, _ = time_steps(sharded, steps, 2, world)
+    run(2)
+    barrier(world)
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    barrier(world)
     wall = max_over_ranks(wall, world)
     dt = wall / steps
     return {"us_per_integration": round(dt * 1e6, 1), "total_input_MSamples_per_s": round(N * F * T / dt / 1e6, 1),
-            "channels_per_rank": Fw, "antennas_per_rank_ingest": N // world,
-            "alltoall_bytes_sent_per_rank": int(loc.numel() * (world - 1) // world)}
+            "integrations": steps, "n_gpus": world, "channels_per_rank": Fw, "antennas_per_rank_ingest": Ng,
+            "alltoall_bytes_sent_per_rank": int(loc[0].numel() * (world - 1) // world),
+            "overlap": "exchange(i+1) on a side stream under correlate(i); receive buffer read in place"}
 
 
 def main():
@@ -283,6 +512,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary per-block lines")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s back-to-back leg")
+    ap.add_argument("--sustain-s", type=float, default=2.0)
     a = ap.parse_args()
 
     import torch
@@ -308,6 +539,11 @@ def main():
     kernel_s = ev / a.steps  # one launch per step: HIP-event time per launch on the launch stream
     achieved = samples_per_step * BYTES_PER_SAMPLE / kernel_s / 1e9
 
+    sus = None
+    if not a.no_sustained:
+        sus = sustained(step, samples_per_step, a.sustain_s)
+        sus["MSamples_per_s"] = round(sus["MSamples_per_s"], 1)
+
     extras = {}
     if not a.no_extra:
         # fixture taps: firdes.low_pass(1,10e6,1e6,372e3) = 65 taps; low_pass(1,64,.5,.0753)+[0] = 2048 taps.
@@ -319,9 +555,23 @@ def main():
                                   local, max(5, a.steps // 5), 2, world, rank)
         except Exception as exc:  # noqa: BLE001
             extras = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    if not a.no_extra and isinstance(extras, dict):
+        # the only data-path collective of the hot path, INSIDE the JSON line (world 1: the same pipeline, no peers)
+        try:
+            extras["clXEngine_sharded"] = sharded_xengine(pkg, local, max(5, a.steps // 5), world, rank)
+        except Exception as exc:  # noqa: BLE001
+            extras["clXEngine_sharded"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        if rank == 0 and world == 1:
+            try:
+                extras.update(hostpath_blocks(pkg, (lowpass_taps(1.0, 10e6, 1e6, 372000.0),
+                                                    np.concatenate([lowpass_taps(1.0, 64.0, 0.5, 0.0753), [0.0]]).astype(np.float32)), local))
+            except Exception as exc:  # noqa: BLE001
+                extras["hostpath_error"] = "%s: %s" % (type(exc).__name__, exc)
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu:
         cpu = cpu_baseline_fft(entry.load_oracle(), window)
+        if isinstance(extras, dict):
+            extras["config1_clMathOp_testCPU_8192"] = config1_testcpu(entry.load_oracle())
         if extras:
             taps_pair = (lowpass_taps(1.0, 10e6, 1e6, 372000.0), np.concatenate([lowpass_taps(1.0, 64.0, 0.5, 0.0753), [0.0]]).astype(np.float32))
             for k, v in cpu_extras(entry.load_oracle(), taps_pair).items():
@@ -353,6 +603,7 @@ def main():
                                    "%d frames/step/GPU device-resident (1 GiB in+out)" % FRAMES_PER_STEP,
                        "fft_size": FFT_N, "frames_per_step": FRAMES_PER_STEP, "parallelism": "replica-per-gpu x%d" % world},
             "per_gpu_MSamples_per_s": round(value / world, 1),
+            "sustained": sus,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": (pmc or {}).get("source"),
@@ -362,13 +613,6 @@ def main():
             "blocks": extras,
         }
         print(json.dumps(line), flush=True)
-    if world > 1 and not a.no_extra:
-        try:
-            r = sharded_xengine(pkg, local, max(5, a.steps // 5), world, rank)
-            if rank == 0:
-                print("sharded X-engine (all-to-all corner turn + correlate): " + json.dumps(r), file=sys.stderr, flush=True)
-        except Exception as exc:  # noqa: BLE001
-            print("sharded X-engine failed on rank %d: %s: %s" % (rank, type(exc).__name__, exc), file=sys.stderr, flush=True)
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()

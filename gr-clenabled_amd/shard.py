@@ -58,13 +58,18 @@ class XEngineCornerTurn:
     """All-to-all of antenna-group frames into per-rank channel slabs.
 
     Rank g holds its group's integration window in the reference's frame layout
-    [T][Ng][F][npol][ncomp] (lib/clXEngine_impl.cc:987-1061 with num_inputs = Ng); after
-    exchange() every rank holds [T][N][F/W][npol][ncomp] -- the same layout with all N antennas
-    and its own F/W channels -- ready for clXEngine(num_inputs=N, num_channels=F/W).xcorrelate().
+    [T][Ng][F][npol][ncomp] (lib/clXEngine_impl.cc:987-1061 with num_inputs = Ng).  The send buffer is
+    [peer][T][Ng][F/W].. (block r = my frames restricted to rank r's channels), packed by ONE strided device copy
+    (mi355_pack3d_dev) straight from the frame buffer; the receive buffer is [group][T][Ng][F/W].. and is what
+    clXEngine.xcorrelate_device(..., stations_per_group=Ng) reads IN PLACE -- no re-layout pass on either side.
     Per rank and integration this moves (W-1)/W of its frame buffer once over xGMI.
+
+    Two buffer pairs and a side stream: start(i+1) packs and exchanges the next integration while the caller's
+    stream correlates integration i.  exchange() is the blocking one-shot form (and, for CPU tensors
+    under gloo -- the world-size-2 tests -- the packing is the same index arithmetic done with torch views).
     """
 
-    def __init__(self, num_inputs, num_channels, integration, npol, ncomp=2, group=None):
+    def __init__(self, num_inputs, num_channels, integration, npol, ncomp=2, group=None, block=None):
         import torch.distributed as dist
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -74,26 +79,85 @@ class XEngineCornerTurn:
         self.slices = channel_slices(num_channels, self.world)
         self.Ng = num_inputs // self.world
         self.Fw = num_channels // self.world
+        self.block = block      # any block of this rank's context (its pack3d_device runs the packing kernel)
+        self._bufs = {}
+        self._side = None
 
     def local_shape(self):
         return (self.T, self.Ng, self.F, self.npol, self.ncomp)
 
+    def grouped_shape(self):
+        """Receive buffer: [group][T][Ng][F/W][npol][ncomp]."""
+        return (self.world, self.T, self.Ng, self.Fw, self.npol, self.ncomp)
+
     def slab_shape(self):
         return (self.T, self.N, self.Fw, self.npol, self.ncomp)
 
-    def exchange(self, local_frames):
+    # ---- packing -------------------------------------------------------------------------------------------
+    def pack(self, local_frames, send):
+        """send[r] = local_frames[:, :, rank r's channels] for every peer r."""
+        x = local_frames.reshape(self.local_shape())
+        esz = x.element_size() * self.npol * self.ncomp
+        if x.is_cuda:
+            if self.block is None:
+                raise RuntimeError("XEngineCornerTurn on GPU tensors needs block= (a gr-clenabled block of this rank) for the packing kernel")
+            rows = self.T * self.Ng
+            self.block.pack3d_device(send, x, self.Fw * esz, rows, self.world, self.F * esz, self.Fw * esz, self.Fw * esz, rows * self.Fw * esz)
+        else:  # gloo / CPU tensors (tests/test_multi_gpu_cpu.py): same index arithmetic through a strided view
+            send.reshape(self.world, self.T, self.Ng, self.Fw, self.npol, self.ncomp).copy_(
+                x.reshape(self.T, self.Ng, self.world, self.Fw, self.npol, self.ncomp).permute(2, 0, 1, 3, 4, 5))
+        return send
+
+    def to_slab(self, grouped):
+        """[group][T][Ng][Fw].. -> the reference layout [T][N][Fw].. (a copy; only the parity tests and non-fused geometries need it)."""
+        return grouped.reshape(self.grouped_shape()).permute(1, 0, 2, 3, 4, 5).reshape(self.slab_shape()).contiguous()
+
+    def _buffers(self, like, slot):
+        import torch
+        key = (slot, like.device, like.dtype)
+        if key not in self._bufs:
+            n = self.T * self.Ng * self.F * self.npol * self.ncomp
+            self._bufs[key] = (torch.empty(n, dtype=like.dtype, device=like.device), torch.empty(n, dtype=like.dtype, device=like.device))
+        return self._bufs[key]
+
+    # ---- overlapped form -----------------------------------------------------------------------------------
+    def start(self, local_frames, slot=0):
+        """Enqueue pack + all-to-all of one integration window (on the side stream for GPU tensors); returns a handle for finish()."""
         import torch
         import torch.distributed as dist
-        x = local_frames.reshape(self.local_shape())
         if self.world == 1:
-            return x.reshape(self.slab_shape()).contiguous()
-        W = self.world
-        # send block r = my group's frames restricted to rank r's channels
-        send = x.reshape(self.T, self.Ng, W, self.Fw, self.npol, self.ncomp).permute(2, 0, 1, 3, 4, 5).contiguous()
-        recv = torch.empty_like(send)  # block g = group g's frames restricted to my channels
-        dist.all_to_all_single(recv, send, group=self.group)
-        # [g][T][Ng][Fw].. -> [T][g*Ng + s][Fw]..
-        return recv.permute(1, 0, 2, 3, 4, 5).reshape(self.slab_shape()).contiguous()
+            return (None, local_frames, None)
+        send, recv = self._buffers(local_frames, slot)
+        if local_frames.is_cuda:
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            cur = torch.cuda.current_stream()
+            self._side.wait_stream(cur)  # the frames were produced on, and the slot's buffers last read by, the caller's stream
+            with torch.cuda.stream(self._side):
+                self.pack(local_frames, send)
+                work = dist.all_to_all_single(recv, send, group=self.group, async_op=True)
+            return (work, recv, self._side)
+        self.pack(local_frames, send)
+        work = dist.all_to_all_single(recv, send, group=self.group, async_op=True)
+        return (work, recv, None)
+
+    def finish(self, handle):
+        """The caller's stream waits for the exchange; returns the group-major receive buffer (flat)."""
+        import torch
+        work, recv, side = handle
+        if work is not None:
+            work.wait()
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        return recv
+
+    # ---- blocking one-shot forms ---------------------------------------------------------------------------
+    def exchange_grouped(self, local_frames):
+        return self.finish(self.start(local_frames, 0))
+
+    def exchange(self, local_frames):
+        """Reference-layout slab [T][N][F/W].. of this rank (one extra copy; the overlapped in-place form is start/finish)."""
+        return self.to_slab(self.exchange_grouped(local_frames))
 
     def output_slice(self, rank=None):
         """(first, last) channel of the rank's rows in the full [F][baseline][pol^2] result."""

@@ -60,6 +60,18 @@ WORKER = textwrap.dedent('''
     f0, f1 = ct.output_slice()
     assert slab.shape == (T, N, F // world, npol, 2)
     assert np.array_equal(slab, full[:, :, f0:f1])       # bit exact: pure data movement
+    # overlapped form: two integrations in flight on alternating buffer slots; the group-major receive buffer
+    # [group][T][Ng][F/W].. is what the GPU kernel reads in place (stations_per_group = Ng)
+    full2 = np.ascontiguousarray(full[::-1])
+    local2 = torch.from_numpy(np.ascontiguousarray(full2[:, g0:g1]))
+    h0 = ct.start(local, 0)
+    h1 = ct.start(local2, 1)
+    r0 = ct.finish(h0).numpy().reshape(ct.grouped_shape()).copy()
+    r1 = ct.finish(h1).numpy().reshape(ct.grouped_shape())
+    for gi, (a0, a1) in enumerate(ct.groups):
+        assert np.array_equal(r0[gi], full[:, a0:a1, f0:f1])
+        assert np.array_equal(r1[gi], full2[:, a0:a1, f0:f1])
+    assert np.array_equal(ct.to_slab(torch.from_numpy(r0)).numpy(), slab)
     # correlating the slab == the rank's channel rows of the full result
     ref = o.xengine_ichar(N, F, npol, T, full.reshape(-1), exact=True).reshape(F, -1)
     got = o.xengine_ichar(N, F // world, npol, T, slab.reshape(-1), exact=True).reshape(F // world, -1)

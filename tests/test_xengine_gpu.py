@@ -257,3 +257,38 @@ def test_zero_copy_acquire_submit(gpu, oracle):
         assert np.array_equal(g, r)
     with pytest.raises(gpu.Mi355Error):
         blk.submit_acquired()          # nothing acquired
+
+
+@pytest.mark.parametrize("N,F,T,npol,W", [(64, 128, 256, 1, 8), (64, 256, 128, 1, 2), (32, 64, 64, 2, 4), (16, 64, 96, 1, 4)])
+def test_group_major_input_read_in_place(gpu, oracle, N, F, T, npol, W):
+    """Multi-GPU corner turn (shard.py): the all-to-all receive buffer [group][t][station in group][chan][pol] goes to the kernel
+    as it is.  Bit-exact against the reference layout and the oracle; the send-side packing kernel against the index arithmetic."""
+    import torch
+    rng = np.random.default_rng(N + W)
+    full = rng.integers(-128, 128, size=(T, N, F, npol, 2), dtype=np.int64).astype(np.int8)
+    Ng = N // W
+    grouped = np.ascontiguousarray(full.reshape(T, W, Ng, F, npol, 2).transpose(1, 0, 2, 3, 4, 5))
+    blk = _xe(gpu, gpu.DTYPE_BYTE, npol, N, F, T)
+    ref = oracle.xengine_ichar(N, F, npol, T, full.reshape(-1), exact=True)
+    xg = torch.from_numpy(grouped).cuda()
+    out = torch.zeros(blk.get_output_buffer_size(), 2, device="cuda")
+    blk.xcorrelate_device(xg, out, stations_per_group=Ng)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.complex64).reshape(-1), ref)
+    # send side: [t][station][peer][chan slice] -> [peer][t][station][chan slice]
+    x = torch.from_numpy(full).cuda()
+    send = torch.empty_like(x)
+    esz, Fw = npol * 2, F // W
+    blk.pack3d_device(send, x, Fw * esz, T * N, W, F * esz, Fw * esz, Fw * esz, T * N * Fw * esz)
+    torch.cuda.synchronize()
+    want = full.reshape(T, N, W, Fw, npol, 2).transpose(2, 0, 1, 3, 4, 5)
+    assert np.array_equal(send.cpu().numpy().reshape(W, T, N, Fw, npol, 2), want)
+
+
+def test_group_major_input_refused_outside_the_fused_path(gpu):
+    import torch
+    blk = _xe(gpu, gpu.DTYPE_BYTE, 1, 8, 16, 32)  # 32-byte rows: not the fused path
+    x = torch.zeros(32 * 8 * 16 * 2, dtype=torch.int8, device="cuda")
+    out = torch.zeros(blk.get_output_buffer_size(), 2, device="cuda")
+    with pytest.raises(gpu.Mi355Error):
+        blk.xcorrelate_device(x, out, stations_per_group=4)
