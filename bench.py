@@ -421,6 +421,28 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank):
         xi = a[:pfb.ninput()]
         yo = c[:pfb.noutput()]
         out[key] = rate(lambda: pfb.work_device([xi], [yo]), buf, 16)
+        if buf == 65536:
+            # The eager figure above is the HOST's launch rate (python + ctypes + hipLaunchKernel per 65536-item call), not the
+            # device's.  Device side: the same launch replayed 256 x from a HIP graph; and what general_work() does when the
+            # scheduler offers several output multiples -- nbuf buffers of the stream in ONE launch (work_device(nbuf=8)).
+            try:
+                gr_ = torch.cuda.CUDAGraph()
+                side = torch.cuda.Stream()
+                with torch.cuda.stream(side):
+                    with torch.cuda.graph(gr_, stream=side):
+                        for _ in range(256):
+                            pfb.work_device([xi], [yo])
+                torch.cuda.synchronize()
+                _, evg = time_steps(gr_.replay, max(5, steps), 2, world)
+                out[key]["us_per_launch_graph_replay"] = round(evg / max(5, steps) / 256 * 1e6, 2)
+            except Exception as exc:  # noqa: BLE001
+                out[key]["graph_replay_error"] = "%s: %s" % (type(exc).__name__, exc)
+            nb = 8
+            xb = a[:nb * buf + 2048 - 64]
+            yb = c[:nb * buf]
+            _, evb = time_steps(lambda: pfb.work_device([xb], [yb], nbuf=nb), steps, warmup, world)
+            out[key]["batched_x8_us_per_buffer"] = round(evb / steps / nb * 1e6, 2)
+            out[key]["batched_x8_MSamples_per_s"] = round(nb * buf * steps / evb / 1e6, 1)
         # BASELINE configs[3] is "8 independent instances, 1 per GPU": every rank's own rate, no collective in the data path
         out[key]["per_gpu_MSamples_per_s"] = [round(v, 1) for v in gather_floats(out[key]["MSamples_per_s"], world)]
     # frequency-domain cross-correlator, 4 time-series inputs of 1024-point vectors (reference + 3):

@@ -84,6 +84,7 @@ def lib():
         "mi355_pfb_ninput": (i, [vp]),
         "mi355_pfb_work": (i, [vp, vp, vp]),
         "mi355_pfb_work_dev": (i, [vp, vp, vp, vp]),
+        "mi355_pfb_work_dev_n": (i, [vp, i, vp, vp, vp]),
         "mi355_xengine_create": (i, [vp, i, i, i, i, i, pp]),
         "mi355_xengine_destroy": (i, [vp]),
         "mi355_xengine_input_bytes": (sz, [vp]),

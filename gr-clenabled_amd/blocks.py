@@ -313,10 +313,16 @@ class clPolyphaseChannelizer(_Block):
         check(self._L.mi355_pfb_work(self._h, _hp(x), _hp(y)), "mi355_pfb_work")
         return self.noutput()
 
-    def work_device(self, input_items, output_items):
-        check(self._L.mi355_pfb_work_dev(self._h, _dp(input_items[0]), _dp(output_items[0]), _torch_stream(self.device)),
-              "mi355_pfb_work_dev")
-        return self.noutput()
+    def work_device(self, input_items, output_items, nbuf=1):
+        """Device-resident call; nbuf > 1: that many consecutive buffers of the stream in one launch (general_work() with
+        noutput_items = nbuf * noutput()); input nbuf * buf_items - ninputs_per_iter + ntaps items, output nbuf * noutput()."""
+        if nbuf == 1:
+            check(self._L.mi355_pfb_work_dev(self._h, _dp(input_items[0]), _dp(output_items[0]), _torch_stream(self.device)),
+                  "mi355_pfb_work_dev")
+            return self.noutput()
+        x, y = input_items[0], output_items[0]
+        check(self._L.mi355_pfb_work_dev_n(self._h, int(nbuf), _dp(x), _dp(y), _torch_stream(self.device)), "mi355_pfb_work_dev_n")
+        return nbuf * self.noutput()
 
 
 class clXEngine(_Block):

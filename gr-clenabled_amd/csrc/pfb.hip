@@ -318,6 +318,88 @@ __global__ __launch_bounds__(M, 2) void k_pfbw(const c32 *__restrict__ in, c32 *
 }
 
 // ------------------------------------------------------------------------------------
+// Small calls (the reference's own call size: buf_items = 65536 -> 1024 steps = 64 groups of 16): the ring kernel above would run
+// 64 waves on a 1024-SIMD device, each a serial chain of row loads -> 512 packed FMAs -> DFT -> stores.  Here a workgroup owns ONE
+// group of 16 steps and four sets of M threads each form 4 of its steps (PMAX + 3 rows per lane instead of PMAX + 16, re-read from
+// L2 by the neighbours: the whole call is 1 MiB); the first set then runs the DFT of the 16 steps and stores.  Same FMA order per
+// output and the same DFT code as k_pfbw, so one long call and several short ones agree bit for bit.
+// ------------------------------------------------------------------------------------
+template <int M, int PMAX, bool IDENT>
+__global__ __launch_bounds__(4 * M) void k_pfbq(const c32 *__restrict__ in, c32 *__restrict__ out, const float *__restrict__ taps_pad,
+                                                 const c32 *__restrict__ tw_inv, const int *__restrict__ ch_map, int nmap, int K,
+                                                 long long n_in, int nsteps)
+{
+    constexpr int U = 16, UQ = 4, RQ = PMAX + UQ - 1;
+    using G = GeoArm<M>;
+    using PL = Plan<M, false>;
+    __shared__ c32 lds[G::PTS];
+    const int lane = threadIdx.x % M, quarter = threadIdx.x / M, grp = blockIdx.x;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)(unsigned)(n_in * 8), 0x00020000);
+    const unsigned lane_off = (unsigned)((M - 1 - lane) * 8);
+    const long long n0 = ((long long)grp * U + quarter * UQ) * M + K - (long long)PMAX * M;  // row 0 of this quarter's window
+    f2v row[RQ];
+#pragma unroll
+    for (int w = 0; w < RQ; w++)
+        row[w] = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (unsigned)((n0 + (long long)w * M) * 8) + lane_off, 0, 0));
+    float hrev[PMAX];
+#pragma unroll
+    for (int pp = 0; pp < PMAX; pp++) hrev[pp] = taps_pad[lane + (PMAX - 1 - pp) * M];
+    TwRegs<M> tw;
+    if (quarter == 0) load_twiddles<M, false, G>(tw, lane, tw_inv);
+    f2v acc[UQ];
+#pragma unroll
+    for (int u = 0; u < UQ; u++) acc[u] = (f2v){0.f, 0.f};
+#pragma unroll
+    for (int pp = 0; pp < PMAX; pp++) {
+        const f2v hh = {hrev[pp], hrev[pp]};
+#pragma unroll
+        for (int u = 0; u < UQ; u++) acc[u] = __builtin_elementwise_fma(row[u + pp], hh, acc[u]);  // per output: pp ascending, like k_pfbw
+    }
+    const int lane_swz = swzn<M>(lane);
+#pragma unroll
+    for (int u = 0; u < UQ; u++) lds[swzn<M>(lane + (quarter * UQ + u) * M)] = mk(acc[u].x, acc[u].y);
+    (void)lane_swz;
+    __syncthreads();
+    if (quarter != 0) return;  // (a finished wave no longer counts at the barriers below)
+    c32 v[16];
+    constexpr int R0 = PL::radix(0), B0 = M / R0;
+    {
+        const int raw_swz = swzn<M>((lane / B0) * M + (lane % B0));
+#pragma unroll
+        for (int r = 0; r < R0; r++) v[r] = lds[raw_swz ^ swzn<M>(r * B0)];
+    }
+    __syncthreads();
+    transform_regs<M, 1, false, G>(v, tw, lds, lane);
+    constexpr int NP = PL::NP, RL = PL::radix(NP - 1), BL = M / RL;
+    const int i0 = grp * U;
+    if constexpr (IDENT) {
+#pragma unroll
+        for (int q = 0; q < 16 / RL; q++) {
+            const int g = lane + M * q, fr = g / BL, j = g % BL;
+            if (i0 + fr < nsteps) {
+                c32 *__restrict__ o = out + (size_t)(i0 + fr) * M + j;
+#pragma unroll
+                for (int t = 0; t < RL; t++) st_stream(o + orev<RL>(t) * BL, v[q * RL + t]);
+            }
+        }
+    } else {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16 / RL; q++) {
+            const int g = lane + M * q, fr = g / BL, j = g % BL;
+#pragma unroll
+            for (int t = 0; t < RL; t++) lds[fr * M + j + orev<RL>(t) * BL] = v[q * RL + t];
+        }
+        __syncthreads();
+        const int steps = (nsteps - i0) < U ? (nsteps - i0) : U;
+        for (int e = lane; e < steps * nmap; e += M) {
+            const int fr = e / nmap, qq = e - fr * nmap;
+            out[(size_t)i0 * nmap + e] = lds[fr * M + ch_map[qq]];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // M == 32 (written for 8 / 16 / 32): the same ring kernel with 64/M independent time streams per wave (lane = (stream, arm)); every
 // stream owns a contiguous run of steps, so each lane still advances 16 rows per iteration and loads every row once.
 // One iteration transforms 16 steps of every stream (1024/M frames of M points, single-wave geometry).
@@ -496,111 +578,126 @@ struct mi355_pfb {
 namespace {
 
 template <int M, int PMAX>
-int launch_wave(mi355_pfb *h, const void *in, void *out, hipStream_t st)
+int launch_wave(mi355_pfb *h, const void *in, void *out, hipStream_t st, int nsteps, long long buf_items)
 {
-    const int ngroups = (h->nsteps + 15) / 16;
+    const int ngroups = (nsteps + 15) / 16;
     const int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
+    // fewer 16-step groups than two per CU: one workgroup per group, its steps split over four sets of M threads (k_pfbq)
+    const int small_on = getenv("MI355_PFB_SMALL") ? atoi(getenv("MI355_PFB_SMALL")) : 1;  // (read per call: a tuning / test switch)
+    if constexpr (!(M == 256 && PMAX > 16)) {  // (1024 threads x 32 taps per arm would spill: that shape keeps the ring kernel)
+        if (small_on && ngroups <= 2 * cus) {
+            const long long n_in = (long long)buf_items - h->R + h->K;
+            if (h->ident)
+                hipLaunchKernelGGL((k_pfbq<M, PMAX, true>), dim3(ngroups), dim3(4 * M), 0, st, (const c32 *)in, (c32 *)out, h->d_taps,
+                                   (const c32 *)h->d_tw, h->d_map, h->nmap, h->K, n_in, nsteps);
+            else
+                hipLaunchKernelGGL((k_pfbq<M, PMAX, false>), dim3(ngroups), dim3(4 * M), 0, st, (const c32 *)in, (c32 *)out, h->d_taps,
+                                   (const c32 *)h->d_tw, h->d_map, h->nmap, h->K, n_in, nsteps);
+            MI355_HIP(hipGetLastError());
+            return MI355_OK;
+        }
+    }
     static const int wpc = getenv("MI355_PFB_WAVES_PER_CU") ? atoi(getenv("MI355_PFB_WAVES_PER_CU")) : 8;
     long long wgs = (long long)cus * (wpc > 0 ? wpc : 8) / (M / 64);  // 8 waves per CU
     if (wgs > ngroups) wgs = ngroups;
     const int per = (int)((ngroups + wgs - 1) / wgs);
     const int grid = (ngroups + per - 1) / per;
-    const long long n_in = (long long)h->buf_items - h->R + h->K;
+    const long long n_in = (long long)buf_items - h->R + h->K;
     if (h->ident)
         hipLaunchKernelGGL((k_pfbw<M, PMAX, true>), dim3(grid), dim3(M), 0, st, (const c32 *)in, (c32 *)out, h->d_taps, (const c32 *)h->d_tw,
-                           h->d_map, h->nmap, h->K, n_in, h->nsteps, per);
+                           h->d_map, h->nmap, h->K, n_in, nsteps, per);
     else
         hipLaunchKernelGGL((k_pfbw<M, PMAX, false>), dim3(grid), dim3(M), 0, st, (const c32 *)in, (c32 *)out, h->d_taps, (const c32 *)h->d_tw,
-                           h->d_map, h->nmap, h->K, n_in, h->nsteps, per);
+                           h->d_map, h->nmap, h->K, n_in, nsteps, per);
     MI355_HIP(hipGetLastError());
     return MI355_OK;
 }
 
 template <int M, int PMAX>
-int launch_streams(mi355_pfb *h, const void *in, void *out, hipStream_t st)
+int launch_streams(mi355_pfb *h, const void *in, void *out, hipStream_t st, int nsteps, long long buf_items)
 {
     constexpr int SEG = 64 / M;
-    const int ngroups = (h->nsteps + 15) / 16;
+    const int ngroups = (nsteps + 15) / 16;
     const int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
     long long streams = (long long)cus * 8 * SEG;  // 8 waves per CU, SEG streams per wave
     if (streams > ngroups) streams = ngroups;
     const int gps = (int)((ngroups + streams - 1) / streams);
     const int nstreams = (ngroups + gps - 1) / gps;
     const int grid = (nstreams + SEG - 1) / SEG;
-    const long long n_in = (long long)h->buf_items - h->R + h->K;
+    const long long n_in = (long long)buf_items - h->R + h->K;
     if (h->ident)
         hipLaunchKernelGGL((k_pfbs<M, PMAX, true>), dim3(grid), dim3(64), 0, st, (const c32 *)in, (c32 *)out, h->d_taps, (const c32 *)h->d_tw,
-                           h->d_map, h->nmap, h->K, n_in, h->nsteps, gps);
+                           h->d_map, h->nmap, h->K, n_in, nsteps, gps);
     else
         hipLaunchKernelGGL((k_pfbs<M, PMAX, false>), dim3(grid), dim3(64), 0, st, (const c32 *)in, (c32 *)out, h->d_taps, (const c32 *)h->d_tw,
-                           h->d_map, h->nmap, h->K, n_in, h->nsteps, gps);
+                           h->d_map, h->nmap, h->K, n_in, nsteps, gps);
     MI355_HIP(hipGetLastError());
     return MI355_OK;
 }
 
 template <int M, int PMAX>
-int launch_fast(mi355_pfb *h, const void *in, void *out, hipStream_t st)
+int launch_fast(mi355_pfb *h, const void *in, void *out, hipStream_t st, int nsteps, long long buf_items)
 {
     // measured: 32 channels gain 6-11 % over the staged kernel; 8 and 16 channels (64-128 byte rows, gathered stores) lose 15 %
     if constexpr (M == 32 && PMAX <= 32) {
         static const bool wave = getenv("MI355_PFB_WAVE") ? atoi(getenv("MI355_PFB_WAVE")) != 0 : true;
-        const long long n_in = (long long)h->buf_items - h->R + h->K;
-        if (wave && n_in * 8 < (4ll << 30) - (64 << 10)) return launch_streams<M, PMAX>(h, in, out, st);
+        const long long n_in = (long long)buf_items - h->R + h->K;
+        if (wave && n_in * 8 < (4ll << 30) - (64 << 10)) return launch_streams<M, PMAX>(h, in, out, st, nsteps, buf_items);
     }
     if constexpr ((M == 64 || M == 128 || M == 256) && PMAX <= 32) {
         static const bool wave = getenv("MI355_PFB_WAVE") ? atoi(getenv("MI355_PFB_WAVE")) != 0 : true;
-        const long long n_in = (long long)h->buf_items - h->R + h->K;
-        if (wave && n_in * 8 < (4ll << 30) - (64 << 10)) return launch_wave<M, PMAX>(h, in, out, st);
+        const long long n_in = (long long)buf_items - h->R + h->K;
+        if (wave && n_in * 8 < (4ll << 30) - (64 << 10)) return launch_wave<M, PMAX>(h, in, out, st, nsteps, buf_items);
     }
     constexpr int T = 4096 / M;
-    int ngroups = (h->nsteps + T - 1) / T;
+    int ngroups = (nsteps + T - 1) / T;
     // many short grid-stride workgroups (measured at 8 and 16 channels: 2 per CU 250 GS/s, 8 per CU 280, 32 per CU 302)
     int grid = mi355_balanced_grid(h->ctx, ngroups, 16, 32);
-    long long n_in = (long long)h->buf_items - h->R + h->K;
+    long long n_in = (long long)buf_items - h->R + h->K;
     if (h->ident)
         hipLaunchKernelGGL((k_pfb<M, PMAX, true>), dim3(grid), dim3(256), 0, st, (const c32 *)in, (c32 *)out, h->d_taps,
-                           (const c32 *)h->d_tw, h->d_map, h->nmap, h->K, n_in, h->nsteps, ngroups);
+                           (const c32 *)h->d_tw, h->d_map, h->nmap, h->K, n_in, nsteps, ngroups);
     else
         hipLaunchKernelGGL((k_pfb<M, PMAX, false>), dim3(grid), dim3(256), 0, st, (const c32 *)in, (c32 *)out, h->d_taps,
-                           (const c32 *)h->d_tw, h->d_map, h->nmap, h->K, n_in, h->nsteps, ngroups);
+                           (const c32 *)h->d_tw, h->d_map, h->nmap, h->K, n_in, nsteps, ngroups);
     MI355_HIP(hipGetLastError());
     return MI355_OK;
 }
 
 template <int M>
-int launch_fast_m(mi355_pfb *h, const void *in, void *out, hipStream_t st)
+int launch_fast_m(mi355_pfb *h, const void *in, void *out, hipStream_t st, int nsteps, long long buf_items)
 {
     switch (h->pmax) {
-    case 8: return launch_fast<M, 8>(h, in, out, st);
-    case 16: return launch_fast<M, 16>(h, in, out, st);
-    case 32: return launch_fast<M, 32>(h, in, out, st);
-    case 64: return launch_fast<M, 64>(h, in, out, st);
+    case 8: return launch_fast<M, 8>(h, in, out, st, nsteps, buf_items);
+    case 16: return launch_fast<M, 16>(h, in, out, st, nsteps, buf_items);
+    case 32: return launch_fast<M, 32>(h, in, out, st, nsteps, buf_items);
+    case 64: return launch_fast<M, 64>(h, in, out, st, nsteps, buf_items);
     }
     return MI355_ERR_STATE;
 }
 
-int launch_pfb(mi355_pfb *h, const void *in, void *out, hipStream_t st)
+int launch_pfb(mi355_pfb *h, const void *in, void *out, hipStream_t st, int nsteps, long long buf_items)
 {
     if (h->fast) {
         switch (h->M) {
-        case 2: return launch_fast_m<2>(h, in, out, st);
-        case 4: return launch_fast_m<4>(h, in, out, st);
-        case 8: return launch_fast_m<8>(h, in, out, st);
-        case 16: return launch_fast_m<16>(h, in, out, st);
-        case 32: return launch_fast_m<32>(h, in, out, st);
-        case 64: return launch_fast_m<64>(h, in, out, st);
-        case 128: return launch_fast_m<128>(h, in, out, st);
-        case 256: return launch_fast_m<256>(h, in, out, st);
+        case 2: return launch_fast_m<2>(h, in, out, st, nsteps, buf_items);
+        case 4: return launch_fast_m<4>(h, in, out, st, nsteps, buf_items);
+        case 8: return launch_fast_m<8>(h, in, out, st, nsteps, buf_items);
+        case 16: return launch_fast_m<16>(h, in, out, st, nsteps, buf_items);
+        case 32: return launch_fast_m<32>(h, in, out, st, nsteps, buf_items);
+        case 64: return launch_fast_m<64>(h, in, out, st, nsteps, buf_items);
+        case 128: return launch_fast_m<128>(h, in, out, st, nsteps, buf_items);
+        case 256: return launch_fast_m<256>(h, in, out, st, nsteps, buf_items);
         }
         return MI355_ERR_STATE;
     }
     int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
-    long long total = (long long)h->nsteps * h->M;
+    long long total = (long long)nsteps * h->M;
     long long blocks = (total + 255) / 256;
     long long grid = blocks < (long long)cus * 8 ? blocks : (long long)cus * 8;
     hipLaunchKernelGGL(k_pfb_branches, dim3((unsigned)grid), dim3(256), 0, st, (const c32 *)in, (c32 *)h->d_filt, h->d_taps, h->K,
                        h->M, h->R, total);
-    total = (long long)h->nsteps * h->nmap;
+    total = (long long)nsteps * h->nmap;
     blocks = (total + 255) / 256;
     grid = blocks < (long long)cus * 8 ? blocks : (long long)cus * 8;
     if (grid < 1) grid = 1;
@@ -682,6 +779,30 @@ extern "C" int mi355_pfb_noutput(const mi355_pfb *h) { return h ? h->nmap * h->n
 // buf_items + history() - num_channels for R == M, lib/clPolyphaseChannelizer_impl.cc:97)
 extern "C" int mi355_pfb_ninput(const mi355_pfb *h) { return h ? h->buf_items - h->R + h->K : MI355_ERR_INVALID_ARG; }
 
+// nbuf consecutive buffers of the stream in ONE launch: what general_work() does when the scheduler offers several output
+// multiples at once (noutput_items = nbuf * noutput()).  in: nbuf * buf_items - ninputs_per_iter + ntaps samples, out: nbuf *
+// noutput().  The reference handles one buffer per call (lib/clPolyphaseChannelizer_impl.cc:83-109); the results are the
+// same samples (identical arithmetic per output), the launch cost is paid once.
+extern "C" int mi355_pfb_work_dev_n(mi355_pfb *h, int nbuf, const void *in, void *out, void *stream)
+{
+    MI355_REQUIRE(h != nullptr, "handle is NULL");
+    MI355_REQUIRE(in && out && nbuf >= 1, "NULL buffer or nbuf < 1");
+    MI355_REQUIRE((reinterpret_cast<uintptr_t>(in) & 7u) == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0,
+                  "device buffers must be 8-byte aligned");
+    MI355_REQUIRE((long long)h->nsteps * nbuf <= 0x7fffffffLL, "too many buffers in one call");
+    MI355_HIP(hipSetDevice(h->ctx->device));
+    hipStream_t st = mi355_pick_stream(h->ctx, stream);
+    if (!h->fast) {  // the generic two-kernel path keeps a one-buffer scratch: one buffer at a time
+        for (int b = 0; b < nbuf; b++) {
+            const int rc = launch_pfb(h, (const char *)in + (size_t)b * h->buf_items * 8, (char *)out + (size_t)b * h->nmap * h->nsteps * 8, st,
+                                      h->nsteps, h->buf_items);
+            if (rc) return rc;
+        }
+        return MI355_OK;
+    }
+    return launch_pfb(h, in, out, st, h->nsteps * nbuf, (long long)h->buf_items * nbuf);
+}
+
 extern "C" int mi355_pfb_work_dev(mi355_pfb *h, const void *in, void *out, void *stream)
 {
     MI355_REQUIRE(h != nullptr, "handle is NULL");
@@ -689,7 +810,7 @@ extern "C" int mi355_pfb_work_dev(mi355_pfb *h, const void *in, void *out, void 
     MI355_REQUIRE((reinterpret_cast<uintptr_t>(in) & 7u) == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0,
                   "device buffers must be 8-byte aligned");
     MI355_HIP(hipSetDevice(h->ctx->device));
-    return launch_pfb(h, in, out, mi355_pick_stream(h->ctx, stream));
+    return launch_pfb(h, in, out, mi355_pick_stream(h->ctx, stream), h->nsteps, h->buf_items);
 }
 
 extern "C" int mi355_pfb_work(mi355_pfb *h, const void *in, void *out)
@@ -706,14 +827,14 @@ extern "C" int mi355_pfb_work(mi355_pfb *h, const void *in, void *out)
     hipStream_t st = h->ctx->stream[0];
     mi355_copy(p.h_in[0][0], in, inb);
     if (mi355_direct_ok(inb > outb ? inb : outb)) {  // small call: the kernel works on the pinned staging itself (common.h)
-        rc = launch_pfb(h, p.h_in[0][0], p.h_out[0], st);
+        rc = launch_pfb(h, p.h_in[0][0], p.h_out[0], st, h->nsteps, h->buf_items);
         if (rc) return rc;
         MI355_HIP(mi355_direct_sync(st));
         mi355_copy(out, p.h_out[0], outb);
         return MI355_OK;
     }
     MI355_HIP(hipMemcpyAsync(p.d_in[0][0], p.h_in[0][0], inb, hipMemcpyHostToDevice, st));
-    rc = launch_pfb(h, p.d_in[0][0], p.d_out[0], st);
+    rc = launch_pfb(h, p.d_in[0][0], p.d_out[0], st, h->nsteps, h->buf_items);
     if (rc) return rc;
     MI355_HIP(hipMemcpyAsync(p.h_out[0], p.d_out[0], outb, hipMemcpyDeviceToHost, st));
     MI355_HIP(hipStreamSynchronize(st));

@@ -194,6 +194,9 @@ int mi355_pfb_noutput(const mi355_pfb *h);
 int mi355_pfb_ninput(const mi355_pfb *h);
 int mi355_pfb_work(mi355_pfb *h, const void *in_with_history, void *out);
 int mi355_pfb_work_dev(mi355_pfb *h, const void *in_with_history, void *out, void *stream);
+/* nbuf consecutive buffers in one launch (general_work() offered nbuf output multiples): in holds
+ * nbuf * buf_items - ninputs_per_iter + ntaps samples, out nbuf * noutput().  Same samples as nbuf single calls. */
+int mi355_pfb_work_dev_n(mi355_pfb *h, int nbuf, const void *in_dev, void *out_dev, void *stream);
 
 /* ---------------------------------------------------------------------------
  * clXEngine: V[f][k][pol2] = sum_t x_s1(t,f) conj(x_s2(t,f)), k = s1(s1+1)/2+s2.

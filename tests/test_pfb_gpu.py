@@ -88,6 +88,34 @@ def test_baseline_config4_shape_and_streaming(gpu, oracle):
     assert p.argmax() == 5 and p[5] > 1e3 * np.delete(p, 5).max()
 
 
+@pytest.mark.parametrize("M,tpa,ident", [(64, 32, True), (64, 8, False), (128, 16, True), (256, 8, True), (256, 32, True), (32, 16, True), (12, 5, False)])
+def test_batched_call_equals_single_calls(gpu, oracle, M, tpa, ident, monkeypatch):
+    """work_device(nbuf=k) -- general_work() offered k output multiples -- returns exactly the samples of k single calls, and the
+    small-call schedule (k_pfbq: one workgroup per 16-step group) exactly those of the ring kernel (MI355_PFB_SMALL=0)."""
+    import torch
+    rng = np.random.default_rng(M * 100 + tpa)
+    taps = rng.standard_normal(M * tpa).astype(np.float32)
+    chmap = list(range(M)) if ident else [int(c) for c in rng.permutation(M)[:max(1, M // 2)]]
+    buf, k = M * 48, 5
+    blk = gpu.clPolyphaseChannelizer(*GPU_ARGS, taps, buf, M, M, chmap)
+    x = torch.randn((k * buf + taps.size - M), 2, device="cuda")
+    ys = torch.empty(k * blk.noutput(), 2, device="cuda")
+    yb = torch.empty_like(ys)
+    for b in range(k):
+        blk.work_device([x[b * buf:]], [ys[b * blk.noutput():]])
+    assert blk.work_device([x], [yb], nbuf=k) == k * blk.noutput()
+    torch.cuda.synchronize()
+    assert torch.equal(ys, yb)
+    ref = oracle.pfb(taps, buf, M, M, chmap, x[:blk.ninput()].cpu().numpy().view(np.complex64).reshape(-1), f64=True)
+    assert relerr(yb[:ref.size].cpu().numpy().view(np.complex64).reshape(-1), ref) <= TOL
+    monkeypatch.setenv("MI355_PFB_SMALL", "0")
+    ring = gpu.clPolyphaseChannelizer(*GPU_ARGS, taps, buf, M, M, chmap)
+    yr = torch.empty_like(ys)
+    ring.work_device([x], [yr], nbuf=k)
+    torch.cuda.synchronize()
+    assert torch.equal(yr, yb)
+
+
 def test_device_path_full_size_linearity(gpu, oracle):
     import torch
     taps = np.concatenate([oracle.firdes_low_pass(1.0, 64.0, 0.5, 0.0753), [0.0]]).astype(np.float32)
