@@ -77,6 +77,34 @@ def widen_golden():
     np.savez_compressed(os.path.join(HERE, "widen_golden.npz"), **g)
 
 
+def cli_golden():
+    """Inputs the reference's own timing CLIs build (closed forms), with float64 expectations:
+    * lib/test-clfilter.cc:98-100 + :76-80: taps i/1000 over a constant (1.0, 0.5) stream -> every output is
+      (1 + 0.5j) * sum(taps) = (1 + 0.5j) * ntaps (ntaps - 1) / 2000  (a true closed form, kept in cli_kat.json);
+    * lib/test_clenabled.cc:835-851: x[i] = (sin(w i), cos(w i)), w = 2 pi / N in FLOAT arithmetic, through the Blackman
+      window + fftshift of BASELINE config 1 (expected spectrum: float64 numpy of the float32 inputs)."""
+    g = {}
+    n = 4096
+    w = np.float32(2 * np.pi * 10) / np.float32(n * 10)            # float frequency_sampling = fftDataSize * frequency_signal
+    ph = (np.float32(0.0) + w * np.arange(n, dtype=np.float32)).astype(np.float32)
+    x = (np.sin(ph).astype(np.float32) + 1j * np.cos(ph).astype(np.float32)).astype(np.complex64)
+    k = np.arange(n)
+    win = (0.42 - 0.5 * np.cos(2 * np.pi * k / (n - 1)) + 0.08 * np.cos(4 * np.pi * k / (n - 1))).astype(np.float32)
+    g["tone4096_x"] = x
+    g["tone4096_win"] = win
+    X = np.fft.fft(x.astype(np.complex128) * win.astype(np.float64))
+    g["tone4096_fwd_win_shift"] = np.fft.fftshift(X).astype(np.complex64)
+    g["tone4096_fwd"] = np.fft.fft(x.astype(np.complex128)).astype(np.complex64)
+    np.savez_compressed(os.path.join(HERE, "cli_golden.npz"), **g)
+    kat = {"_source": "closed forms of the inputs the reference's timing CLIs build",
+           "filter_ramp_taps": [{"ntaps": nt, "tap_i": "i/1000", "input": [1.0, 0.5],
+                                 "expect": [nt * (nt - 1) / 2000.0, 0.5 * nt * (nt - 1) / 2000.0],
+                                 "ref": "lib/test-clfilter.cc:76-80,98-100"} for nt in (3, 65, 128, 1000)],
+           "fft_tone_4096": {"peak_bin_unshifted": n - 1, "peak": [0.0, float(n)], "ref": "lib/test_clenabled.cc:835-851"}}
+    with open(os.path.join(HERE, "cli_kat.json"), "w") as f:
+        json.dump(kat, f, indent=1)
+
+
 def main():
     kat = {
         "_source": "reference known-answer tests and SURVEY.md section 8(c)",
@@ -231,6 +259,7 @@ def main():
     xe["p4_x"], xe["p4_y"] = pk.reshape(-1), o.reshape(-1).astype(np.complex64)
     np.savez_compressed(os.path.join(HERE, "xengine_golden.npz"), **xe)
     widen_golden()
+    cli_golden()
 
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith((".npz", ".json")))
     print("golden fixtures written, %.1f KiB" % (tot / 1024))

@@ -232,3 +232,27 @@ def test_two_kernel_real_input_and_tone(gpu, oracle):
     z = np.empty_like(t)
     _fft(gpu, 65536, gpu.CLFFT_FORWARD).work(1, [t], [z])
     assert abs(z[12345] - 65536) < 1.0 and np.abs(np.delete(z, 12345)).max() < 1.0
+
+
+def test_reference_cli_tone_through_window_and_shift(gpu):
+    """The input the reference's clFFT timing CLI builds (lib/test_clenabled.cc:835-851): (sin, cos) of one cycle per frame in float
+    arithmetic; unwindowed its spectrum is j*N in bin N-1 (closed form), windowed + shifted it is compared with the float64 fixture."""
+    import json
+    import os
+    from conftest import GOLDEN
+    g = golden("cli_golden.npz")
+    with open(os.path.join(GOLDEN, "cli_kat.json")) as f:
+        k = json.load(f)["fft_tone_4096"]
+    x = np.tile(g["tone4096_x"], 3)
+    y = np.empty_like(x)
+    blk = gpu.clFFT(4096, gpu.CLFFT_FORWARD, None, gpu.DTYPE_COMPLEX, *GPU_ARGS, 0, 1, False)
+    assert blk.testOpenCL(x.size, [x], [y]) == x.size  # the CLI's hook counts samples (lib/clFFT_impl.cc:520-524)
+    for v in range(3):
+        X = y[v * 4096:(v + 1) * 4096]
+        assert abs(X[k["peak_bin_unshifted"]] - complex(*k["peak"])) < 1e-2
+        assert np.abs(np.delete(X, k["peak_bin_unshifted"])).max() < 2e-2
+        assert relerr(X, g["tone4096_fwd"]) <= TOL
+    blk = gpu.clFFT(4096, gpu.CLFFT_FORWARD, g["tone4096_win"], gpu.DTYPE_COMPLEX, *GPU_ARGS, 0, 1, True)
+    blk.work(3, [x], [y])
+    for v in range(3):
+        assert relerr(y[v * 4096:(v + 1) * 4096], g["tone4096_fwd_win_shift"]) <= TOL

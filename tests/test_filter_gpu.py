@@ -215,3 +215,24 @@ def test_zero_outputs_and_bad_args(gpu):
         blk.work(10, [np.zeros(5, np.complex64)], [np.empty(10, np.complex64)])  # not enough input for the history
     with pytest.raises(gpu.Mi355Error):
         gpu.clFilter(*GPU_ARGS, 0, [1.0])  # decimation < 1
+
+
+@pytest.mark.parametrize("use_time", [False, True])
+def test_reference_cli_ramp_taps_closed_form(gpu, use_time):
+    """The reference's filter timing CLI (lib/test-clfilter.cc:76-80,98-100): taps i/1000 over a constant (1.0, 0.5) stream.
+    Every output is (1 + 0.5j) * ntaps (ntaps - 1) / 2000 -- a closed form held in tests/golden/cli_kat.json."""
+    import json
+    import os
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, "cli_kat.json")) as f:
+        cases = json.load(f)["filter_ramp_taps"]
+    for case in cases:
+        nt = case["ntaps"]
+        taps = (np.arange(nt, dtype=np.float32) / np.float32(1000.0)).astype(np.float32)
+        n = 8192  # the CLI's default block size
+        x = np.full(n + nt - 1, complex(*case["input"]), np.complex64)
+        y = np.empty(n, np.complex64)
+        blk = gpu.clFilter(*GPU_ARGS, 1, taps, 1, 0, use_time)
+        assert blk.work(n, [x], [y]) == n
+        want = complex(*case["expect"])
+        assert np.abs(y - want).max() <= TOL * abs(want), (nt, use_time)

@@ -62,6 +62,71 @@ def test_window_and_firdes_recorded_values(oracle):
     assert np.allclose(t, t[::-1], atol=1e-7) and abs(float(t.sum()) - 1.0) < 1e-6
 
 
+def test_windows_vs_scipy(oracle):
+    """Independent implementation (scipy.signal.windows, symmetric form = GNU Radio's N-1 denominators) for every window type
+    the reference's window.cc builds.  Flat-top: the reference's last coefficient is 0.028/4.63867 (lib/window.cc:243-248), scipy's
+    0.0322/4.63867 -- compared against the cosine sum with the reference's coefficients, and against scipy within that difference."""
+    from scipy.signal import windows as W
+    o = oracle
+    for n in (2, 7, 64, 65, 1000, 4096):
+        pairs = [(o.WIN_HAMMING, W.hamming(n, sym=True)), (o.WIN_HANN, W.hann(n, sym=True)), (o.WIN_BLACKMAN, W.blackman(n, sym=True)),
+                 (o.WIN_RECTANGULAR, np.ones(n)), (o.WIN_BLACKMAN_HARRIS, W.blackmanharris(n, sym=True)),
+                 (o.WIN_BARTLETT, W.bartlett(n, sym=True))]
+        for wt, ref in pairs:
+            assert np.abs(o.window(wt, n).astype(np.float64) - ref).max() < 3e-7, (wt, n)
+        for beta in (0.0, 3.5, 6.76, 12.0):
+            assert np.abs(o.window(o.WIN_KAISER, n, beta).astype(np.float64) - W.kaiser(n, beta, sym=True)).max() < 3e-7, (n, beta)
+        k = np.arange(n)
+        c = np.array([1.0, 1.93, 1.29, 0.388, 0.028]) / 4.63867
+        ft = sum(((-1) ** i) * c[i] * np.cos(2 * np.pi * i * k / max(n - 1, 1)) for i in range(5))
+        assert np.abs(o.window(o.WIN_FLATTOP, n).astype(np.float64) - ft).max() < 3e-7
+        assert np.abs(o.window(o.WIN_FLATTOP, n).astype(np.float64) - W.flattop(n, sym=True)).max() < 2.1 * (0.0322 - 0.028) / 4.63867
+
+
+def test_firdes_low_pass_vs_scipy_firwin(oracle):
+    """scipy.signal.firwin = windowed sinc scaled to unit DC gain: an independent design of the three fixture filters (and the
+    other window types), within float32 rounding of the oracle's restatement of firdes::low_pass."""
+    from scipy.signal import firwin
+    o = oracle
+    for args in ((1.0, 10e6, 1e6, 372000.0), (1.0, 64.0, 0.5, 0.0753), (1.0, 300e3, 48e3, 5e3), (2.5, 48000.0, 3000.0, 900.0)):
+        gain, fs, fc, tw = args
+        t = o.firdes_low_pass(*args)
+        ref = gain * firwin(t.size, fc, window="hamming", fs=fs, scale=True)
+        assert np.abs(t.astype(np.float64) - ref).max() < 2e-7 * max(1.0, gain), args
+    for wt, name in ((o.WIN_HANN, "hann"), (o.WIN_BLACKMAN, "blackman"), (o.WIN_BLACKMAN_HARRIS, "blackmanharris"), (o.WIN_RECTANGULAR, "boxcar")):
+        t = o.firdes_low_pass(1.0, 32000.0, 4000.0, 1000.0, wt)
+        assert np.abs(t.astype(np.float64) - firwin(t.size, 4000.0, window=name, fs=32000.0, scale=True)).max() < 2e-7, name
+    t = o.firdes_low_pass(1.0, 32000.0, 4000.0, 1000.0, o.WIN_KAISER, 6.76)
+    assert np.abs(t.astype(np.float64) - firwin(t.size, 4000.0, window=("kaiser", 6.76), fs=32000.0, scale=True)).max() < 2e-7
+
+
+def test_reference_cli_closed_forms(oracle):
+    """The inputs the reference's timing CLIs build have closed-form answers (tests/golden/cli_kat.json, cli_golden.npz):
+    ramp taps i/1000 over a constant (1, 0.5) stream (lib/test-clfilter.cc:76-80,98-100) and the (sin, cos) tone of
+    lib/test_clenabled.cc:835-851 through window + shift."""
+    with open(os.path.join(GOLDEN, "cli_kat.json")) as f:
+        k = json.load(f)
+    for case in k["filter_ramp_taps"]:
+        nt = case["ntaps"]
+        taps = (np.arange(nt, dtype=np.float32) / np.float32(1000.0)).astype(np.float32)
+        x = np.full(4096 + nt - 1, complex(*case["input"]), np.complex64)
+        want = complex(*case["expect"])
+        y = oracle.fir_ccf(taps, x, 4096)
+        assert np.abs(y - want).max() <= 1e-5 * abs(want), nt
+        f = oracle.FFTFilter(1, taps)
+        yf = f.filter(4096, x[:4096])
+        whole = (4096 // f.nsamples) * f.nsamples  # the stateful filter works in blocks of nsamples; after its start-up transient
+        assert np.abs(yf[nt:whole] - want).max() <= 1e-5 * abs(want), nt
+    g = golden("cli_golden.npz")
+    o = oracle
+    X = o.fft_block(4096, True, None, False, o.DTYPE_COMPLEX, g["tone4096_x"])
+    kk = k["fft_tone_4096"]
+    assert abs(X[kk["peak_bin_unshifted"]] - complex(*kk["peak"])) < 1e-2 and np.abs(np.delete(X, kk["peak_bin_unshifted"])).max() < 2e-2
+    assert relerr(X, g["tone4096_fwd"]) < 2e-6
+    Xw = o.fft_block(4096, True, g["tone4096_win"], True, o.DTYPE_COMPLEX, g["tone4096_x"])
+    assert relerr(Xw, g["tone4096_fwd_win_shift"]) < 2e-6
+
+
 def test_fft_tone_known_answer(oracle):
     k = _kat()["fft_tone"]
     x = golden("fft_golden.npz")["tone2048"]
