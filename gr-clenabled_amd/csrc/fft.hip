@@ -75,8 +75,8 @@ __device__ __forceinline__ void load_group(c32 (&v)[16], const void *__restrict_
     }
 }
 
-template <int N, int SIGN, bool REAL, bool PF, class G>
-__global__ __launch_bounds__(G::TH, (N <= 4096 ? MI355_FFT_WPE : 1)) void k_fft(const void *__restrict__ in, c32 *__restrict__ out,
+template <int N, int SIGN, bool REAL, int PF, class G>
+__global__ __launch_bounds__(G::TH, (N <= 4096 ? (PF == 2 ? 2 : MI355_FFT_WPE) : 1)) void k_fft(const void *__restrict__ in, c32 *__restrict__ out,
                                                                  const float *__restrict__ window,
                                                                  const c32 *__restrict__ twtab, int nframes, int ngroups,
                                                                  int shift)
@@ -110,24 +110,10 @@ __global__ __launch_bounds__(G::TH, (N <= 4096 ? MI355_FFT_WPE : 1)) void k_fft(
         }
     }
 
-    // Software pipeline over the persistent loop: the loads of the NEXT frame group are issued
-    // before the current group is transformed, so every workgroup always has 32 KiB in flight.
-    c32 cur[16];
-    if ((int)blockIdx.x < ngroups) load_group<N, REAL, G>(cur, in, blockIdx.x, tid0, nframes, in_xor);
-    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        // Opaque per-iteration copy of the thread id: address arithmetic is recomputed
-        // (a few dozen integer ops) rather than hoisted into ~60 loop-carried registers.
-        int tid = tid0;
-        asm volatile("" : "+v"(tid));
+    // One frame group: window, transform, store.  `tid` is an opaque per-iteration copy of the thread id: address arithmetic is
+    // recomputed (a few dozen integer ops) rather than hoisted into ~60 loop-carried registers.
+    auto body = [&](c32 (&cur)[16], int grp, int tid) {
         const int frames_left = nframes - grp * F;  // frames of this group that exist
-        c32 nxt[16];
-        if constexpr (PF) {
-            const int gnext = grp + gridDim.x;
-            if (gnext < ngroups) load_group<N, REAL, G>(nxt, in, gnext, tid, nframes, in_xor);
-            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the transform
-        } else if (grp != (int)blockIdx.x) {
-            load_group<N, REAL, G>(cur, in, grp, tid, nframes, in_xor);
-        }
         c32 v[16];
         if constexpr (SMALL) {
             // cur[k] = source element tid + TH*k of the group (position (tid % N) of its frame: one window value per thread)
@@ -194,11 +180,53 @@ __global__ __launch_bounds__(G::TH, (N <= 4096 ? MI355_FFT_WPE : 1)) void k_fft(
                 }
             }
         }
-        if constexpr (PF) {
-#pragma unroll
-            for (int s = 0; s < 16; s++) cur[s] = nxt[s];
-        }
         if constexpr (NP > 1 || SMALL) __syncthreads();  // last pass' LDS reads finish before the next group's writes
+    };
+    const int stride = gridDim.x;
+    if constexpr (PF == 2) {
+        // Two groups of lead (64 KiB in flight per workgroup, two persistent workgroups per CU): the loop is unrolled three times so
+        // that the three register buffers rotate by name, not by moves.
+        c32 b0[16], b1[16], b2[16];
+        int grp = blockIdx.x;
+        if (grp < ngroups) load_group<N, REAL, G>(b0, in, grp, tid0, nframes, in_xor);
+        if (grp + stride < ngroups) load_group<N, REAL, G>(b1, in, grp + stride, tid0, nframes, in_xor);
+#define MI355_FFT_STEP(CUR, FREE)                                                                   \
+        {                                                                                           \
+            if (grp >= ngroups) break;                                                              \
+            int tid = tid0;                                                                         \
+            asm volatile("" : "+v"(tid));                                                           \
+            if (grp + 2 * stride < ngroups) load_group<N, REAL, G>(FREE, in, grp + 2 * stride, tid, nframes, in_xor); \
+            __builtin_amdgcn_sched_barrier(0);                                                      \
+            body(CUR, grp, tid);                                                                    \
+            grp += stride;                                                                          \
+        }
+        for (;;) {
+            MI355_FFT_STEP(b0, b2)
+            MI355_FFT_STEP(b1, b0)
+            MI355_FFT_STEP(b2, b1)
+        }
+#undef MI355_FFT_STEP
+    } else {
+        // PF == 1: the loads of the NEXT frame group are issued before the current group is transformed
+        c32 cur[16];
+        if ((int)blockIdx.x < ngroups) load_group<N, REAL, G>(cur, in, blockIdx.x, tid0, nframes, in_xor);
+        for (int grp = blockIdx.x; grp < ngroups; grp += stride) {
+            int tid = tid0;
+            asm volatile("" : "+v"(tid));
+            c32 nxt[16];
+            if constexpr (PF == 1) {
+                const int gnext = grp + stride;
+                if (gnext < ngroups) load_group<N, REAL, G>(nxt, in, gnext, tid, nframes, in_xor);
+                __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the transform
+            } else if (grp != (int)blockIdx.x) {
+                load_group<N, REAL, G>(cur, in, grp, tid, nframes, in_xor);
+            }
+            body(cur, grp, tid);
+            if constexpr (PF == 1) {
+#pragma unroll
+                for (int s = 0; s < 16; s++) cur[s] = nxt[s];
+            }
+        }
     }
 }
 
@@ -425,22 +453,30 @@ int launch_g(mi355_ctx *ctx, int sign, const void *in, void *out, const float *w
     int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
     // MI355_FFT_PREFETCH=1 selects the register-prefetch variant (2 workgroups/CU); measured equal to the
     // plain variant at 3 workgroups/CU on MI355X, so it is off by default.
-    static const bool pf = getenv("MI355_FFT_PREFETCH") ? atoi(getenv("MI355_FFT_PREFETCH")) != 0 : false;
-    // resident waves per CU are what matters: 8..12 (2..3 workgroups of 4 waves, or 8..12 single-wave workgroups)
-    // N <= 4096: 3 workgroups per CU are resident, but 8-16 per CU (each still loops over >= 4 frame groups with its
-    // twiddles and window in registers) measured 3-6 % faster at every size: workgroups that finish early are replaced at
-    // once, so slow CUs / HBM channels do not hold a fixed share of the work
+    int pf = getenv("MI355_FFT_PREFETCH") ? atoi(getenv("MI355_FFT_PREFETCH")) : -1;  // (per call: tuning switch)
+    // N <= 4096, 256-thread workgroups.  Measured on MI355X with interleaved A/B runs inside one process (tools/probe_fft_ab.py; the
+    // drift between processes is +-4 %): EXACTLY two persistent workgroups per CU with the next group's loads issued before the
+    // current group is transformed (PF = 1) beat every other residency by 3-4 % at N = 16 ... 4096 (4096: 178.8 -> 173.6 us per
+    // GiB of traffic); 3 or 4 per CU with the same prefetch are 5-10 % SLOWER, a second group of lead (PF = 2, 190 registers) too.
+    // Without the prefetch many short workgroups (8-16 per CU, each still looping over >= 4 groups with its twiddles and window in
+    // registers) are best: that remains the schedule of calls too small to give every persistent workgroup >= 8 groups.
+    const bool persistent2 = N <= 4096 && WAVES == 4 && ngroups >= cus * 2 * 8;
+    if (pf < 0) pf = persistent2 ? 1 : 0;
     int grid = (N <= 4096) ? mi355_balanced_grid(ctx, ngroups, 32 / WAVES, 64 / WAVES, 0.015) : mi355_balanced_grid(ctx, ngroups, 1, 1);
+    if (pf == 1 && persistent2) grid = cus * 2;
     if (const char *e = getenv("MI355_FFT_WG_PER_CU")) {
         if (atoi(e) > 0) grid = ngroups < cus * atoi(e) ? ngroups : cus * atoi(e);
     }
 #define LAUNCH_FFT(SG, RL)                                                                                              \
     do {                                                                                                                     \
-        if (pf)                                                                                                              \
-            hipLaunchKernelGGL((k_fft<N, SG, RL, true, G>), dim3(grid), dim3(TH), 0, st, in, (c32 *)out, window, (const c32 *)tw, \
+        if (pf == 2)                                                                                                         \
+            hipLaunchKernelGGL((k_fft<N, SG, RL, 2, G>), dim3(grid), dim3(TH), 0, st, in, (c32 *)out, window, (const c32 *)tw, \
+                               nframes, ngroups, shift);                                                                     \
+        else if (pf == 1)                                                                                                    \
+            hipLaunchKernelGGL((k_fft<N, SG, RL, 1, G>), dim3(grid), dim3(TH), 0, st, in, (c32 *)out, window, (const c32 *)tw, \
                                nframes, ngroups, shift);                                                                     \
         else                                                                                                                 \
-            hipLaunchKernelGGL((k_fft<N, SG, RL, false, G>), dim3(grid), dim3(TH), 0, st, in, (c32 *)out, window,                \
+            hipLaunchKernelGGL((k_fft<N, SG, RL, 0, G>), dim3(grid), dim3(TH), 0, st, in, (c32 *)out, window,                \
                                (const c32 *)tw, nframes, ngroups, shift);                                                    \
     } while (0)
     if (sign < 0) { if (real_in) LAUNCH_FFT(-1, true); else LAUNCH_FFT(-1, false); }
