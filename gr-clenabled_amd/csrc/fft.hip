@@ -238,24 +238,113 @@ __global__ __launch_bounds__(G::TH, (N <= 4096 ? (PF == 2 ? 2 : MI355_FFT_WPE) :
 // instead of three per frame); X[k + m*4096] = sum_s W_N^(s k) W_S^(s m) E_s[k] needs all E_s[k] of one k in one thread,
 // which the common sub-transform layout guarantees.  W_N^(s k) = W_N^(s tid) * (compile-time constant), k = tid + 256 c.
 // ------------------------------------------------------------------------------------
-__host__ __device__ constexpr float cos64(int m)
-{
-    constexpr float t[64] = {1.0f, 0.995184727f, 0.98078528f, 0.956940336f, 0.923879533f, 0.881921264f, 0.831469612f, 0.773010453f, 0.707106781f, 0.634393284f, 0.555570233f, 0.471396737f, 0.382683432f, 0.290284677f, 0.195090322f, 0.0980171403f, 0.0f, -0.0980171403f, -0.195090322f, -0.290284677f, -0.382683432f, -0.471396737f, -0.555570233f, -0.634393284f, -0.707106781f, -0.773010453f, -0.831469612f, -0.881921264f, -0.923879533f, -0.956940336f, -0.98078528f, -0.995184727f, -1.0f, -0.995184727f, -0.98078528f, -0.956940336f, -0.923879533f, -0.881921264f, -0.831469612f, -0.773010453f, -0.707106781f, -0.634393284f, -0.555570233f, -0.471396737f, -0.382683432f, -0.290284677f, -0.195090322f, -0.0980171403f, 0.0f, 0.0980171403f, 0.195090322f, 0.290284677f, 0.382683432f, 0.471396737f, 0.555570233f, 0.634393284f, 0.707106781f, 0.773010453f, 0.831469612f, 0.881921264f, 0.923879533f, 0.956940336f, 0.98078528f, 0.995184727f};
-    return t[m];
-}
-__host__ __device__ constexpr float sin64(int m)
-{
-    constexpr float t[64] = {0.0f, 0.0980171403f, 0.195090322f, 0.290284677f, 0.382683432f, 0.471396737f, 0.555570233f, 0.634393284f, 0.707106781f, 0.773010453f, 0.831469612f, 0.881921264f, 0.923879533f, 0.956940336f, 0.98078528f, 0.995184727f, 1.0f, 0.995184727f, 0.98078528f, 0.956940336f, 0.923879533f, 0.881921264f, 0.831469612f, 0.773010453f, 0.707106781f, 0.634393284f, 0.555570233f, 0.471396737f, 0.382683432f, 0.290284677f, 0.195090322f, 0.0980171403f, 0.0f, -0.0980171403f, -0.195090322f, -0.290284677f, -0.382683432f, -0.471396737f, -0.555570233f, -0.634393284f, -0.707106781f, -0.773010453f, -0.831469612f, -0.881921264f, -0.923879533f, -0.956940336f, -0.98078528f, -0.995184727f, -1.0f, -0.995184727f, -0.98078528f, -0.956940336f, -0.923879533f, -0.881921264f, -0.831469612f, -0.773010453f, -0.707106781f, -0.634393284f, -0.555570233f, -0.471396737f, -0.382683432f, -0.290284677f, -0.195090322f, -0.0980171403f};
-    return t[m];
-}
 typedef float f4v __attribute__((ext_vector_type(4)));
+// cos / sin of 2 pi m / circ (circ divides 128) as compile-time constants: the combine twiddles of k_fft_s.  A literal table:
+// indexing a constexpr array folds away once the loops are unrolled (a constexpr series evaluation did not, and left the
+// whole frame in scratch memory).
+__host__ __device__ constexpr float cos128(int m)
+{
+    constexpr float t[128] = {1.0f, 0.99879545f, 0.99518472f, 0.989176512f, 0.980785251f, 0.970031261f, 0.956940353f, 0.941544056f, 0.923879504f, 0.903989315f, 0.881921291f, 0.857728601f, 0.831469595f, 0.803207517f, 0.773010433f, 0.740951121f, 0.707106769f, 0.671558976f, 0.634393275f, 0.59569931f, 0.555570245f, 0.514102757f, 0.471396744f, 0.427555084f, 0.382683426f, 0.336889863f, 0.290284663f, 0.242980182f, 0.195090324f, 0.146730468f, 0.0980171412f, 0.0490676761f, 0.0f, -0.0490676761f, -0.0980171412f, -0.146730468f, -0.195090324f, -0.242980182f, -0.290284663f, -0.336889863f, -0.382683426f, -0.427555084f, -0.471396744f, -0.514102757f, -0.555570245f, -0.59569931f, -0.634393275f, -0.671558976f, -0.707106769f, -0.740951121f, -0.773010433f, -0.803207517f, -0.831469595f, -0.857728601f, -0.881921291f, -0.903989315f, -0.923879504f, -0.941544056f, -0.956940353f, -0.970031261f, -0.980785251f, -0.989176512f, -0.99518472f, -0.99879545f, -1.0f, -0.99879545f, -0.99518472f, -0.989176512f, -0.980785251f, -0.970031261f, -0.956940353f, -0.941544056f, -0.923879504f, -0.903989315f, -0.881921291f, -0.857728601f, -0.831469595f, -0.803207517f, -0.773010433f, -0.740951121f, -0.707106769f, -0.671558976f, -0.634393275f, -0.59569931f, -0.555570245f, -0.514102757f, -0.471396744f, -0.427555084f, -0.382683426f, -0.336889863f, -0.290284663f, -0.242980182f, -0.195090324f, -0.146730468f, -0.0980171412f, -0.0490676761f, 0.0f, 0.0490676761f, 0.0980171412f, 0.146730468f, 0.195090324f, 0.242980182f, 0.290284663f, 0.336889863f, 0.382683426f, 0.427555084f, 0.471396744f, 0.514102757f, 0.555570245f, 0.59569931f, 0.634393275f, 0.671558976f, 0.707106769f, 0.740951121f, 0.773010433f, 0.803207517f, 0.831469595f, 0.857728601f, 0.881921291f, 0.903989315f, 0.923879504f, 0.941544056f, 0.956940353f, 0.970031261f, 0.980785251f, 0.989176512f, 0.99518472f, 0.99879545f};
+    return t[m & 127];
+}
+__host__ __device__ constexpr float circ_cos(int m, int circ) { return cos128(m * (128 / circ)); }
+__host__ __device__ constexpr float circ_sin(int m, int circ) { return cos128(m * (128 / circ) - 32); }
+static_assert(circ_cos(0, 128) == 1.0f && circ_cos(32, 128) == 0.0f && circ_cos(16, 128) == 0.707106781f && circ_sin(32, 128) == 1.0f &&
+                  circ_sin(8, 64) == 0.707106781f && circ_cos(16, 32) == -1.0f, "twiddle table");
+
+// N = 32768: eight interleaved 4096-point sub-transforms per frame (x[8 n + s]), one frame per workgroup iteration, ONE pass
+// over HBM.  The whole frame in the registers of 256 threads (k_fft_s with S = 8) leaves one wave per SIMD running eight
+// transforms one after the other (400 us per 2^26 samples, no better than the two-kernel workspace scheme).  Here 512 threads
+// form two sets of 256: set g transforms sub-frames 4g .. 4g+3 (64 complex values per thread, its own 32 KiB of LDS; the
+// two sets run the same code between the same barriers), then each set hands the other the half of its outputs the other
+// combines (128 KiB of LDS, reusing the transform areas) and runs the radix-8 combine
+//   X[k + 4096 m] = sum_s W_N^(s k) W_8^(s m) E_s[k]
+// for 8 of the 16 output rows a thread holds; rows are stored k-contiguous.
+template <int SIGN, bool REAL>
+__global__ __launch_bounds__(512, 2) void k_fft_32k(const void *__restrict__ in, c32 *__restrict__ out, const float *__restrict__ window,
+                                                    const c32 *__restrict__ twN, int nframes, int shift)
+{
+    constexpr int N = 32768, NS = 4096, S = 8, H = 4, BL = 256;
+    using G = Geo<NS>;
+    __shared__ c32 sm[4 * NS];  // transform areas of the two sets (2 x 32 KiB), then the exchange image (128 KiB)
+    const int set = threadIdx.x >> 8, tid0 = threadIdx.x & 255;
+    c32 *lds = sm + set * 2 * NS;  // two transform areas per set: sub-frames are transformed two at a time in lockstep
+    TwRegs<NS> tw;
+    load_twiddles<NS, false, G>(tw, tid0, twN + N);  // the 4096-point table follows the N-point one
+    const int in_xor = (SIGN > 0 && shift) ? 8 : 0;       // reverse: halves swapped on load == n ^ 2048 == r ^ 8
+    const int m_xor = (SIGN < 0 && shift) ? (S / 2) : 0;  // forward: halves swapped on store
+
+    for (int frame = blockIdx.x; frame < nframes; frame += gridDim.x) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        c32 v[H][16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const unsigned n = (unsigned)(tid + ((r ^ in_xor) * BL));  // element n of every sub-frame
+            const f4v w = *((const f4v *)window + (size_t)n * 2 + set);
+            if constexpr (REAL) {
+                const f4v t = __builtin_nontemporal_load((const f4v *)in + (size_t)frame * (N / 4) + (size_t)n * 2 + set);
+                v[0][r] = mk(t.x * w.x, 0.f); v[1][r] = mk(t.y * w.y, 0.f); v[2][r] = mk(t.z * w.z, 0.f); v[3][r] = mk(t.w * w.w, 0.f);
+            } else {
+                const f4v t0 = __builtin_nontemporal_load((const f4v *)in + (size_t)frame * (N / 2) + (size_t)n * 4 + set * 2);
+                const f4v t1 = __builtin_nontemporal_load((const f4v *)in + (size_t)frame * (N / 2) + (size_t)n * 4 + set * 2 + 1);
+                v[0][r] = mk(t0.x * w.x, t0.y * w.x); v[1][r] = mk(t0.z * w.y, t0.w * w.y);
+                v[2][r] = mk(t1.x * w.z, t1.y * w.z); v[3][r] = mk(t1.z * w.w, t1.w * w.w);
+            }
+        }
+        transform_regs2<NS, SIGN, false, G>(v[0], v[1], tw, lds, lds + NS, tid);
+        __syncthreads();
+        transform_regs2<NS, SIGN, false, G>(v[2], v[3], tw, lds, lds + NS, tid);
+        __syncthreads();
+        c32 wb[S - 1];
+#pragma unroll
+        for (int s = 1; s < S; s++) wb[s - 1] = twN[(s * tid) & (N - 1)];
+        f2v *__restrict__ out_f = (f2v *)out + (size_t)frame * N + tid;
+        // exchange image: xch[set of origin][sub-frame in set][row of the receiving set's half][tid]
+        auto finish = [&](auto set_tag) {
+            constexpr int SET = decltype(set_tag)::value, OTHER = 1 - SET;
+#pragma unroll
+            for (int s = 0; s < H; s++)
+#pragma unroll
+                for (int tl = 0; tl < 8; tl++) sm[((SET * H + s) * 8 + tl) * BL + tid] = v[s][8 * OTHER + tl];  // rows the other set combines
+            __syncthreads();
+#pragma unroll
+            for (int tl = 0; tl < 8; tl++) {
+                constexpr int CIRC = 16 * S;  // W_N^(s * c * 256) = exp(sign 2 pi i s c / 128): a point of the 128-point circle
+                const int t = 8 * SET + tl, c = orev<16>(t);
+                c32 a[S];
+#pragma unroll
+                for (int s = 0; s < S; s++) {
+                    const c32 e = (s / H == SET) ? v[s % H][t] : sm[((OTHER * H + s % H) * 8 + tl) * BL + tid];
+                    if (s == 0) { a[0] = e; continue; }
+                    const int m = (s * c) % CIRC;
+                    const c32 k = mk(circ_cos(m, CIRC), SIGN < 0 ? -circ_sin(m, CIRC) : circ_sin(m, CIRC));
+                    a[s] = cmul(e, (m == 0) ? wb[s - 1] : cmul(wb[s - 1], k));
+                }
+                bfly<S, SIGN>(a);  // slot m holds y[orev<8>(m)]
+#pragma unroll
+                for (int m = 0; m < S; m++) {
+                    f2v o;
+                    o.x = a[m].x;
+                    o.y = a[m].y;
+                    __builtin_nontemporal_store(o, out_f + c * BL + ((orev<S>(m) ^ m_xor) * NS));
+                }
+            }
+        };
+        if (set == 0) finish(std::integral_constant<int, 0>{});
+        else finish(std::integral_constant<int, 1>{});
+        __syncthreads();  // the exchange image is read before the next frame's transforms overwrite it
+    }
+}
 
 template <int N, int SIGN, bool REAL>
-__global__ __launch_bounds__(256, 2) void k_fft_s(const void *__restrict__ in, c32 *__restrict__ out, const float *__restrict__ window,
+__global__ __launch_bounds__(256, (N / 4096 == 8 ? 1 : 2)) void k_fft_s(const void *__restrict__ in, c32 *__restrict__ out, const float *__restrict__ window,
                                                   const c32 *__restrict__ twN, int nframes, int shift)
 {
     constexpr int NS = 4096, S = N / NS, BL = 256;
-    static_assert(S == 2 || S == 4, "two or four sub-transforms");
+    // S = 8 (32768 points): 128 complex values per thread -- one workgroup (one wave per SIMD, up to 512 registers) per CU, the
+    // whole 256 KiB frame of loads in flight at once; still ONE pass over HBM instead of the two of the workspace scheme
+    static_assert(S == 2 || S == 4 || S == 8, "two, four or eight sub-transforms");
     using G = Geo<NS>;
     __shared__ c32 lds[NS];
     const int tid0 = threadIdx.x;
@@ -282,8 +371,11 @@ __global__ __launch_bounds__(256, 2) void k_fft_s(const void *__restrict__ in, c
                 const f2v t = *((const f2v *)window + n);
                 w[0] = t.x; w[1] = t.y;
             } else {
-                const f4v t = *((const f4v *)window + n);
-                w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
+#pragma unroll
+                for (int h = 0; h < S / 4; h++) {
+                    const f4v t = *((const f4v *)window + (size_t)n * (S / 4) + h);
+                    w[4 * h] = t.x; w[4 * h + 1] = t.y; w[4 * h + 2] = t.z; w[4 * h + 3] = t.w;
+                }
             }
             if constexpr (REAL) {
                 float x[S];
@@ -291,8 +383,11 @@ __global__ __launch_bounds__(256, 2) void k_fft_s(const void *__restrict__ in, c
                     const f2v t = __builtin_nontemporal_load((const f2v *)in + (size_t)frame * (N / 2) + n);
                     x[0] = t.x; x[1] = t.y;
                 } else {
-                    const f4v t = __builtin_nontemporal_load((const f4v *)in + (size_t)frame * (N / 4) + n);
-                    x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
+#pragma unroll
+                    for (int h = 0; h < S / 4; h++) {
+                        const f4v t = __builtin_nontemporal_load((const f4v *)in + (size_t)frame * (N / 4) + (size_t)n * (S / 4) + h);
+                        x[4 * h] = t.x; x[4 * h + 1] = t.y; x[4 * h + 2] = t.z; x[4 * h + 3] = t.w;
+                    }
                 }
 #pragma unroll
                 for (int s = 0; s < S; s++) v[s][r] = mk(x[s] * w[s], 0.f);
@@ -306,11 +401,15 @@ __global__ __launch_bounds__(256, 2) void k_fft_s(const void *__restrict__ in, c
             }
         }
         if constexpr (RELOAD) load_twiddles<NS, false, G>(tw, tid, twN + N);
-#pragma unroll
-        for (int s = 0; s < S; s++) {
-            transform_regs<NS, SIGN, false, G>(v[s], tw, lds, tid);
-            __syncthreads();  // the last pass' LDS reads are done before the next sub-transform writes
+        // (spelled out: eight inlined transforms exceed the optimiser's pragma-unroll size limit, and a rolled loop would index
+        // v[] dynamically, i.e. move the whole frame to scratch memory)
+#define MI355_SUBT(K)                                                                                                  \
+        if constexpr (S > K) {                                                                                         \
+            transform_regs<NS, SIGN, false, G>(v[K], tw, lds, tid);                                                    \
+            __syncthreads(); /* the last pass' LDS reads are done before the next sub-transform writes */              \
         }
+        MI355_SUBT(0) MI355_SUBT(1) MI355_SUBT(2) MI355_SUBT(3) MI355_SUBT(4) MI355_SUBT(5) MI355_SUBT(6) MI355_SUBT(7)
+#undef MI355_SUBT
         if constexpr (RELOAD) {
 #pragma unroll
             for (int s = 1; s < S; s++) wb[s - 1] = twN[(s * tid) & (N - 1)];
@@ -318,24 +417,23 @@ __global__ __launch_bounds__(256, 2) void k_fft_s(const void *__restrict__ in, c
         f2v *__restrict__ out_f = (f2v *)out + (size_t)frame * N + tid;
 #pragma unroll
         for (int t = 0; t < 16; t++) {
-            constexpr int STEP = 64 / (16 * S);  // W_N^(s * c * 256) = exp(sign 2 pi i s c / (16 S)) on the 64-point circle
+            constexpr int CIRC = 16 * S;  // W_N^(s * c * 256) = exp(sign 2 pi i s c / (16 S)): a point of the (16 S)-point circle
             const int c = orev<16>(t);
             c32 a[S];
             a[0] = v[0][t];
 #pragma unroll
             for (int s = 1; s < S; s++) {
-                const int m = (s * c * STEP) & 63;
-                const c32 k = mk(cos64(m), SIGN < 0 ? -sin64(m) : sin64(m));
+                const int m = (s * c) % CIRC;
+                const c32 k = mk(circ_cos(m, CIRC), SIGN < 0 ? -circ_sin(m, CIRC) : circ_sin(m, CIRC));
                 a[s] = cmul(v[s][t], (m == 0) ? wb[s - 1] : cmul(wb[s - 1], k));
             }
-            if constexpr (S == 2) bfly2<SIGN>(a[0], a[1]);
-            else bfly4<SIGN>(a[0], a[1], a[2], a[3]);
+            bfly<S, SIGN>(a);  // slot m holds y[orev<S>(m)] (identity for S = 2, 4)
 #pragma unroll
             for (int m = 0; m < S; m++) {
                 f2v o;
                 o.x = a[m].x;
                 o.y = a[m].y;
-                __builtin_nontemporal_store(o, out_f + c * BL + ((m ^ m_xor) * NS));
+                __builtin_nontemporal_store(o, out_f + c * BL + ((orev<S>(m) ^ m_xor) * NS));
             }
         }
     }
@@ -345,7 +443,17 @@ template <int N>
 int launch_s(mi355_ctx *ctx, int sign, const void *in, void *out, const float *window, const void *tw, int nframes, int shift,
              int real_in, hipStream_t st)
 {
-    const int grid = mi355_balanced_grid(ctx, nframes, 2, N == 8192 ? 3 : 2, 0.015);
+    const int grid = N == 32768 ? mi355_balanced_grid(ctx, nframes, 1, 1) : mi355_balanced_grid(ctx, nframes, 2, N == 8192 ? 3 : 2, 0.015);
+    if constexpr (N == 32768) {
+        if (!getenv("MI355_FFT_32768_IN_REGISTERS")) {
+#define LAUNCH_32K(SG, RL) hipLaunchKernelGGL((k_fft_32k<SG, RL>), dim3(grid), dim3(512), 0, st, in, (c32 *)out, window, (const c32 *)tw, nframes, shift)
+            if (sign < 0) { if (real_in) LAUNCH_32K(-1, true); else LAUNCH_32K(-1, false); }
+            else          { if (real_in) LAUNCH_32K(1, true);  else LAUNCH_32K(1, false); }
+#undef LAUNCH_32K
+            MI355_HIP(hipGetLastError());
+            return MI355_OK;
+        }
+    }
 #define LAUNCH_S(SG, RL) hipLaunchKernelGGL((k_fft_s<N, SG, RL>), dim3(grid), dim3(256), 0, st, in, (c32 *)out, window, (const c32 *)tw, nframes, shift)
     if (sign < 0) { if (real_in) LAUNCH_S(-1, true); else LAUNCH_S(-1, false); }
     else          { if (real_in) LAUNCH_S(1, true);  else LAUNCH_S(1, false); }
@@ -495,12 +603,13 @@ int launch_n(mi355_ctx *ctx, int sign, const void *in, void *out, const float *w
         static const bool wave = getenv("MI355_FFT_WAVE_GEO") ? atoi(getenv("MI355_FFT_WAVE_GEO")) != 0 : false;
         if (wave) return launch_g<N, GeoW<N>>(ctx, sign, in, out, window, tw, nframes, shift, real_in, st);
     }
-    if constexpr (N == 8192 || N == 16384) {
+    if constexpr (N == 32768) return launch_s<N>(ctx, sign, in, out, window, tw, nframes, shift, real_in, st);
+    else if constexpr (N == 8192 || N == 16384) {
         // MI355_FFT_WHOLE_FRAME=1 selects the whole-frame kernel (512/1024 threads, frame image in LDS) for comparison
         static const bool whole = getenv("MI355_FFT_WHOLE_FRAME") ? atoi(getenv("MI355_FFT_WHOLE_FRAME")) != 0 : false;
         if (!whole) return launch_s<N>(ctx, sign, in, out, window, tw, nframes, shift, real_in, st);
     }
-    return launch_g<N, Geo<N>>(ctx, sign, in, out, window, tw, nframes, shift, real_in, st);
+    if constexpr (N != 32768) return launch_g<N, Geo<N>>(ctx, sign, in, out, window, tw, nframes, shift, real_in, st);
 }
 
 int launch_fft(mi355_ctx *ctx, int n, int sign, const void *in, void *out, const float *window, const void *tw, int nframes,
@@ -509,10 +618,10 @@ int launch_fft(mi355_ctx *ctx, int n, int sign, const void *in, void *out, const
     switch (n) {
 #define CASE_N(NN) case NN: return launch_n<NN>(ctx, sign, in, out, window, tw, nframes, shift, real_in, st)
         CASE_N(2); CASE_N(4); CASE_N(8); CASE_N(16); CASE_N(32); CASE_N(64); CASE_N(128); CASE_N(256); CASE_N(512);
-        CASE_N(1024); CASE_N(2048); CASE_N(4096); CASE_N(8192); CASE_N(16384);
+        CASE_N(1024); CASE_N(2048); CASE_N(4096); CASE_N(8192); CASE_N(16384); CASE_N(32768);
 #undef CASE_N
     }
-    mi355_set_error("fft size %d unsupported (power of two, 2..16384)", n);
+    mi355_set_error("fft size %d unsupported (power of two, 2..32768)", n);
     return MI355_ERR_UNSUPPORTED;
 }
 
@@ -534,6 +643,7 @@ struct mi355_fft {
     // The two-kernel sizes (> 16384 points) and the unfused chirp-z path go through ONE workspace per handle.  Calls on
     // different streams / threads are serialised on it: the lock covers the enqueue, ws_done orders the streams (the next
     // user's stream waits for the previous user's kernels) and guards the re-allocation.
+    bool two_kernel = false;  // workspace scheme (65536 points; 32768 only with MI355_FFT_32768_TWO_KERNELS)
     std::mutex ws_lock;
     hipEvent_t ws_done = nullptr;
     bool ws_used = false;
@@ -795,7 +905,7 @@ int launch_big(mi355_fft *h, const void *in, void *out, int nframes, hipStream_t
 int launch_handle(mi355_fft *h, const void *in, void *out, int nvec, hipStream_t st)
 {
     if (h->m) return launch_bluestein(h, in, out, nvec, st);
-    if (h->n > 16384) return launch_big(h, in, out, nvec, st);
+    if (h->n > 32768 || (h->n == 32768 && h->two_kernel)) return launch_big(h, in, out, nvec, st);
     return launch_fft(h->ctx, h->n, h->sign, in, out, h->d_window, h->d_tw, nvec, h->shift, h->dtype == MI355_DTYPE_FLOAT, st);
 }
 
@@ -938,7 +1048,8 @@ extern "C" int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, con
     {
         std::vector<float> w(fft_size, 1.0f);  // no window == all ones: the kernel has a single code path
         if (window_len) memcpy(w.data(), window, sizeof(float) * (size_t)fft_size);
-        if (pow2 && fft_size > 16384) {
+        h->two_kernel = pow2 && (fft_size > 32768 || (fft_size == 32768 && getenv("MI355_FFT_32768_TWO_KERNELS") != nullptr));
+        if (h->two_kernel) {
             // two-kernel sizes: k_fft_sub reads the window values of the sub-frame pair (s, s+1) for every n -- stored
             // pair-major, [s/2][n][2], they are one contiguous 8-byte load per lane instead of 8 bytes out of every S*4
             const int S = fft_size / 4096;
@@ -1031,7 +1142,7 @@ extern "C" int mi355_fft_work(mi355_fft *h, int nvec, const void *const *in_stre
         char *pout = (char *)out_streams[s_i];
         for (size_t ci = 0; ci < nchunks; ci++, seq++) {
             int s = (int)(seq & 1);
-            hipStream_t st = h->ctx->stream[(h->m || h->n > 16384) ? 0 : s];  // chirp-z / two-kernel paths share work buffers: one stream
+            hipStream_t st = h->ctx->stream[(h->m || h->n > 32768 || (h->n == 32768 && h->two_kernel)) ? 0 : s];  // chirp-z / two-kernel paths share work buffers: one stream
             if (pend_bytes[s]) {
                 MI355_HIP(hipEventSynchronize(p.done[s]));
                 mi355_copy(pend_dst[s], p.h_out[s], pend_bytes[s]);

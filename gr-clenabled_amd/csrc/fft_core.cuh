@@ -271,4 +271,52 @@ __device__ __forceinline__ void transform_regs(c32 (&v)[16], const TwRegs<N> &tw
     }
 }
 
+// Two independent N-point transforms in lockstep (each with its own PTS-slot LDS area): the same passes as transform_regs,
+// but every barrier and every LDS round trip is shared by the two, and their butterflies interleave in the instruction
+// stream -- for kernels that run one wave per SIMD and cannot hide those latencies with other waves.
+template <int N, int SIGN, bool REV, class G = Geo<N>, int P = 0, bool CJ = false>
+__device__ __forceinline__ void transform_regs2(c32 (&va)[16], c32 (&vb)[16], const TwRegs<N> &tw, c32 *lds_a, c32 *lds_b, int tid)
+{
+    using PL = Plan<N, REV>;
+    if constexpr (P < PL::NP) {
+        constexpr int TH = G::TH, NP = PL::NP, R = PL::radix(P), NS = PL::ns(P), B = N / R;
+        if constexpr (P > 0) {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 16 / R; q++) {
+                const int g = tid + TH * q, raw = (g / B) * N + (g % B), rs = swzn<N>(raw);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    va[q * R + r] = lds_a[lds_at<B, N>(raw, rs, r * B)];
+                    vb[q * R + r] = lds_b[lds_at<B, N>(raw, rs, r * B)];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 16 / R; q++) {
+                apply_twiddles<R, CJ>(&va[q * R], &tw.w[P - 1][q * tw_slots<R>()]);
+                apply_twiddles<R, CJ>(&vb[q * R], &tw.w[P - 1][q * tw_slots<R>()]);
+            }
+            if constexpr (P < NP - 1) __syncthreads();
+        }
+#pragma unroll
+        for (int q = 0; q < 16 / R; q++) {
+            bfly<R, SIGN>(&va[q * R]);
+            bfly<R, SIGN>(&vb[q * R]);
+        }
+        if constexpr (P < NP - 1) {
+#pragma unroll
+            for (int q = 0; q < 16 / R; q++) {
+                const int g = tid + TH * q, fr = g / B, j = g % B;
+                const int raw = fr * N + (j / NS) * NS * R + (j % NS), rs = swzn<N>(raw);
+#pragma unroll
+                for (int s = 0; s < R; s++) {
+                    lds_a[lds_at<NS, N>(raw, rs, orev<R>(s) * NS)] = va[q * R + s];
+                    lds_b[lds_at<NS, N>(raw, rs, orev<R>(s) * NS)] = vb[q * R + s];
+                }
+            }
+        }
+        transform_regs2<N, SIGN, REV, G, P + 1, CJ>(va, vb, tw, lds_a, lds_b, tid);
+    }
+}
+
 }  // namespace fftc
