@@ -762,6 +762,7 @@ struct mi355_xengine {
     } slot[2];
     int next_submit = 0, next_wait = 0, pending = 0;
     bool acquired = false;  // the next slot's pinned frame buffer is handed out (zero-copy gather)
+    unsigned fused_epoch[2] = {0, 0};  // launches of the fused IChar path per tile workspace (slot 0 / the handle's, slot 1)
     int pad = 0;            // one zero channel appended on the device (odd channel count of 2-byte samples)
     size_t pad_bytes = 0;
     unsigned char *d_pad = nullptr;
@@ -860,7 +861,8 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
     if (g.mode == 0 && (reinterpret_cast<uintptr_t>(in) & 15u) == 0) {
         const XeFusedPlan fp = mi355_xe_fused_plan(g.N, g.F, g.Fout, g.npol, g.T, h->ctx->num_cus);
         if (fp.ok && (fp.part_bytes == 0 || (tiles && fp.part_bytes <= h->tile_bytes)))
-            return mi355_xe_fused_launch(fp, in, out, tiles, g.N, g.F, g.Fout, g.T, 0.007874015748031496063, accumulate, st, stations_per_group);
+            return mi355_xe_fused_launch(fp, in, out, tiles, g.N, g.F, g.Fout, g.T, 0.007874015748031496063, accumulate, st, stations_per_group,
+                                         ++h->fused_epoch[tiles == h->d_tiles ? 0 : 1]);
     }
     if (stations_per_group > 0 && stations_per_group < g.N) {
         mi355_set_error("antenna-group-major input needs the fused IChar path (<= 64 rows, whole 128-byte rows, integration %% 32 == 0)");

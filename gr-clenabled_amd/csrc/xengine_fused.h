@@ -9,15 +9,17 @@ struct XeFusedPlan {
     int npol = 1, ntt = 0;
     int units = 0;       // 32-byte column slices of an input row
     int tsplit = 1;      // time ranges (partial sums are combined by the reduce kernel when > 1)
-    size_t part_bytes = 0;  // int32 partial-sum workspace needed (0 when tsplit == 1)
+    size_t part_bytes = 0;  // workspace needed: int32 partial sums + the reduction's counters (0 when tsplit == 1)
+    size_t flag_offset = 0; // where the counters start
 };
 
 // stations N, channels F (F * npol * 2 bytes per (t, station) row), integration T
 XeFusedPlan mi355_xe_fused_plan(int N, int F, int Fout, int npol, int T, int num_cus);
 
 // in: [t][station][chan][pol]{I,Q} int8 (16-byte aligned), out: [chan][baseline][pol^2] complex float.
-// part: workspace of plan.part_bytes (unused when tsplit == 1).  kd: 1/127.
+// part: workspace of plan.part_bytes, zeroed once (unused when tsplit == 1); epoch: 1, 2, 3, ... per launch on that workspace
+// (the in-kernel reduction's counters hold launch numbers; launches sharing a workspace must be stream-ordered).  kd: 1/127.
 // stations_per_group (0 or N: the reference layout): the input is [group][t][station in group][chan][pol]{I,Q}, the blocks an
 // all-to-all corner turn delivers (gr-clenabled_amd/shard.py) -- read in place, no re-layout pass.
 int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void *part, int N, int F, int Fout, int T, double kd,
-                          int accumulate, hipStream_t st, int stations_per_group = 0);
+                          int accumulate, hipStream_t st, int stations_per_group = 0, unsigned epoch = 1);

@@ -7,7 +7,7 @@
 // workgroups that share a 128-byte line sit on one XCD (blockIdx % 8) and run the same time range, so HBM sees every line
 // once (24.8 us for the 134 MB of BASELINE config 5; 16-byte slices 40 us, 8-byte slices 75 us: the L2 request rate, not the
 // byte count, is the limit).  16 channels per workgroup x 256 CUs = 4 x the channels -> the integration is split into 4
-// time ranges whose exact int32 partial sums are combined afterwards (k_xe_i8_reduce).
+// time ranges whose exact int32 partial sums are combined afterwards (k_xe_i8_reduce, or the tail of k_xe_i8_fused).
 //
 // Workgroup = 8 waves.  Raw input goes global -> LDS by DMA (global_load_lds_dwordx4, no staging registers) into a ring of
 // four 16-time-step stages; two stages (32 steps = one K block of v_mfma_i32_16x16x32_i8) are consumed while two are in
@@ -36,6 +36,9 @@ struct FuArgs {
     int ng;     // stations per antenna group: input is [group][t][station in group][...] (ng == N: the reference layout)
     int nlines, tsplit, steps;  // 128-byte lines per input row; time ranges; K blocks (32 time steps) per time range
     int pinned, accumulate;
+    int *flags;        // pub[units] then claim[units * tsplit]: arrival counters / piece claims of the in-kernel reduction (epoch valued)
+    unsigned epoch;    // launch number on this workspace (>= 1)
+    int inkernel;      // 1: time ranges are combined by the kernel's own tail, 0: by k_xe_i8_reduce
     int dbg;  // tuning aid (MI355_XE_DBG): 1 = no compute, 2 = no stores, 4 = no DMA
     double kd;
 };
@@ -65,7 +68,12 @@ __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst)
                  : "memory");
 }
 
-template <int NPOL, int NTT>
+// partial-sum traffic between the workgroups of one unit: write-through stores and L1/L2-bypassing loads on both sides (one of
+// the valid hand-off forms of MI355X_MICROARCH.md: no fences, the flag follows the stores' completion)
+__device__ __forceinline__ void st_sys(v4i *p, v4i v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void ld_sys(v4i &d, const v4i *p) { asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(d) : "v"(p) : "memory"); }
+
+template <int NPOL, int NTT, bool SPLIT>
 __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
 {
     constexpr int NSH = (NTT * 16 / NPOL > 32) ? 2 : 1;     // 32-station halves of a time step
@@ -234,9 +242,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) vim[reg] += corr[reg];
                 if (a.dbg & 2) { if (vre[0] == 0x12345678 && vim[1] == 0x7654321) a.part[lane] = vre; continue; }
-                if (a.tsplit > 1) {
+                if constexpr (SPLIT) {
                     v4i *dst = a.part + ((((size_t)q * a.F + f) * NP + p) * 2) * 64 + lane;
-                    if (a.dbg & 8) { dst[0] = vre; dst[64] = vim; }
+                    if (a.inkernel) { st_sys(dst, vre); st_sys(dst + 64, vim); }
                     else { __builtin_nontemporal_store(vre, dst); __builtin_nontemporal_store(vim, dst + 64); }
                 } else {
                     if (f >= a.Fout) continue;
@@ -259,9 +267,104 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
             }
         }
     }
+    if constexpr (SPLIT) {
+        if (!a.inkernel) return;
+        // ---- the time ranges of this slice are combined HERE (no second kernel).  Every workgroup has published its partial
+        // matrix; it raises the unit's arrival counter and waits -- for a bounded time -- until all tsplit ranges have arrived.
+        // The unit's (channel, tile pair) items are cut into tsplit pieces; a workgroup claims pieces (its own first) with a
+        // compare-and-swap and finishes them: sum of the ranges in int64, one rounding, scatter into the output order.  A
+        // workgroup that gives up waiting leaves its piece unclaimed; the last range to arrive sees the full count at once
+        // and sweeps whatever is unclaimed, so the result is complete for any dispatch order (nobody waits on a workgroup that
+        // has not started).  Counters and claims hold launch numbers (epoch): nothing is reset between launches.
+        __shared__ int s_flag;
+        const int units = a.nlines * 4;
+        int *pub = a.flags + slice, *claim = a.flags + units + slice * a.tsplit;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have completed
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(pub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int target = (int)(a.epoch * (unsigned)a.tsplit);
+            int ok = 0;
+            for (int spin = 0; spin < 4096 && !ok; spin++) {
+                ok = (__hip_atomic_load(pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0;
+                if (!ok) __builtin_amdgcn_s_sleep(16);
+            }
+            s_flag = ok;
+        }
+        __syncthreads();
+        if (!s_flag) return;
+        const int cpwg = 16 / NPOL, total = cpwg * NP, per = (total + a.tsplit - 1) / a.tsplit;
+        for (int kk = 0; kk < a.tsplit; kk++) {
+            const int k = (q + kk) % a.tsplit;
+            __syncthreads();
+            if (tid == 0) s_flag = atomicCAS((unsigned *)claim + k, a.epoch - 1u, a.epoch) == a.epoch - 1u;
+            __syncthreads();
+            if (!s_flag) continue;
+            const int it_end = (k + 1) * per < total ? (k + 1) * per : total;
+            // four items per wave and round, four time ranges per group: 32 16-byte loads in flight per lane (the loads come from
+            // the memory side -- the partial sums were stored write-through -- so a wave's time is (rounds) x (one latency))
+            for (int it0 = k * per + wave; it0 < it_end; it0 += 4 * kWaves) {
+                long sre[4][4], sim[4][4];
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) sre[b][e] = sim[b][e] = 0;
+                for (int q0 = 0; q0 < a.tsplit; q0 += 4) {
+                    v4i x[4][8];
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const int it = (it0 + b * kWaves < it_end) ? it0 + b * kWaves : it0;  // (a missing item re-reads the first, unused)
+                        const int cu = it / NP, p = it - cu * NP, f = slice * cpwg + cu;
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int qq = (q0 + u < a.tsplit) ? q0 + u : q0;
+                            const v4i *src = a.part + ((((size_t)qq * a.F + f) * NP + p) * 2) * 64 + lane;
+                            ld_sys(x[b][2 * u], src);
+                            ld_sys(x[b][2 * u + 1], src + 64);
+                        }
+                    }
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[b][0]), "+v"(x[b][1]), "+v"(x[b][2]), "+v"(x[b][3]), "+v"(x[b][4]), "+v"(x[b][5]), "+v"(x[b][6]), "+v"(x[b][7])::"memory");
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            if (q0 + u >= a.tsplit) continue;
+#pragma unroll
+                            for (int e = 0; e < 4; e++) { sre[b][e] += x[b][2 * u][e]; sim[b][e] += x[b][2 * u + 1][e]; }
+                        }
+                }
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int it = it0 + b * kWaves;
+                    if (it >= it_end) continue;
+                    const int cu = it / NP, p = it - cu * NP, f = slice * cpwg + cu;
+                    if (f >= a.Fout) continue;
+                    int bi = 0;
+                    while ((bi + 1) * (bi + 2) / 2 <= p) bi++;
+                    const int bj = p - bi * (bi + 1) / 2;
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) {
+                        const int r1 = bi * 16 + 4 * g + reg, r2 = bj * 16 + r;
+                        if (r1 >= A || r2 >= A) continue;
+                        const int s1 = r1 / NPOL, p1 = r1 % NPOL, s2 = r2 / NPOL, p2 = r2 % NPOL;
+                        if (s1 < s2) continue;
+                        const size_t o = ((size_t)f * nb + (s1 * (s1 + 1) / 2 + s2)) * np2 + p1 * NPOL + p2;
+                        c32 v;
+                        v.x = (float)((double)sre[b][reg] * a.kd * a.kd);  // the oracle's expression: (double)S * kd * kd, rounded once
+                        v.y = (float)((double)sim[b][reg] * a.kd * a.kd);
+                        if (a.accumulate) { v.x += a.out[o].x; v.y += a.out[o].y; }
+                        a.out[o] = v;
+                    }
+                }
+            }
+        }
+    }
 }
 
 // sum of the time ranges' partial matrices (exact, int64), scale, scatter into the reference's output order
+// (the default form of the reduction; MI355_XE_INKERNEL_REDUCE=1 selects the tail of k_xe_i8_fused instead)
 template <int NPOL>
 __global__ __launch_bounds__(256) void k_xe_i8_reduce(const v4i *__restrict__ part, c32 *__restrict__ out, int N, int F, int Fout, int NP,
                                                       int tsplit, double kd, int accumulate, int dbg)
@@ -296,18 +399,14 @@ __global__ __launch_bounds__(256) void k_xe_i8_reduce(const v4i *__restrict__ pa
     }
 }
 
-template <int NPOL, int NTT> int launch_fused(const XeFusedPlan &p, const FuArgs &a, hipStream_t st)
+template <int NPOL, int NTT, bool SPLIT> int launch_fused_s(const XeFusedPlan &p, const FuArgs &a, hipStream_t st)
 {
     constexpr int NSH = (NTT * 16 / NPOL > 32) ? 2 : 1;
     constexpr int lds_bytes = kRing * (kStageT * NSH * kChunk + 16);
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
-        MI355_HIP(hipFuncSetAttribute((const void *)k_xe_i8_fused<NPOL, NTT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((k_xe_i8_fused<NPOL, NTT>), dim3(p.units * p.tsplit), dim3(kThreads), lds_bytes, st, a);
+    MI355_HIP(hipFuncSetAttribute((const void *)k_xe_i8_fused<NPOL, NTT, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL((k_xe_i8_fused<NPOL, NTT, SPLIT>), dim3(p.units * p.tsplit), dim3(kThreads), lds_bytes, st, a);
     MI355_HIP(hipGetLastError());
-    if (p.tsplit > 1) {
+    if (SPLIT && !a.inkernel) {
         const int NP = NTT * (NTT + 1) / 2;
         const size_t items = (size_t)a.Fout * NP;
         hipLaunchKernelGGL((k_xe_i8_reduce<NPOL>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, (const v4i *)a.part, a.out, a.N, a.F,
@@ -315,6 +414,10 @@ template <int NPOL, int NTT> int launch_fused(const XeFusedPlan &p, const FuArgs
         MI355_HIP(hipGetLastError());
     }
     return MI355_OK;
+}
+template <int NPOL, int NTT> int launch_fused(const XeFusedPlan &p, const FuArgs &a, hipStream_t st)
+{
+    return p.tsplit > 1 ? launch_fused_s<NPOL, NTT, true>(p, a, st) : launch_fused_s<NPOL, NTT, false>(p, a, st);
 }
 
 }  // namespace
@@ -339,17 +442,25 @@ XeFusedPlan mi355_xe_fused_plan(int N, int F, int Fout, int npol, int T, int num
     while (s > 1 && (T % (32 * s) != 0)) s /= 2;
     p.tsplit = s;
     const int NP = p.ntt * (p.ntt + 1) / 2;
-    p.part_bytes = s > 1 ? (size_t)s * F * NP * 2 * 1024 : 0;
+    p.flag_offset = s > 1 ? (size_t)s * F * NP * 2 * 1024 : 0;
+    p.part_bytes = s > 1 ? p.flag_offset + (((size_t)p.units * (s + 1) * 4 + 255) & ~(size_t)255) : 0;
     p.ok = true;
     return p;
 }
 
 int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void *part, int N, int F, int Fout, int T, double kd, int accumulate,
-                          hipStream_t st, int stations_per_group)
+                          hipStream_t st, int stations_per_group, unsigned epoch)
 {
     FuArgs a;
     a.in = (const unsigned char *)in;
     a.part = (v4i *)part;
+    a.flags = p.tsplit > 1 ? (int *)((char *)part + p.flag_offset) : nullptr;
+    a.epoch = epoch;
+    // Measured at BASELINE config 5: 69-70 us with the reduction inside the launch, 67 us with k_xe_i8_reduce -- the 84 MB of partial
+    // sums do not fit the XCD's L2 (10.5 MB per XCD against 4 MiB), so either way they are written to and read back from the
+    // memory side at HBM-like rates (~28 us of the total); the second kernel streams them with every CU, the in-launch tail is
+    // kept as an option (MI355_XE_INKERNEL_REDUCE=1) and for the tests.
+    a.inkernel = (getenv("MI355_XE_INKERNEL_REDUCE") && atoi(getenv("MI355_XE_INKERNEL_REDUCE")) != 0) ? 1 : 0;
     a.out = (c32 *)out;
     a.N = N; a.F = F; a.Fout = Fout; a.T = T;
     a.ng = (stations_per_group > 0 && stations_per_group < N) ? stations_per_group : N;

@@ -80,6 +80,24 @@ def test_fused_full_range_extremes(gpu, oracle, monkeypatch, tsplit):
     assert np.array_equal(out, ref + ref)
 
 
+@pytest.mark.parametrize("N,F,T,npol,tsplit", [(64, 64, 256, 1, "4"), (33, 128, 512, 1, "8"), (32, 64, 128, 2, "2"), (20, 64, 1024, 1, "16")])
+def test_fused_in_launch_reduction(gpu, oracle, monkeypatch, N, F, T, npol, tsplit):
+    """The time ranges combined by the fused kernel's own tail (arrival counters, claimed pieces, epoch-valued flags) instead of the
+    second kernel: bit-exact, also over repeated launches on the same workspace and with accumulation."""
+    monkeypatch.setenv("MI355_XE_INKERNEL_REDUCE", "1")
+    monkeypatch.setenv("MI355_XE_TSPLIT", tsplit)
+    rng = np.random.default_rng(N + T)
+    blk = _xe(gpu, gpu.DTYPE_BYTE, npol, N, F, T)
+    out = np.empty(blk.get_output_buffer_size(), np.complex64)
+    for rep in range(3):
+        x = rng.integers(-128, 128, size=T * N * F * npol * 2, dtype=np.int64).astype(np.int8)
+        ref = oracle.xengine_ichar(N, F, npol, T, x, exact=True)
+        blk.xcorrelate(x, out)
+        assert np.array_equal(out, ref), rep
+    blk.xcorrelate(x, out, True)
+    assert np.array_equal(out, ref + ref)
+
+
 def test_closed_form_cases(gpu):
     N, F, T = 8, 6, 32
     blk = _xe(gpu, gpu.DTYPE_BYTE, 1, N, F, T)
