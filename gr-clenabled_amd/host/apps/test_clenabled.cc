@@ -312,6 +312,97 @@ static int xengine_e2e(int nint)
     return ok ? 0 : 1;
 }
 
+// The blocks against a caller acting as the GNU Radio scheduler (stand-alone build: the scaffold of gr_compat.h records what a
+// block asks of the scheduler): io signatures, history / output multiple, consume counts of general_work(), the X-engine's
+// "xcorr" / "sync" message ports and its stream-tag synchroniser (lib/clXEngine_impl.cc:1152-1232).
+static int scheduler_contract_test()
+{
+#ifdef MI355_WITH_GNURADIO
+    printf("scheduler contract: run inside a GNU Radio flowgraph instead\n");
+    return 0;
+#else
+    const int G = OCLTYPE_GPU, S = OCLDEVICESELECTOR_SPECIFIC;
+    int fails = 0;
+    auto check = [&](bool ok, const char *what) { printf("%-78s %s\n", what, ok ? "ok" : "MISMATCH"); if (!ok) fails++; };
+    {
+        auto m = clMathOp::make(DTYPE_COMPLEX, G, S, 0, g_dev, MATHOP_MULTIPLY);
+        check(m->input_signature()->min_streams() == 2 && m->input_signature()->max_streams() == 2 && m->input_signature()->sizeof_stream_item(0) == 8 &&
+                  m->output_signature()->max_streams() == 1, "clMathOp io signature: 2 x complex in, 1 x complex out");
+        auto f = clFFT::make(1024, CLFFT_FORWARD, std::vector<float>(), DTYPE_FLOAT, G, S, 0, g_dev, 0, 3, false);
+        check(f->input_signature()->max_streams() == 3 && f->input_signature()->sizeof_stream_item(0) == 4096 && f->output_signature()->sizeof_stream_item(0) == 8192,
+              "clFFT io signature: num_streams vectors, float in / complex out");
+        auto d = clFilter::make(G, S, 0, g_dev, 4, std::vector<float>(65, 0.01f));
+        check(d->history() == 65 && d->decimation() == 4, "clFilter history = taps, sync_decimator decimation");
+    }
+    {   // polyphase channelizer: k output multiples per general_work() call
+        const int M = 8, tpa = 4, buf = M * 32, k = 3;
+        std::vector<float> taps((size_t)M * tpa);
+        for (size_t i = 0; i < taps.size(); i++) taps[i] = 0.01f * (float)(i % 7) - 0.02f;
+        std::vector<int> map(M);
+        for (int i = 0; i < M; i++) map[i] = i;
+        auto p = clPolyphaseChannelizer::make(G, S, 0, g_dev, taps, buf, M, M, map);
+        check(p->history() == taps.size() && p->output_multiple() == buf, "clPolyphaseChannelizer history = taps, output multiple = items per buffer");
+        std::vector<gr_complex> x((size_t)k * buf + taps.size() - M), y1((size_t)k * buf), yk(y1.size());
+        for (size_t i = 0; i < x.size(); i++) x[i] = gr_complex((float)std::sin(0.37 * (double)i), (float)std::cos(0.11 * (double)i));
+        gr_vector_int ninput(1, (int)x.size());
+        for (int b = 0; b < k; b++) {
+            gr_vector_const_void_star in = {x.data() + (size_t)b * buf}; gr_vector_void_star out = {y1.data() + (size_t)b * buf};
+            p->general_work(buf, ninput, in, out);
+        }
+        const long single = p->nitems_consumed(0);
+        p->reset_consumed();
+        gr_vector_const_void_star in = {x.data()}; gr_vector_void_star out = {yk.data()};
+        gr_vector_int req(1, 0);
+        p->forecast(k * buf, req);
+        const int produced = p->general_work(k * buf, ninput, in, out);
+        check(single == (long)k * buf && p->nitems_consumed(0) == (long)k * buf && produced == k * buf && req[0] == (int)x.size(),
+              "clPolyphaseChannelizer general_work(k multiples): consume_each(k * buf_items), forecast");
+        check(memcmp(y1.data(), yk.data(), y1.size() * sizeof(gr_complex)) == 0, "clPolyphaseChannelizer k buffers in one call == k single calls (bit exact)");
+    }
+    {   // X-engine: message ports and the tag synchroniser
+        const int N = 4, F = 64, T = 16;
+        auto xe = clXEngine::make(G, S, 0, g_dev, false, DTYPE_BYTE, 1, N, CLXCORR_TRIANGULAR_ORDER, 0, F, T, {}, false, "", 0, true /* synchroniser */);
+        check(xe->message_ports_out().size() == 2 && xe->message_ports_out()[0] == "xcorr" && xe->message_ports_out()[1] == "sync" && xe->output_multiple() == 16,
+              "clXEngine registers \"xcorr\" and \"sync\"; synchroniser sets output multiple 16");
+        check(xe->input_signature()->min_streams() == 2 && xe->input_signature()->max_streams() == N && xe->input_signature()->sizeof_stream_item(0) == F * 2 &&
+                  xe->output_signature()->max_streams() == 0, "clXEngine io signature: antennas x channel rows in, no stream out");
+        std::vector<char> frames((size_t)F * 2 * 64);
+        for (size_t i = 0; i < frames.size(); i += 2) { frames[i] = 127; frames[i + 1] = 0; }
+        gr_vector_const_void_star in(N, frames.data());
+        gr_vector_void_star out;
+        gr_vector_int ninput(N, 64);
+        xe->set_first_tags({1000, 1016, 1000, 1048});  // inputs 0 and 2 are 48 behind the latest, input 1 is 32 behind
+        int r = xe->general_work(32, ninput, in, out);
+        check(r == 0 && !xe->synchronized() && xe->nitems_consumed(0) == 32 && xe->nitems_consumed(1) == 32 && xe->nitems_consumed(2) == 32 &&
+                  xe->nitems_consumed(3) == 0, "unaligned tags: nothing produced, lagging inputs advance by min(highest - own, noutput_items)");
+        xe->reset_consumed();
+        xe->set_first_tags({1032, 1048, 1032, 1048});
+        r = xe->general_work(32, ninput, in, out);
+        check(r == 0 && xe->nitems_consumed(0) == 16 && xe->nitems_consumed(1) == 0 && xe->nitems_consumed(3) == 0, "second round: the remaining 16 items");
+        xe->reset_consumed();
+        xe->set_first_tags({1048, 1048, 1048, 1048});
+        r = xe->general_work(32, ninput, in, out);  // aligned: synchronised, then T = 16 frames of the window are taken
+        gr::shim_message msg;
+        const bool got_sync = xe->pop_message(msg) && msg.port == "sync" && msg.key == "synctimestamp" && msg.u64 == 1048;
+        check(r == T && xe->synchronized() && xe->sync_tag() == 1048 && got_sync && xe->nitems_consumed(0) == T && xe->nitems_consumed(3) == T,
+              "aligned tags: \"sync\" message (synctimestamp, 1048), work proceeds, consume_each(items)");
+        for (int i = 0; i < 3; i++) xe->general_work(T, ninput, in, out);
+        xe->stop();
+        int nmsg = 0;
+        bool ok = true;
+        const size_t len = (size_t)F * (N * (N + 1) / 2);
+        while (xe->pop_message(msg)) {
+            nmsg++;
+            ok = ok && msg.port == "xcorr" && msg.key == "triang_matrix" && msg.c32.size() == len && std::fabs(msg.c32[0].real() - (float)T) < 1e-3f &&
+                 std::fabs(msg.c32[len - 1].real() - (float)T) < 1e-3f && msg.c32[5].imag() == 0.0f;
+        }
+        check(nmsg == 4 && ok, "\"xcorr\" messages: (triang_matrix, c32vector of nchan * nbaselines) per integration");
+    }
+    printf("%s\n", fails ? "MISMATCH" : "ok");
+    return fails ? 1 : 0;
+#endif
+}
+
 int main(int argc, char **argv)
 {
     size_t n = 8192;  // the reference's default block size
@@ -326,6 +417,10 @@ int main(int argc, char **argv)
         else if (!strncmp(argv[i], "--xengine-stream=", 17)) {
             try { return xengine_stream_test(argv[i] + 17); }
             catch (const std::exception &e) { std::cerr << "error: " << e.what() << std::endl; return 2; }
+        }
+        else if (!strcmp(argv[i], "--scheduler-contract")) {
+            try { return scheduler_contract_test(); }
+            catch (const std::exception &e) { fprintf(stderr, "scheduler contract test: %s\n", e.what()); return 2; }
         }
         else if (!strncmp(argv[i], "--xengine-e2e", 13)) {
             try { return xengine_e2e(argv[i][13] == '=' ? atoi(argv[i] + 14) : 5); }

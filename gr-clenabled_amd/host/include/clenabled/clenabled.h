@@ -3,6 +3,7 @@
 //   clMathOp.h:42, clMathConst.h:51-54, clFFT.h:54-55 (+ lib/clFFT_impl.cc:34-36 order),
 //   clFilter.h:52-61, clComplexFilter.h:706-709, clPolyphaseChannelizer.h:48-49, clXEngine.h:48-52.
 #pragma once
+#include <cstdint>
 #include <memory>
 #include <string>
 #include <vector>
@@ -46,8 +47,6 @@ public:
                      int setDebug = 0);
     virtual int testOpenCL(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
                            gr_vector_void_star &output_items) = 0;
-protected:
-    clMathOp() : gr::sync_block("clMathOp") {}
 };
 
 class clMathConst : virtual public gr::sync_block {
@@ -59,8 +58,6 @@ public:
     virtual void set_k(float newValue) = 0;
     virtual int testOpenCL(int noutput_items, gr_vector_int &ninput_items, gr_vector_const_void_star &input_items,
                            gr_vector_void_star &output_items) = 0;
-protected:
-    clMathConst() : gr::sync_block("clMathConst") {}
 };
 
 class clFFT : virtual public gr::sync_block {
@@ -71,8 +68,6 @@ public:
                      int devSelector, int platformId, int devId, int setDebug = 0, int num_streams = 1, bool shift = false);
     // counts SAMPLES like the reference's test hook (lib/clFFT_impl.cc:520-524)
     virtual int testOpenCL(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &output_items) = 0;
-protected:
-    clFFT() : gr::sync_block("clFFT") {}
 };
 
 const bool DEFAULT_USE_TIME_DOMAIN_SETTING = false;  // clFilter.h:32
@@ -87,8 +82,6 @@ public:
     virtual std::vector<float> taps() const = 0;
     virtual void set_nthreads(int n) = 0;
     virtual int testOpenCL(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &output_items) = 0;
-protected:
-    clFilter() : gr::sync_decimator("clFilter", 1) {}
 };
 
 class clComplexFilter : virtual public gr::sync_decimator {
@@ -99,8 +92,6 @@ public:
     virtual void set_taps2(const std::vector<gr_complex> &taps) = 0;
     virtual std::vector<gr_complex> taps() const = 0;
     virtual int testOpenCL(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &output_items) = 0;
-protected:
-    clComplexFilter() : gr::sync_decimator("clComplexFilter", 1) {}
 };
 
 class clPolyphaseChannelizer : virtual public gr::block {
@@ -108,8 +99,6 @@ public:
     typedef std::shared_ptr<clPolyphaseChannelizer> sptr;
     static sptr make(int openCLPlatformType, int devSelector, int platformId, int devId, const std::vector<float> &taps,
                      int buf_items, int num_channels, int ninputs_per_iter, const std::vector<int> &ch_map, int setDebug = 0);
-protected:
-    clPolyphaseChannelizer() : gr::block("clPolyphaseChannelizer") {}
 };
 
 class clXEngine : virtual public gr::block {
@@ -141,8 +130,9 @@ public:
     virtual long integrations_delivered() const = 0;
     // frames of every input stream -> the frame buffer, lib/clXEngine_impl.cc:987-1061
     virtual int gather_frames(int nframes, int frame0, gr_vector_const_void_star &input_items, void *frame_buffer) = 0;
-protected:
-    clXEngine() : gr::block("clXEngine") {}
+    // stream-tag synchroniser state (internal_synchronizer = true, lib/clXEngine_impl.cc:1158-1226)
+    virtual bool synchronized() const = 0;
+    virtual uint64_t sync_tag() const = 0;
 };
 
 // ---- remaining elementwise family; make() signatures of include/clenabled/cl<Name>.h:49 ----
@@ -153,8 +143,6 @@ protected:
         static sptr make(__VA_ARGS__);                                                                                \
         virtual int testOpenCL(int noutput_items, gr_vector_const_void_star &input_items,                            \
                                gr_vector_void_star &output_items) = 0;                                                \
-    protected:                                                                                                        \
-        NAME() : gr::sync_block(#NAME) {}                                                                             \
     }
 MI355_DECLARE_SYNC_BLOCK(clLog, int openCLPlatformType, int devSelector, int platformId, int devId, float nValue, float kValue,
                          int setDebug = 0);
@@ -177,8 +165,6 @@ public:
     static sptr make(int fftSize, int num_inputs, int openCLPlatformType, int devSelector, int platformId, int devId,
                      int input_type = 1);
     virtual int work_test(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &output_items) = 0;
-protected:
-    clxcorrelate_fft_vcf() : gr::sync_block("clxcorrelate_fft_vcf") {}
 };
 
 }  // namespace clenabled

@@ -41,7 +41,8 @@ class clMathOp_impl : public clMathOp, public MI355Base {
     mi355_mathop *d_h = nullptr;
 public:
     clMathOp_impl(int idataType, int openCLPlatformType, int devSelector, int platformId, int devId, int operatorType, bool setDebug)
-        : gr::sync_block("clMathOp"), MI355Base(openCLPlatformType, devSelector, platformId, devId, setDebug)
+        : gr::sync_block("clMathOp", gr::io_signature::make(2, 2, (int)dsize(idataType)), gr::io_signature::make(1, 1, (int)dsize(idataType))),  // lib/clMathOp_impl.cc:63-65
+          MI355Base(openCLPlatformType, devSelector, platformId, devId, setDebug)
     {
         chk(mi355_mathop_create(d_ctx, idataType, operatorType, 8192, &d_h), "mi355_mathop_create");
     }
@@ -59,7 +60,8 @@ class clMathConst_impl : public clMathConst, public MI355Base {
 public:
     clMathConst_impl(int idataType, int openCLPlatformType, int devSelector, int platformId, int devId, float fValue,
                      int operatorType, bool setDebug)
-        : gr::sync_block("clMathConst"), MI355Base(openCLPlatformType, devSelector, platformId, devId, setDebug)
+        : gr::sync_block("clMathConst", gr::io_signature::make(1, 1, (int)dsize(idataType)), gr::io_signature::make(1, 1, (int)dsize(idataType))),
+          MI355Base(openCLPlatformType, devSelector, platformId, devId, setDebug)
     {
         chk(mi355_mathconst_create(d_ctx, idataType, operatorType, fValue, 8192, &d_h), "mi355_mathconst_create");
     }
@@ -80,7 +82,8 @@ class clFFT_impl : public clFFT, public MI355Base {
 public:
     clFFT_impl(int fftSize, int clFFTDir, const std::vector<float> &window, int idataType, int openCLPlatformType, int devSelector,
                int platformId, int devId, bool setDebug, int num_streams, bool shift)
-        : gr::sync_block("clFFT"), MI355Base(openCLPlatformType, devSelector, platformId, devId, setDebug), d_fft_size(fftSize)
+        : gr::sync_block("clFFT", gr::io_signature::make(1, num_streams, fftSize * (int)dsize(idataType)), gr::io_signature::make(1, num_streams, fftSize * (int)sizeof(gr_complex))),  // lib/clFFT_impl.cc:68-70
+          MI355Base(openCLPlatformType, devSelector, platformId, devId, setDebug), d_fft_size(fftSize)
     {
         if (!(window.empty() || window.size() == (size_t)fftSize))  // lib/clFFT_impl.cc:74-76
             throw std::runtime_error("OpenCL FFT: window not the same length as fft_size\n");
@@ -108,7 +111,8 @@ protected:
 public:
     filter_impl_t(const char *name, int openclPlatform, int devSelector, int platformId, int devId, int decimation,
                   const std::vector<Tap> &taps, bool setDebug, bool complex_taps, bool use_time)
-        : gr::sync_decimator(name, decimation), MI355Base(openclPlatform, devSelector, platformId, devId, setDebug)
+        : gr::sync_decimator(name, gr::io_signature::make(1, 1, (int)sizeof(gr_complex)), gr::io_signature::make(1, 1, (int)sizeof(gr_complex)), decimation),
+          MI355Base(openclPlatform, devSelector, platformId, devId, setDebug)
     {
         chk(mi355_filter_create(d_ctx, decimation, taps.data(), (int)taps.size(), complex_taps, use_time, &d_h), "mi355_filter_create");
         this->set_history(taps.size());  // lib/clFilter_impl.cc:78
@@ -143,14 +147,16 @@ public:
 class clFilter_impl : public filter_impl_t<clFilter, float> {
 public:
     clFilter_impl(int p, int s, int pl, int d, int decim, const std::vector<float> &taps, bool dbg, bool use_time)
-        : gr::sync_decimator("clFilter", decim), filter_impl_t("clFilter", p, s, pl, d, decim, taps, dbg, false, use_time) {}
+        : gr::sync_decimator("clFilter", gr::io_signature::make(1, 1, (int)sizeof(gr_complex)), gr::io_signature::make(1, 1, (int)sizeof(gr_complex)), decim),
+          filter_impl_t("clFilter", p, s, pl, d, decim, taps, dbg, false, use_time) {}
     void set_nthreads(int) override {}  // lib/clFilter_impl.cc:413-415 only configured the CPU FFTW plan
 };
 
 class clComplexFilter_impl : public filter_impl_t<clComplexFilter, gr_complex> {
 public:
     clComplexFilter_impl(int p, int s, int pl, int d, int decim, const std::vector<gr_complex> &taps, bool dbg)
-        : gr::sync_decimator("clComplexFilter", decim), filter_impl_t("clComplexFilter", p, s, pl, d, decim, taps, dbg, true, true) {}
+        : gr::sync_decimator("clComplexFilter", gr::io_signature::make(1, 1, (int)sizeof(gr_complex)), gr::io_signature::make(1, 1, (int)sizeof(gr_complex)), decim),
+          filter_impl_t("clComplexFilter", p, s, pl, d, decim, taps, dbg, true, true) {}
 };
 
 class clPolyphaseChannelizer_impl : public clPolyphaseChannelizer, public MI355Base {
@@ -159,7 +165,8 @@ class clPolyphaseChannelizer_impl : public clPolyphaseChannelizer, public MI355B
 public:
     clPolyphaseChannelizer_impl(int p, int s, int pl, int d, const std::vector<float> &taps, int buf_items, int num_channels,
                                 int ninputs_per_iter, const std::vector<int> &ch_map, bool dbg)
-        : gr::block("clPolyphaseChannelizer"), MI355Base(p, s, pl, d, dbg), d_buf_items(buf_items)
+        : gr::block("clPolyphaseChannelizer", gr::io_signature::make(1, 1, (int)sizeof(gr_complex)), gr::io_signature::make(1, 1, (int)sizeof(gr_complex))),  // lib/clPolyphaseChannelizer_impl.cc:50-51
+          MI355Base(p, s, pl, d, dbg), d_buf_items(buf_items)
     {
         if (num_channels <= 0 || buf_items % num_channels != 0)  // lib/clPolyphaseChannelizer_impl.cc:59-62
             throw std::invalid_argument("buf_items must be a multiple of num_channels");
@@ -169,12 +176,22 @@ public:
         set_output_multiple(mi355_pfb_noutput(d_h));  // :64
     }
     ~clPolyphaseChannelizer_impl() override { mi355_pfb_destroy(d_h); }
-    void forecast(int, gr_vector_int &req) override { req[0] = mi355_pfb_ninput(d_h); }
-    int general_work(int, gr_vector_int &, gr_vector_const_void_star &in, gr_vector_void_star &out) override
+    // ninput_items_required = ninputs_per_iter * noutput_items / nmap + history() - num_channels (:78-82); for one output multiple
+    // that is mi355_pfb_ninput(); every further multiple needs buf_items more
+    void forecast(int noutput_items, gr_vector_int &req) override
     {
-        chk(mi355_pfb_work(d_h, in[0], out[0]), "mi355_pfb_work");
-        // consume_each(d_buf_items) with a real scheduler (:105)
-        return mi355_pfb_noutput(d_h);
+        const int per = mi355_pfb_noutput(d_h), k = noutput_items > per ? noutput_items / per : 1;
+        req[0] = mi355_pfb_ninput(d_h) + (k - 1) * d_buf_items;
+    }
+    // The reference handles exactly one buffer per call (:83-109).  The scheduler calls with a multiple of the output multiple;
+    // all whole buffers it offers are processed (same samples, fewer launches), consume_each(k * buf_items), k * noutput() returned.
+    int general_work(int noutput_items, gr_vector_int &, gr_vector_const_void_star &in, gr_vector_void_star &out) override
+    {
+        const int per = mi355_pfb_noutput(d_h), k = noutput_items > per ? noutput_items / per : 1;
+        for (int b = 0; b < k; b++)
+            chk(mi355_pfb_work(d_h, (const gr_complex *)in[0] + (size_t)b * d_buf_items, (gr_complex *)out[0] + (size_t)b * per), "mi355_pfb_work");
+        consume_each(k * d_buf_items);  // :105
+        return k * per;
     }
 };
 
@@ -202,6 +219,9 @@ class clXEngine_impl : public clXEngine, public MI355Base {
     double d_start_freq, d_chan_width;
     FILE *d_fp = nullptr;
     std::mutex d_lock;
+    bool d_use_synchronizer = false, d_synchronized = false, d_publish = true;
+    uint64_t d_sync_tag = 0;
+    std::vector<uint64_t> d_tag_list;
 
     bool open_file()
     {
@@ -242,8 +262,10 @@ class clXEngine_impl : public clXEngine, public MI355Base {
             if (d_rollover && d_bytes_written >= d_rollover_bytes) open_file();  // :1264-1267
             if (!d_wrote_json) write_json(first_frame);
             if (fwrite(m, d_matrix_len * sizeof(XComplex), 1, d_fp) == 1) d_bytes_written += d_matrix_len * sizeof(XComplex);
-        } else if (d_handler) {
-            d_handler(d_handler_user, m, d_matrix_len);
+        } else {
+            // message_port_pub("xcorr", cons("triang_matrix", c32vector)) -- :1070-1094; a C callback may be set instead / as well
+            if (d_handler) d_handler(d_handler_user, m, d_matrix_len);
+            if (d_publish) sched::publish_c32vector(this, "xcorr", "triang_matrix", (const gr_complex *)m, d_matrix_len);
         }
     }
     void collect_one()
@@ -255,11 +277,16 @@ class clXEngine_impl : public clXEngine, public MI355Base {
     std::vector<long> d_pending_first;  // first frame number of each integration in flight
 
 public:
+    static int item_bytes(int data_type) { return data_type == DTYPE_COMPLEX ? (int)sizeof(gr_complex) : data_type == DTYPE_BYTE ? 2 : 1; }
     clXEngine_impl(int p, int s, int pl, int d, bool dbg, int data_type, int polarization, int num_inputs, int first_channel,
                    int num_channels, int integration, const std::vector<std::string> &antennas, bool output_file,
-                   const std::string &file_base, int rollover_size_mb, long sync_timestamp, const std::string &object_name,
-                   double start_freq, double chan_width, bool disable_output, int pipeline_integration)
-        : gr::block("clXEngine"), MI355Base(p, s, pl, d, dbg), d_npol(data_type == DTYPE_PACKEDXY ? 2 : polarization),
+                   const std::string &file_base, int rollover_size_mb, bool internal_synchronizer, long sync_timestamp,
+                   const std::string &object_name, double start_freq, double chan_width, bool disable_output, int pipeline_integration)
+        : gr::block("clXEngine",  // lib/clXEngine_impl.cc:88-90: up to num_inputs * polarization streams of one channel row each, no stream output
+                    gr::io_signature::make(2, num_inputs * (data_type == DTYPE_PACKEDXY ? 1 : polarization),
+                                           num_channels * (data_type == DTYPE_PACKEDXY ? 2 : item_bytes(data_type))),
+                    gr::io_signature::make(0, 0, 0)),
+          MI355Base(p, s, pl, d, dbg), d_npol(data_type == DTYPE_PACKEDXY ? 2 : polarization),
           d_num_inputs(num_inputs), d_num_channels(num_channels), d_integration(integration),
           d_pipeline_integration(pipeline_integration), d_first_channel(first_channel), d_disable_output(disable_output),
           d_output_file(output_file && !disable_output), d_file_base(file_base), d_object_name(object_name),
@@ -282,6 +309,14 @@ public:
             if (rollover_size_mb > 0) { d_rollover = true; d_rollover_bytes = (size_t)rollover_size_mb * 1000000; }  // :121-125
             if (!open_file()) throw std::runtime_error("[X-Engine] can't open file: " + d_filename);                 // :130-137
         }
+        sched::register_out(this, "xcorr");  // :294-295
+        sched::register_out(this, "sync");
+        d_use_synchronizer = internal_synchronizer;
+        d_tag_list.assign((size_t)num_inputs, 0);
+        if (d_use_synchronizer) {  // :297-301: the SNAP boards send 16-time-step packets
+            sched::no_tag_propagation(this);
+            set_output_multiple(16);
+        }
     }
     ~clXEngine_impl() override
     {
@@ -296,10 +331,43 @@ public:
         return true;
     }
     void forecast(int n, gr_vector_int &req) override { for (auto &r : req) r = n; }
-    int general_work(int n, gr_vector_int &, gr_vector_const_void_star &in, gr_vector_void_star &out) override
+    // lib/clXEngine_impl.cc:1152-1232.  With the tag synchroniser on, nothing is correlated until the first tag of every input
+    // carries the same timestamp: inputs that are behind are advanced by (highest - own) items (timestamps step with the items),
+    // capped at noutput_items, and 0 is returned; once aligned, the timestamp is published on "sync" and normal work begins.
+    int general_work(int noutput_items, gr_vector_int &, gr_vector_const_void_star &in, gr_vector_void_star &out) override
     {
-        return work_test(n, in, out);  // + consume_each(items_processed) with a real scheduler (:1230)
+        if (d_use_synchronizer && !d_synchronized) {
+            uint64_t highest = 0, first = 0;
+            bool aligned = true;
+            for (int i = 0; i < d_num_inputs; i++) {
+                uint64_t t = 0;
+                if (!sched::first_tag(this, i, t)) {  // no tag in the window yet: cannot decide, consume nothing
+                    return 0;
+                }
+                if (i == 0) first = t;
+                else if (t != first) aligned = false;
+                d_tag_list[i] = t;
+                if (t > highest) highest = t;
+            }
+            if (!aligned) {
+                for (int i = 0; i < d_num_inputs; i++) {
+                    uint64_t n = highest - d_tag_list[i];
+                    if (n > (uint64_t)noutput_items) n = (uint64_t)noutput_items;
+                    consume(i, (int)n);
+                }
+                return 0;
+            }
+            d_synchronized = true;
+            d_sync_tag = highest;
+            if (d_fp && !d_wrote_json) write_json((long)highest);
+            sched::publish_u64(this, "sync", "synctimestamp", highest);  // :1203-1204
+        }
+        const int done = work_test(noutput_items, in, out);
+        consume_each(done);  // :1230
+        return done;
     }
+    bool synchronized() const override { return d_synchronized; }
+    uint64_t sync_tag() const override { return d_sync_tag; }
     int work_test(int noutput_items, gr_vector_const_void_star &in, gr_vector_void_star &) override
     {
         std::lock_guard<std::mutex> g(d_lock);
@@ -363,9 +431,16 @@ class elem_impl_t : public Base, public MI355Base {
     mi355_elem *d_h = nullptr;
     int d_nin, d_nout;
 public:
+    // item sizes as in the reference's constructors (e.g. lib/clComplexToMagPhase_impl.cc:49-50: complex in, two floats out)
+    static int in_size(int kind)
+    {
+        return (kind == MI355_ELEM_LOG10 || kind == MI355_ELEM_SNR || kind == MI355_ELEM_MAGPHASE2C) ? (int)sizeof(float) : (int)sizeof(gr_complex);
+    }
+    static int out_size(int kind) { return kind == MI355_ELEM_MAGPHASE2C ? (int)sizeof(gr_complex) : (int)sizeof(float); }
     elem_impl_t(const char *name, int kind, int nin, int nout, float p0, float p1, int openCLPlatformType, int devSelector,
                 int platformId, int devId, bool setDebug)
-        : gr::sync_block(name), MI355Base(openCLPlatformType, devSelector, platformId, devId, setDebug), d_nin(nin), d_nout(nout)
+        : gr::sync_block(name, gr::io_signature::make(nin, nin, in_size(kind)), gr::io_signature::make(nout, nout, out_size(kind))),
+          MI355Base(openCLPlatformType, devSelector, platformId, devId, setDebug), d_nin(nin), d_nout(nout)
     {
         chk(mi355_elem_create(d_ctx, kind, p0, p1, &d_h), "mi355_elem_create");
         this->set_history((unsigned)mi355_elem_history(d_h));  // clQuadratureDemod: 2 (lib/clQuadratureDemod_impl.cc:81)
@@ -388,7 +463,9 @@ class clxcorrelate_fft_vcf_impl : public clxcorrelate_fft_vcf, public MI355Base 
 public:
     clxcorrelate_fft_vcf_impl(int fftSize, int num_inputs, int openCLPlatformType, int devSelector, int platformId, int devId,
                               int input_type)
-        : gr::sync_block("clxcorrelate_fft_vcf"), MI355Base(openCLPlatformType, devSelector, platformId, devId, false)
+        : gr::sync_block("clxcorrelate_fft_vcf", gr::io_signature::make(2, num_inputs, (int)sizeof(gr_complex) * fftSize),
+                         gr::io_signature::make(1, num_inputs - 1, (int)sizeof(float) * fftSize)),  // lib/clxcorrelate_fft_vcf_impl.cc:701-702
+          MI355Base(openCLPlatformType, devSelector, platformId, devId, false)
     {
         chk(mi355_xcorr_fft_create(d_ctx, fftSize, num_inputs, input_type, &d_h), "mi355_xcorr_fft_create");
     }
@@ -470,13 +547,13 @@ clXEngine::sptr clXEngine::make(int openCLPlatformType, int devSelector, int pla
                                 int polarization, int num_inputs, int /*output_format: the kernel always writes triangular
                                 order, lib/clXEngine_impl.cc:208-211*/, int first_channel, int num_channels, int integration,
                                 std::vector<std::string> antenna_list, bool output_file, std::string file_base, int rollover_size_mb,
-                                bool /*internal_synchronizer: ATA tag alignment needs the scheduler's tags*/, long sync_timestamp,
+                                bool internal_synchronizer, long sync_timestamp,
                                 std::string object_name, double starting_chan_center_freq, double channel_width, bool disable_output,
                                 int pipeline_integration)
 {
     return sptr(new clXEngine_impl(openCLPlatformType, devSelector, platformId, devId, setDebug, data_type, polarization, num_inputs,
                                    first_channel, num_channels, integration, antenna_list, output_file, file_base, rollover_size_mb,
-                                   sync_timestamp, object_name, starting_chan_center_freq, channel_width, disable_output,
+                                   internal_synchronizer, sync_timestamp, object_name, starting_chan_center_freq, channel_width, disable_output,
                                    pipeline_integration));
 }
 

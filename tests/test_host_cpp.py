@@ -38,6 +38,15 @@ def test_cli_runs_every_block_and_checks_known_answers(gpu):
 
 
 @pytest.mark.gpu
+def test_blocks_against_a_scheduler(gpu):
+    """The caller plays GNU Radio's scheduler: io signatures, history / output multiple, consume counts of general_work() with several
+    output multiples, the X-engine's "xcorr" / "sync" message ports and its stream-tag synchroniser (lib/clXEngine_impl.cc:1152-1232)."""
+    r = subprocess.run([CLI, "--scheduler-contract"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "MISMATCH" not in r.stdout and r.stdout.count(" ok") >= 11, r.stdout
+
+
+@pytest.mark.gpu
 def test_xengine_streaming_file_sink_and_json(gpu, tmp_path):
     """work_test() streaming with ragged calls: result-handler delivery, file sink with 1 MB rollover and
     JSON sidecars (format of lib/clXEngine_impl.cc:438-465), pipeline integration."""
