@@ -19,7 +19,7 @@
 #include <vector>
 
 #include "common.h"
-#include "fft_core.cuh"
+#include "fft_core.hpp"
 
 using namespace fftc;
 #ifndef MI355_FFT_WPE

@@ -26,7 +26,7 @@
 #include <vector>
 
 #include "common.h"
-#include "fft_core.cuh"
+#include "fft_core.hpp"
 
 using namespace fftc;
 

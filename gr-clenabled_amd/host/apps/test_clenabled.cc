@@ -144,7 +144,7 @@ static void on_matrix(void *user, const XComplex *m, size_t n)
 static int xengine_stream_test(const std::string &dir)
 {
     const int N = 8, F = 64, T = 16, nint = 60, chunk = 7;
-    std::vector<char> stream((size_t)nint * T * F * 2);
+    std::vector<char> stream((size_t)(nint * T + 8) * F * 2);  // (+ the frames of the unfinished window of the first run)
     for (size_t i = 0; i < stream.size(); i += 2) { stream[i] = 127; stream[i + 1] = 0; }
     auto run = [&](clXEngine::sptr xe, int frames_total) {
         gr_vector_void_star out;

@@ -1,3 +1,4 @@
-for k in 0 12 24 48 96; do echo "== ols k=$k"; if [ $k = 0 ]; then timeout 200 python tools/probe_filter2.py | grep -E "ntaps= *(65|129|1000) FFT decim=1"; else MI355_WG_PER_CU=$k timeout 200 python tools/probe_filter2.py | grep -E "ntaps= *(65|129|1000) FFT decim=1"; fi; done
-for k in 0 8 16 32 64; do echo "== pfb k=$k"; if [ $k = 0 ]; then timeout 200 python tools/probe_pfb.py | tail -2; else MI355_WG_PER_CU=$k timeout 200 python tools/probe_pfb.py | tail -2; fi; done
-for k in 0 4 8 16; do echo "== xcorr k=$k"; if [ $k = 0 ]; then timeout 200 python tools/probe_xcorr.py | tail -3; else MI355_WG_PER_CU=$k timeout 200 python tools/probe_xcorr.py | tail -3; fi; done
+#!/bin/bash
+# workgroups-per-CU sweeps behind the grid sizes in the launchers: interleaved A/B inside one process per block
+V='[{}, {"MI355_WG_PER_CU": "4"}, {"MI355_WG_PER_CU": "8"}, {"MI355_WG_PER_CU": "16"}, {"MI355_WG_PER_CU": "32"}, {"MI355_WG_PER_CU": "64"}]'
+for case in filter65 fir65 filter3000 fft4096; do python tools/probe.py ab $case "$V"; done
