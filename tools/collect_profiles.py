@@ -23,25 +23,24 @@ h, f = counters(G + tag + "_fetch.txt")
 _, w = counters(G + tag + "_write.txt")
 with open(P + tag + "_traffic.txt", "w") as o:
     o.write("# HBM traffic per launch from PMC counters, separate passes (rocprofv3 --pmc FETCH_SIZE ; rocprofv3 --pmc WRITE_SIZE), "
-            "bench.py --steps 5 --warmup 1 --no-cpu  (tools/make_profiles.sh %s)\n" % tag)
+            "bench.py --steps 5 --warmup 1 --no-cpu --no-sustained  (tools/make_profiles.sh %s)\n" % tag)
     o.write("# values are KiB per dispatch; on gfx950 FETCH_SIZE counts 128-B read requests as 64 B, so HBM read bytes = 2 x FETCH_SIZE x 1024 "
             "(MI355X_MICROARCH.md, HBM section)\n")
     o.write(h + "\n" + "\n".join(f) + "\n" + "\n".join(w) + "\n")
 with open(P + tag + "_kernel_stats.txt", "w") as o:
-    o.write("# command: rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --no-cpu   (tools/make_profiles.sh %s)\n" % tag)
+    o.write("# command: rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 3 --no-cpu --sustain-s 0.5   (tools/make_profiles.sh %s)\n" % tag)
     o.write("# bench.py's own line from the same box, unprofiled run: profiles/%s_bench.json (roofline.kernel_us = HIP-event time over the K launches / K)\n" % tag)
     o.write(open(G + tag + "_stats.txt").read())
 open(P + tag + "_bench.json", "w").write(open(G + tag + "_bench.json").read().strip().splitlines()[-1] + "\n")
 
 
 def val(lines):
-    for l in lines:
-        if l.startswith("k_fft<4096"):
-            return float(l.split()[-2])
+    # the headline launches (16384 frames) and the one-vector host-path calls run the same kernel family: take the large one
+    return max(float(l.split()[-2]) for l in lines if l.startswith("k_fft<4096"))
 
 
 fs, ws = val(f), val(w)
-d = {"kernel": "k_fft<4096,-1,false,false,Geo<4096>>",
+d = {"kernel": "k_fft<4096,-1,false,1,Geo<4096>>",
      "command": "bench.py --steps 5 --warmup 1 --no-cpu (tools/make_profiles.sh, separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes)",
      "FETCH_SIZE_KiB_per_launch": fs, "WRITE_SIZE_KiB_per_launch": ws, "fetch_correction": 2.0,
      "hbm_bytes_per_launch": int(round((2 * fs + ws) * 1024)), "algorithmic_bytes_per_launch": 1073741824,

@@ -9,9 +9,9 @@ O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 600 python $R/bench.py --steps 20 --warmup 3 > $O/${tag}_bench.json 2> $O/${tag}_bench.err
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/${tag}_stats -o r -- python $R/bench.py --steps 20 --warmup 3 --no-cpu > $O/${tag}_stats.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/${tag}_fetch -o r -- python $R/bench.py --steps 5 --warmup 1 --no-cpu > $O/${tag}_fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE -d $O/${tag}_write -o r -- python $R/bench.py --steps 5 --warmup 1 --no-cpu > $O/${tag}_write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/${tag}_stats -o r -- python $R/bench.py --steps 20 --warmup 3 --no-cpu --sustain-s 0.5 > $O/${tag}_stats.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/${tag}_fetch -o r -- python $R/bench.py --steps 5 --warmup 1 --no-cpu --no-sustained > $O/${tag}_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE -d $O/${tag}_write -o r -- python $R/bench.py --steps 5 --warmup 1 --no-cpu --no-sustained > $O/${tag}_write.log 2>&1
 python $R/tools/prof_summary.py $O/${tag}_stats/r_results.db > $O/${tag}_stats.txt 2>&1
 python $R/tools/prof_summary.py $O/${tag}_fetch/r_results.db > $O/${tag}_fetch.txt 2>&1
 python $R/tools/prof_summary.py $O/${tag}_write/r_results.db > $O/${tag}_write.txt 2>&1
