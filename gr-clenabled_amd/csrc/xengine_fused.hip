@@ -39,6 +39,7 @@ struct FuArgs {
     int *flags;        // pub[units] then claim[units * tsplit]: arrival counters / piece claims of the in-kernel reduction (epoch valued)
     unsigned epoch;    // launch number on this workspace (>= 1)
     int inkernel;      // 1: time ranges are combined by the kernel's own tail, 0: by k_xe_i8_reduce
+    int compact;       // partial matrices of the diagonal tile pairs as ONE record (re on and below the diagonal, im above it)
     int dbg;  // tuning aid (MI355_XE_DBG): 1 = no compute, 2 = no stores, 4 = no DMA
     double kd;
 };
@@ -243,9 +244,25 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
                 for (int reg = 0; reg < 4; reg++) vim[reg] += corr[reg];
                 if (a.dbg & 2) { if (vre[0] == 0x12345678 && vim[1] == 0x7654321) a.part[lane] = vre; continue; }
                 if constexpr (SPLIT) {
-                    v4i *dst = a.part + ((((size_t)q * a.F + f) * NP + p) * 2) * 64 + lane;
-                    if (a.inkernel) { st_sys(dst, vre); st_sys(dst + 64, vim); }
-                    else { __builtin_nontemporal_store(vre, dst); __builtin_nontemporal_store(vim, dst + 64); }
+                    if (a.compact) {
+                        // A diagonal tile pair needs re (symmetric) and im (antisymmetric, zero diagonal) of ONE triangle: both go into one
+                        // 16 x 16 record, re on and below the diagonal, im above it (im[i][j] = -im[j][i] is rebuilt by the reduction).
+                        // 2 NP - NTT records of 1 KiB per channel and time range instead of 2 NP: a fifth less partial-sum traffic at 64 rows.
+                        v4i *dst = a.part + (((size_t)q * a.F + f) * (2 * NP - NTT) + (2 * p - bi)) * 64 + lane;
+                        if (bi == bj) {
+                            v4i comb;
+#pragma unroll
+                            for (int reg = 0; reg < 4; reg++) comb[reg] = (4 * g + reg >= r) ? vre[reg] : vim[reg];
+                            __builtin_nontemporal_store(comb, dst);
+                        } else {
+                            __builtin_nontemporal_store(vre, dst);
+                            __builtin_nontemporal_store(vim, dst + 64);
+                        }
+                    } else {
+                        v4i *dst = a.part + ((((size_t)q * a.F + f) * NP + p) * 2) * 64 + lane;
+                        if (a.inkernel) { st_sys(dst, vre); st_sys(dst + 64, vim); }
+                        else { __builtin_nontemporal_store(vre, dst); __builtin_nontemporal_store(vim, dst + 64); }
+                    }
                 } else {
                     if (f >= a.Fout) continue;
 #pragma unroll
@@ -366,23 +383,51 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
 // sum of the time ranges' partial matrices (exact, int64), scale, scatter into the reference's output order
 // (the default form of the reduction; MI355_XE_INKERNEL_REDUCE=1 selects the tail of k_xe_i8_fused instead)
 template <int NPOL>
-__global__ __launch_bounds__(256) void k_xe_i8_reduce(const v4i *__restrict__ part, c32 *__restrict__ out, int N, int F, int Fout, int NP,
-                                                      int tsplit, double kd, int accumulate, int dbg)
+__global__ __launch_bounds__(256) void k_xe_i8_reduce(const v4i *__restrict__ part, c32 *__restrict__ out, int N, int F, int Fout, int NP, int NTT,
+                                                      int tsplit, double kd, int accumulate, int compact)
 {
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-    const size_t item = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (f, p)
-    if (item >= (size_t)Fout * NP) return;
+    size_t item = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (f, p)
+    const bool live = item < (size_t)Fout * NP;                 // (whole waves; a dead wave still takes part in the shuffles below)
+    if (!live) item = 0;
     const int f = (int)(item / NP), p = (int)(item % NP);
     int bi = 0;
     while ((bi + 1) * (bi + 2) / 2 <= p) bi++;
     const int bj = p - bi * (bi + 1) / 2;
+    const bool diag = compact && bi == bj;
+    const int rpc = compact ? 2 * NP - NTT : 2 * NP, rec = compact ? 2 * p - bi : 2 * p;
     long sre[4] = {0, 0, 0, 0}, sim[4] = {0, 0, 0, 0};
     for (int q = 0; q < tsplit; q++) {
-        const v4i *src = part + ((((size_t)q * F + f) * NP + p) * 2) * 64 + lane;
-        const v4i a = (dbg & 16) ? src[0] : __builtin_nontemporal_load(src), b = (dbg & 16) ? src[64] : __builtin_nontemporal_load(src + 64);
+        const v4i *src = part + (((size_t)q * F + f) * rpc + rec) * 64 + lane;
+        const v4i a = __builtin_nontemporal_load(src);
 #pragma unroll
-        for (int k = 0; k < 4; k++) { sre[k] += a[k]; sim[k] += b[k]; }
+        for (int k = 0; k < 4; k++) sre[k] += a[k];
+        if (!diag) {
+            const v4i b = __builtin_nontemporal_load(src + 64);
+#pragma unroll
+            for (int k = 0; k < 4; k++) sim[k] += b[k];
+        }
     }
+    if (diag) {
+        // sre holds the combined tile C: C[i][j] = re[i][j] (i >= j), im[i][j] (i < j), at i = 4 g + reg, j = r.  The transposed entry
+        // C[j][i] sits in lane 16 (j / 4) + i, register j % 4.
+        const long cc[4] = {sre[0], sre[1], sre[2], sre[3]};  // (the loop below overwrites sre while other lanes still read C)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int i = 4 * g + reg, src_lane = 16 * (r >> 2) + i;
+            long t[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int lo = __shfl((int)(unsigned)(unsigned long)cc[k], src_lane), hi = __shfl((int)((unsigned long)cc[k] >> 32), src_lane);
+                t[k] = (long)(((unsigned long)(unsigned)hi << 32) | (unsigned long)(unsigned)lo);
+            }
+            const long tr = (r & 3) == 0 ? t[0] : (r & 3) == 1 ? t[1] : (r & 3) == 2 ? t[2] : t[3];
+            if (i > r) sim[reg] = -tr;                         // im[i][j] = -im[j][i]
+            else if (i == r) sim[reg] = 0;
+            else { sim[reg] = cc[reg]; sre[reg] = tr; }        // above the diagonal (same-station polarisation products): re[i][j] = re[j][i]
+        }
+    }
+    if (!live) return;
     const int nb = N * (N + 1) / 2, np2 = NPOL * NPOL, A = N * NPOL;
 #pragma unroll
     for (int reg = 0; reg < 4; reg++) {
@@ -410,7 +455,7 @@ template <int NPOL, int NTT, bool SPLIT> int launch_fused_s(const XeFusedPlan &p
         const int NP = NTT * (NTT + 1) / 2;
         const size_t items = (size_t)a.Fout * NP;
         hipLaunchKernelGGL((k_xe_i8_reduce<NPOL>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, (const v4i *)a.part, a.out, a.N, a.F,
-                           a.Fout, NP, p.tsplit, a.kd, a.accumulate, a.dbg);
+                           a.Fout, NP, NTT, p.tsplit, a.kd, a.accumulate, a.compact);
         MI355_HIP(hipGetLastError());
     }
     return MI355_OK;
@@ -461,6 +506,7 @@ int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void 
     // memory side at HBM-like rates (~28 us of the total); the second kernel streams them with every CU, the in-launch tail is
     // kept as an option (MI355_XE_INKERNEL_REDUCE=1) and for the tests.
     a.inkernel = (getenv("MI355_XE_INKERNEL_REDUCE") && atoi(getenv("MI355_XE_INKERNEL_REDUCE")) != 0) ? 1 : 0;
+    a.compact = (!a.inkernel && !getenv("MI355_XE_NO_COMPACT")) ? 1 : 0;
     a.out = (c32 *)out;
     a.N = N; a.F = F; a.Fout = Fout; a.T = T;
     a.ng = (stations_per_group > 0 && stations_per_group < N) ? stations_per_group : N;
