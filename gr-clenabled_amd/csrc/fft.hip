@@ -1013,8 +1013,8 @@ extern "C" int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, con
     MI355_REQUIRE(ctx && out, "NULL argument");
     *out = nullptr;
     const bool pow2 = fft_size >= 2 && (fft_size & (fft_size - 1)) == 0;
-    if (fft_size < 2 || (pow2 && fft_size > 65536) || (!pow2 && fft_size > 8192)) {
-        mi355_set_error("fft size %d unsupported (powers of two 2..65536, any other size 3..8192)", fft_size);
+    if (fft_size < 2 || (pow2 && fft_size > 65536) || (!pow2 && fft_size > 16384)) {
+        mi355_set_error("fft size %d unsupported (powers of two 2..65536, any other size 3..16384)", fft_size);
         return fft_size < 2 ? MI355_ERR_INVALID_ARG : MI355_ERR_UNSUPPORTED;
     }
     MI355_REQUIRE(window_len == 0 || window_len == fft_size, "window not the same length as fft_size");

@@ -68,6 +68,17 @@ public:
     ~clMathConst_impl() override { mi355_mathconst_destroy(d_h); }
     float k() const override { float v = 0; mi355_mathconst_get_k(d_h, &v); return v; }
     void set_k(float v) override { chk(mi355_mathconst_set_k(d_h, v), "mi355_mathconst_set_k"); }
+#if defined(MI355_WITH_GNURADIO) && defined(GR_CTRLPORT)
+    // ControlPort: the constant as a readable and writable real "Constant" (lib/clMathConst_impl.cc:377-401)
+    void setup_rpc() override
+    {
+        const pmt::pmt_t lo = pmt::from_double(-4.29e9), hi = pmt::from_double(4.29e9), def = pmt::from_double(0);
+        add_rpc_variable(rpcbasic_sptr(new rpcbasic_register_get<clMathConst, float>(alias(), "Constant", &clMathConst::k, lo, hi, def, "", "Constant",
+                                                                                      RPC_PRIVLVL_MIN, DISPTIME | DISPOPTSTRIP)));
+        add_rpc_variable(rpcbasic_sptr(new rpcbasic_register_set<clMathConst, float>(alias(), "Constant", &clMathConst::set_k, lo, hi, def, "", "Constant",
+                                                                                      RPC_PRIVLVL_MIN, DISPNULL)));
+    }
+#endif
     int work(int noutput_items, gr_vector_const_void_star &in, gr_vector_void_star &out) override
     {
         chk(mi355_mathconst_work(d_h, (size_t)noutput_items, in[0], out[0]), "mi355_mathconst_work");

@@ -153,7 +153,7 @@ int mi355_fft_work(mi355_fft *h, int nvec, const void *const *in_streams, void *
 /* Concurrency: sizes up to 32768 are stateless (any number of work_dev calls of one handle may be in flight on any streams).
  * 65536 points and the non-power-of-two sizes above 2048 go through ONE per-handle workspace: calls from different threads or
  * streams are accepted and serialised on it (the later stream waits for the earlier call's kernels); use one handle per
- * stream for overlap.  Sizes: powers of two 2 .. 65536, any other length 2 .. 8192 (chirp-z); larger ones return
+ * stream for overlap.  Sizes: powers of two 2 .. 65536, any other length 2 .. 16384 (chirp-z); larger ones return
  * MI355_ERR_UNSUPPORTED. */
 int mi355_fft_work_dev(mi355_fft *h, int nvec, const void *in, void *out, void *stream);
 

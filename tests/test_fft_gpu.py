@@ -161,13 +161,13 @@ def test_zero_vectors_and_bad_sizes(gpu):
     with pytest.raises(gpu.Mi355Error):
         _fft(gpu, 131072, gpu.CLFFT_FORWARD)  # powers of two above 65536 are refused, not emulated
     with pytest.raises(gpu.Mi355Error):
-        _fft(gpu, 9000, gpu.CLFFT_FORWARD)   # other sizes above 8192 too
+        _fft(gpu, 16385, gpu.CLFFT_FORWARD)  # other sizes above 16384 too
     with pytest.raises(gpu.Mi355Error):
         _fft(gpu, 1, gpu.CLFFT_FORWARD)
 
 
 # sizes that are not a power of two (clFFT's radix-3/5/7 plans in the reference) run through the chirp-z path
-@pytest.mark.parametrize("n", [3, 5, 12, 48, 100, 1000, 1536, 2000, 4095, 6000, 8191])
+@pytest.mark.parametrize("n", [3, 5, 12, 48, 100, 1000, 1536, 2000, 4095, 6000, 8191, 10000, 16383])
 @pytest.mark.parametrize("fwd,shift,win", [(True, False, False), (True, True, True), (False, True, True), (False, False, False)])
 def test_sizes_that_are_not_a_power_of_two(gpu, oracle, n, fwd, shift, win):
     rng = np.random.default_rng(n + 3)
