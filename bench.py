@@ -363,11 +363,12 @@ def gather_floats(value, world):
     return [float(o.item()) for o in outs]
 
 
-def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank):
+def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank, out=None):
     """Secondary lines: the other hot-path blocks, device resident, same timing method
-    (per-GPU figures of this rank; the headline above carries the multi-GPU aggregate)."""
+    (per-GPU figures of this rank; the headline above carries the multi-GPU aggregate).  Results go into `out` as they are
+    measured, so whatever exists survives a failure or the watchdog."""
     import torch
-    out = {}
+    out = {} if out is None else out
     args = (1, 2, 0, dev)
 
     def rate(fn, nsamples, bytes_per_sample, extra=None):
@@ -536,6 +537,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s back-to-back leg")
     ap.add_argument("--sustain-s", type=float, default=2.0)
+    ap.add_argument("--secondary-timeout", type=int, default=420, help="seconds the secondary legs may take before the line is printed without the rest")
     a = ap.parse_args()
 
     import torch
@@ -566,39 +568,6 @@ def main():
     kernel_s = ev / a.steps  # one launch per step: HIP-event time per launch on the launch stream
     achieved = samples_per_step * BYTES_PER_SAMPLE / kernel_s / 1e9
 
-    extras = {}
-    if not a.no_extra:
-        # fixture taps (SURVEY 8d): firdes.low_pass(1,10e6,1e6,372e3) = 65 taps; low_pass(1,64,.5,.0753)+[0] = 2048 taps.
-        # Designed by the product-independent formula below (same definition as tests/golden/gen_golden.py).
-        # The secondary lines must never cost the headline: a failure here is reported in the line, not raised.
-        try:
-            extras = extra_blocks(pkg, (lowpass_taps(1.0, 10e6, 1e6, 372000.0),
-                                        np.concatenate([lowpass_taps(1.0, 64.0, 0.5, 0.0753), [0.0]]).astype(np.float32)),
-                                  local, max(5, a.steps // 5), 2, world, rank)
-        except Exception as exc:  # noqa: BLE001
-            extras = {"error": "%s: %s" % (type(exc).__name__, exc)}
-    if not a.no_extra and isinstance(extras, dict):
-        # the only data-path collective of the hot path, INSIDE the JSON line (world 1: the same pipeline, no peers)
-        try:
-            extras["clXEngine_sharded"] = sharded_xengine(pkg, local, max(5, a.steps // 5), world, rank)
-        except Exception as exc:  # noqa: BLE001
-            extras["clXEngine_sharded"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
-        if rank == 0 and world == 1:
-            try:
-                extras.update(hostpath_blocks(pkg, (lowpass_taps(1.0, 10e6, 1e6, 372000.0),
-                                                    np.concatenate([lowpass_taps(1.0, 64.0, 0.5, 0.0753), [0.0]]).astype(np.float32)), local))
-            except Exception as exc:  # noqa: BLE001
-                extras["hostpath_error"] = "%s: %s" % (type(exc).__name__, exc)
-    cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu:
-        cpu = cpu_baseline_fft(entry.load_oracle(), window)
-        if isinstance(extras, dict):
-            extras["config1_clMathOp_testCPU_8192"] = config1_testcpu(entry.load_oracle())
-        if extras:
-            taps_pair = (lowpass_taps(1.0, 10e6, 1e6, 372000.0), np.concatenate([lowpass_taps(1.0, 64.0, 0.5, 0.0753), [0.0]]).astype(np.float32))
-            for k, v in cpu_extras(entry.load_oracle(), taps_pair).items():
-                if k in extras and isinstance(extras[k], dict):
-                    extras[k]["cpu_1core_MSamples_per_s"] = v
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "fft4096_pmc.json")) as fh:
@@ -606,35 +575,82 @@ def main():
         traffic = pmc["hbm_bytes_per_launch"]
     except Exception:
         pmc = None
+    extras = {}
+    line = {
+        "metric": "MSamples/sec (complex-float) through clFFT 4096 fwd + window + shift",
+        "value": round(value, 1),
+        "unit": "MSamples/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": round(wall / a.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: forward clFFT 4096-pt complex, blackman window + fftshift, "
+                               "%d frames/step/GPU device-resident (1 GiB in+out)" % FRAMES_PER_STEP,
+                   "fft_size": FFT_N, "frames_per_step": FRAMES_PER_STEP, "parallelism": "replica-per-gpu x%d" % world},
+        "per_gpu_MSamples_per_s": round(value / world, 1),
+        "sustained": sus,
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "traffic_source": (pmc or {}).get("source"),
+                     "kernel": "k_fft<4096,-1,false,1>", "kernel_us": round(kernel_s * 1e6, 2),
+                     "algorithmic_bytes_per_launch": samples_per_step * BYTES_PER_SAMPLE},
+        "cpu_baseline": None,
+        "blocks": extras,
+    }
+    # The headline is measured; everything below is secondary.  A watchdog guarantees the ONE JSON line even if a secondary
+    # leg hangs (e.g. a rank lost inside a collective of the sharded X-engine): rank 0 prints what exists, every rank exits.
+    import threading
+    emitted = threading.Event()
 
-    if rank == 0:
-        line = {
-            "metric": "MSamples/sec (complex-float) through clFFT 4096 fwd + window + shift",
-            "value": round(value, 1),
-            "unit": "MSamples/s",
-            "n_gpus": world,
-            "steps": a.steps,
-            "warmup": a.warmup,
-            "ms_per_step": round(wall / a.steps * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: forward clFFT 4096-pt complex, blackman window + fftshift, "
-                                   "%d frames/step/GPU device-resident (1 GiB in+out)" % FRAMES_PER_STEP,
-                       "fft_size": FFT_N, "frames_per_step": FRAMES_PER_STEP, "parallelism": "replica-per-gpu x%d" % world},
-            "per_gpu_MSamples_per_s": round(value / world, 1),
-            "sustained": sus,
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_source": (pmc or {}).get("source"),
-                         "kernel": "k_fft<4096,-1,false>", "kernel_us": round(kernel_s * 1e6, 2),
-                         "algorithmic_bytes_per_launch": samples_per_step * BYTES_PER_SAMPLE},
-            "cpu_baseline": cpu,
-            "blocks": extras,
-        }
-        print(json.dumps(line), flush=True)
+    def emit(note=None):
+        if emitted.is_set():
+            return
+        emitted.set()
+        if note:
+            line["watchdog"] = note
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+
+    def fire():
+        emit("secondary legs exceeded %d s: line printed with what was measured" % a.secondary_timeout)
+        os._exit(0)
+
+    dog = threading.Timer(a.secondary_timeout, fire)
+    dog.daemon = True
+    dog.start()
+    taps_pair = (lowpass_taps(1.0, 10e6, 1e6, 372000.0), np.concatenate([lowpass_taps(1.0, 64.0, 0.5, 0.0753), [0.0]]).astype(np.float32))
+    if not a.no_extra:
+        # fixture taps (SURVEY 8d): firdes.low_pass(1,10e6,1e6,372e3) = 65 taps; low_pass(1,64,.5,.0753)+[0] = 2048 taps.
+        # Designed by the product-independent formula above (same definition as tests/golden/gen_golden.py).
+        # The secondary lines must never cost the headline: a failure here is reported in the line, not raised.
+        try:
+            extra_blocks(pkg, taps_pair, local, max(5, a.steps // 5), 2, world, rank, extras)
+        except Exception as exc:  # noqa: BLE001
+            extras["error"] = "%s: %s" % (type(exc).__name__, exc)
+        # the only data-path collective of the hot path, INSIDE the JSON line (world 1: the same pipeline, no peers)
+        try:
+            extras["clXEngine_sharded"] = sharded_xengine(pkg, local, max(5, a.steps // 5), world, rank)
+        except Exception as exc:  # noqa: BLE001
+            extras["clXEngine_sharded"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        if rank == 0 and world == 1:
+            try:
+                extras.update(hostpath_blocks(pkg, taps_pair, local))
+            except Exception as exc:  # noqa: BLE001
+                extras["hostpath_error"] = "%s: %s" % (type(exc).__name__, exc)
+    if rank == 0 and world == 1 and not a.no_cpu:
+        line["cpu_baseline"] = cpu_baseline_fft(entry.load_oracle(), window)
+        extras["config1_clMathOp_testCPU_8192"] = config1_testcpu(entry.load_oracle())
+        if not a.no_extra:
+            for k, v in cpu_extras(entry.load_oracle(), taps_pair).items():
+                if k in extras and isinstance(extras[k], dict):
+                    extras[k]["cpu_1core_MSamples_per_s"] = v
+    dog.cancel()
+    emit()
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
