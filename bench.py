@@ -372,8 +372,13 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank, out=None):
     args = (1, 2, 0, dev)
 
     def rate(fn, nsamples, bytes_per_sample, extra=None):
-        _, ev = time_steps(fn, steps, warmup, world)
-        dt = ev / steps
+        # at least ~60 ms of back-to-back launches per row (a 5-launch burst right after an idle gap runs at lower clocks: the
+        # same kernels measured 10-15 % slower that way); the launch count is fixed from one probe launch, identically on every rank
+        _, probe = time_steps(fn, 1, 3, world)
+        n_steps = int(min(400, max(steps, 0.06 / max(probe, 1e-6))))
+        n_steps = int(max_over_ranks(float(n_steps), world))
+        _, ev = time_steps(fn, n_steps, warmup, world)
+        dt = ev / n_steps
         d = {"MSamples_per_s": round(nsamples / dt / 1e6, 1), "us_per_launch": round(dt * 1e6, 2),
              "GBps": round(nsamples * bytes_per_sample / dt / 1e9, 1),
              "hbm_frac": round(nsamples * bytes_per_sample / dt / 1e9 / HBM_PEAK_GBS, 4)}

@@ -443,7 +443,12 @@ template <int N>
 int launch_s(mi355_ctx *ctx, int sign, const void *in, void *out, const float *window, const void *tw, int nframes, int shift,
              int real_in, hipStream_t st)
 {
-    const int grid = N == 32768 ? mi355_balanced_grid(ctx, nframes, 1, 1) : mi355_balanced_grid(ctx, nframes, 2, N == 8192 ? 3 : 2, 0.015);
+    // interleaved A/B (tools/probe.py ab fft<N>, 2^26 samples): 16384 points 229 us with the two resident workgroups per CU as the grid,
+    // 217 with 8 per CU, 206 with 12-16 (one or two frames per workgroup: nothing but the base twiddles is kept across frames, so short
+    // workgroups cost nothing and even out the CUs); 8192 points 189.5 -> 185.4 us at 4 per CU; 32768 is flat (one workgroup fills a CU)
+    const int grid = N == 32768   ? mi355_balanced_grid(ctx, nframes, 1, 1)
+                     : N == 16384 ? mi355_balanced_grid(ctx, nframes, 16, 16)
+                                  : mi355_balanced_grid(ctx, nframes, 4, 4);
     if constexpr (N == 32768) {
         if (!getenv("MI355_FFT_32768_IN_REGISTERS")) {
 #define LAUNCH_32K(SG, RL) hipLaunchKernelGGL((k_fft_32k<SG, RL>), dim3(grid), dim3(512), 0, st, in, (c32 *)out, window, (const c32 *)tw, nframes, shift)
