@@ -769,7 +769,7 @@ int launch_ols_g(mi355_filter *h, size_t nout, const void *in, void *out, hipStr
     const long long n_y = (long long)nout * h->decim;
     static const bool align_stores = getenv("MI355_OLS_ALIGN") ? atoi(getenv("MI355_OLS_ALIGN")) != 0 : true;
     // XCD-contiguous groups: +5-7 % when the buffers fit the 256 MiB Infinity Cache, -6 % at 1 GiB buffers, equal for long filters: off
-    static const int xcd_map = getenv("MI355_OLS_XCD_MAP") ? atoi(getenv("MI355_OLS_XCD_MAP")) : 0;
+    const int xcd_map = getenv("MI355_OLS_XCD_MAP") ? atoi(getenv("MI355_OLS_XCD_MAP")) : 0;
     static const bool one_pass = !getenv("MI355_OLS_PART_ONE_PASS") || atoi(getenv("MI355_OLS_PART_ONE_PASS")) != 0;
     if constexpr (NF == 4096) {
         if (h->nseg > 1 && one_pass) {
@@ -816,7 +816,7 @@ int launch_ols(mi355_filter *h, size_t nout, const void *in, void *out, hipStrea
     if constexpr (NF <= 1024) {
         // one-wave workgroups (every exchange inside the wave, no workgroup barrier): +5 % at NF = 256, slower at 512/1024
         // (measured on MI355X); MI355_FILTER_WAVE_GEO=0/1 forces either geometry
-        static const int wave = getenv("MI355_FILTER_WAVE_GEO") ? atoi(getenv("MI355_FILTER_WAVE_GEO")) : -1;
+        const int wave = getenv("MI355_FILTER_WAVE_GEO") ? atoi(getenv("MI355_FILTER_WAVE_GEO")) : -1;
         if (wave == 1 || (wave < 0 && NF <= 256)) return launch_ols_g<NF, GeoW<NF>>(h, nout, in, out, st);
     }
     return launch_ols_g<NF, Geo<NF>>(h, nout, in, out, st);
@@ -852,7 +852,8 @@ int launch_filter(mi355_filter *h, size_t nout, const void *in, void *out, hipSt
         const size_t smem = ((size_t)2 * (mf_pad(nq * kMfThreads + 16) + 1) + (size_t)(h->complex_taps ? 2 : 1) * (4 * h->mf_kk + 24)) * sizeof(float);
         const long long n_y = (long long)nout * h->decim;  // undecimated outputs
         const long long ntiles = (n_y + kMfTile - 1) / kMfTile;
-        static const int per_cu = getenv("MI355_TD_WG_PER_CU") && atoi(getenv("MI355_TD_WG_PER_CU")) > 0 ? atoi(getenv("MI355_TD_WG_PER_CU")) : 16;
+        // grid-stride workgroups per CU (interleaved A/B, 65 taps over 2^26 samples: 8 -> 241 us, 16 -> 239, 32 -> 234)
+        const int per_cu = getenv("MI355_TD_WG_PER_CU") && atoi(getenv("MI355_TD_WG_PER_CU")) > 0 ? atoi(getenv("MI355_TD_WG_PER_CU")) : 32;
         const long long grid = ntiles < (long long)cus * per_cu ? ntiles : (long long)cus * per_cu;
 #define LAUNCH_MF(CT, DC)                                                                                                     \
     do {                                                                                                                      \

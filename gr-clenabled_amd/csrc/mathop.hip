@@ -137,7 +137,7 @@ inline int grid_for(const mi355_ctx *ctx, size_t nvec)
 {
     size_t per_block = (size_t)kThreads * kUnroll;
     size_t blocks = (nvec + per_block - 1) / per_block;
-    static const int per_cu = getenv("MI355_MATH_WG_PER_CU") && atoi(getenv("MI355_MATH_WG_PER_CU")) > 0 ? atoi(getenv("MI355_MATH_WG_PER_CU")) : 128;  // measured: 8 per CU 6.0 TB/s, 32 6.45, 128 6.6 (grid-stride blocks that finish early are replaced at once)
+    const int per_cu = getenv("MI355_MATH_WG_PER_CU") && atoi(getenv("MI355_MATH_WG_PER_CU")) > 0 ? atoi(getenv("MI355_MATH_WG_PER_CU")) : 128;  // measured: 8 per CU 6.0 TB/s, 32 6.45, 128 6.6 (grid-stride blocks that finish early are replaced at once)
     size_t cap = (size_t)(ctx->num_cus > 0 ? ctx->num_cus : 256) * per_cu;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;

@@ -597,8 +597,9 @@ int launch_wave(mi355_pfb *h, const void *in, void *out, hipStream_t st, int nst
             return MI355_OK;
         }
     }
-    static const int wpc = getenv("MI355_PFB_WAVES_PER_CU") ? atoi(getenv("MI355_PFB_WAVES_PER_CU")) : 8;
-    long long wgs = (long long)cus * (wpc > 0 ? wpc : 8) / (M / 64);  // 8 waves per CU
+    // waves per CU of the ring kernel; interleaved A/B at 64 x 32 over 2^26 samples: 4 -> 227 us, 8 -> 218, 16 -> 214, 32 -> 218
+    const int wpc = getenv("MI355_PFB_WAVES_PER_CU") ? atoi(getenv("MI355_PFB_WAVES_PER_CU")) : 16;
+    long long wgs = (long long)cus * (wpc > 0 ? wpc : 16) / (M / 64);
     if (wgs > ngroups) wgs = ngroups;
     const int per = (int)((ngroups + wgs - 1) / wgs);
     const int grid = (ngroups + per - 1) / per;
