@@ -475,57 +475,64 @@ int launch_s(mi355_ctx *ctx, int sign, const void *in, void *out, const float *w
 // ------------------------------------------------------------------------------------
 template <int SIGN, bool REAL>
 __global__ __launch_bounds__(256, 2) void k_fft_sub(const void *__restrict__ in, c32 *__restrict__ ws, const float *__restrict__ window,
-                                                    const c32 *__restrict__ tw4096, int S, int npair /* frames * S / 2 */, int in_xor)
+                                                    const c32 *__restrict__ tw4096, int S, int nquad /* frames * S / 4 */, int in_xor)
 {
-    // one iteration = the two neighbouring sub-frames (s, s+1): their elements x[S n + s], x[S n + s + 1] are adjacent, so
-    // every lane moves 16 bytes of each line it touches instead of 8
-    constexpr int NS = 4096, BL = 256;
+    // one iteration = FOUR neighbouring sub-frames (s .. s+3): their elements x[S n + s .. s + 3] are adjacent, so every lane
+    // moves 32 bytes of each line it touches (pairs, 16 bytes: 226 us per 2^25 samples -- the L2 request rate of partial-line
+    // reads, the same wall as the X-engine's column slices; 128 data registers = the budget of k_fft_s<16384>)
+    constexpr int NS = 4096, BL = 256, Q = 4;
     using G = Geo<NS>;
     __shared__ c32 lds[NS];
     const int tid0 = threadIdx.x;
-    TwRegs<NS> tw;
-    load_twiddles<NS, false, G>(tw, tid0, tw4096);
-    // The S/2 pair iterations of one frame each touch EVERY 128-byte line of the frame (16 bytes of every S*8), so they must
-    // share an L2: workgroup id % 8 is the XCD, and frame f is given to XCD f % 8, whose workgroups walk its pairs together
-    // (the grid is a multiple of 8).  Unmapped, every XCD fetched every frame from HBM: 111 -> 1xx GS/s at N = 32768.
-    const int half = S / 2, nframes = npair / half;
+    // The S/4 iterations of one frame each touch EVERY 128-byte line of the frame (32 bytes of every S*8), so they must
+    // share an L2: workgroup id % 8 is the XCD, and frame f is given to XCD f % 8, whose workgroups walk its quads together
+    // (the grid is a multiple of 8).  Unmapped, every XCD fetched every frame from HBM.
+    const int per = S / Q, nframes = nquad / per;
     const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
     for (int q = blockIdx.x >> 3;; q += per_xcd) {
-        const int frame = (q / half) * 8 + xcd, s = 2 * (q % half);
-        if (q / half >= (nframes + 7) / 8) break;
+        const int frame = (q / per) * 8 + xcd, s = Q * (q % per);
+        if (q / per >= (nframes + 7) / 8) break;
         if (frame >= nframes) continue;
         int tid = tid0;
         asm volatile("" : "+v"(tid));
         const size_t fb = (size_t)frame * NS * S;
-        c32 v[2][16];
+        c32 v[Q][16];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int n = tid + ((r ^ in_xor) * BL);  // reverse + shift: n ^ 2048
-            const size_t e = (size_t)n * S + s;       // x[S n + s]; e is even
-            const f2v w = *((const f2v *)window + (size_t)(s >> 1) * NS + n);  // pair-major window (see the plan)
+            const size_t e = (size_t)n * S + s;       // x[S n + s]; e is a multiple of 4
+            const f4v w = *((const f4v *)window + (size_t)(s >> 2) * NS + n);  // quad-major window (see the plan)
             if constexpr (REAL) {
-                const f2v x = __builtin_nontemporal_load((const f2v *)((const float *)in + fb + e));
+                const f4v x = *(const f4v *)((const float *)in + fb + e);  // plain loads: the line is shared with the other quads of the frame
                 v[0][r] = mk(x.x * w.x, 0.f);
                 v[1][r] = mk(x.y * w.y, 0.f);
+                v[2][r] = mk(x.z * w.z, 0.f);
+                v[3][r] = mk(x.w * w.w, 0.f);
             } else {
-                const f4v x = __builtin_nontemporal_load((const f4v *)((const c32 *)in + fb + e));
-                v[0][r] = mk(x.x * w.x, x.y * w.x);
-                v[1][r] = mk(x.z * w.y, x.w * w.y);
+                const f4v x0 = *(const f4v *)((const c32 *)in + fb + e);  // plain loads: a nontemporal one drops the line the other quads share
+                const f4v x1 = *((const f4v *)((const c32 *)in + fb + e) + 1);
+                v[0][r] = mk(x0.x * w.x, x0.y * w.x);
+                v[1][r] = mk(x0.z * w.y, x0.w * w.y);
+                v[2][r] = mk(x1.x * w.z, x1.y * w.z);
+                v[3][r] = mk(x1.z * w.w, x1.w * w.w);
             }
         }
-#pragma unroll
-        for (int h2 = 0; h2 < 2; h2++) {
-            transform_regs<NS, SIGN, false, G>(v[h2], tw, lds, tid);
-            f2v *__restrict__ o = (f2v *)ws + ((size_t)frame * S + s + h2) * NS + tid;
-#pragma unroll
-            for (int t = 0; t < 16; t++) {
-                f2v z;
-                z.x = v[h2][t].x;
-                z.y = v[h2][t].y;
-                o[orev<16>(t) * BL] = z;  // plain store: the combine kernel reads it back from L2 / the Infinity Cache
-            }
-            __syncthreads();
+        TwRegs<NS> tw;  // re-read (L1/L2) per iteration, after the frame's loads are issued: 128 data registers leave no room to keep them
+        load_twiddles<NS, false, G>(tw, tid, tw4096);
+#define MI355_SUBQ(K)                                                                                                   \
+        {                                                                                                              \
+            transform_regs<NS, SIGN, false, G>(v[K], tw, lds, tid);                                                    \
+            f2v *__restrict__ o = (f2v *)ws + ((size_t)frame * S + s + K) * NS + tid;                                  \
+            _Pragma("unroll") for (int t = 0; t < 16; t++) {                                                           \
+                f2v z;                                                                                                 \
+                z.x = v[K][t].x;                                                                                       \
+                z.y = v[K][t].y;                                                                                       \
+                o[orev<16>(t) * BL] = z; /* plain store: the combine kernel reads it back */                           \
+            }                                                                                                          \
+            __syncthreads();                                                                                           \
         }
+        MI355_SUBQ(0) MI355_SUBQ(1) MI355_SUBQ(2) MI355_SUBQ(3)
+#undef MI355_SUBQ
     }
 }
 
@@ -887,8 +894,10 @@ int launch_big(mi355_fft *h, const void *in, void *out, int nframes, hipStream_t
     const c32 *tw4096 = (const c32 *)h->d_tw + N;
     for (size_t f0 = 0; f0 < (size_t)nframes; f0 += chunk) {
         const int nf = (int)((size_t)nframes - f0 < chunk ? (size_t)nframes - f0 : chunk);
-        const int nsub = nf * S / 2;  // pairs of sub-frames
-        const int grid = (mi355_balanced_grid(h->ctx, nsub, 2, 2) + 7) & ~7;  // whole octets: workgroup id % 8 = XCD (see k_fft_sub)
+        const int nsub = nf * S / 4;  // quads of sub-frames
+        // whole octets: workgroup id % 8 = XCD (see k_fft_sub); one quad per workgroup (8 per CU) measures 465 us per 2^26 samples
+        // against 494 with the two resident workgroups per CU walking four quads each
+        const int grid = (mi355_balanced_grid(h->ctx, nsub, 8, 8) + 7) & ~7;
         const void *src = (const char *)in + f0 * N * isz;
 #define SUB(SG, RL) hipLaunchKernelGGL((k_fft_sub<SG, RL>), dim3(grid), dim3(256), 0, st, src, (c32 *)h->d_wa, h->d_window, tw4096, S, nsub, in_xor)
         if (h->sign < 0) { if (h->dtype == MI355_DTYPE_FLOAT) SUB(-1, true); else SUB(-1, false); }
@@ -1055,15 +1064,13 @@ extern "C" int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, con
         if (window_len) memcpy(w.data(), window, sizeof(float) * (size_t)fft_size);
         h->two_kernel = pow2 && (fft_size > 32768 || (fft_size == 32768 && getenv("MI355_FFT_32768_TWO_KERNELS") != nullptr));
         if (h->two_kernel) {
-            // two-kernel sizes: k_fft_sub reads the window values of the sub-frame pair (s, s+1) for every n -- stored
-            // pair-major, [s/2][n][2], they are one contiguous 8-byte load per lane instead of 8 bytes out of every S*4
+            // two-kernel sizes: k_fft_sub reads the window values of the sub-frames (s .. s+3) for every n -- stored
+            // quad-major, [s/4][n][4], they are one contiguous 16-byte load per lane instead of 16 bytes out of every S*4
             const int S = fft_size / 4096;
             std::vector<float> p((size_t)fft_size);
-            for (int sp = 0; sp < S / 2; sp++)
-                for (int n = 0; n < 4096; n++) {
-                    p[((size_t)sp * 4096 + n) * 2] = w[(size_t)n * S + 2 * sp];
-                    p[((size_t)sp * 4096 + n) * 2 + 1] = w[(size_t)n * S + 2 * sp + 1];
-                }
+            for (int sq = 0; sq < S / 4; sq++)
+                for (int n = 0; n < 4096; n++)
+                    for (int j = 0; j < 4; j++) p[((size_t)sq * 4096 + n) * 4 + j] = w[(size_t)n * S + 4 * sq + j];
             w.swap(p);
         }
         if (hipMalloc((void **)&h->d_window, sizeof(float) * (size_t)fft_size) != hipSuccess) return fail(MI355_ERR_NOMEM);
