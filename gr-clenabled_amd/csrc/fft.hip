@@ -283,11 +283,11 @@ __global__ __launch_bounds__(512, 2) void k_fft_32k(const void *__restrict__ in,
             const unsigned n = (unsigned)(tid + ((r ^ in_xor) * BL));  // element n of every sub-frame
             const f4v w = *((const f4v *)window + (size_t)n * 2 + set);
             if constexpr (REAL) {
-                const f4v t = __builtin_nontemporal_load((const f4v *)in + (size_t)frame * (N / 4) + (size_t)n * 2 + set);
+                const f4v t = *((const f4v *)in + (size_t)frame * (N / 4) + (size_t)n * 2 + set);
                 v[0][r] = mk(t.x * w.x, 0.f); v[1][r] = mk(t.y * w.y, 0.f); v[2][r] = mk(t.z * w.z, 0.f); v[3][r] = mk(t.w * w.w, 0.f);
             } else {
-                const f4v t0 = __builtin_nontemporal_load((const f4v *)in + (size_t)frame * (N / 2) + (size_t)n * 4 + set * 2);
-                const f4v t1 = __builtin_nontemporal_load((const f4v *)in + (size_t)frame * (N / 2) + (size_t)n * 4 + set * 2 + 1);
+                const f4v t0 = *((const f4v *)in + (size_t)frame * (N / 2) + (size_t)n * 4 + set * 2);
+                const f4v t1 = *((const f4v *)in + (size_t)frame * (N / 2) + (size_t)n * 4 + set * 2 + 1);
                 v[0][r] = mk(t0.x * w.x, t0.y * w.x); v[1][r] = mk(t0.z * w.y, t0.w * w.y);
                 v[2][r] = mk(t1.x * w.z, t1.y * w.z); v[3][r] = mk(t1.z * w.w, t1.w * w.w);
             }
@@ -394,7 +394,8 @@ __global__ __launch_bounds__(256, (N / 4096 == 8 ? 1 : 2)) void k_fft_s(const vo
             } else {
 #pragma unroll
                 for (int h = 0; h < S / 2; h++) {
-                    const f4v t = __builtin_nontemporal_load((const f4v *)in + (size_t)frame * (N / 2) + (size_t)n * (S / 2) + h);
+                    const f4v *src = (const f4v *)in + (size_t)frame * (N / 2) + (size_t)n * (S / 2) + h;
+                    const f4v t = (S > 2) ? *src : __builtin_nontemporal_load(src);  // S > 2: a line is touched by S/2 load instructions
                     v[2 * h][r] = mk(t.x * w[2 * h], t.y * w[2 * h]);
                     v[2 * h + 1][r] = mk(t.z * w[2 * h + 1], t.w * w[2 * h + 1]);
                 }
