@@ -269,29 +269,51 @@ __global__ __launch_bounds__(512, 2) void k_fft_32k(const void *__restrict__ in,
     __shared__ c32 sm[4 * NS];  // transform areas of the two sets (2 x 32 KiB), then the exchange image (128 KiB)
     const int set = threadIdx.x >> 8, tid0 = threadIdx.x & 255;
     c32 *lds = sm + set * 2 * NS;  // two transform areas per set: sub-frames are transformed two at a time in lockstep
-    TwRegs<NS> tw;
-    load_twiddles<NS, false, G>(tw, tid0, twN + N);  // the 4096-point table follows the N-point one
     const int in_xor = (SIGN > 0 && shift) ? 8 : 0;       // reverse: halves swapped on load == n ^ 2048 == r ^ 8
     const int m_xor = (SIGN < 0 && shift) ? (S / 2) : 0;  // forward: halves swapped on store
 
+    // rows 0..7 of the NEXT frame are fetched before the combine of the current one (64 registers that are free at that
+    // point: the peak is inside the transforms), so half of a frame's load latency runs under the combine and the stores
+    constexpr int PFW = REAL ? 1 : 2, PFR = REAL ? 8 : 5;  // complex: 4 rows 300 us, 5 rows 290 (13 spilled registers), 6 rows 306, 8 rows 333 per 2^26 samples
+    f4v pf[PFR][PFW];
+    auto fetch = [&](int frame, int r, int tid, f4v (&t)[PFW]) {
+        const unsigned n = (unsigned)(tid + ((r ^ in_xor) * BL));  // element n of every sub-frame
+        if constexpr (REAL) {
+            t[0] = *((const f4v *)in + (size_t)frame * (N / 4) + (size_t)n * 2 + set);
+        } else {
+            // plain loads: the other set takes the other 32 bytes of the same 64 (a nontemporal load would drop the line first)
+            t[0] = *((const f4v *)in + (size_t)frame * (N / 2) + (size_t)n * 4 + set * 2);
+            t[1] = *((const f4v *)in + (size_t)frame * (N / 2) + (size_t)n * 4 + set * 2 + 1);
+        }
+    };
+    if ((int)blockIdx.x < nframes) {
+#pragma unroll
+        for (int r = 0; r < PFR; r++) fetch(blockIdx.x, r, tid0, pf[r]);
+    }
     for (int frame = blockIdx.x; frame < nframes; frame += gridDim.x) {
         int tid = tid0;
         asm volatile("" : "+v"(tid));
         c32 v[H][16];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const unsigned n = (unsigned)(tid + ((r ^ in_xor) * BL));  // element n of every sub-frame
+            const unsigned n = (unsigned)(tid + ((r ^ in_xor) * BL));
             const f4v w = *((const f4v *)window + (size_t)n * 2 + set);
-            if constexpr (REAL) {
-                const f4v t = *((const f4v *)in + (size_t)frame * (N / 4) + (size_t)n * 2 + set);
-                v[0][r] = mk(t.x * w.x, 0.f); v[1][r] = mk(t.y * w.y, 0.f); v[2][r] = mk(t.z * w.z, 0.f); v[3][r] = mk(t.w * w.w, 0.f);
+            f4v t[PFW];
+            if (r < PFR) {
+#pragma unroll
+                for (int j = 0; j < PFW; j++) t[j] = pf[r][j];
             } else {
-                const f4v t0 = *((const f4v *)in + (size_t)frame * (N / 2) + (size_t)n * 4 + set * 2);
-                const f4v t1 = *((const f4v *)in + (size_t)frame * (N / 2) + (size_t)n * 4 + set * 2 + 1);
-                v[0][r] = mk(t0.x * w.x, t0.y * w.x); v[1][r] = mk(t0.z * w.y, t0.w * w.y);
-                v[2][r] = mk(t1.x * w.z, t1.y * w.z); v[3][r] = mk(t1.z * w.w, t1.w * w.w);
+                fetch(frame, r, tid, t);
+            }
+            if constexpr (REAL) {
+                v[0][r] = mk(t[0].x * w.x, 0.f); v[1][r] = mk(t[0].y * w.y, 0.f); v[2][r] = mk(t[0].z * w.z, 0.f); v[3][r] = mk(t[0].w * w.w, 0.f);
+            } else {
+                v[0][r] = mk(t[0].x * w.x, t[0].y * w.x); v[1][r] = mk(t[0].z * w.y, t[0].w * w.y);
+                v[2][r] = mk(t[PFW - 1].x * w.z, t[PFW - 1].y * w.z); v[3][r] = mk(t[PFW - 1].z * w.w, t[PFW - 1].w * w.w);
             }
         }
+        TwRegs<NS> tw;  // re-read (L1/L2) per frame: their 24 registers are what the prefetch of the next frame lives in during the combine
+        load_twiddles<NS, false, G>(tw, tid, twN + N);  // the 4096-point table follows the N-point one
         transform_regs2<NS, SIGN, false, G>(v[0], v[1], tw, lds, lds + NS, tid);
         __syncthreads();
         transform_regs2<NS, SIGN, false, G>(v[2], v[3], tw, lds, lds + NS, tid);
@@ -307,6 +329,11 @@ __global__ __launch_bounds__(512, 2) void k_fft_32k(const void *__restrict__ in,
             for (int s = 0; s < H; s++)
 #pragma unroll
                 for (int tl = 0; tl < 8; tl++) sm[((SET * H + s) * 8 + tl) * BL + tid] = v[s][8 * OTHER + tl];  // rows the other set combines
+            // (half of v[] is dead from here on: room for the first rows of the next frame)
+            if (frame + (int)gridDim.x < nframes) {
+#pragma unroll
+                for (int r = 0; r < PFR; r++) fetch(frame + gridDim.x, r, tid, pf[r]);
+            }
             __syncthreads();
 #pragma unroll
             for (int tl = 0; tl < 8; tl++) {
