@@ -316,6 +316,163 @@ __global__ __launch_bounds__(G::TH, 2) void k_ols_part(const c32 *__restrict__ i
 }
 
 // ------------------------------------------------------------------------------------
+// uniformly partitioned overlap-save (2 .. 5 segments = 2049 .. 10240 taps): segments of exactly L = 2048 taps, the block
+// length, so the input block that segment p needs for output block b IS the input block of output block b - p.  A workgroup
+// walks a contiguous run of blocks and keeps the spectra of the last P - 1 input blocks in registers:
+//     X_b = FFT(in block b);   y_blk(b) = IFFT( sum_p X_(b-p) * H_p )
+// = TWO transforms per 2048 outputs whatever the filter length (k_ols_part: P + 1 per 2049 - 2600), plus P - 1 forward
+// transforms at the start of a run.  Input samples in front of / behind the buffer are zeros: they meet only the zero
+// padding of the last segment or outputs that are not stored.  H_p are read from L1/L2 per block (16 values per thread, segment).
+// ------------------------------------------------------------------------------------
+template <class G, int P>
+__global__ __launch_bounds__(G::TH, 2) void k_ols_ups(const c32 *__restrict__ in, c32 *__restrict__ out, const c32 *__restrict__ Hspec,  // [P][NF]
+                                                     const c32 *__restrict__ tw_fwd, int ktot, int decim, long long n_y, int nblocks, int run)
+{
+    constexpr int NF = 4096, L = 2048, S0 = 2048;
+    using PF = Plan<NF, false>;
+    using PI = Plan<NF, true>;
+    constexpr int TH = G::TH, NP = PF::NP;
+    static_assert(G::F == 1 && G::PTS == NF && TH * 16 == NF, "one block per workgroup iteration, 16 points per thread");
+    static_assert((PF::L % 4) == 0, "all-radix-16 size: one twiddle set serves both directions");
+    constexpr int RL = PF::radix(NP - 1), BL = NF / RL, R0 = PF::radix(0), B0 = NF / R0, RO = PI::radix(NP - 1), BO = NF / RO;
+    static_assert(RL == 16 && R0 == 16 && RO == 16, "4096 = 16^3");
+    __shared__ c32 lds[NF];
+    const int tid0 = threadIdx.x;
+    // P >= 4: the twiddles are re-read (L1) per transform; their 24 registers go to the spectrum ring (P = 3 with the reload: 767 us per 2^26 samples against 674)
+    constexpr bool RELOAD = P >= 4;
+    TwRegs<NF> twf0;
+    if constexpr (!RELOAD) load_twiddles<NF, false, G>(twf0, tid0, tw_fwd);
+    const int b_first = blockIdx.x * run, b_end = min(nblocks, b_first + run);
+    const long long n_in = n_y + ktot - 1;  // samples in the buffer (history in front)
+
+    // half h (0: n < 2048, 1: n >= 2048) of input block b = in[] index b * L - S0 + ktot - 1 + n, n < NF: 8 values per thread,
+    // v[8 h + r] = element tid + (8 h + r) * 256; zeros outside the buffer
+    auto load_half = [&](int b, int h, int tid, c32 (&d)[8]) {
+        const long long start = (long long)b * L - S0 + ktot - 1 + (long long)h * (NF / 2);
+        if (start >= 0) {
+            const long long left_b = (n_in - start) * 8;
+            const __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(in + start), 0, left_b <= 0 ? 0 : (left_b > 0x7ffffff8LL ? 0x7ffffff8 : (int)left_b), 0x00020000);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const f2v t = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(rs, (unsigned)(tid + r * B0) * 8u, 0, 0));
+                d[r] = mk(t.x, t.y);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const long long e = start + tid + r * B0;
+                const bool ok = e >= 0 && e < n_in;
+                const c32 t = in[ok ? e : 0];
+                d[r] = ok ? t : mk(0.f, 0.f);
+            }
+        }
+    };
+    // spectrum of the block whose halves are lo / hi, in the register order the inverse transform consumes
+    auto spectrum = [&](const c32 (&lo)[8], const c32 (&hi)[8], int tid, c32 (&x)[16]) {
+        c32 v[16];
+#pragma unroll
+        for (int r = 0; r < 8; r++) { v[r] = lo[r]; v[8 + r] = hi[r]; }
+        if constexpr (RELOAD) {
+            TwRegs<NF> tw;
+            load_twiddles<NF, false, G>(tw, tid, tw_fwd);
+            transform_regs<NF, -1, false, G>(v, tw, lds, tid);
+        } else {
+            transform_regs<NF, -1, false, G>(v, twf0, lds, tid);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[r] = v[irev<RL>(r)];
+        __syncthreads();  // this transform's LDS reads are done before the next one (or the inverse) writes
+    };
+
+    // consecutive input blocks overlap by half: the upper half of block b - 1 is the lower half of block b.  `keep` carries it,
+    // `nx` is the upper half of the block about to be transformed, fetched one iteration ahead.
+    // (P >= 3: the ring takes those 32 registers; both halves are loaded when they are needed)
+    constexpr bool PREF = P == 2;
+    c32 ring[P - 1][16];  // ring[p - 1] = spectrum of input block b - p
+    c32 keep[8], nx[8];
+    {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        if constexpr (PREF) load_half(b_first - (P - 1), 0, tid, keep);
+#pragma unroll
+        for (int p = P - 1; p >= 1; p--) {
+            if constexpr (!PREF) load_half(b_first - p, 0, tid, keep);
+            load_half(b_first - p, 1, tid, nx);
+            spectrum(keep, nx, tid, ring[p - 1]);
+            if constexpr (PREF) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) keep[r] = nx[r];
+            }
+        }
+        if constexpr (PREF) load_half(b_first, 1, tid, nx);
+    }
+    for (int b = b_first; b < b_end; b++) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        c32 x0[16], w[16];
+        if constexpr (PREF) {
+            c32 hi[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) hi[r] = nx[r];
+            if (b + 1 < b_end) load_half(b + 1, 1, tid, nx);  // in flight under both transforms of this block
+            spectrum(keep, hi, tid, x0);
+#pragma unroll
+            for (int r = 0; r < 8; r++) keep[r] = hi[r];
+        } else {
+            c32 lo[8], hi[8];
+            load_half(b, 0, tid, lo);
+            load_half(b, 1, tid, hi);
+            spectrum(lo, hi, tid, x0);
+        }
+        const int j = tid % BL;
+#pragma unroll
+        for (int r = 0; r < 16; r++) w[r] = cmul(x0[r], Hspec[j + orev<RL>(irev<RL>(r)) * BL]);
+#pragma unroll
+        for (int p = 1; p < P; p++) {
+            const c32 *__restrict__ Hs = Hspec + (size_t)p * NF;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const c32 t = cmul(ring[p - 1][r], Hs[j + orev<RL>(irev<RL>(r)) * BL]);
+                w[r].x += t.x;
+                w[r].y += t.y;
+            }
+        }
+#pragma unroll
+        for (int p = P - 1; p >= 2; p--)
+#pragma unroll
+            for (int r = 0; r < 16; r++) ring[p - 1][r] = ring[p - 2][r];
+#pragma unroll
+        for (int r = 0; r < 16; r++) ring[0][r] = x0[r];
+        if constexpr (RELOAD) {
+            TwRegs<NF> tw;
+            load_twiddles<NF, false, G>(tw, tid, tw_fwd);
+            transform_regs<NF, 1, true, G, 0, true>(w, tw, lds, tid);
+        } else {
+            transform_regs<NF, 1, true, G, 0, true>(w, twf0, lds, tid);
+        }
+        const long long g0 = (long long)b * L;
+        const long long y_left64 = n_y - g0;
+        const unsigned y_left = y_left64 > 0x7fffffffLL ? 0x7fffffffu : (unsigned)(y_left64 > 0 ? y_left64 : 0);
+        const unsigned g_phase = (unsigned)(g0 % decim);
+        const long long g_quot = g0 / decim;
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            const int n = tid + orev<RO>(s) * BO;
+            const int rel = n - S0;
+            if (n >= S0 && (unsigned)rel < y_left) {
+                if (decim == 1) st_stream(out + g0 + (unsigned)rel, w[s]);
+                else {
+                    const unsigned t = g_phase + (unsigned)rel;
+                    if (t % (unsigned)decim == 0) out[g_quot + t / (unsigned)decim] = w[s];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // direct-form FIR, decimation 1.  256 threads x 8 CONSECUTIVE outputs; the thread
 // slides an 8+8 register window over its inputs, so U+K-1 LDS reads feed U*K FMAs.
 // The tile is stored transposed in LDS -- sample n at slot (n%8)*S + n/8 with
@@ -617,6 +774,8 @@ struct mi355_filter {
     float *d_hb = nullptr;  // matrix-core direct form: zero-padded reversed taps (real taps only)
     int mf_kk = 0;          // MFMA steps per output block, 0 = kernel not applicable
     void *d_H = nullptr, *d_twf = nullptr, *d_twi = nullptr;
+    void *d_Hu = nullptr;  // uniformly partitioned long filter (k_ols_ups): spectra of the 2048-tap segments, [ups][4096]
+    int ups = 0;           // number of those segments (0: not applicable)
     HostPipe pipe;
     std::mutex lock;
 };
@@ -624,6 +783,7 @@ struct mi355_filter {
 namespace {
 
 constexpr int kOlsMaxTaps = 2048;  // longest filter one NF = 4096 block can overlap with at least half of it new samples
+constexpr int kUpsMaxSeg = 5;      // k_ols_ups keeps the spectra of the previous segments' input blocks in registers: up to 10240 taps
 
 int pick_fft_size(int ntaps)
 {
@@ -659,6 +819,9 @@ void free_dev(mi355_filter *h)
     if (h->d_hb) (void)hipFree(h->d_hb);
     h->d_hb = nullptr;
     if (h->d_H) (void)hipFree(h->d_H);
+    if (h->d_Hu) (void)hipFree(h->d_Hu);
+    h->d_Hu = nullptr;
+    h->ups = 0;
     if (h->d_twf) (void)hipFree(h->d_twf);
     if (h->d_twi) (void)hipFree(h->d_twi);
     h->d_taps_rev = nullptr;
@@ -738,6 +901,27 @@ int upload_taps_impl(mi355_filter *h, const void *taps, int ntaps)
             }
         }
         size_t bytes = 2 * (size_t)nf * sizeof(float);
+        if (nseg > 1 && ntaps <= kUpsMaxSeg * kOlsMaxTaps) {
+            // uniform partition for k_ols_ups: segment p = taps [2048 p, 2048 p + 2048), the last one zero padded
+            const int ups = (ntaps + kOlsMaxTaps - 1) / kOlsMaxTaps;
+            std::vector<float> Hu(2 * (size_t)nf * ups);
+            for (int sgm = 0; sgm < ups; sgm++) {
+                const int t0 = sgm * kOlsMaxTaps, tn = std::min(kOlsMaxTaps, ntaps - t0);
+                for (int k = 0; k < nf; k++) {
+                    double re = 0, im = 0;
+                    for (int n = 0; n < tn; n++) {
+                        double hr = h->taps_host[(size_t)per * (t0 + n)], hi = h->complex_taps ? h->taps_host[2 * (size_t)(t0 + n) + 1] : 0.0;
+                        int idx = (int)(((long long)k * n) % nf);
+                        re += hr * cs[idx] - hi * sn[idx];
+                        im += hr * sn[idx] + hi * cs[idx];
+                    }
+                    Hu[2 * ((size_t)sgm * nf + k)] = (float)(re / nf); Hu[2 * ((size_t)sgm * nf + k) + 1] = (float)(im / nf);
+                }
+            }
+            MI355_HIP(hipMalloc(&h->d_Hu, bytes * ups));
+            MI355_HIP(hipMemcpy(h->d_Hu, Hu.data(), bytes * ups, hipMemcpyHostToDevice));
+            h->ups = ups;
+        }
         MI355_HIP(hipMalloc(&h->d_H, bytes * nseg));
         MI355_HIP(hipMalloc(&h->d_twf, bytes));
         MI355_HIP(hipMalloc(&h->d_twi, bytes));
@@ -772,6 +956,29 @@ int launch_ols_g(mi355_filter *h, size_t nout, const void *in, void *out, hipStr
     const int xcd_map = getenv("MI355_OLS_XCD_MAP") ? atoi(getenv("MI355_OLS_XCD_MAP")) : 0;
     static const bool one_pass = !getenv("MI355_OLS_PART_ONE_PASS") || atoi(getenv("MI355_OLS_PART_ONE_PASS")) != 0;
     if constexpr (NF == 4096) {
+        const bool ups_on = !getenv("MI355_OLS_UPS") || atoi(getenv("MI355_OLS_UPS")) != 0;
+        if (h->ups > 1 && ups_on) {
+            const long long nblocks = (n_y + 2047) / 2048;
+            if (nblocks > 0x7fffffffLL) { mi355_set_error("work() call too large"); return MI355_ERR_INVALID_ARG; }
+            // a run of consecutive blocks per workgroup (the P - 1 warm-up transforms of a run are the overhead): two
+            // workgroups per CU when the call is large enough, one block per workgroup for scheduler-sized calls
+            const int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
+            int wgs = cus * 2;
+            if (const char *e = getenv("MI355_OLS_UPS_WGS")) wgs = atoi(e) > 0 ? atoi(e) : wgs;
+            const int run = (int)((nblocks + wgs - 1) / wgs);
+            const unsigned grid = (unsigned)((nblocks + run - 1) / run);
+#define LAUNCH_UPS(PP) hipLaunchKernelGGL((k_ols_ups<G, PP>), dim3(grid), dim3(TH), 0, st, (const c32 *)in, (c32 *)out, (const c32 *)h->d_Hu, \
+                                          (const c32 *)h->d_twf, h->ntaps, h->decim, n_y, (int)nblocks, run)
+            switch (h->ups) {
+            case 2: LAUNCH_UPS(2); break;
+            case 3: LAUNCH_UPS(3); break;
+            case 4: LAUNCH_UPS(4); break;
+            default: LAUNCH_UPS(5); break;
+            }
+#undef LAUNCH_UPS
+            MI355_HIP(hipGetLastError());
+            return MI355_OK;
+        }
         if (h->nseg > 1 && one_pass) {
             const int s0 = (h->seg_len - 1 + 15) & ~15;
             const int L = (NF - s0) & ~15;

@@ -83,6 +83,30 @@ def test_long_filter_partitioned_streaming(gpu, oracle, decim):
     assert relerr(yd.cpu().numpy().view(np.complex64).reshape(-1), ref) <= TOL
 
 
+@pytest.mark.parametrize("wgs", ["2", "3", "1000"])
+@pytest.mark.parametrize("ntaps,decim", [(2049, 1), (3000, 1), (4096, 2), (4097, 1), (6001, 3), (8000, 1), (8192, 1), (9000, 2), (10240, 1), (10241, 1)])
+def test_long_filter_runs_of_blocks(gpu, oracle, monkeypatch, ntaps, decim, wgs):
+    """2049 .. 10240 taps run the uniformly partitioned kernel (segments of 2048 taps = the block length; a workgroup walks a
+    run of blocks and carries the spectra of the previous input blocks in registers).  A small grid (MI355_OLS_UPS_WGS) makes
+    the runs many blocks long at a test-sized call; 1000 workgroups = one block each (every block warms up its own ring).
+    10241 taps = six segments: the general partitioned kernel."""
+    monkeypatch.setenv("MI355_OLS_UPS_WGS", wgs)
+    rng = np.random.default_rng(ntaps + decim)
+    taps = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    n = 2048 * 13 // decim + 77  # 13-14 blocks, ragged end
+    xh = crandn(rng, n * decim + ntaps - 1)
+    blk = gpu.clFilter(*GPU_ARGS, decim, taps)
+    assert blk.fftsize() == 4096
+    y = np.empty(n, np.complex64)
+    assert blk.work(n, [xh], [y]) == n
+    ref = oracle.fir_ccf(taps, xh, n, decim)
+    assert relerr(y, ref) <= TOL
+    monkeypatch.setenv("MI355_OLS_UPS", "0")  # the general partitioned kernel on the same call
+    y2 = np.empty(n, np.complex64)
+    assert blk.work(n, [xh], [y2]) == n
+    assert relerr(y2, ref) <= TOL
+
+
 def test_long_complex_filter_partitioned(gpu, oracle):
     """clComplexFilter, 4500 complex taps in the fast-convolution mode = three accumulating segments; tiny and ragged calls."""
     rng = np.random.default_rng(77)
