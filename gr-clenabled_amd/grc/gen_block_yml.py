@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Writes grc/clenabled_<X>.block.yml for the hot-path blocks.
+"""Writes grc/clenabled_<X>.block.yml for the hot-path blocks and the widened rows (8f-3 / 8f-4).
 
 What an existing flowgraph stores is the block id, the parameter ids with their values, and the port layout; what it needs
 from the block description is a `make` template that turns those into `clenabled.<class>(...)` with the reference's
@@ -202,6 +202,42 @@ BLOCKS.append(dict(
         "with a JSON side-car."))
 
 
+# ---- widened rows: the remaining elementwise blocks and the reference correlator.  The ids are the
+# reference's (lower case where its files have them so: a saved flowgraph names the id, not the file).
+def elem(file, bid, label, cls, ins, outs, extra=(), lead="", doc=""):
+    tail = "".join(",${%s}" % e["id"] for e in extra)
+    make = two_branch("clenabled.%s(%s%s%s,${setDebug})" % (cls, lead, dev_args(True), tail),
+                      "clenabled.%s(%s%s%s,${setDebug})" % (cls, lead, dev_args(False), tail))
+    return dict(id=bid, file=file, label=label, params=DEV + [DEBUG] + [e for e in extra] + ([GAIN] if lead else []),
+                inputs=[dict(domain="stream", dtype=t, **({"label": l} if l else {})) for l, t in ins],
+                outputs=[dict(domain="stream", dtype=t, **({"label": l} if l else {})) for l, t in outs], imports="import clenabled", make=make, doc=doc)
+
+
+GAIN = dict(id="gain", label="Gain", dtype="float", default="1.0")
+NK = [dict(id="n_val", label="n", dtype="float", default="1"), dict(id="k_val", label="k", dtype="float", default="0")]
+BLOCKS.append(elem("clenabled_clLog10", "clenabled_clLog10", "MI355X n*log10(x)+k", "clLog", [("", "float")], [("", "float")], NK,
+                   doc="out = n * log10(in) + k"))
+BLOCKS.append(elem("clenabled_clSNR", "clenabled_clsnr", "MI355X SNR helper", "clSNR", [("signal", "float"), ("noise", "float")], [("", "float")], NK,
+                   doc="out = abs(n * log10(signal / noise) + k)"))
+BLOCKS.append(elem("clenabled_clComplexToMag", "clenabled_complextomag", "MI355X complex to magnitude", "clComplexToMag", [("", "complex")], [("", "float")]))
+BLOCKS.append(elem("clenabled_clComplexToArg", "clenabled_complextoarg", "MI355X complex to phase", "clComplexToArg", [("", "complex")], [("", "float")]))
+BLOCKS.append(elem("clenabled_clComplexToMagPhase", "clenabled_complextomagphase", "MI355X complex to magnitude and phase", "clComplexToMagPhase",
+                   [("", "complex")], [("mag", "float"), ("phase", "float")]))
+BLOCKS.append(elem("clenabled_clMagPhaseToComplex", "clenabled_magphasetocomplex", "MI355X magnitude and phase to complex", "clMagPhaseToComplex",
+                   [("mag", "float"), ("phase", "float")], [("", "complex")]))
+BLOCKS.append(elem("clenabled_clQuadratureDemod", "clenabled_clQuadratureDemod", "MI355X quadrature demodulator", "clQuadratureDemod",
+                   [("", "complex")], [("", "float")], lead="${gain},", doc="out[i] = gain * arg(in[i] * conj(in[i-1]))"))
+BLOCKS.append(dict(
+    id="clenabled_clxcorrelate_fft_vcf", label="MI355X reference correlator (frequency domain)",
+    params=[dict(id="input_type", label="Inputs are", dtype="enum", options=["1", "2"], option_labels=["Spectra", "Time series"], hide="part"),
+            dict(id="vec_len", label="Vector length", dtype="int", default="1024", hide="none"), INT("num_inputs", "Signals", "2")] + DEV,
+    inputs=[dict(domain="stream", dtype="complex", vlen="${vec_len}", multiplicity="${ num_inputs }")],
+    outputs=[dict(domain="stream", dtype="float", vlen="${vec_len}", multiplicity="${ num_inputs - 1 }")], imports="import clenabled",
+    make=two_branch("clenabled.clxcorrelate_fft_vcf(${vec_len},${num_inputs},%s,${input_type})" % dev_args(True),
+                    "clenabled.clxcorrelate_fft_vcf(${vec_len},${num_inputs},%s,${input_type})" % dev_args(False)),
+    doc="Input 0 is the reference; output s-1 is the half-swapped magnitude of the inverse transform of X0 * conj(Xs)."))
+
+
 def emit_value(v, indent):
     if isinstance(v, bool):
         return "true" if v else "false"
@@ -250,7 +286,7 @@ def render(b):
 
 def main():
     for b in BLOCKS:
-        with open(os.path.join(HERE, b["id"] + ".block.yml"), "w") as f:
+        with open(os.path.join(HERE, b.get("file", b["id"]) + ".block.yml"), "w") as f:
             f.write(render(b))
     print("%d block descriptions written to %s" % (len(BLOCKS), HERE))
 

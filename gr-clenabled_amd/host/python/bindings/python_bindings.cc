@@ -130,4 +130,21 @@ PYBIND11_MODULE(clenabled_python, m)
         .def("synchronized", &clXEngine::synchronized)
         .def("general_work", &call_general_work<clXEngine>, py::arg("noutput_items"), py::arg("input_items"), py::arg("output_items"))
         .def("stop", [](clXEngine &x) { return x.stop(); });  // (a member of the virtual base: no pointer-to-member through it)
+
+    // ---- the remaining elementwise family and the reference correlator: python/bindings/clLog_python.cc etc.
+#define MI355_BIND_ELEM(NAME, ...)                                                                                     \
+    py::class_<NAME SYNC_BASES, std::shared_ptr<NAME>>(m, #NAME)                                                       \
+        .def(py::init(&NAME::make), __VA_ARGS__)                                                                       \
+        .def("work", &call_work<NAME>, py::arg("noutput_items"), py::arg("input_items"), py::arg("output_items"))
+#define MI355_DEV_ARGS py::arg("openCLPlatformType"), py::arg("devSelector"), py::arg("platformId"), py::arg("devId")
+    MI355_BIND_ELEM(clLog, MI355_DEV_ARGS, py::arg("nValue"), py::arg("kValue"), py::arg("setDebug") = 0);
+    MI355_BIND_ELEM(clSNR, MI355_DEV_ARGS, py::arg("nValue"), py::arg("kValue"), py::arg("setDebug") = 0);
+    MI355_BIND_ELEM(clComplexToMag, MI355_DEV_ARGS, py::arg("setDebug") = 0);
+    MI355_BIND_ELEM(clComplexToArg, MI355_DEV_ARGS, py::arg("setDebug") = 0);
+    MI355_BIND_ELEM(clComplexToMagPhase, MI355_DEV_ARGS, py::arg("setDebug") = 0);
+    MI355_BIND_ELEM(clMagPhaseToComplex, MI355_DEV_ARGS, py::arg("setDebug") = 0);
+    MI355_BIND_ELEM(clQuadratureDemod, py::arg("gain"), MI355_DEV_ARGS, py::arg("setDebug") = 0);
+    MI355_BIND_ELEM(clxcorrelate_fft_vcf, py::arg("fftSize"), py::arg("num_inputs"), MI355_DEV_ARGS, py::arg("input_type") = 1);
+#undef MI355_DEV_ARGS
+#undef MI355_BIND_ELEM
 }

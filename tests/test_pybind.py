@@ -89,3 +89,47 @@ def test_blocks_built_the_way_grc_builds_them(gpu, oracle):
     assert p.general_work(2 * buf, [xin], [yo]) == 2 * buf  # two output multiples in one call
     r = oracle.pfb(pt, buf, M, M, list(range(M)), xin[:buf + pt.size - M], f64=True)
     assert np.abs(yo[:buf] - r).max() <= 1e-5 * np.abs(r).max()
+
+
+def test_module_exposes_the_widened_blocks():
+    m = _mod()
+    for cls in ("clLog", "clSNR", "clComplexToMag", "clComplexToArg", "clComplexToMagPhase", "clMagPhaseToComplex", "clQuadratureDemod",
+                "clxcorrelate_fft_vcf"):
+        assert inspect.isclass(getattr(m, cls)), cls
+
+
+@pytest.mark.gpu
+def test_widened_blocks_built_the_way_grc_builds_them(gpu, oracle):
+    """The elementwise family and the reference correlator through the pybind classes, positional arguments in the
+    order of their GRC make templates, against the oracle."""
+    m = _mod()
+    rng = np.random.default_rng(5)
+    n = 8192
+    z = (rng.standard_normal(n + 1) + 1j * rng.standard_normal(n + 1)).astype(np.complex64)
+    a = (np.abs(rng.standard_normal(n)) + 0.1).astype(np.float32)
+    b = (np.abs(rng.standard_normal(n)) + 0.1).astype(np.float32)
+    ph = rng.uniform(-3, 3, n).astype(np.float32)
+    # clenabled.clLog(${openCLPlatform},${devices},${platformId},${deviceId},${n_val},${k_val},${setDebug}) etc.
+    cases = [
+        (m.clLog(1, 2, 0, 0, 2.5, -3.0, 0), oracle.ELEM_LOG10, (a,), (np.float32,), (2.5, -3.0)),
+        (m.clSNR(1, 2, 0, 0, 10.0, 1.0, 0), oracle.ELEM_SNR, (a, b), (np.float32,), (10.0, 1.0)),
+        (m.clComplexToMag(1, 2, 0, 0, 0), oracle.ELEM_C2MAG, (z[:n],), (np.float32,), (0, 0)),
+        (m.clComplexToArg(1, 2, 0, 0, 0), oracle.ELEM_C2ARG, (z[:n],), (np.float32,), (0, 0)),
+        (m.clComplexToMagPhase(1, 2, 0, 0, 0), oracle.ELEM_C2MAGPHASE, (z[:n],), (np.float32, np.float32), (0, 0)),
+        (m.clMagPhaseToComplex(1, 2, 0, 0, 0), oracle.ELEM_MAGPHASE2C, (a, ph), (np.complex64,), (0, 0)),
+        (m.clQuadratureDemod(0.75, 1, 2, 0, 0, 0), oracle.ELEM_QUADDEMOD, (z,), (np.float32,), (0.75, 0)),
+    ]
+    for blk, kind, ins, out_t, (p0, p1) in cases:
+        outs = [np.empty(n, t) for t in out_t]
+        assert blk.work(n, list(ins), outs) == n
+        for o, e in zip(outs, oracle.elem(kind, n, ins, p0, p1)):
+            assert np.abs(o - e).max() <= 2e-6 * max(1.0, np.abs(e).max()), kind
+    # clenabled.clxcorrelate_fft_vcf(${vec_len},${num_inputs},${openCLPlatform},${devices},${platformId},${deviceId},${input_type})
+    N, nin, fr = 256, 3, 5
+    xs = [(rng.standard_normal(fr * N) + 1j * rng.standard_normal(fr * N)).astype(np.complex64) for _ in range(nin)]
+    xc = m.clxcorrelate_fft_vcf(N, nin, 1, 2, 0, 0, 2)
+    ys = [np.empty(fr * N, np.float32) for _ in range(nin - 1)]
+    assert xc.work(fr, xs, ys) == fr
+    ref = oracle.xcorr_fft(N, 2, xs, use_f64=True)
+    for y, r in zip(ys, ref):
+        assert np.abs(y - np.asarray(r, np.float32).reshape(-1)).max() <= 2e-5 * np.abs(r).max()
