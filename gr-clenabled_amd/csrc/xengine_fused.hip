@@ -382,10 +382,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
 
 // sum of the time ranges' partial matrices (exact, int64), scale, scatter into the reference's output order
 // (the default form of the reduction; MI355_XE_INKERNEL_REDUCE=1 selects the tail of k_xe_i8_fused instead)
-template <int NPOL>
+template <int NPOL, int TS>  // TS > 0: the number of time ranges at compile time (all loads of an item issued back to back)
 __global__ __launch_bounds__(256) void k_xe_i8_reduce(const v4i *__restrict__ part, c32 *__restrict__ out, int N, int F, int Fout, int NP, int NTT,
-                                                      int tsplit, double kd, int accumulate, int compact)
+                                                      int tsplit_rt, double kd, int accumulate, int compact)
 {
+    const int tsplit = TS > 0 ? TS : tsplit_rt;
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
     size_t item = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (f, p)
     const bool live = item < (size_t)Fout * NP;                 // (whole waves; a dead wave still takes part in the shuffles below)
@@ -397,15 +398,29 @@ __global__ __launch_bounds__(256) void k_xe_i8_reduce(const v4i *__restrict__ pa
     const bool diag = compact && bi == bj;
     const int rpc = compact ? 2 * NP - NTT : 2 * NP, rec = compact ? 2 * p - bi : 2 * p;
     long sre[4] = {0, 0, 0, 0}, sim[4] = {0, 0, 0, 0};
-    for (int q = 0; q < tsplit; q++) {
-        const v4i *src = part + (((size_t)q * F + f) * rpc + rec) * 64 + lane;
-        const v4i a = __builtin_nontemporal_load(src);
+    if constexpr (TS > 0) {
+        v4i a[TS], b[TS];
 #pragma unroll
-        for (int k = 0; k < 4; k++) sre[k] += a[k];
-        if (!diag) {
-            const v4i b = __builtin_nontemporal_load(src + 64);
+        for (int q = 0; q < TS; q++) {
+            const v4i *src = part + (((size_t)q * F + f) * rpc + rec) * 64 + lane;
+            a[q] = __builtin_nontemporal_load(src);  // (plain loads / plain partial stores measure the same: 61.0 us either way)
+            b[q] = diag ? (v4i){0, 0, 0, 0} : __builtin_nontemporal_load(src + 64);
+        }
 #pragma unroll
-            for (int k = 0; k < 4; k++) sim[k] += b[k];
+        for (int q = 0; q < TS; q++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) { sre[k] += a[q][k]; sim[k] += b[q][k]; }
+    } else {
+        for (int q = 0; q < tsplit; q++) {
+            const v4i *src = part + (((size_t)q * F + f) * rpc + rec) * 64 + lane;
+            const v4i a = __builtin_nontemporal_load(src);
+#pragma unroll
+            for (int k = 0; k < 4; k++) sre[k] += a[k];
+            if (!diag) {
+                const v4i b = __builtin_nontemporal_load(src + 64);
+#pragma unroll
+                for (int k = 0; k < 4; k++) sim[k] += b[k];
+            }
         }
     }
     if (diag) {
@@ -454,8 +469,12 @@ template <int NPOL, int NTT, bool SPLIT> int launch_fused_s(const XeFusedPlan &p
     if (SPLIT && !a.inkernel) {
         const int NP = NTT * (NTT + 1) / 2;
         const size_t items = (size_t)a.Fout * NP;
-        hipLaunchKernelGGL((k_xe_i8_reduce<NPOL>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, (const v4i *)a.part, a.out, a.N, a.F,
-                           a.Fout, NP, NTT, p.tsplit, a.kd, a.accumulate, a.compact);
+        if (p.tsplit == 4)
+            hipLaunchKernelGGL((k_xe_i8_reduce<NPOL, 4>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, (const v4i *)a.part, a.out, a.N, a.F,
+                               a.Fout, NP, NTT, p.tsplit, a.kd, a.accumulate, a.compact);
+        else
+            hipLaunchKernelGGL((k_xe_i8_reduce<NPOL, 0>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, (const v4i *)a.part, a.out, a.N, a.F,
+                               a.Fout, NP, NTT, p.tsplit, a.kd, a.accumulate, a.compact);
         MI355_HIP(hipGetLastError());
     }
     return MI355_OK;
@@ -516,7 +535,7 @@ int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void 
     a.pinned = ((a.nlines * p.tsplit) % 8 == 0) ? 1 : 0;
     a.accumulate = accumulate;
     a.kd = kd;
-    static const int dbg = getenv("MI355_XE_DBG") ? atoi(getenv("MI355_XE_DBG")) : 0;
+    const int dbg = getenv("MI355_XE_DBG") ? atoi(getenv("MI355_XE_DBG")) : 0;
     a.dbg = dbg;
     if (p.npol == 1) {
         if (p.ntt == 1) return launch_fused<1, 1>(p, a, st);
