@@ -74,6 +74,26 @@ __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst)
 __device__ __forceinline__ void st_sys(v4i *p, v4i v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void ld_sys(v4i &d, const v4i *p) { asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(d) : "v"(p) : "memory"); }
 
+// ---- 24-bit partial sums (compact == 2): a time range of <= 256 steps keeps |re - 1| and |im - 1| below 2^23 (re <= 2^23 only for
+// -128 * -128 throughout, im <= 255 * 128 * 256), so a value travels as its low 16 bits in one plane and bits 16..23 in another:
+// 24 instead of 32 bytes per eight values, both planes whole dwords per lane (the 12-byte records of the first attempt were slower
+// than the bytes they saved).  Per (range, channel): OD off-diagonal tile pairs x (64 x 16 B + 64 x 8 B), then NTT diagonal ones x
+// (64 x 8 B + 64 x 4 B).
+typedef int v2i __attribute__((ext_vector_type(2)));
+__host__ __device__ constexpr int pk_block_bytes(int NTT) { return NTT * (NTT - 1) / 2 * 1536 + NTT * 768; }
+__device__ __forceinline__ unsigned pk_lo(int a, int b) { return perm((unsigned)b, (unsigned)a, 0x05040100u); }            // a.lo16 | b.lo16 << 16
+__device__ __forceinline__ unsigned pk_hi(v4i w)                                                                             // bits 16..23 of the four
+{
+    return perm((unsigned)w[1], (unsigned)w[0], 0x0c0c0602u) | (perm((unsigned)w[3], (unsigned)w[2], 0x0c0c0602u) << 16);
+}
+__device__ __forceinline__ v4i pk_bias(v4i v) { return (v4i){v[0] - 1, v[1] - 1, v[2] - 1, v[3] - 1}; }
+// value k of a packed quartet: lo = the dword holding its low half (k even: bits 0..15, odd: 16..31), hi = the dword of the four top bytes
+__device__ __forceinline__ int pk_get(unsigned lo, unsigned hi, int k)
+{
+    const unsigned l16 = (k & 1) ? (lo >> 16) : (lo & 0xffffu), h8 = (hi >> (8 * k)) & 0xffu;
+    return ((int)((h8 << 24) | (l16 << 8)) >> 8) + 1;
+}
+
 template <int NPOL, int NTT, bool SPLIT>
 __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
 {
@@ -244,7 +264,25 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
                 for (int reg = 0; reg < 4; reg++) vim[reg] += corr[reg];
                 if (a.dbg & 2) { if (vre[0] == 0x12345678 && vim[1] == 0x7654321) a.part[lane] = vre; continue; }
                 if constexpr (SPLIT) {
-                    if (a.compact) {
+                    if (a.compact == 2) {
+                        constexpr int OD = NTT * (NTT - 1) / 2;
+                        unsigned char *blk = (unsigned char *)a.part + ((size_t)q * a.F + f) * pk_block_bytes(NTT);
+                        if (bi == bj) {
+                            v4i comb;
+#pragma unroll
+                            for (int reg = 0; reg < 4; reg++) comb[reg] = (4 * g + reg >= r) ? vre[reg] : vim[reg];
+                            comb = pk_bias(comb);
+                            unsigned char *d = blk + OD * 1536 + bi * 768;
+                            __builtin_nontemporal_store((v2i){(int)pk_lo(comb[0], comb[1]), (int)pk_lo(comb[2], comb[3])}, (v2i *)d + lane);
+                            __builtin_nontemporal_store((int)pk_hi(comb), (int *)(d + 512) + lane);
+                        } else {
+                            const v4i wr = pk_bias(vre), wi = pk_bias(vim);
+                            unsigned char *d = blk + (bi * (bi - 1) / 2 + bj) * 1536;
+                            __builtin_nontemporal_store((v4i){(int)pk_lo(wr[0], wr[1]), (int)pk_lo(wr[2], wr[3]), (int)pk_lo(wi[0], wi[1]), (int)pk_lo(wi[2], wi[3])},
+                                                        (v4i *)d + lane);
+                            __builtin_nontemporal_store((v2i){(int)pk_hi(wr), (int)pk_hi(wi)}, (v2i *)(d + 1024) + lane);
+                        }
+                    } else if (a.compact) {
                         // A diagonal tile pair needs re (symmetric) and im (antisymmetric, zero diagonal) of ONE triangle: both go into one
                         // 16 x 16 record, re on and below the diagonal, im above it (im[i][j] = -im[j][i] is rebuilt by the reduction).
                         // 2 NP - NTT records of 1 KiB per channel and time range instead of 2 NP: a fifth less partial-sum traffic at 64 rows.
@@ -398,7 +436,38 @@ __global__ __launch_bounds__(256) void k_xe_i8_reduce(const v4i *__restrict__ pa
     const bool diag = compact && bi == bj;
     const int rpc = compact ? 2 * NP - NTT : 2 * NP, rec = compact ? 2 * p - bi : 2 * p;
     long sre[4] = {0, 0, 0, 0}, sim[4] = {0, 0, 0, 0};
-    if constexpr (TS > 0) {
+    if (compact == 2) {
+        const int OD = NTT * (NTT - 1) / 2;
+        const size_t bb = (size_t)pk_block_bytes(NTT);
+        const unsigned char *base = (const unsigned char *)part + (size_t)f * bb + (diag ? OD * 1536 + bi * 768 : (bi * (bi - 1) / 2 + bj) * 1536);
+        constexpr int QB = TS > 0 ? TS : 4;
+        for (int q0 = 0; q0 < tsplit; q0 += QB) {
+            v4i lo[QB];
+            v2i hi[QB];
+#pragma unroll
+            for (int u = 0; u < QB; u++) {
+                const unsigned char *d = base + (size_t)(q0 + u) * F * bb;
+                if (q0 + u >= tsplit) { lo[u] = (v4i){0, 0, 0, 0}; hi[u] = (v2i){0, 0}; continue; }
+                if (diag) {
+                    const v2i l = __builtin_nontemporal_load((const v2i *)d + lane);
+                    lo[u] = (v4i){l[0], l[1], 0, 0};
+                    hi[u] = (v2i){__builtin_nontemporal_load((const int *)(d + 512) + lane), 0};
+                } else {
+                    lo[u] = __builtin_nontemporal_load((const v4i *)d + lane);
+                    hi[u] = __builtin_nontemporal_load((const v2i *)(d + 1024) + lane);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < QB; u++) {
+                if (q0 + u >= tsplit) continue;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    sre[k] += pk_get((unsigned)lo[u][k >> 1], (unsigned)hi[u][0], k);
+                    if (!diag) sim[k] += pk_get((unsigned)lo[u][2 + (k >> 1)], (unsigned)hi[u][1], k);
+                }
+            }
+        }
+    } else if constexpr (TS > 0) {
         v4i a[TS], b[TS];
 #pragma unroll
         for (int q = 0; q < TS; q++) {
@@ -526,6 +595,8 @@ int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void 
     // kept as an option (MI355_XE_INKERNEL_REDUCE=1) and for the tests.
     a.inkernel = (getenv("MI355_XE_INKERNEL_REDUCE") && atoi(getenv("MI355_XE_INKERNEL_REDUCE")) != 0) ? 1 : 0;
     a.compact = (!a.inkernel && !getenv("MI355_XE_NO_COMPACT")) ? 1 : 0;
+    // 24-bit planes: time ranges of at most 256 steps, at least two row tiles (a lone diagonal record has nothing to pair with)
+    if (a.compact && p.tsplit > 1 && T / p.tsplit <= 256 && p.ntt >= 2 && !getenv("MI355_XE_NO_PACK24")) a.compact = 2;
     a.out = (c32 *)out;
     a.N = N; a.F = F; a.Fout = Fout; a.T = T;
     a.ng = (stations_per_group > 0 && stations_per_group < N) ? stations_per_group : N;

@@ -80,6 +80,40 @@ def test_fused_full_range_extremes(gpu, oracle, monkeypatch, tsplit):
     assert np.array_equal(out, ref + ref)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,F,T,npol,tsplit", [(64, 64, 1024, 1, "4"), (33, 64, 4096, 1, "16"), (32, 64, 512, 2, "2"), (17, 128, 2048, 1, "8"), (64, 64, 2048, 1, "4")])
+def test_fused_24_bit_partial_sums_at_their_limits(gpu, oracle, monkeypatch, N, F, T, npol, tsplit):
+    """Time ranges of at most 256 steps travel as 24-bit partial sums (16-bit and 8-bit planes, value - 1).  The extremes of that
+    form: every sample (-128, -128) makes re = 2^23 per range (the one value that needs the -1), alternating (-128, -128) /
+    (-128, 127) stations make |im| = 255 * 128 * 256 per range; plus random data; all bit-exact against the oracle's exact mode and
+    equal to the 32-bit form.  (T / ranges = 512 in the last case: stays 32-bit.)"""
+    monkeypatch.setenv("MI355_XE_TSPLIT", tsplit)
+    rng = np.random.default_rng(T + N)
+    A = N * npol
+    cases = []
+    cases.append(np.full((T, A, F, 2), -128, np.int8))
+    alt = np.full((T, A, F, 2), -128, np.int8)
+    alt[:, 1::2, :, 1] = 127
+    cases.append(alt)
+    alt2 = alt.copy()
+    alt2[:, :, F // 2:, 0] = 127  # I = 127 on half of the channels: the most negative re
+    cases.append(alt2)
+    cases.append(rng.integers(-128, 128, size=(T, A, F, 2), dtype=np.int64).astype(np.int8))
+    blk = _xe(gpu, gpu.DTYPE_BYTE, npol, N, F, T)
+    for x4 in cases:
+        # input layout [t][station][chan][pol]{I,Q}
+        x = np.ascontiguousarray(x4.reshape(T, N, npol, F, 2).transpose(0, 1, 3, 2, 4)).reshape(-1)
+        out = np.empty(blk.get_output_buffer_size(), np.complex64)
+        blk.xcorrelate(x, out)
+        ref = oracle.xengine_ichar(N, F, npol, T, x, exact=True)
+        assert np.array_equal(out, ref)
+        monkeypatch.setenv("MI355_XE_NO_PACK24", "1")
+        out32 = np.empty_like(out)
+        blk.xcorrelate(x, out32)
+        monkeypatch.delenv("MI355_XE_NO_PACK24")
+        assert np.array_equal(out32, ref)
+
+
 @pytest.mark.parametrize("N,F,T,npol,tsplit", [(64, 64, 256, 1, "4"), (33, 128, 512, 1, "8"), (32, 64, 128, 2, "2"), (20, 64, 1024, 1, "16")])
 def test_fused_in_launch_reduction(gpu, oracle, monkeypatch, N, F, T, npol, tsplit):
     """The time ranges combined by the fused kernel's own tail (arrival counters, claimed pieces, epoch-valued flags) instead of the
