@@ -422,11 +422,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
 // (the default form of the reduction; MI355_XE_INKERNEL_REDUCE=1 selects the tail of k_xe_i8_fused instead)
 template <int NPOL, int TS>  // TS > 0: the number of time ranges at compile time (all loads of an item issued back to back)
 __global__ __launch_bounds__(256) void k_xe_i8_reduce(const v4i *__restrict__ part, c32 *__restrict__ out, int N, int F, int Fout, int NP, int NTT,
-                                                      int tsplit_rt, double kd, int accumulate, int compact)
+                                                      int tsplit_rt, double kd, int accumulate, int compact, int ipw)
 {
     const int tsplit = TS > 0 ? TS : tsplit_rt;
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-    size_t item = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (f, p)
+    // ipw consecutive items per wave: the grid is sized so that every wave is resident at once (one round of load latency, not two)
+#pragma unroll 2
+    for (int it = 0; it < ipw; it++) {
+    size_t item = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * ipw + it;  // (f, p)
     const bool live = item < (size_t)Fout * NP;                 // (whole waves; a dead wave still takes part in the shuffles below)
     if (!live) item = 0;
     const int f = (int)(item / NP), p = (int)(item % NP);
@@ -511,7 +514,7 @@ __global__ __launch_bounds__(256) void k_xe_i8_reduce(const v4i *__restrict__ pa
             else { sim[reg] = cc[reg]; sre[reg] = tr; }        // above the diagonal (same-station polarisation products): re[i][j] = re[j][i]
         }
     }
-    if (!live) return;
+    if (!live) continue;
     const int nb = N * (N + 1) / 2, np2 = NPOL * NPOL, A = N * NPOL;
 #pragma unroll
     for (int reg = 0; reg < 4; reg++) {
@@ -526,6 +529,7 @@ __global__ __launch_bounds__(256) void k_xe_i8_reduce(const v4i *__restrict__ pa
         if (accumulate) { v.x += out[o].x; v.y += out[o].y; }
         out[o] = v;
     }
+    }
 }
 
 template <int NPOL, int NTT, bool SPLIT> int launch_fused_s(const XeFusedPlan &p, const FuArgs &a, hipStream_t st)
@@ -538,12 +542,16 @@ template <int NPOL, int NTT, bool SPLIT> int launch_fused_s(const XeFusedPlan &p
     if (SPLIT && !a.inkernel) {
         const int NP = NTT * (NTT + 1) / 2;
         const size_t items = (size_t)a.Fout * NP;
+        int ipw = 1;  // items per wave: as many as it takes for all waves to be resident together (32 per CU)
+        if (const char *e = getenv("MI355_XE_REDUCE_IPW")) ipw = atoi(e) > 0 ? atoi(e) : 1;
+        else while (items > (size_t)ipw * 8192 && ipw < 8) ipw++;
+        const unsigned grid = (unsigned)((items + (size_t)4 * ipw - 1) / ((size_t)4 * ipw));
         if (p.tsplit == 4)
-            hipLaunchKernelGGL((k_xe_i8_reduce<NPOL, 4>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, (const v4i *)a.part, a.out, a.N, a.F,
-                               a.Fout, NP, NTT, p.tsplit, a.kd, a.accumulate, a.compact);
+            hipLaunchKernelGGL((k_xe_i8_reduce<NPOL, 4>), dim3(grid), dim3(256), 0, st, (const v4i *)a.part, a.out, a.N, a.F,
+                               a.Fout, NP, NTT, p.tsplit, a.kd, a.accumulate, a.compact, ipw);
         else
-            hipLaunchKernelGGL((k_xe_i8_reduce<NPOL, 0>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, (const v4i *)a.part, a.out, a.N, a.F,
-                               a.Fout, NP, NTT, p.tsplit, a.kd, a.accumulate, a.compact);
+            hipLaunchKernelGGL((k_xe_i8_reduce<NPOL, 0>), dim3(grid), dim3(256), 0, st, (const v4i *)a.part, a.out, a.N, a.F,
+                               a.Fout, NP, NTT, p.tsplit, a.kd, a.accumulate, a.compact, ipw);
         MI355_HIP(hipGetLastError());
     }
     return MI355_OK;
