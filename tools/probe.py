@@ -96,7 +96,7 @@ def rates_longfilter():
     for nt in (2049, 3000, 4096, 6000, 8192, 10240, 16384):
         t = (rng.standard_normal(nt) / np.sqrt(nt)).astype(np.float32)
         blk = pkg.clFilter(*ARGS, 1, t, 1, 0, False)
-        show("clFilter fast-conv %5d taps (partitioned)" % nt, ev_time(lambda: blk.work_device(N - nt, [a], [c]), iters=5), N - nt, 16)
+        show("clFilter fast-conv %5d taps (partitioned)" % nt, ev_time(lambda: blk.work_device(N - nt, [a], [c]), iters=100, warm=20), N - nt, 16)
 
 
 def rates_pfb():
