@@ -542,7 +542,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s back-to-back leg")
     ap.add_argument("--sustain-s", type=float, default=2.0)
-    ap.add_argument("--secondary-timeout", type=int, default=420, help="seconds the secondary legs may take before the line is printed without the rest")
+    ap.add_argument("--secondary-timeout", type=int, default=300, help="seconds the secondary legs may take before the line is printed without the rest")
     a = ap.parse_args()
 
     import torch
