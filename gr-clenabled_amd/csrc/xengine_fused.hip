@@ -579,7 +579,9 @@ XeFusedPlan mi355_xe_fused_plan(int N, int F, int Fout, int npol, int T, int num
     int s = 1;
     if (const char *e = getenv("MI355_XE_TSPLIT")) s = atoi(e) > 0 ? atoi(e) : 1;
     else
-        while (p.units * s < cus && s < 16) s *= 2;
+        // (not below four K blocks per range: 128 / 256 channels x 1024 frames measure 27.4 / 31.3 us with 8 ranges, 28.6 / 33.9 with 16 --
+        // the per-rank problem of the 8-GPU sharded form, where two dispatches and the first-load latency dominate)
+        while (p.units * s < cus && s < 16 && T / (32 * s * 2) >= 4) s *= 2;
     while (s > 1 && (T % (32 * s) != 0)) s /= 2;
     p.tsplit = s;
     const int NP = p.ntt * (p.ntt + 1) / 2;
