@@ -426,8 +426,7 @@ __global__ __launch_bounds__(256) void k_xe_i8_reduce(const v4i *__restrict__ pa
 {
     const int tsplit = TS > 0 ? TS : tsplit_rt;
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-    // ipw consecutive items per wave: the grid is sized so that every wave is resident at once (one round of load latency, not two)
-#pragma unroll 2
+    // ipw consecutive items per wave, one after the other: the grid is sized so that every wave is resident from the start
     for (int it = 0; it < ipw; it++) {
     size_t item = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * ipw + it;  // (f, p)
     const bool live = item < (size_t)Fout * NP;                 // (whole waves; a dead wave still takes part in the shuffles below)
