@@ -801,13 +801,16 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
         const bool mfma = ((size_t)g.F * g.npol * 8) % 128 == 0 && (reinterpret_cast<uintptr_t>(in) & 15u) == 0 && tiles &&
                           xe_f32_row_tiles(g.NT) != 0 && !getenv("MI355_XE_CF32_VALU");
         // fused kernel: rows <= 64, whole groups of 8 channels; the partial matrices live in the tile workspace
-        static const int ts_env = getenv("MI355_XE_CF32_TSPLIT") ? atoi(getenv("MI355_XE_CF32_TSPLIT")) : 0;
+        const int ts_env = getenv("MI355_XE_CF32_TSPLIT") ? atoi(getenv("MI355_XE_CF32_TSPLIT")) : 0;
         const int tsplit = (ts_env > 0 && g.T % (16 * ts_env) == 0) ? ts_env : (g.T >= 64 ? 2 : 1);
         const size_t out_items = (size_t)g.F * (g.N * (g.N + 1) / 2) * g.npol * g.npol;
         if (mfma && g.NT <= 4 && g.F % 8 == 0 && h->tile_bytes >= (size_t)tsplit * out_items * 8 && !getenv("MI355_XE_CF32_TWO_KERNELS")) {
             const int ntt = g.NT == 3 ? 4 : g.NT;
-            // 4 channels per workgroup: two independent workgroups per CU whose load / multiply phases interleave
-            static const int chw = getenv("MI355_XE_CF32_CH") ? atoi(getenv("MI355_XE_CF32_CH")) : 4;
+            // 4 channels per workgroup = two independent workgroups per CU whose load / multiply phases interleave; 8 channels = one
+            // workgroup per CU reading 64-byte instead of 32-byte pieces of a row.  Interleaved A/B at 1024 channels x 1024 frames, one
+            // polarisation: 64 antennas 227 -> 221 us with 8, 32 antennas 101 -> 80, 16 antennas 68 -> 52 (few row tiles: the piece size
+            // decides), 48 antennas 180 -> 189 (padded fourth tile); two polarisations, 32 antennas: 175 -> 178.
+            const int chw = getenv("MI355_XE_CF32_CH") ? atoi(getenv("MI355_XE_CF32_CH")) : ((g.npol == 1 && (ntt <= 2 || g.A > 56)) ? 8 : 4);
             const int ch = (chw == 8) ? 8 : 4;
             dim3 grid((g.F / ch) * tsplit);
 #define FUSED(NTT, NPOL, CHN) hipLaunchKernelGGL((k_xe_f32_fused<NTT, NPOL, CHN>), grid, dim3(CHN * 64), 0, st, (const v4i *)in, (c32 *)tiles, g, tsplit)

@@ -180,6 +180,11 @@ def ab(case, variants):
             if key not in blks:
                 blks[key] = pkg.clXEngine(*ARGS, False, pkg.DTYPE_BYTE, 1, 64, 1, 0, 1024, 1024, [])
             blks[key].xcorrelate_device(x, out)
+    elif case == "xengine_cf32":
+        x = torch.randn(1024 * 64 * 1024, 2, device="cuda")
+        blk = pkg.clXEngine(*ARGS, False, pkg.DTYPE_COMPLEX, 1, 64, 1, 0, 1024, 1024, [])
+        out = torch.zeros(blk.get_output_buffer_size(), 2, device="cuda")
+        f = lambda: blk.xcorrelate_device(x, out)
     elif case.startswith("fft"):
         n = int(case[3:])
         blk = pkg.clFFT(n, pkg.CLFFT_FORWARD, np.blackman(n).astype(np.float32), pkg.DTYPE_COMPLEX, *ARGS, 0, 1, True); f = lambda: blk.work_device(N // n, [a], [c])
