@@ -572,9 +572,7 @@ __global__ __launch_bounds__(CH * 64) void k_xe_f32_fused(const v4i *__restrict_
 #pragma unroll
     for (int q = 0; q < NP; q++) re[q] = uu[q] = ww[q] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-    // One register stage: the loads of K block kb+1 are in flight while block kb is multiplied.  (Measured on MI355X: the
-    // multiply loop alone runs in 178 us = 79 % MFMA-busy, the load loop alone in 152 us, together 272 us -- the loads make
-    // little progress while the matrix pipes are saturated; a second stage, i.e. two blocks of lead, changed nothing.)
+    // One register stage: the loads of K block kb+1 are in flight while block kb is multiplied.
     v4i stA[PER];
     const int t_end = (kb1 * kKB32 < g.T) ? kb1 * kKB32 : g.T;  // a block past this workgroup's time range loads nothing (zeros)
     auto load_block = [&](int kb, v4i(&stage)[PER]) {
@@ -611,28 +609,31 @@ __global__ __launch_bounds__(CH * 64) void k_xe_f32_fused(const v4i *__restrict_
             }
         }
     };
-    auto multiply = [&](const unsigned char *buf) {
+    // x1 conj(x2) = (I1 I2 + Q1 Q2) + i (Q1 I2 - I1 Q2) with THREE real products per element instead of four:
+    //   k1 = (I1 + Q1) I2,  k2 = I1 (I2 + Q2),  k3 = Q1 (I2 - Q2)   =>   re = k1 - k3,  im = k1 - k2   (epilogue)
+    // S = I + Q and D = I - Q are formed in registers from the operand vectors (8 packed adds per K block).
+    v4f I[NTT], Q[NTT], S[NTT], D[NTT];
+    auto operands = [&](const unsigned char *buf) {
         const unsigned char *base = buf + wave * CBYTES + lane * 16;
-        v4f I[NTT], Q[NTT];
 #pragma unroll
         for (int rt = 0; rt < NTT; rt++) {
             I[rt] = *(const v4f *)(base + rt * kTileBytes);
             Q[rt] = *(const v4f *)(base + (NTT + rt) * kTileBytes);
         }
-        // x1 conj(x2) = (I1 I2 + Q1 Q2) + i (Q1 I2 - I1 Q2) with THREE real products per element instead of four:
-        //   k1 = (I1 + Q1) I2,  k2 = I1 (I2 + Q2),  k3 = Q1 (I2 - Q2)   =>   re = k1 - k3,  im = k1 - k2   (epilogue)
-        // S = I + Q and D = I - Q are formed in registers from the operand vectors (8 packed adds per K block).
-        v4f S[NTT], D[NTT];
 #pragma unroll
         for (int rt = 0; rt < NTT; rt++) {
             S[rt] = I[rt] + Q[rt];
             D[rt] = I[rt] - Q[rt];
         }
+    };
+    auto products = [&](auto lo_tag, auto hi_tag) {  // tile pairs [lo, hi)
+        constexpr int LO = decltype(lo_tag)::value, HI = decltype(hi_tag)::value;
 #pragma unroll
         for (int bi = 0; bi < NTT; bi++) {
 #pragma unroll
             for (int bj = 0; bj <= bi; bj++) {
                 const int q = bi * (bi + 1) / 2 + bj;
+                if (q < LO || q >= HI) continue;
 #pragma unroll
                 for (int kc = 0; kc < 4; kc++) {
                     re[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(S[bi][kc], I[bj][kc], re[q], 0, 0, 0);  // k1 = (I1+Q1) I2
@@ -642,15 +643,30 @@ __global__ __launch_bounds__(CH * 64) void k_xe_f32_fused(const v4i *__restrict_
             }
         }
     };
-
+    // The order of a K block is pinned (scheduling barriers): the global loads of the next block, the products of the first eight
+    // tile pairs, THEN the staging stores of the next block, the workgroup barrier, and the last two pairs' products, which run
+    // while the other waves arrive.  Left to itself the scheduler hoists the stores -- and with them the wait for global loads
+    // issued a few hundred cycles before -- to a third of the way into the products: the wave then sits on that wait with the
+    // matrix pipe idle.  That, not "loads making no progress under saturated MFMA", was the gap between the multiply loop alone
+    // (178 us) and the whole kernel in round 1.  Measured at 64 antennas (interleaved A/B): 221 us unpinned, 199 with the stores
+    // behind all products, 198 with 8 + 2 (6 + 4: 203; loads issued after the stores, two blocks ahead: 205-215).
+    constexpr int P1 = NP >= 10 ? 8 : NP;  // tile pairs before the staging stores
+    using T0 = std::integral_constant<int, 0>;
+    using T1 = std::integral_constant<int, P1>;
+    using T2 = std::integral_constant<int, NP>;
     load_block(kb0, stA);
     store_block(lds[0], stA);
     __syncthreads();
     for (int kb = kb0; kb < kb1; kb++) {
-        load_block(kb + 1, stA);  // unconditional (the block after the last one reads as zeros): no control flow in the loop body
-        multiply(lds[(kb - kb0) & 1]);
+        load_block(kb + 1, stA);  // unconditional (a block past the range reads as zeros): no control flow in the loop body
+        operands(lds[(kb - kb0) & 1]);
+        products(T0{}, T1{});
+        __builtin_amdgcn_sched_barrier(0);
         store_block(lds[(kb + 1 - kb0) & 1], stA);
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
+        products(T1{}, T2{});
+        __builtin_amdgcn_sched_barrier(0);
     }
     // partial matrix of this time range, channel = cgrp*8 + wave
     const int f = cgrp * CH + wave;
@@ -806,11 +822,11 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
         const size_t out_items = (size_t)g.F * (g.N * (g.N + 1) / 2) * g.npol * g.npol;
         if (mfma && g.NT <= 4 && g.F % 8 == 0 && h->tile_bytes >= (size_t)tsplit * out_items * 8 && !getenv("MI355_XE_CF32_TWO_KERNELS")) {
             const int ntt = g.NT == 3 ? 4 : g.NT;
-            // 4 channels per workgroup = two independent workgroups per CU whose load / multiply phases interleave; 8 channels = one
-            // workgroup per CU reading 64-byte instead of 32-byte pieces of a row.  Interleaved A/B at 1024 channels x 1024 frames, one
-            // polarisation: 64 antennas 227 -> 221 us with 8, 32 antennas 101 -> 80, 16 antennas 68 -> 52 (few row tiles: the piece size
-            // decides), 48 antennas 180 -> 189 (padded fourth tile); two polarisations, 32 antennas: 175 -> 178.
-            const int chw = getenv("MI355_XE_CF32_CH") ? atoi(getenv("MI355_XE_CF32_CH")) : ((g.npol == 1 && (ntt <= 2 || g.A > 56)) ? 8 : 4);
+            // 8 channels per workgroup (one workgroup per CU, 64-byte pieces of a row) or 4 (two workgroups per CU, 32-byte pieces).
+            // Interleaved A/B at 1024 channels x 1024 frames with the pinned K-block schedule: 64 antennas 226 us with 4 / 198 with 8,
+            // 48 antennas 179 / 172, 32 antennas 95 / 72, 16 antennas x 2048 channels 64 / 50; two polarisations: 32 antennas
+            // 176 / 178, 16 antennas 64 / 60.
+            const int chw = getenv("MI355_XE_CF32_CH") ? atoi(getenv("MI355_XE_CF32_CH")) : 8;
             const int ch = (chw == 8) ? 8 : 4;
             dim3 grid((g.F / ch) * tsplit);
 #define FUSED(NTT, NPOL, CHN) hipLaunchKernelGGL((k_xe_f32_fused<NTT, NPOL, CHN>), grid, dim3(CHN * 64), 0, st, (const v4i *)in, (c32 *)tiles, g, tsplit)
