@@ -639,7 +639,7 @@ def main():
             extras["error"] = "%s: %s" % (type(exc).__name__, exc)
         # the only data-path collective of the hot path, INSIDE the JSON line (world 1: the same pipeline, no peers)
         try:
-            extras["clXEngine_sharded"] = sharded_xengine(pkg, local, max(5, a.steps // 5), world, rank)
+            extras["clXEngine_sharded"] = sharded_xengine(pkg, local, max(20, a.steps // 2), world, rank)
         except Exception as exc:  # noqa: BLE001
             extras["clXEngine_sharded"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         if rank == 0 and world == 1:
