@@ -592,6 +592,43 @@ __global__ __launch_bounds__(256) void k_fft_combine(const c32 *__restrict__ ws,
     }
 }
 
+// Powers of two above 65536 (131072 .. 1048576 = 4096 x 16 x S2, S2 = 2 .. 16): one more level of the same decimation in time.
+//   sub-frame s = S2 a + b  =>  X[k] = sum_b W_N^(b k) G_b[k mod 65536],  G_b = 65536-point transform of x[S2 m + b]
+//                                  = radix-16 combine of the sub-frames E_(S2 a + b), a = 0 .. 15
+// k_fft_sub (all S sub-frames) -> workspace A;  k_fft_combine2<16> per b (A -> B: G_b);  k_fft_combine2<S2> (B -> out).
+// Three passes over the frame instead of two: functional coverage of the sizes the reference's clFFT plans accept
+// (lib/clFFT_impl.cc:91-128), one item of such a stream being 1 .. 8 MiB.
+// One generalised combine: `nsub` points per input sub-transform, S of them `src_sub` elements apart (blockIdx.y selects one
+// of gridDim.y interleaved sets, `src_set` / `dst_set` elements apart); W_(nsub S)^(s k) = twN[(s k tw_mul) & nmask].
+template <int S, int SIGN>
+__global__ __launch_bounds__(256) void k_fft_combine2(const c32 *__restrict__ src, c32 *__restrict__ dst, const c32 *__restrict__ twN,
+                                                      long long total /* frames * nsub */, int nsub, long long frame_elems, long long src_sub,
+                                                      long long src_set, long long dst_set, int tw_mul, int nmask, int m_xor)
+{
+    const int set = blockIdx.y;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long frame = e / nsub;
+        const int k = (int)(e - frame * nsub);
+        const c32 *in = src + (size_t)frame * frame_elems + (size_t)set * src_set + k;
+        c32 a[S];
+#pragma unroll
+        for (int s = 0; s < S; s++) a[s] = in[(size_t)s * src_sub];
+        c32 wsl[tw_slots<S>()];
+#pragma unroll
+        for (int i = 0; i < tw_slots<S>(); i++) wsl[i] = twN[(int)(((long long)tw_power<S>(i) * k * tw_mul) & nmask)];
+        apply_twiddles<S>(a, wsl);
+        bfly<S, SIGN>(a);  // slot t holds y[orev<S>(t)]
+        f2v *out = (f2v *)dst + (size_t)frame * frame_elems + (size_t)set * dst_set + k;
+#pragma unroll
+        for (int t = 0; t < S; t++) {
+            f2v z;
+            z.x = a[t].x;
+            z.y = a[t].y;
+            out[(size_t)((orev<S>(t) ^ m_xor)) * nsub] = z;
+        }
+    }
+}
+
 template <int N, class G>
 int launch_g(mi355_ctx *ctx, int sign, const void *in, void *out, const float *window, const void *tw, int nframes, int shift,
              int real_in, hipStream_t st)
@@ -909,11 +946,14 @@ int launch_big(mi355_fft *h, const void *in, void *out, int nframes, hipStream_t
         const int rc = ws_acquire(h, st, chunk > h->cap_frames);
         if (rc) return rc;
     }
+    const bool three_pass = S > 16;  // 131072 .. 1048576 points: a second workspace for the 65536-point intermediate transforms
     if (chunk > h->cap_frames) {
         MI355_HIP(hipStreamSynchronize(st));
         if (h->d_wa) (void)hipFree(h->d_wa);
-        h->d_wa = nullptr; h->cap_frames = 0;
+        if (h->d_wb) (void)hipFree(h->d_wb);
+        h->d_wa = h->d_wb = nullptr; h->cap_frames = 0;
         MI355_HIP(hipMalloc(&h->d_wa, chunk * (size_t)N * 8));
+        if (three_pass) MI355_HIP(hipMalloc(&h->d_wb, chunk * (size_t)N * 8));
         h->cap_frames = chunk;
     }
     const int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
@@ -931,10 +971,34 @@ int launch_big(mi355_fft *h, const void *in, void *out, int nframes, hipStream_t
         if (h->sign < 0) { if (h->dtype == MI355_DTYPE_FLOAT) SUB(-1, true); else SUB(-1, false); }
         else             { if (h->dtype == MI355_DTYPE_FLOAT) SUB(1, true);  else SUB(1, false); }
 #undef SUB
+        c32 *dst = (c32 *)out + f0 * N;
+        if (three_pass) {
+            const int S2 = S / 16;
+            {   // G_b = radix-16 combine of the sub-frames S2 a + b  (workspace A -> B), all b in one launch
+                const long long total = (long long)nf * 4096;
+                long long blocks = (total + 255) / 256;
+                if (blocks > (long long)cus * 16 / S2 + 1) blocks = (long long)cus * 16 / S2 + 1;
+#define COMB2(SS, SG, GY, ...) hipLaunchKernelGGL((k_fft_combine2<SS, SG>), dim3((unsigned)blocks, GY), dim3(256), 0, st, __VA_ARGS__)
+                if (h->sign < 0) COMB2(16, -1, S2, (const c32 *)h->d_wa, (c32 *)h->d_wb, (const c32 *)h->d_tw, total, 4096, (long long)N, (long long)S2 * 4096, 4096LL, 65536LL, S2, N - 1, 0);
+                else             COMB2(16, 1, S2, (const c32 *)h->d_wa, (c32 *)h->d_wb, (const c32 *)h->d_tw, total, 4096, (long long)N, (long long)S2 * 4096, 4096LL, 65536LL, S2, N - 1, 0);
+            }
+            {   // X = radix-S2 combine of the G_b  (workspace B -> out)
+                const long long total = (long long)nf * 65536;
+                long long blocks = (total + 255) / 256;
+                if (blocks > (long long)cus * 16) blocks = (long long)cus * 16;
+                const int mx = (h->sign < 0 && h->shift) ? S2 / 2 : 0;
+#define COMB2F(SS) do { if (h->sign < 0) COMB2(SS, -1, 1, (const c32 *)h->d_wb, dst, (const c32 *)h->d_tw, total, 65536, (long long)N, 65536LL, 0LL, 0LL, 1, N - 1, mx); \
+                        else             COMB2(SS, 1, 1, (const c32 *)h->d_wb, dst, (const c32 *)h->d_tw, total, 65536, (long long)N, 65536LL, 0LL, 0LL, 1, N - 1, mx); } while (0)
+                if (S2 == 2) COMB2F(2); else if (S2 == 4) COMB2F(4); else if (S2 == 8) COMB2F(8); else COMB2F(16);
+#undef COMB2F
+#undef COMB2
+            }
+            MI355_HIP(hipGetLastError());
+            continue;
+        }
         const long long total = (long long)nf * 4096;
         long long blocks = (total + 255) / 256;
         if (blocks > (long long)cus * 16) blocks = (long long)cus * 16;
-        c32 *dst = (c32 *)out + f0 * N;
 #define COMB(SS, SG) hipLaunchKernelGGL((k_fft_combine<SS, SG>), dim3((unsigned)blocks), dim3(256), 0, st, (const c32 *)h->d_wa, dst, (const c32 *)h->d_tw, total, m_xor)
         if (S == 8) { if (h->sign < 0) COMB(8, -1); else COMB(8, 1); }
         else        { if (h->sign < 0) COMB(16, -1); else COMB(16, 1); }
@@ -1055,8 +1119,8 @@ extern "C" int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, con
     MI355_REQUIRE(ctx && out, "NULL argument");
     *out = nullptr;
     const bool pow2 = fft_size >= 2 && (fft_size & (fft_size - 1)) == 0;
-    if (fft_size < 2 || (pow2 && fft_size > 65536) || (!pow2 && fft_size > 16384)) {
-        mi355_set_error("fft size %d unsupported (powers of two 2..65536, any other size 3..16384)", fft_size);
+    if (fft_size < 2 || (pow2 && fft_size > 1048576) || (!pow2 && fft_size > 16384)) {
+        mi355_set_error("fft size %d unsupported (powers of two 2..1048576, any other size 3..16384)", fft_size);
         return fft_size < 2 ? MI355_ERR_INVALID_ARG : MI355_ERR_UNSUPPORTED;
     }
     MI355_REQUIRE(window_len == 0 || window_len == fft_size, "window not the same length as fft_size");
@@ -1111,6 +1175,8 @@ extern "C" int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, con
         rc = setup_bluestein(h, window_len ? window : nullptr);
         if (rc) return fail(rc);
     }
+    // the table uploads ran on the null stream, which the context's non-blocking streams do not wait for
+    if (hipDeviceSynchronize() != hipSuccess) return fail(MI355_ERR_HIP);
     *out = h;
     return MI355_OK;
 }

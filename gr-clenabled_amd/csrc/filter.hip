@@ -848,6 +848,8 @@ int upload_taps_impl(mi355_filter *h, const void *taps, int ntaps)
         }
     }
     MI355_HIP(hipSetDevice(h->ctx->device));
+    // kernels of earlier device-path calls may still be reading the tables that are about to be freed
+    MI355_HIP(hipDeviceSynchronize());
     free_dev(h);
     h->ntaps = ntaps;
     h->nf = nf;
@@ -929,6 +931,8 @@ int upload_taps_impl(mi355_filter *h, const void *taps, int ntaps)
         MI355_HIP(hipMemcpy(h->d_twf, twf.data(), bytes, hipMemcpyHostToDevice));
         MI355_HIP(hipMemcpy(h->d_twi, twi.data(), bytes, hipMemcpyHostToDevice));
     }
+    // the uploads above run on the null stream, which the context's non-blocking streams do not wait for
+    MI355_HIP(hipDeviceSynchronize());
     return MI355_OK;
 }
 

@@ -770,6 +770,8 @@ extern "C" int mi355_pfb_create(mi355_ctx *ctx, const float *taps, int ntaps, in
     if (hipMemcpy(h->d_map, ch_map, (size_t)nmap * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return fail(MI355_ERR_HIP);
     int rc = h->pipe.init(ctx);
     if (rc) return fail(rc);
+    // the table uploads ran on the null stream, which the context's non-blocking streams do not wait for
+    if (hipDeviceSynchronize() != hipSuccess) return fail(MI355_ERR_HIP);
     *out = h;
     return MI355_OK;
 }

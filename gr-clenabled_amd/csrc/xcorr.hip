@@ -262,6 +262,7 @@ extern "C" int mi355_xcorr_fft_create(mi355_ctx *ctx, int fft_size, int num_inpu
         mi355_set_error("device allocation of the twiddle tables failed");
         return MI355_ERR_NOMEM;
     }
+    (void)hipDeviceSynchronize();  // the uploads ran on the null stream, which the context's non-blocking streams do not wait for
     *out = h;
     return MI355_OK;
 }

@@ -1001,7 +1001,12 @@ extern "C" int mi355_xengine_create(mi355_ctx *ctx, int data_type, int npol, int
         delete h;
         return MI355_ERR_NOMEM;
     }
-    if (h->tile_bytes && hipMemset(h->d_tiles, 0, h->tile_bytes) != hipSuccess) { mi355_xengine_destroy(h); return MI355_ERR_HIP; }
+    // (hipMemset of device memory may return before the fill has run, and the fill is on the null stream, which the context's
+    // non-blocking streams do not wait for: without the synchronisation the first integration's corner turn can be overwritten by it)
+    if (h->tile_bytes && (hipMemset(h->d_tiles, 0, h->tile_bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) {
+        mi355_xengine_destroy(h);
+        return MI355_ERR_HIP;
+    }
     if (pad) {
         h->pad_bytes = (size_t)g.T * g.N * g.F * 2;
         if (hipMalloc((void **)&h->d_pad, h->pad_bytes) != hipSuccess) { mi355_xengine_destroy(h); return MI355_ERR_NOMEM; }
@@ -1056,7 +1061,9 @@ int slot_prepare(mi355_xengine *h, int s)
     if (s == 0 || h->tile_bytes == 0) sl.d_tiles = h->d_tiles;
     else {
         MI355_HIP(hipMalloc((void **)&sl.d_tiles, h->tile_bytes));
-        MI355_HIP(hipMemset(sl.d_tiles, 0, h->tile_bytes));  // padding rows stay zero
+        // padding rows stay zero.  On the slot's own stream: a null-stream fill is not ordered with the kernels that follow on a
+        // non-blocking stream and, when the device is busy, ran AFTER the slot's first corner turn (one wrong integration in ~2000)
+        MI355_HIP(hipMemsetAsync(sl.d_tiles, 0, h->tile_bytes, h->ctx->stream[s]));
     }
     return MI355_OK;
 }

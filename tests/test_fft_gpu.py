@@ -159,7 +159,7 @@ def test_zero_vectors_and_bad_sizes(gpu):
     e = np.empty(0, np.complex64)
     assert blk.work(0, [e], [e]) == 0
     with pytest.raises(gpu.Mi355Error):
-        _fft(gpu, 131072, gpu.CLFFT_FORWARD)  # powers of two above 65536 are refused, not emulated
+        _fft(gpu, 2097152, gpu.CLFFT_FORWARD)  # powers of two above 2^20 are refused, not emulated
     with pytest.raises(gpu.Mi355Error):
         _fft(gpu, 16385, gpu.CLFFT_FORWARD)  # other sizes above 16384 too
     with pytest.raises(gpu.Mi355Error):
@@ -219,6 +219,38 @@ def test_two_kernel_sizes(gpu, oracle, n, fwd, shift, win):
     blk = _fft(gpu, n, gpu.CLFFT_FORWARD if fwd else gpu.CLFFT_BACKWARD, w, shift=shift)
     assert blk.work(nvec, [x], [y]) == nvec
     assert relerr(y, oracle.fft_block(n, fwd, w, shift, oracle.DTYPE_COMPLEX, x, f64=True)) <= TOL
+
+
+# 131072 .. 1048576: three passes (sub-transforms, radix-16 combine into 65536-point transforms, radix-2/4/8/16 combine)
+@pytest.mark.parametrize("n", [131072, 262144, 524288, 1048576])
+@pytest.mark.parametrize("fwd,shift,win", [(True, True, True), (False, True, True), (True, False, False)])
+def test_sizes_above_65536(gpu, oracle, n, fwd, shift, win):
+    rng = np.random.default_rng(n + 9)
+    nvec = 2
+    w = oracle.window(oracle.WIN_BLACKMAN_HARRIS, n) if win else None
+    x = crandn(rng, nvec * n)
+    y = np.empty_like(x)
+    blk = _fft(gpu, n, gpu.CLFFT_FORWARD if fwd else gpu.CLFFT_BACKWARD, w, shift=shift)
+    assert blk.work(nvec, [x], [y]) == nvec
+    assert relerr(y, oracle.fft_block(n, fwd, w, shift, oracle.DTYPE_COMPLEX, x, f64=True)) <= TOL
+    if fwd and not win:  # one bin, real input, and many frames through the device path (more than one workspace chunk at 2^20 points)
+        import torch
+        t = np.exp(2j * np.pi * 54321 * np.arange(n) / n).astype(np.complex64)
+        z = np.empty_like(t)
+        blk.work(1, [t], [z])
+        assert abs(z[54321] - n) < 1e-5 * n * 8 and np.abs(np.delete(z, 54321)).max() < 1e-5 * n * 8
+        xr = rng.standard_normal(n).astype(np.float32)
+        yr = np.empty(n, np.complex64)
+        _fft(gpu, n, gpu.CLFFT_FORWARD, dtype=gpu.DTYPE_FLOAT, shift=True).work(1, [xr], [yr])
+        assert relerr(yr, oracle.fft_block(n, True, None, True, oracle.DTYPE_FLOAT, xr, f64=True)) <= TOL
+        frames = (256 << 20) // (n * 8) + 3
+        xd = torch.randn(frames * n, 2, device="cuda")
+        yd = torch.empty_like(xd)
+        blk.work_device(frames, [xd], [yd])
+        for f in (0, frames - 1):
+            xs = xd[f * n:(f + 1) * n].cpu().numpy().view(np.complex64).reshape(-1)
+            ys = yd[f * n:(f + 1) * n].cpu().numpy().view(np.complex64).reshape(-1)
+            assert relerr(ys, oracle.fft_block(n, True, None, False, oracle.DTYPE_COMPLEX, xs, f64=True)) <= TOL
 
 
 def test_two_kernel_real_input_and_tone(gpu, oracle):
