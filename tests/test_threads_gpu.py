@@ -54,7 +54,40 @@ def test_blocks_work_concurrently_from_threads(gpu, oracle):
             if not np.array_equal(out, ref):
                 errs.append("xengine")
 
-    ts = [threading.Thread(target=f) for f in (run_fft, run_filter, run_math, run_xe, run_fft, run_math)]
+    def run_pfb():
+        M, buf = 64, 64 * 64
+        taps = np.random.default_rng(6).standard_normal(M * 8).astype(np.float32)
+        x = crandn(np.random.default_rng(7), buf + taps.size - M)
+        y = np.empty(buf, np.complex64)
+        blk = gpu.clPolyphaseChannelizer(*GPU_ARGS, taps, buf, M, M, list(range(M)))
+        ref = oracle.pfb(taps, buf, M, M, list(range(M)), x, f64=True)
+        for _ in range(100):
+            blk.general_work(buf, [x.size], [x], [y])
+            if relerr(y, ref) > 1e-5:
+                errs.append("pfb")
+
+    big = gpu.clFFT(65536, gpu.CLFFT_FORWARD, [], gpu.DTYPE_COMPLEX, *GPU_ARGS)  # ONE handle, two threads: its workspace is shared
+    xb = crandn(np.random.default_rng(8), 3 * 65536)
+    refb = oracle.fft_block(65536, True, None, False, oracle.DTYPE_COMPLEX, xb, f64=True)
+
+    def run_big_fft():
+        y = np.empty_like(xb)
+        for _ in range(30):
+            big.work(3, [xb], [y])
+            if relerr(y, refb) > 1e-5:
+                errs.append("fft65536")
+
+    def run_large_copy():  # 2^22 items: the pinned double buffers and the helper pool of the host path
+        a = crandn(np.random.default_rng(9), 1 << 22)
+        c = np.empty_like(a)
+        blk = gpu.clMathConst(gpu.DTYPE_COMPLEX, *GPU_ARGS, 3.0, gpu.MATHOP_MULTIPLY)
+        for _ in range(10):
+            blk.work(a.size, [a], [c])
+            if not np.array_equal(c, np.float32(3.0) * a):
+                errs.append("large copy")
+
+    ts = [threading.Thread(target=f) for f in (run_fft, run_filter, run_math, run_xe, run_fft, run_math, run_pfb, run_big_fft, run_big_fft,
+                                               run_large_copy, run_large_copy)]
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errs, errs[:5]
