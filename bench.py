@@ -415,8 +415,9 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank, out=None):
     nl = n - 3000
     lfl = pkg.clFilter(*args, 1, taps3000, 1, 0, False)
     out["clFilter_fft_3000taps"] = rate(lambda: lfl.work_device(nl, [a], [c]), nl, 16)
-    # other transform sizes of the headline block: one smaller, one two-kernel size
-    for fn_ in (1024, 32768):
+    # other transform sizes of the headline block: one smaller, the one-pass 16384 / 32768 kernels, the two-kernel and the
+    # three-pass workspace schemes
+    for fn_ in (1024, 16384, 32768, 65536, 1048576):
         fb = pkg.clFFT(fn_, pkg.CLFFT_FORWARD, np.blackman(fn_).astype(np.float32), pkg.DTYPE_COMPLEX, *args, 0, 1, True)
         nv = n // fn_
         out["clFFT_%d" % fn_] = rate(lambda: fb.work_device(nv, [a], [c]), nv * fn_, 16)
