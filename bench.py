@@ -277,11 +277,16 @@ def sustained(fn, samples_per_launch, min_s=2.0, batch=64):
                 break
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    per = sorted(a.elapsed_time(b) * 1e3 / batch for a, b in evs)  # us per launch
-    return {"seconds": round(wall, 2), "launches": launches, "MSamples_per_s": round(launches * samples_per_launch / wall / 1e6, 1),
-            "us_per_launch_median": round(per[len(per) // 2], 2), "us_per_launch_min": round(per[0], 2),
-            "us_per_launch_max": round(per[-1], 2),
-            "hbm_frac_median": round(samples_per_launch * BYTES_PER_SAMPLE / (per[len(per) // 2] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    def finish():
+        # (read out afterwards: ~200 event queries are milliseconds of host time during which the device would sit idle
+        # right before the K timed steps)
+        per = sorted(a.elapsed_time(b) * 1e3 / batch for a, b in evs)  # us per launch
+        return {"seconds": round(wall, 2), "launches": launches, "MSamples_per_s": round(launches * samples_per_launch / wall / 1e6, 1),
+                "us_per_launch_median": round(per[len(per) // 2], 2), "us_per_launch_min": round(per[0], 2),
+                "us_per_launch_max": round(per[-1], 2),
+                "hbm_frac_median": round(samples_per_launch * BYTES_PER_SAMPLE / (per[len(per) // 2] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+    return finish
 
 
 def hostpath_blocks(pkg, o_taps, dev):
@@ -573,6 +578,8 @@ def main():
     if not a.no_sustained:
         sus = sustained(step, samples_per_step, a.sustain_s)
     wall, ev = time_steps(step, a.steps, a.warmup, world)
+    if sus is not None:
+        sus = sus()
     wall = max_over_ranks(wall, world)
     ev = max_over_ranks(ev, world)
     value = world * samples_per_step * a.steps / wall / 1e6
