@@ -5,7 +5,7 @@ load it with ``importlib`` under the module name ``gr_clenabled_amd`` -- see
 ``__graft_entry__.load_package()`` -- or put the repo root on sys.path and call
 ``importlib.import_module("gr-clenabled_amd")``.
 """
-from ._lib import LIB_PATH, Mi355Error, lib  # noqa: F401
+from ._lib import LIB_PATH, Mi355Error, lib, set_log_callback  # noqa: F401
 from .blocks import *  # noqa: F401,F403
 from . import blocks as clenabled  # noqa: F401  (flowgraph-style alias: clenabled.clFFT(...))
 from . import shard  # noqa: F401

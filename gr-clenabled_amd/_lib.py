@@ -24,6 +24,18 @@ def _strerror(code):
         return "?"
 
 
+LOG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_char_p)  # mi355_log_fn
+_log_keepalive = None
+
+
+def set_log_callback(fn):
+    """fn(level, message) receives every diagnostics / error line of the library (None restores stderr)."""
+    global _log_keepalive
+    cb = LOG_FN(lambda user, level, msg: fn(level, msg.decode())) if fn is not None else C.cast(None, LOG_FN)
+    check(lib().mi355_set_log_callback(cb, None), "mi355_set_log_callback")
+    _log_keepalive = cb  # the C side holds the pointer: keep the thunk alive
+
+
 def lib():
     """Return the ctypes handle, loading the library on first use."""
     global _lib
@@ -46,6 +58,7 @@ def lib():
         "mi355_strerror": (C.c_char_p, [i]),
         "mi355_last_error": (C.c_char_p, []),
         "mi355_version": (C.c_char_p, []),
+        "mi355_set_log_callback": (i, [LOG_FN, vp]),
         "mi355_device_count": (i, []),
         "mi355_ctx_create": (i, [i, i, i, i, i, pp]),
         "mi355_ctx_destroy": (i, [vp]),

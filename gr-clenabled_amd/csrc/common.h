@@ -20,6 +20,9 @@ struct mi355_ctx {
 };
 
 void mi355_set_error(const char *fmt, ...);
+// one diagnostics line to the registered sink (mi355_set_log_callback) or, by default, to stderr; DEBUG / INFO lines are
+// dropped unless the context was created with debug != 0 (the reference's setDebug)
+void mi355_log(const mi355_ctx *ctx, int level, const char *fmt, ...) __attribute__((format(printf, 3, 4)));
 
 #define MI355_HIP(call)                                                                  \
     do {                                                                                 \

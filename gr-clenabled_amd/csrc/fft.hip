@@ -1177,6 +1177,9 @@ extern "C" int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, con
     }
     // the table uploads ran on the null stream, which the context's non-blocking streams do not wait for
     if (hipDeviceSynchronize() != hipSuccess) return fail(MI355_ERR_HIP);
+    mi355_log(ctx, MI355_LOG_INFO, "clFFT: %d points, %s, %s input, %d stream(s), shift %d, window %s: %s", fft_size,
+              h->sign < 0 ? "forward" : "reverse", dtype == MI355_DTYPE_COMPLEX ? "complex" : "float", num_streams, h->shift,
+              window_len ? "given" : "none", !pow2 ? "chirp-z over a power-of-two transform" : h->two_kernel ? "multi-pass" : "one pass");
     *out = h;
     return MI355_OK;
 }

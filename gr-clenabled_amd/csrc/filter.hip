@@ -1131,6 +1131,8 @@ extern "C" int mi355_filter_create(mi355_ctx *ctx, int decimation, const void *t
     int rc = upload_taps(h, taps, ntaps);
     if (rc == MI355_OK) rc = h->pipe.init(ctx);
     if (rc != MI355_OK) { free_dev(h); h->pipe.release(); delete h; return rc; }
+    mi355_log(ctx, MI355_LOG_INFO, "%s: %d %s taps, decimation %d: %s (transform size %d)", complex_taps ? "clComplexFilter" : "clFilter", ntaps,
+              complex_taps ? "complex" : "real", decimation, h->nf ? "overlap-save in the frequency domain" : "direct form", h->nf);
     *out = h;
     return MI355_OK;
 }

@@ -772,6 +772,8 @@ extern "C" int mi355_pfb_create(mi355_ctx *ctx, const float *taps, int ntaps, in
     if (rc) return fail(rc);
     // the table uploads ran on the null stream, which the context's non-blocking streams do not wait for
     if (hipDeviceSynchronize() != hipSuccess) return fail(MI355_ERR_HIP);
+    mi355_log(ctx, MI355_LOG_INFO, "clPolyphaseChannelizer: %d channels, %d taps, %d inputs per step, %d of %d outputs mapped, %d items per call: %s kernel",
+              num_channels, ntaps, ninputs_per_iter, nmap, num_channels, buf_items, h->fast ? "fused filter + transform" : "two-pass");
     *out = h;
     return MI355_OK;
 }

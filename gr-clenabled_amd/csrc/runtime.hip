@@ -6,7 +6,30 @@
 
 #include "common.h"
 
+#include <atomic>
+
 static thread_local char g_err[512] = "";
+
+namespace {
+struct LogSink {
+    mi355_log_fn fn;
+    void *user;
+};
+std::mutex g_log_lock;            // writers only; readers take a snapshot of the pair under it (calls are rare: not a hot path)
+LogSink g_log_sink = {nullptr, nullptr};
+LogSink log_sink()
+{
+    std::lock_guard<std::mutex> g(g_log_lock);
+    return g_log_sink;
+}
+}  // namespace
+
+extern "C" int mi355_set_log_callback(mi355_log_fn fn, void *user)
+{
+    std::lock_guard<std::mutex> g(g_log_lock);
+    g_log_sink = {fn, fn ? user : nullptr};
+    return MI355_OK;
+}
 
 void mi355_set_error(const char *fmt, ...)
 {
@@ -14,6 +37,23 @@ void mi355_set_error(const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+    const LogSink s = log_sink();
+    if (s.fn) s.fn(s.user, MI355_LOG_ERROR, g_err);
+}
+
+void mi355_log(const mi355_ctx *ctx, int level, const char *fmt, ...)
+{
+    if (level < MI355_LOG_WARN && !(ctx && ctx->debug)) return;
+    char line[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(line, sizeof(line), fmt, ap);
+    va_end(ap);
+    const LogSink s = log_sink();
+    if (s.fn)
+        s.fn(s.user, level, line);
+    else
+        fprintf(stderr, "[mi355] %s\n", line);
 }
 
 extern "C" const char *mi355_last_error(void) { return g_err; }
@@ -105,9 +145,8 @@ extern "C" int mi355_ctx_create(int ocl_type, int dev_selector, int platform_id,
         mi355_ctx_destroy(c);
         return MI355_ERR_HIP;
     }
-    if (debug)
-        fprintf(stderr, "[mi355] context on device %d (%s, %d CUs, %.1f GB)\n", dev, prop.gcnArchName, prop.multiProcessorCount,
-                prop.totalGlobalMem / 1e9);
+    mi355_log(c, MI355_LOG_INFO, "context on device %d (%s, %d CUs, %.1f GB)", dev, prop.gcnArchName, prop.multiProcessorCount,
+              prop.totalGlobalMem / 1e9);
     *out = c;
     return MI355_OK;
 }

@@ -1011,6 +1011,9 @@ extern "C" int mi355_xengine_create(mi355_ctx *ctx, int data_type, int npol, int
         h->pad_bytes = (size_t)g.T * g.N * g.F * 2;
         if (hipMalloc((void **)&h->d_pad, h->pad_bytes) != hipSuccess) { mi355_xengine_destroy(h); return MI355_ERR_NOMEM; }
     }
+    mi355_log(ctx, MI355_LOG_INFO, "clXEngine: %d inputs x %d pol, %d channels, %d frames per integration, %s input: %zu input bytes, %zu output items, %zu workspace bytes",
+              g.N, npol, g.Fout, g.T, data_type == MI355_DTYPE_COMPLEX ? "complex" : data_type == MI355_DTYPE_BYTE ? "IChar" : "packed 4-bit",
+              h->in_bytes, h->out_items, h->tile_bytes);
     *out = h;
     return MI355_OK;
 }

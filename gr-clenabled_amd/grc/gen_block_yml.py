@@ -64,13 +64,13 @@ def mathconst(block, label, op, typed=True, doc=""):
                 callbacks=["set_k(${const})"] if typed else None, doc=doc)
 
 
-def design_filter(block, label, design, extra_params, doc, win_raw=False):
+def design_filter(block, label, design, extra_params, doc, win_raw=False, bid=None):
     """The five filter-design front-ends: all construct clenabled.clFilter with gnuradio firdes taps."""
     call = "firdes.%s(%s)" % (design[0], ", ".join("${%s}" % a for a in design[1]))
     make = two_branch("clenabled.clFilter(%s,${decimation},%s,1,${setDebug},${use_time})" % (dev_args(True), call),
                       "clenabled.clFilter(%s,${decimation},%s,1,${setDebug},${use_time})" % (dev_args(False), call))
     imports = "import clenabled\nfrom gnuradio.filter import firdes" + ("\nfrom gnuradio.filter import window" if win_raw else "")
-    return dict(id="clenabled_" + block, label=label, params=DEV + [MODE] + extra_params + [DEBUG],
+    return dict(id=bid or "clenabled_" + block, file="clenabled_" + block, label=label, params=DEV + [MODE] + extra_params + [DEBUG],
                 inputs=[dict(domain="stream", dtype="complex")], outputs=[dict(domain="stream", dtype="complex")], imports=imports, make=make,
                 callbacks=["set_taps2(%s)" % call], doc=doc)
 
@@ -109,7 +109,7 @@ BLOCKS.append(dict(
     doc="Vector FFT on the GPU: window multiply, transform and fftshift in one kernel (any power of two up to 1048576; other "
         "lengths up to 16384 by chirp-z).  One item = one vector of `Points` samples."))
 BLOCKS.append(dict(
-    id="clenabled_clFIRTapFilter", label="MI355X FIR filter (given taps)",
+    id="clenabled_cltapfirfilter", file="clenabled_clFIRTapFilter", label="MI355X FIR filter (given taps)",
     params=DEV + [dict(id="taps", label="Taps", dtype="real_vector"), MODE, INT("decimation", "Decimation", "1"),
                   REAL("samp_rate", "Sample rate", "samp_rate"), DEBUG],
     inputs=[dict(domain="stream", dtype="complex")], outputs=[dict(domain="stream", dtype="complex")],
@@ -137,9 +137,9 @@ BLOCKS.append(design_filter("clBandRejectFilter", "MI355X band-reject filter",
 BLOCKS.append(design_filter("clRootRaisedCosine", "MI355X root-raised-cosine filter",
                             ("root_raised_cosine", ["gain", "samp_rate", "sym_rate", "alpha", "ntaps"]),
                             COMMON_DESIGN + [REAL("sym_rate", "Symbol rate", "1.0"), REAL("alpha", "Roll-off", "0.35"), INT("ntaps", "Taps", "11*samp_rate")],
-                            "firdes.root_raised_cosine taps into the GPU filter."))
+                            "firdes.root_raised_cosine taps into the GPU filter.", bid="clenabled_clRootRaisedCosineFilter"))
 BLOCKS.append(dict(
-    id="clenabled_clComplexFilter", label="MI355X FIR filter (complex taps)",
+    id="clenabled_clcomplexfilter", file="clenabled_clComplexFilter", label="MI355X FIR filter (complex taps)",
     params=DEV + [dict(id="taps", label="Taps", dtype="complex_vector"), INT("decimation", "Decimation", "1"),
                   REAL("samp_rate", "Sample rate", "samp_rate"), DEBUG],
     inputs=[dict(domain="stream", dtype="complex")], outputs=[dict(domain="stream", dtype="complex")],

@@ -10,6 +10,8 @@
 #ifdef MI355_WITH_GNURADIO
 #include <gnuradio/block.h>
 #include <gnuradio/io_signature.h>
+#include <gnuradio/logger.h>
+#include <gnuradio/sptr_magic.h>
 #include <gnuradio/sync_block.h>
 #include <gnuradio/sync_decimator.h>
 #include <pmt/pmt.h>
@@ -101,9 +103,12 @@ public:
         d_messages.pop_front();
         return true;
     }
-    // stream tags: the first tag value of every input in the current window
+    // stream tags: the first tag value of every input in the current window (set by the caller acting as scheduler)
     void set_first_tags(const std::vector<uint64_t> &t) { d_first_tags = t; }
-    bool first_tag(int which_input, uint64_t &value) const
+
+protected:
+    // reading tags is a protected service of gr::block (get_tags_in_window): only the block itself may ask
+    bool shim_first_tag(int which_input, uint64_t &value) const
     {
         if ((size_t)which_input >= d_first_tags.size()) return false;
         value = d_first_tags[which_input];
@@ -154,15 +159,9 @@ inline void publish_u64(gr::basic_block *b, const char *port, const char *key, u
 {
     b->message_port_pub(pmt::mp(port), pmt::cons(pmt::intern(key), pmt::from_uint64(value)));
 }
-// first tag of an input in the current window (get_tags_in_window(tags, input, 0, 1), :1173-1175)
-inline bool first_tag(gr::block *b, int input, uint64_t &value)
-{
-    std::vector<gr::tag_t> tags;
-    b->get_tags_in_window(tags, input, 0, 1);
-    if (tags.empty()) return false;
-    value = pmt::to_uint64(tags[0].value);
-    return true;
-}
+// (reading the first tag of an input, get_tags_in_window, is protected in gr::block: a member of clXEngine_impl does it)
+// blocks are handed to the scheduler through GNU Radio's initial-sptr registry, as every make() of the reference does
+template <class T> std::shared_ptr<T> adopt(T *p) { return gnuradio::get_initial_sptr(p); }
 inline void no_tag_propagation(gr::block *b) { b->set_tag_propagation_policy(gr::block::TPP_DONT); }
 #else
 inline void register_out(gr::basic_block_shim *b, const char *port) { b->message_port_register_out(port); }
@@ -182,7 +181,7 @@ inline void publish_u64(gr::basic_block_shim *b, const char *port, const char *k
     m.u64 = value;
     b->shim_publish(std::move(m));
 }
-inline bool first_tag(gr::basic_block_shim *b, int input, uint64_t &value) { return b->first_tag(input, value); }
+template <class T> std::shared_ptr<T> adopt(T *p) { return std::shared_ptr<T>(p); }
 inline void no_tag_propagation(gr::basic_block_shim *) {}
 #endif
 }  // namespace sched

@@ -12,6 +12,28 @@ namespace gr {
 namespace clenabled {
 
 namespace {
+// The library's diagnostics (mi355_set_log_callback) go where the reference's go: GNU Radio's logger (GR_LOG_INFO / GR_LOG_ERROR,
+// lib/clXEngine_impl.cc:107,137,257).  Stand-alone build: stderr, one "clenabled :level: text" line each, like the logger's format.
+void log_sink(void *, int level, const char *message)
+{
+#ifdef MI355_WITH_GNURADIO
+    // (configure_default_loggers + the GR_LOG_* macros exist in 3.9's log4cpp logger and in 3.10's spdlog one alike)
+    static gr::logger_ptr logger, debug_logger;
+    static const bool configured = gr::configure_default_loggers(logger, debug_logger, "clenabled");
+    (void)configured;
+    const std::string text(message);
+    switch (level) {
+    case MI355_LOG_DEBUG: GR_LOG_DEBUG(debug_logger, text); break;
+    case MI355_LOG_INFO: GR_LOG_INFO(logger, text); break;
+    case MI355_LOG_WARN: GR_LOG_WARN(logger, text); break;
+    default: GR_LOG_ERROR(logger, text); break;
+    }
+#else
+    static const char *const names[] = {"debug", "info", "warning", "error"};
+    fprintf(stderr, "clenabled :%s: %s\n", names[level < 0 ? 0 : level > 3 ? 3 : level], message);
+#endif
+}
+
 // stands where "public GRCLBase" was (include/clenabled/GRCLBase.h:77-141)
 class MI355Base {
 protected:
@@ -19,6 +41,8 @@ protected:
     bool debugMode;
     MI355Base(int openCLPlatformType, int devSelector, int platformId, int devId, bool setDebug) : debugMode(setDebug)
     {
+        static std::once_flag once;
+        std::call_once(once, [] { mi355_set_log_callback(&log_sink, nullptr); });
         // the reference prints and exit(0)s on failure (lib/GRCLBase.cpp:239-257); throw instead
         chk(mi355_ctx_create(openCLPlatformType, devSelector, platformId, devId, setDebug ? 1 : 0, &d_ctx), "mi355_ctx_create");
     }
@@ -345,6 +369,20 @@ public:
     // lib/clXEngine_impl.cc:1152-1232.  With the tag synchroniser on, nothing is correlated until the first tag of every input
     // carries the same timestamp: inputs that are behind are advanced by (highest - own) items (timestamps step with the items),
     // capped at noutput_items, and 0 is returned; once aligned, the timestamp is published on "sync" and normal work begins.
+    // first tag of an input in the current window: get_tags_in_window(tags, input, 0, 1), lib/clXEngine_impl.cc:1173-1175
+    // (a protected member of gr::block, hence a member here)
+    bool first_tag(int input, uint64_t &value)
+    {
+#ifdef MI355_WITH_GNURADIO
+        std::vector<gr::tag_t> tags;
+        this->get_tags_in_window(tags, (unsigned)input, 0, 1);
+        if (tags.empty()) return false;
+        value = pmt::to_uint64(tags[0].value);
+        return true;
+#else
+        return shim_first_tag(input, value);
+#endif
+    }
     int general_work(int noutput_items, gr_vector_int &, gr_vector_const_void_star &in, gr_vector_void_star &out) override
     {
         if (d_use_synchronizer && !d_synchronized) {
@@ -352,7 +390,7 @@ public:
             bool aligned = true;
             for (int i = 0; i < d_num_inputs; i++) {
                 uint64_t t = 0;
-                if (!sched::first_tag(this, i, t)) {  // no tag in the window yet: cannot decide, consume nothing
+                if (!first_tag(i, t)) {  // no tag in the window yet: cannot decide, consume nothing
                     return 0;
                 }
                 if (i == 0) first = t;
@@ -372,6 +410,7 @@ public:
             d_sync_tag = highest;
             if (d_fp && !d_wrote_json) write_json((long)highest);
             sched::publish_u64(this, "sync", "synctimestamp", highest);  // :1203-1204
+            log_sink(nullptr, MI355_LOG_INFO, ("Synchronized on timestamp " + std::to_string(highest)).c_str());  // :1206-1208
         }
         const int done = work_test(noutput_items, in, out);
         consume_each(done);  // :1230
@@ -495,7 +534,7 @@ public:
 
 #define MI355_ELEM_MAKE(NAME, KIND, NIN, NOUT, P0, P1, ...)                                                              \
     {                                                                                                                     \
-        return sptr(new elem_impl_t<NAME>(#NAME, KIND, NIN, NOUT, P0, P1, openCLPlatformType, devSelector, platformId, devId, \
+        return sched::adopt(new elem_impl_t<NAME>(#NAME, KIND, NIN, NOUT, P0, P1, openCLPlatformType, devSelector, platformId, devId, \
                                           setDebug == 1));                                                                \
     }
 clLog::sptr clLog::make(int openCLPlatformType, int devSelector, int platformId, int devId, float nValue, float kValue, int setDebug)
@@ -518,40 +557,40 @@ MI355_ELEM_MAKE(clQuadratureDemod, MI355_ELEM_QUADDEMOD, 1, 1, gain, 0.f)
 clxcorrelate_fft_vcf::sptr clxcorrelate_fft_vcf::make(int fftSize, int num_inputs, int openCLPlatformType, int devSelector,
                                                       int platformId, int devId, int input_type)
 {
-    return sptr(new clxcorrelate_fft_vcf_impl(fftSize, num_inputs, openCLPlatformType, devSelector, platformId, devId, input_type));
+    return sched::adopt(new clxcorrelate_fft_vcf_impl(fftSize, num_inputs, openCLPlatformType, devSelector, platformId, devId, input_type));
 }
 
 clMathOp::sptr clMathOp::make(int idataType, int openCLPlatformType, int devSelector, int platformId, int devId, int operatorType,
                               int setDebug)
 {
-    return sptr(new clMathOp_impl(idataType, openCLPlatformType, devSelector, platformId, devId, operatorType, setDebug == 1));
+    return sched::adopt(new clMathOp_impl(idataType, openCLPlatformType, devSelector, platformId, devId, operatorType, setDebug == 1));
 }
 clMathConst::sptr clMathConst::make(int idataType, int openCLPlatformType, int devSelector, int platformId, int devId, float fValue,
                                     int operatorType, int setDebug)
 {
-    return sptr(new clMathConst_impl(idataType, openCLPlatformType, devSelector, platformId, devId, fValue, operatorType, setDebug == 1));
+    return sched::adopt(new clMathConst_impl(idataType, openCLPlatformType, devSelector, platformId, devId, fValue, operatorType, setDebug == 1));
 }
 clFFT::sptr clFFT::make(int fftSize, int clFFTDir, const std::vector<float> &window, int idataType, int openCLPlatformType,
                         int devSelector, int platformId, int devId, int setDebug, int num_streams, bool shift)
 {
-    return sptr(new clFFT_impl(fftSize, clFFTDir, window, idataType, openCLPlatformType, devSelector, platformId, devId, setDebug == 1,
+    return sched::adopt(new clFFT_impl(fftSize, clFFTDir, window, idataType, openCLPlatformType, devSelector, platformId, devId, setDebug == 1,
                                num_streams, shift));
 }
 clFilter::sptr clFilter::make(int openclPlatform, int devSelector, int platformId, int devId, int decimation,
                               const std::vector<float> &taps, int, int setDebug, bool use_time)
 {
-    return sptr(new clFilter_impl(openclPlatform, devSelector, platformId, devId, decimation, taps, setDebug == 1, use_time));
+    return sched::adopt(new clFilter_impl(openclPlatform, devSelector, platformId, devId, decimation, taps, setDebug == 1, use_time));
 }
 clComplexFilter::sptr clComplexFilter::make(int openclPlatform, int devSelector, int platformId, int devId, int decimation,
                                             const std::vector<gr_complex> &taps, int, int setDebug)
 {
-    return sptr(new clComplexFilter_impl(openclPlatform, devSelector, platformId, devId, decimation, taps, setDebug == 1));
+    return sched::adopt(new clComplexFilter_impl(openclPlatform, devSelector, platformId, devId, decimation, taps, setDebug == 1));
 }
 clPolyphaseChannelizer::sptr clPolyphaseChannelizer::make(int openCLPlatformType, int devSelector, int platformId, int devId,
                                                           const std::vector<float> &taps, int buf_items, int num_channels,
                                                           int ninputs_per_iter, const std::vector<int> &ch_map, int setDebug)
 {
-    return sptr(new clPolyphaseChannelizer_impl(openCLPlatformType, devSelector, platformId, devId, taps, buf_items, num_channels,
+    return sched::adopt(new clPolyphaseChannelizer_impl(openCLPlatformType, devSelector, platformId, devId, taps, buf_items, num_channels,
                                                 ninputs_per_iter, ch_map, setDebug == 1));
 }
 clXEngine::sptr clXEngine::make(int openCLPlatformType, int devSelector, int platformId, int devId, bool setDebug, int data_type,
@@ -562,7 +601,7 @@ clXEngine::sptr clXEngine::make(int openCLPlatformType, int devSelector, int pla
                                 std::string object_name, double starting_chan_center_freq, double channel_width, bool disable_output,
                                 int pipeline_integration)
 {
-    return sptr(new clXEngine_impl(openCLPlatformType, devSelector, platformId, devId, setDebug, data_type, polarization, num_inputs,
+    return sched::adopt(new clXEngine_impl(openCLPlatformType, devSelector, platformId, devId, setDebug, data_type, polarization, num_inputs,
                                    first_channel, num_channels, integration, antenna_list, output_file, file_base, rollover_size_mb,
                                    internal_synchronizer, sync_timestamp, object_name, starting_chan_center_freq, channel_width, disable_output,
                                    pipeline_integration));

@@ -15,6 +15,9 @@
 
 #include <clenabled/clenabled.h>
 
+#include <string>
+#include <type_traits>
+
 namespace py = pybind11;
 using namespace gr::clenabled;
 
@@ -29,31 +32,72 @@ using namespace gr::clenabled;
 #endif
 
 namespace {
-// numpy buffers -> the pointer vectors work() takes (stand-alone use and tests; inside GNU Radio the scheduler calls work())
+// numpy buffers -> the pointer vectors work() takes (stand-alone use and tests; inside GNU Radio the scheduler calls work()).
+// The scheduler guarantees buffer sizes; a Python caller does not, so every buffer is checked against the block's own io
+// signature, history and decimation before a pointer reaches work(): C-contiguous, and at least as many bytes as the call reads
+// or writes.
+void need(bool ok, const std::string &what)
+{
+    if (!ok) throw py::value_error(what);
+}
+template <class B> size_t item_size(const B &b, bool input, size_t k)
+{
+    auto sig = input ? b.input_signature() : b.output_signature();
+    return (size_t)sig->sizeof_stream_item((int)k);
+}
 gr_vector_const_void_star in_ptrs(const std::vector<py::array> &a)
 {
     gr_vector_const_void_star v;
-    for (auto &x : a) v.push_back(x.data());
+    for (auto &x : a) {
+        need((x.flags() & py::array::c_style) != 0, "input buffers must be C-contiguous numpy arrays");
+        v.push_back(x.data());
+    }
     return v;
 }
 gr_vector_void_star out_ptrs(std::vector<py::array> &a)
 {
     gr_vector_void_star v;
-    for (auto &x : a) v.push_back(x.mutable_data());
+    for (auto &x : a) {
+        need((x.flags() & py::array::c_style) != 0 && x.writeable(), "output buffers must be writable C-contiguous numpy arrays");
+        v.push_back(x.mutable_data());
+    }
     return v;
+}
+template <class B> unsigned decimation_of(const B &b)
+{
+    if constexpr (std::is_base_of<gr::sync_decimator, B>::value) return b.decimation();
+    else return 1;
 }
 template <class B> int call_work(B &b, int noutput_items, const std::vector<py::array> &in, std::vector<py::array> out)
 {
+    need(noutput_items >= 0, "noutput_items is negative");
     auto i = in_ptrs(in);
     auto o = out_ptrs(out);
+    const size_t items_in = (size_t)noutput_items * decimation_of(b) + (b.history() > 0 ? b.history() - 1 : 0);
+    for (size_t k = 0; k < in.size(); k++)
+        need((size_t)in[k].nbytes() >= items_in * item_size(b, true, k),
+             "input " + std::to_string(k) + " holds fewer than noutput_items * decimation + history - 1 items");
+    for (size_t k = 0; k < out.size(); k++)
+        need((size_t)out[k].nbytes() >= (size_t)noutput_items * item_size(b, false, k),
+             "output " + std::to_string(k) + " holds fewer than noutput_items items");
     return b.work(noutput_items, i, o);
 }
 template <class B> int call_general_work(B &b, int noutput_items, const std::vector<py::array> &in, std::vector<py::array> out)
 {
+    need(noutput_items >= 0, "noutput_items is negative");
     auto i = in_ptrs(in);
     auto o = out_ptrs(out);
-    gr_vector_int n(in.size(), 0);
-    for (size_t k = 0; k < in.size(); k++) n[k] = (int)in[k].size();
+    gr_vector_int n(in.size(), 0), req(in.size(), 0);
+    for (size_t k = 0; k < in.size(); k++) {  // items, not array elements: one item = sizeof_stream_item bytes
+        const size_t isz = item_size(b, true, k);
+        n[k] = isz ? (int)((size_t)in[k].nbytes() / isz) : 0;
+    }
+    b.forecast(noutput_items, req);
+    for (size_t k = 0; k < in.size(); k++)
+        need(n[k] >= req[k], "input " + std::to_string(k) + " holds fewer items than forecast() asks for");
+    for (size_t k = 0; k < out.size(); k++)
+        need((size_t)out[k].nbytes() >= (size_t)noutput_items * item_size(b, false, k),
+             "output " + std::to_string(k) + " holds fewer than noutput_items items");
     return b.general_work(noutput_items, n, i, o);
 }
 }  // namespace
@@ -98,7 +142,7 @@ PYBIND11_MODULE(clenabled_python, m)
 
     py::class_<clFilter DECIM_BASES, std::shared_ptr<clFilter>>(m, "clFilter")
         .def(py::init(&clFilter::make), py::arg("openclPlatform"), py::arg("devSelector"), py::arg("platformId"), py::arg("devId"),
-             py::arg("decimation"), py::arg("taps"), py::arg("nthreads") = 1, py::arg("setDebug") = 0, py::arg("use_time") = true)
+             py::arg("decimation"), py::arg("taps"), py::arg("nthreads") = 1, py::arg("setDebug") = 0, py::arg("use_time") = DEFAULT_USE_TIME_DOMAIN_SETTING)
         .def("set_taps2", &clFilter::set_taps2, py::arg("taps"))
         .def("taps", &clFilter::taps)
         .def("set_nthreads", &clFilter::set_nthreads, py::arg("n"))

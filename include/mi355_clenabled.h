@@ -88,6 +88,17 @@ typedef struct mi355_xcorr_fft mi355_xcorr_fft;
 const char *mi355_strerror(int code);
 const char *mi355_last_error(void);
 const char *mi355_version(void);
+/* Diagnostics sink.  The reference writes through GNU Radio's logger (GR_LOG_INFO / GR_LOG_ERROR, lib/clXEngine_impl.cc:107,
+ * 137,257) and to std::cout when setDebug is on (lib/GRCLBase.cpp:96-120); a C library has neither, so the block layer hands
+ * its logger in here.  Process wide; fn == NULL restores the default (DEBUG/INFO lines of a context created with debug != 0 go
+ * to stderr, errors are only kept for mi355_last_error()).  The callback receives every such line and every error message at
+ * MI355_LOG_ERROR, on the calling thread, with no lock held; `message` is valid only during the call. */
+#define MI355_LOG_DEBUG 0
+#define MI355_LOG_INFO  1
+#define MI355_LOG_WARN  2
+#define MI355_LOG_ERROR 3
+typedef void (*mi355_log_fn)(void *user, int level, const char *message);
+int mi355_set_log_callback(mi355_log_fn fn, void *user);
 /* number of gfx950 devices visible, or a negative error */
 int mi355_device_count(void);
 /* ocl_type 1/2/4 -> HIP device; 3 (CPU) -> MI355_ERR_UNSUPPORTED.

@@ -42,6 +42,43 @@ def test_cpu_device_type_is_refused_not_emulated(pkg):
     assert L.mi355_ctx_create(1, 7, 0, 0, 0, C.byref(ctx)) == -1
 
 
+def test_log_callback_receives_errors_and_can_be_removed(pkg):
+    """mi355_set_log_callback: the sink the block layer hands GNU Radio's logger to (GR_LOG_ERROR of lib/clXEngine_impl.cc:107)."""
+    L = pkg.lib()
+    got = []
+    pkg.set_log_callback(lambda level, msg: got.append((level, msg)))
+    try:
+        ctx = C.c_void_p()
+        assert L.mi355_ctx_create(3, 1, 0, 0, 0, C.byref(ctx)) == -3
+        assert got == [(3, "OCLTYPE_CPU requested: this library has no CPU path")]  # MI355_LOG_ERROR, same text as last_error
+        assert L.mi355_last_error().decode() == got[0][1]
+    finally:
+        pkg.set_log_callback(None)
+    assert L.mi355_ctx_create(3, 1, 0, 0, 0, C.byref(ctx)) == -3
+    assert len(got) == 1
+
+
+@pytest.mark.gpu
+def test_debug_contexts_log_through_the_callback(gpu):
+    """setDebug: what the reference prints to std::cout (lib/GRCLBase.cpp:96-120) arrives as INFO lines; silent without debug."""
+    import numpy as np
+    got = []
+    gpu.set_log_callback(lambda level, msg: got.append((level, msg)))
+    try:
+        gpu.clFFT(4096, gpu.CLFFT_FORWARD, list(np.ones(4096, np.float32)), gpu.DTYPE_COMPLEX, 1, 2, 0, 0, 0, 1, True)
+        assert got == []
+        gpu.clFFT(4096, gpu.CLFFT_FORWARD, list(np.ones(4096, np.float32)), gpu.DTYPE_COMPLEX, 1, 2, 0, 0, 1, 1, True)
+        gpu.clFilter(1, 2, 0, 0, 1, [0.1] * 65, 1, 1, False)
+        gpu.clXEngine(1, 2, 0, 0, True, gpu.DTYPE_BYTE, 1, 8, 1, 0, 16, 32, [])
+    finally:
+        gpu.set_log_callback(None)
+    text = [m for lvl, m in got if lvl == 1]
+    assert any(m.startswith("context on device 0 (gfx950") for m in text)
+    assert any(m.startswith("clFFT: 4096 points, forward") for m in text)
+    assert any(m.startswith("clFilter: 65 real taps") and "transform size 256" in m for m in text)
+    assert any(m.startswith("clXEngine: 8 inputs x 1 pol, 16 channels, 32 frames") for m in text)
+
+
 def test_block_constructor_errors_mirror_reference(pkg):
     # lib/clFFT_impl.cc:74-76 -> runtime_error before any device work
     with pytest.raises(RuntimeError):

@@ -2,7 +2,7 @@
 
 What a saved flowgraph depends on is checked here: block ids, parameter ids (the reference's, SURVEY.md 2.1 row 12 -- frozen
 below), that every ${...} of a template names a declared parameter, and that each `make` template calls the class with a
-positional argument count the declared `make(...)` of host/include/clenabled/clenabled.h (and blocks.py) accepts."""
+positional argument count the declared `make(...)` of host/include/clenabled/<Block>.h (and blocks.py) accepts."""
 import glob
 import inspect
 import os
@@ -14,7 +14,7 @@ import yaml
 from conftest import ROOT
 
 GRC = os.path.join(ROOT, "gr-clenabled_amd", "grc")
-HEADER = os.path.join(ROOT, "gr-clenabled_amd", "host", "include", "clenabled", "clenabled.h")
+HEADERS = os.path.join(ROOT, "gr-clenabled_amd", "host", "include", "clenabled", "cl*.h")  # one public header per block
 
 DEVP = ["openCLPlatform", "devices", "platformId", "deviceId"]
 DESIGN = DEVP + ["use_time", "decimation", "gain", "samp_rate"]
@@ -42,9 +42,22 @@ REFERENCE_IDS = {
     "clMagPhaseToComplex": DEVP + ["setDebug"], "clQuadratureDemod": DEVP + ["setDebug", "gain"],
     "clxcorrelate_fft_vcf": ["input_type", "vec_len", "num_inputs"] + DEVP,
 }
-# block ids that differ from the file stem (the reference's own spelling: a saved flowgraph carries the id)
-BLOCK_ID = {"clSNR": "clenabled_clsnr", "clComplexToMag": "clenabled_complextomag", "clComplexToArg": "clenabled_complextoarg",
-            "clComplexToMagPhase": "clenabled_complextomagphase", "clMagPhaseToComplex": "clenabled_magphasetocomplex"}
+# the block id of every description, frozen from the reference's grc/clenabled_<X>.block.yml line 3 (a saved flowgraph carries
+# the id, not the file name; several of the reference's ids are spelled differently from their file stems)
+BLOCK_ID = {
+    "clFFT": "clenabled_clFFT", "clFIRTapFilter": "clenabled_cltapfirfilter", "clLowPassFilter": "clenabled_clLowPassFilter",
+    "clHighPassFilter": "clenabled_clHighPassFilter", "clBandPassFilter": "clenabled_clBandPassFilter",
+    "clBandRejectFilter": "clenabled_clBandRejectFilter", "clRootRaisedCosine": "clenabled_clRootRaisedCosineFilter",
+    "clComplexFilter": "clenabled_clcomplexfilter", "clAdd": "clenabled_clAdd", "clSubtract": "clenabled_clSubtract",
+    "clMultiply": "clenabled_clMultiply", "clMultiplyConjugate": "clenabled_clMultiplyConjugate",
+    "clComplexConjugate": "clenabled_clComplexConjugate", "clAddConst": "clenabled_clAddConst", "clMultConst": "clenabled_clMultConst",
+    "clPolyphaseChannelizer": "clenabled_clPolyphaseChannelizer", "clXEngine": "clenabled_clXEngine",
+    "clLog10": "clenabled_clLog10", "clSNR": "clenabled_clsnr", "clComplexToMag": "clenabled_complextomag",
+    "clComplexToArg": "clenabled_complextoarg", "clComplexToMagPhase": "clenabled_complextomagphase",
+    "clMagPhaseToComplex": "clenabled_magphasetocomplex", "clQuadratureDemod": "clenabled_clQuadratureDemod",
+    "clxcorrelate_fft_vcf": "clenabled_clxcorrelate_fft_vcf",
+}
+REFERENCE_GRC = "/root/reference/grc"  # present in the build container only; never read by the GPU tests
 
 
 def split_args(s):
@@ -66,20 +79,15 @@ def split_args(s):
 
 
 def header_signatures():
-    """class name -> (required, total) positional parameters of its static make()."""
-    txt = open(HEADER).read()
-    txt = re.sub(r"#define MI355_DECLARE_SYNC_BLOCK(.*\\\n)+.*\n", "", txt)  # the macro's own body is not a class
+    """class name -> (required, total) positional parameters of its static make(), from the per-block public headers."""
     sigs = {}
-    for m in re.finditer(r"class\s+(\w+)\s*:[^{]*\{(.*?)\n\};", txt, re.S):
-        mk = re.search(r"static\s+sptr\s+make\((.*?)\);", m.group(2), re.S)
-        if mk:
-            params = split_args(mk.group(1).replace("\n", " "))
-            sigs[m.group(1)] = (sum("=" not in p for p in params), len(params))
-    for m in re.finditer(r"MI355_DECLARE_SYNC_BLOCK\((\w+),(.*?)\);", txt, re.S):  # the elementwise family is declared through a macro
-        if m.group(1) == "NAME":
-            continue
-        params = split_args(m.group(2).replace("\n", " "))
-        sigs[m.group(1)] = (sum("=" not in p for p in params), len(params))
+    for path in sorted(glob.glob(HEADERS)):
+        txt = open(path).read()
+        for m in re.finditer(r"class\s+(?:CLENABLED_API\s+)?(\w+)\s*:[^{]*\{(.*?)\n\};", txt, re.S):
+            mk = re.search(r"static\s+sptr\s+make\((.*?)\);", m.group(2), re.S)
+            if mk:
+                params = split_args(mk.group(1).replace("\n", " "))
+                sigs[m.group(1)] = (sum("=" not in p for p in params), len(params))
     return sigs
 
 
@@ -100,14 +108,31 @@ FILES = sorted(glob.glob(os.path.join(GRC, "clenabled_*.block.yml")))
 
 def test_every_hot_path_block_has_a_description():
     names = {os.path.basename(f)[len("clenabled_"):-len(".block.yml")] for f in FILES}
-    assert names == set(REFERENCE_IDS)
+    assert names == set(REFERENCE_IDS) == set(BLOCK_ID) and len(BLOCK_ID) == 25
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_GRC), reason="reference tree not present (GPU box)")
+@pytest.mark.parametrize("name", sorted(BLOCK_ID))
+def test_frozen_tables_equal_the_reference_files(name):
+    """The frozen id / parameter tables above are what the reference's own block descriptions say (same file names)."""
+    ref = yaml.safe_load(open(os.path.join(REFERENCE_GRC, "clenabled_%s.block.yml" % name)))
+    assert ref["id"] == BLOCK_ID[name]
+    ref_params = [p["id"] for p in ref.get("parameters", [])]
+    assert sorted(ref_params) == sorted(REFERENCE_IDS[name]), (ref_params, REFERENCE_IDS[name])
+    ours = yaml.safe_load(open(os.path.join(GRC, "clenabled_%s.block.yml" % name)))
+    assert ours["id"] == ref["id"]
+    # port layout a saved connection depends on: number of declared ports per domain, their dtypes and multiplicities
+    for side in ("inputs", "outputs"):
+        r, o = ref.get(side) or [], ours.get(side) or []
+        assert [(x.get("domain"), str(x.get("dtype", "")).replace(" ", "")) for x in r] == \
+               [(x.get("domain"), str(x.get("dtype", "")).replace(" ", "")) for x in o], side
 
 
 @pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
 def test_block_yaml_contract(path, pkg):
     name = os.path.basename(path)[len("clenabled_"):-len(".block.yml")]
     d = yaml.safe_load(open(path))
-    assert d["id"] == BLOCK_ID.get(name, "clenabled_" + name) and d["file_format"] == 1
+    assert d["id"] == BLOCK_ID[name] and d["file_format"] == 1
     ids = [p["id"] for p in d["parameters"]]
     assert len(ids) == len(set(ids))
     missing = [i for i in REFERENCE_IDS[name] if i not in ids]

@@ -133,3 +133,36 @@ def test_widened_blocks_built_the_way_grc_builds_them(gpu, oracle):
     ref = oracle.xcorr_fft(N, 2, xs, use_f64=True)
     for y, r in zip(ys, ref):
         assert np.abs(y - np.asarray(r, np.float32).reshape(-1)).max() <= 2e-5 * np.abs(r).max()
+
+
+def test_clfilter_use_time_defaults_to_the_reference_value():
+    """include/clenabled/clFilter.h:32,53 / python/bindings/clFilter_python.cc:48: use_time = DEFAULT_USE_TIME_DOMAIN_SETTING = false."""
+    m = _mod()
+    assert "use_time: bool = False" in m.clFilter.__init__.__doc__
+
+
+@pytest.mark.gpu
+def test_work_refuses_buffers_smaller_than_the_call(gpu):
+    """The scheduler guarantees buffer sizes; a Python caller does not: undersized, strided or read-only buffers raise before any
+    pointer reaches work()."""
+    m = _mod()
+    a, b, c = (np.zeros(8192, np.complex64) for _ in range(3))
+    blk = m.clMathOp(1, 1, 2, 0, 0, 1, 0)
+    with pytest.raises(ValueError):
+        blk.work(8192, [a, b[:100]], [c])
+    with pytest.raises(ValueError):
+        blk.work(8192, [a, b], [c[:8000]])
+    with pytest.raises(ValueError):
+        blk.work(4096, [a[::2], b], [c])  # strided view
+    ro = np.zeros(8192, np.complex64)
+    ro.setflags(write=False)
+    with pytest.raises(ValueError):
+        blk.work(8192, [a, b], [ro])
+    f = m.clFilter(1, 2, 0, 0, 2, [0.1] * 65, 1, 0)  # decimation 2, history 65 -> 4096 outputs need 8192 + 64 inputs
+    x, y = np.zeros(8192 + 64, np.complex64), np.zeros(4096, np.complex64)
+    assert f.work(4096, [x], [y]) == 4096
+    with pytest.raises(ValueError):
+        f.work(4096, [x[:8192]], [y])
+    p = m.clPolyphaseChannelizer(1, 2, 0, 0, [0.1] * 48, 512, 8, 8, list(range(8)))
+    with pytest.raises(ValueError):
+        p.general_work(512, [np.zeros(512, np.complex64)], [np.zeros(512, np.complex64)])  # forecast() asks for 512 + 40
