@@ -23,6 +23,7 @@
 // Complex-float input keeps fp32 arithmetic (register-tiled VALU kernel, 8x8 station blocks).
 #include <cmath>
 #include <cstdlib>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -379,6 +380,284 @@ __global__ __launch_bounds__(WAVES * 64) void k_xe_corr_lds(const unsigned char 
             if (accumulate) { v.x += out[o].x; v.y += out[o].y; }
             out[o] = v;
         }
+    }
+}
+
+// (2c) Large arrays (129 .. 256 rows: 9 .. 16 row tiles, padded to an even count NT).  One PERSISTENT workgroup per CU walks a contiguous
+// run of channels; a channel's whole lower triangle is accumulated in the workgroup's registers in ONE pass over its K blocks (time
+// is not split, nothing is re-read):
+//   * the K-block stream of a channel run is one contiguous byte range of the tile workspace ([chan][kblock][plane][rowtile][1 KiB]):
+//     it is pulled global -> LDS by DMA (global_load_lds_dwordx4, one instruction = one 1 KiB tile, no staging registers) into a
+//     ring of four K blocks, three in flight while one is multiplied; the ring runs straight across channel boundaries, so the
+//     next channel's operands arrive while the finished channel's matrix is scaled and stored;
+//   * NT / 2 waves; wave w owns the tile rows w and NT-1-w of the triangle: (w + 1) + (NT - w) = NT + 1 tile pairs for EVERY wave
+//     (17 at 256 rows), i.e. the matrix-core work is balanced exactly.  Its two row operands stay in registers for the K block,
+//     the column tiles are streamed from LDS two tiles ahead of their use (hand-issued ds_read_b128 with immediate offsets and
+//     explicit lgkmcnt waits: left to the compiler every column tile went through one register quad and each group of MFMAs
+//     waited out an LDS round trip), each feeding 4 or 8 v_mfma_i32_16x16x64_i8;
+//   * two accumulators per pair: re += I_a I_b^T + Q_a Q_b^T, im' += Q_a I_b^T + (~I_a) Q_b^T with ~i = -i - 1 (exact for every int8,
+//     one v_not per row operand and K block), im = im' + sum_t Q_b(t): every wave sums Q over its own two tile rows (v_sad_u8 on
+//     the operand bytes) and the sums are exchanged through LDS when a channel is complete;
+//   * output: 16 lanes x 8 B = one contiguous 128-byte run per accumulator register (tools/ubench/tri_store.hip: this shape writes
+//     the 135 MB of 512 channels x 256 rows in 23 us = 5.9 TB/s, the column-operand-first shape -- 32 contiguous bytes per lane,
+//     rows across lanes -- in 30 us).  The write burst at the end of a channel is what the kernel cannot hide: a CU holds one
+//     channel's accumulators (1088 of its 2048 registers), so every CU stores at the same time.
+// Per channel at 256 rows: 16 K blocks x 32 KiB from HBM against 16 x 136 x 4 MFMAs (2176 cycles per K block and SIMD): the kernel
+// is bound by the tile stream (268 MB at 512 channels) and the matrix store (135 MB), not by the matrix cores.
+__device__ __forceinline__ void sb_dma_tile(const void *gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+// one 16-byte LDS read whose completion the CALLER waits for (s_waitcnt lgkmcnt): the result must not be touched before that
+template <int OFF> __device__ __forceinline__ void sb_lds_read(v4i &dst, unsigned addr)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+
+template <int... Js, class F> __device__ __forceinline__ void sb_unroll(std::integer_sequence<int, Js...>, F &&f)
+{
+    (f(std::integral_constant<int, Js>{}), ...);
+}
+
+struct SbArgs {
+    const unsigned char *tiles;
+    c32 *out;
+    XeGeo g;      // g.NT = even (padded) row-tile count
+    double kd;
+    int accumulate;
+    int chan_per_wg;  // channels of the slab per workgroup (the last workgroups may get fewer / none)
+    int dbg;          // tuning aid (MI355_XE_DBG): 1 = no matrix products, 2 = no output, 4 = no DMA
+};
+
+// Output side.  Lane (r = lane % 16, q = lane / 16) holds, for pair (bi, bj), matrix rows r1 = 16 bi + 4 q + reg and column r2 = 16 bj + r.
+// Element offsets within a channel's block are (row part) + (column part):
+//   one polarisation:  r1 (r1 + 1) / 2            +  r2
+//   two:               4 (s1 (s1 + 1) / 2) + 2 p1  +  4 (r2 / 2) + (r2 & 1)      (row r1 = 2 s1 + p1, column r2 = 2 s2 + p2)
+template <int NPOL> struct SbRow {
+    c32 *ptr[4];   // out + channel block + row part + the lane's column part within a tile, per accumulator register
+    bool live[4];  // r1 < A
+    int s1[4];
+};
+
+template <int NPOL> __device__ __forceinline__ void sb_row_setup(SbRow<NPOL> &row, const SbArgs &a, c32 *chan, int bi, int lane)
+{
+    const int r = lane & 15, q = lane >> 4;
+    const int lanecol = (NPOL == 1) ? r : 4 * (r >> 1) + (r & 1);
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+        const int r1 = bi * kRowTile + 4 * q + reg, s1 = r1 / NPOL, p1 = r1 % NPOL;
+        row.s1[reg] = s1;
+        row.live[reg] = r1 < a.g.A;
+        row.ptr[reg] = chan + ((NPOL == 1) ? r1 * (r1 + 1) / 2 : 4 * (s1 * (s1 + 1) / 2) + 2 * p1) + lanecol;
+    }
+}
+
+template <int NPOL, bool DIAG>
+__device__ __forceinline__ void sb_store_pair(const SbArgs &a, const SbRow<NPOL> &row, int bj, v4i vre, v4i vim, const int *colsum, int lane)
+{
+    const int r2 = bj * kRowTile + (lane & 15);
+    const int cs = colsum[r2];  // sum_t Q of the lane's column (LDS)
+    const bool col_live = r2 < a.g.A;
+    c32 v[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+        // int32 wrap-around can only have happened for re == +2^31 (every sample -128 over 65536 frames)
+        const double dre = (vre[reg] == (int)0x80000000) ? 2147483648.0 : (double)vre[reg];
+        v[reg].x = (float)(dre * a.kd * a.kd);  // the oracle's expression: (double)S * kd * kd, rounded once
+        v[reg].y = (float)((double)(vim[reg] + cs) * a.kd * a.kd);
+    }
+    if (a.dbg & 16) {  // tuning aid: the arithmetic without the stores
+        if (v[0].x == 1.2345e-30f && v[3].y == 5.4321e-30f) *row.ptr[0] = v[1];
+        return;
+    }
+    if constexpr (NPOL == 2) {
+        // Registers (0, 1) and (2, 3) are the two polarisations p1 of one station s1, lanes (r, r ^ 1) the two p2 of one station s2: the
+        // four products of a baseline are 32 contiguous bytes [p1 p2] = 00 01 10 11.  A lane pair swaps one value, then the even lane
+        // holds 00 01 and the odd lane 10 11: one 16-byte store each, and 16 lanes cover 256 contiguous bytes.
+        typedef float v4f_ __attribute__((ext_vector_type(4)));
+        const bool odd = (lane & 1) != 0;
+        if (!a.accumulate) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const c32 mine = odd ? v[2 * h + 1] : v[2 * h], give = odd ? v[2 * h] : v[2 * h + 1];
+                c32 got;
+                got.x = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(give.x), 0xB1, 0xF, 0xF, false));  // quad_perm [1, 0, 3, 2]
+                got.y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(give.y), 0xB1, 0xF, 0xF, false));
+                bool ok = row.live[2 * h] && col_live;
+                if (DIAG) ok = ok && row.s1[2 * h] >= r2 / 2;
+                // even lane: [00 (mine), 01 (from the odd lane)] at the baseline's start; odd lane: [10 (from the even lane), 11 (mine)] 16 bytes on
+                c32 *dst = row.ptr[2 * h] + bj * (kRowTile * 2) - (odd ? 1 : 0) + (odd ? 2 : 0);
+                if (ok) *(v4f_ *)dst = odd ? (v4f_){got.x, got.y, mine.x, mine.y} : (v4f_){mine.x, mine.y, got.x, got.y};
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+        bool ok = row.live[reg] && col_live;
+        if (DIAG) ok = ok && row.s1[reg] >= r2 / NPOL;  // station s1 >= s2 (off the diagonal tiles that holds by construction)
+        c32 *dst = row.ptr[reg] + bj * (kRowTile * NPOL);
+        if (ok) {
+            c32 w = v[reg];
+            if (a.accumulate) { w.x += dst->x; w.y += dst->y; }
+            *dst = w;
+        }
+    }
+}
+
+// the whole K loop of wave W (tile rows W and NT-1-W): the accumulators never leave the registers
+template <int NT, int W, int NPOL>
+__device__ __forceinline__ void sb_wave(const SbArgs &a, unsigned char *lds, int c0, int nblk, int lane)
+{
+    constexpr int WAVES = NT / 2, RING = 4, KBYTES = 2 * NT * kTileBytes, PER = 4;  // DMA instructions per wave and K block: 2 NT / WAVES
+    constexpr int RA = W, RB = NT - 1 - W;  // RB > RA
+    constexpr int QOFF = NT * kTileBytes;   // plane Q of a K block
+    const XeGeo &g = a.g;
+    const unsigned char *stream = a.tiles + (size_t)c0 * g.KB * KBYTES + (size_t)lane * 16;
+    const unsigned lds0 = (unsigned)(size_t)lds;
+    int *colsum = (int *)(lds + RING * KBYTES);  // [NT * 16]: sum_t Q of every matrix row of the channel just completed
+    auto issue = [&](int b) {
+        const unsigned char *src = stream + (size_t)b * KBYTES;
+        const unsigned dst = lds0 + (unsigned)(b & (RING - 1)) * KBYTES;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int tile = W + WAVES * k;
+            if (!(a.dbg & 4)) sb_dma_tile(src + (size_t)tile * kTileBytes, __builtin_amdgcn_readfirstlane(dst + tile * kTileBytes));
+        }
+    };
+    v4i reA[RA + 1], imA[RA + 1], reB[RB + 1], imB[RB + 1];
+    unsigned qsA = 0u, qsB = 0u;
+    auto clear = [&]() {
+        qsA = qsB = 0u;
+#pragma unroll
+        for (int j = 0; j <= RA; j++) reA[j] = imA[j] = (v4i){0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j <= RB; j++) reB[j] = imB[j] = (v4i){0, 0, 0, 0};
+    };
+    clear();
+    for (int b = 0; b < RING - 1 && b < nblk; b++) issue(b);
+    // Stores and loads share vmcnt and may complete out of order with each other, so with stores in flight only vmcnt(0) identifies a
+    // landed K block.  The channel epilogue therefore drains the (old) DMAs FIRST, then issues its stores, and the next RING - 1
+    // iterations need no wait at all (their K blocks are known to be in LDS): the matrix store overlaps three K blocks of products
+    // instead of stalling the workgroup until the device-wide write burst has drained.
+    int landed_ahead = 0;       // K blocks after the current one known to have landed
+    bool stores_pending = false;
+    const unsigned lbase_u = lds0 + (unsigned)lane * 16;
+    for (int b = 0; b < nblk; b++) {
+        if (landed_ahead > 0) {
+            landed_ahead--;
+        } else {
+            if (stores_pending || b + 1 >= nblk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (b + 2 >= nblk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+            stores_pending = false;
+        }
+        __syncthreads();  // K block b has landed for every wave, and every wave is done with block b - 1 (whose slot is refilled now)
+        const unsigned slot = lbase_u + (unsigned)(b & (RING - 1)) * KBYTES;
+        v4i IA, QA, IB, QB, X[3][2];
+        sb_lds_read<RB * kTileBytes>(IB, slot);
+        sb_lds_read<QOFF + RB * kTileBytes>(QB, slot);
+        sb_lds_read<0>(X[0][0], slot);
+        sb_lds_read<QOFF>(X[0][1], slot);
+        sb_lds_read<RA * kTileBytes>(IA, slot);
+        sb_lds_read<QOFF + RA * kTileBytes>(QA, slot);
+        sb_lds_read<kTileBytes>(X[1][0], slot);
+        sb_lds_read<QOFF + kTileBytes>(X[1][1], slot);
+        if (b + RING - 1 < nblk) issue(b + RING - 1);
+        if (a.dbg & 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); continue; }
+        v4i nIA, nIB;
+        sb_unroll(std::make_integer_sequence<int, RB + 1>{}, [&](auto J) {
+            constexpr int j = decltype(J)::value;
+            v4i &Ij = X[j % 3][0], &Qj = X[j % 3][1];
+            // (LDS returns in order: with the reads for tiles j + 1 and j + 2 behind it, tile j has landed at lgkmcnt <= 4)
+            if constexpr (j + 2 <= RB) {
+                sb_lds_read<(j + 2) * kTileBytes>(X[(j + 2) % 3][0], slot);
+                sb_lds_read<QOFF + (j + 2) * kTileBytes>(X[(j + 2) % 3][1], slot);
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(Ij), "+v"(Qj), "+v"(IA), "+v"(QA), "+v"(IB), "+v"(QB)::"memory");
+            } else if constexpr (j + 1 <= RB) {
+                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(Ij), "+v"(Qj), "+v"(IA), "+v"(QA), "+v"(IB), "+v"(QB)::"memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Ij), "+v"(Qj), "+v"(IA), "+v"(QA), "+v"(IB), "+v"(QB)::"memory");
+            }
+            if constexpr (j == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    qsA = __builtin_amdgcn_sad_u8((unsigned)QA[e] ^ 0x80808080u, 0u, qsA);
+                    qsB = __builtin_amdgcn_sad_u8((unsigned)QB[e] ^ 0x80808080u, 0u, qsB);
+                }
+                nIA = (v4i){~IA[0], ~IA[1], ~IA[2], ~IA[3]};
+                nIB = (v4i){~IB[0], ~IB[1], ~IB[2], ~IB[3]};
+            }
+            reB[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(IB, Ij, reB[j], 0, 0, 0);
+            imB[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(QB, Ij, imB[j], 0, 0, 0);
+            if constexpr (j <= RA) {
+                reA[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(IA, Ij, reA[j], 0, 0, 0);
+                imA[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(QA, Ij, imA[j], 0, 0, 0);
+            }
+            reB[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(QB, Qj, reB[j], 0, 0, 0);
+            imB[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(nIB, Qj, imB[j], 0, 0, 0);
+            if constexpr (j <= RA) {
+                reA[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(QA, Qj, reA[j], 0, 0, 0);
+                imA[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(nIA, Qj, imA[j], 0, 0, 0);
+            }
+        });
+        if ((b + 1) % g.KB == 0) {  // the channel is complete
+            const int f = g.f0 + c0 + b / g.KB;
+            // every wave publishes sum_t Q of its two tile rows; lane (r, q) summed 16 of a K block's 64 bytes of row r, each biased by 128
+            {
+                int vA = (int)qsA - 128 * 16 * g.KB, vB = (int)qsB - 128 * 16 * g.KB;
+                vA += __shfl_xor(vA, 16); vA += __shfl_xor(vA, 32);
+                vB += __shfl_xor(vB, 16); vB += __shfl_xor(vB, 32);
+                if (lane < 16) { colsum[RA * 16 + lane] = vA; colsum[RB * 16 + lane] = vB; }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMAs for the next RING - 1 K blocks (issued long ago) have landed
+            landed_ahead = RING - 1;
+            __syncthreads();  // (the next reader-side hazard is a channel away: one buffer is enough)
+            if (f < g.Fout && !(a.dbg & 2)) {
+                c32 *chan = a.out + (size_t)((a.dbg & 8) ? (f & 7) : f) * ((size_t)g.N * (g.N + 1) / 2) * (NPOL * NPOL);
+                SbRow<NPOL> row;
+                sb_row_setup<NPOL>(row, a, chan, RA, lane);
+#pragma unroll
+                for (int j = 0; j < RA; j++) sb_store_pair<NPOL, false>(a, row, j, reA[j], imA[j], colsum, lane);
+                sb_store_pair<NPOL, true>(a, row, RA, reA[RA], imA[RA], colsum, lane);
+                sb_row_setup<NPOL>(row, a, chan, RB, lane);
+#pragma unroll
+                for (int j = 0; j < RB; j++) sb_store_pair<NPOL, false>(a, row, j, reB[j], imB[j], colsum, lane);
+                sb_store_pair<NPOL, true>(a, row, RB, reB[RB], imB[RB], colsum, lane);
+                stores_pending = true;
+            }
+            clear();
+        }
+    }
+}
+
+template <int NT, int NPOL>
+__global__ __launch_bounds__(NT * 32, 2) void k_xe_corr_sb(SbArgs a)
+{
+    static_assert(NT % 2 == 0 && NT >= 10 && NT <= 16, "even row-tile counts 10 .. 16");
+    extern __shared__ __attribute__((aligned(16))) unsigned char sb_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c0 = blockIdx.x * a.chan_per_wg;
+    int c1 = c0 + a.chan_per_wg;
+    if (c1 > a.g.Fs) c1 = a.g.Fs;
+    if (c0 >= c1) return;
+    const int nblk = (c1 - c0) * a.g.KB;
+    switch (wave) {  // one instantiation per wave: its tile rows, hence its accumulator set, are compile-time constants
+    case 0: sb_wave<NT, 0, NPOL>(a, sb_lds, c0, nblk, lane); break;
+    case 1: sb_wave<NT, 1, NPOL>(a, sb_lds, c0, nblk, lane); break;
+    case 2: sb_wave<NT, 2, NPOL>(a, sb_lds, c0, nblk, lane); break;
+    case 3: sb_wave<NT, 3, NPOL>(a, sb_lds, c0, nblk, lane); break;
+    case 4: sb_wave<NT, 4, NPOL>(a, sb_lds, c0, nblk, lane); break;
+    case 5: if constexpr (NT >= 12) sb_wave<NT, 5, NPOL>(a, sb_lds, c0, nblk, lane); break;
+    case 6: if constexpr (NT >= 14) sb_wave<NT, 6, NPOL>(a, sb_lds, c0, nblk, lane); break;
+    default: if constexpr (NT >= 16) sb_wave<NT, 7, NPOL>(a, sb_lds, c0, nblk, lane); break;
     }
 }
 
@@ -916,7 +1195,31 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
 #define CORR_LDS(NTT, WV, PPW)                                                                                               \
     hipLaunchKernelGGL((k_xe_corr_lds<NTT, WV, PPW>), dim3(gs.Fs, (npairs + WV * PPW - 1) / (WV * PPW)), dim3(WV * 64), 0, st,  \
                        (const unsigned char *)tiles, (c32 *)out, gs, npairs, kd, accumulate)
-        if (lds_corr && g.NT == 2) CORR_LDS(2, 4, 1);        //  3 pairs
+        if (g.NT > 8 && g.NT <= 16 && g.NT % 2 == 0 && !getenv("MI355_XE_NO_SB")) {  // 129 .. 256 rows: the row-tile count was padded to an even number at create
+            SbArgs sa;
+            sa.tiles = tiles; sa.out = (c32 *)out; sa.g = gs; sa.kd = kd; sa.accumulate = accumulate;
+            sa.dbg = getenv("MI355_XE_DBG") ? atoi(getenv("MI355_XE_DBG")) : 0;
+            const int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
+            sa.chan_per_wg = (gs.Fs + cus - 1) / cus;
+            const unsigned grid = (unsigned)((gs.Fs + sa.chan_per_wg - 1) / sa.chan_per_wg);
+#define CORR_SB(NTT)                                                                                                          \
+    do {                                                                                                                      \
+        constexpr int lds_bytes = 4 * 2 * NTT * kTileBytes + NTT * 64;                                                                  \
+        if (g.npol == 1) {                                                                                                    \
+            MI355_HIP(hipFuncSetAttribute((const void *)k_xe_corr_sb<NTT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
+            hipLaunchKernelGGL((k_xe_corr_sb<NTT, 1>), dim3(grid), dim3(NTT * 32), lds_bytes, st, sa);                        \
+        } else {                                                                                                              \
+            MI355_HIP(hipFuncSetAttribute((const void *)k_xe_corr_sb<NTT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
+            hipLaunchKernelGGL((k_xe_corr_sb<NTT, 2>), dim3(grid), dim3(NTT * 32), lds_bytes, st, sa);                        \
+        }                                                                                                                     \
+    } while (0)
+            if (g.NT == 16) CORR_SB(16);
+            else if (g.NT == 14) CORR_SB(14);
+            else if (g.NT == 12) CORR_SB(12);
+            else CORR_SB(10);
+#undef CORR_SB
+        }
+        else if (lds_corr && g.NT == 2) CORR_LDS(2, 4, 1);        //  3 pairs
         else if (lds_corr && g.NT == 4) CORR_LDS(4, 4, 3);   // 10 pairs
         else if (lds_corr && g.NT == 6) CORR_LDS(6, 4, 6);   // 21 pairs
         else if (lds_corr && g.NT == 8) CORR_LDS(8, 8, 5);   // 36 pairs: one workgroup per channel
@@ -972,6 +1275,9 @@ extern "C" int mi355_xengine_create(mi355_ctx *ctx, int data_type, int npol, int
     g.N = num_inputs; g.F = num_channels + pad; g.Fout = num_channels; g.npol = npol; g.T = integration;
     h->pad = pad;
     g.A = g.N * npol; g.NT = (g.A + kRowTile - 1) / kRowTile; g.KB = (g.T + kKBlock - 1) / kKBlock;
+    // 129 .. 256 rows of int8 / 4-bit samples go to k_xe_corr_sb, whose waves own two tile rows each: an odd row-tile count gets one
+    // zero tile row (written by the corner turn's grid, or left at the workspace's initial zero by the slow turn)
+    if (data_type != MI355_DTYPE_COMPLEX && g.NT > 8 && g.NT <= 16) g.NT = (g.NT + 1) / 2 * 2;
     g.mode = (data_type == MI355_DTYPE_PACKEDXY) ? 1 : 0;
     const size_t items = (size_t)g.N * g.Fout * npol * g.T;
     h->in_bytes = items * mi355_dtype_size(data_type);  // frame_size_times_integration_bytes, :198

@@ -53,6 +53,44 @@ def test_ichar_bit_exact_vs_oracle(gpu, oracle, N, F, T, npol):
     assert relerr(out, oracle.xengine_ichar(N, F, npol, T, x, exact=False)) <= TOL
 
 
+@pytest.mark.parametrize("N,F,T,npol", [(128, 64, 256, 1), (256, 16, 128, 1), (64, 64, 256, 2),  # 8 and 16 row tiles, whole 128-byte rows
+                                        (130, 64, 128, 1), (200, 64, 64, 1), (96, 32, 192, 2), (81, 32, 100, 2),  # 9 -> 10, 13 -> 14, 12, 11 -> 12 row tiles
+                                        (160, 10, 70, 1), (129, 3, 65, 1),                                        # rows that are not whole lines (slow corner turn)
+                                        (256, 300, 64, 1)])                                                       # more channels than CUs: a run of channels per workgroup
+def test_large_arrays_bit_exact_vs_oracle(gpu, oracle, N, F, T, npol):
+    """More than 64 rows: corner turn + the persistent one-pass correlator (k_xe_corr_sb: a channel's whole triangle in one workgroup's
+    registers, waves own tile rows w and NT-1-w).  Full int8 range; every padded row-tile count; two polarisations; ragged time."""
+    rng = np.random.default_rng(N * 1000 + T + npol)
+    x = rng.integers(-128, 128, size=T * N * F * npol * 2, dtype=np.int64).astype(np.int8)
+    blk = _xe(gpu, gpu.DTYPE_BYTE, npol, N, F, T)
+    out = np.empty(blk.get_output_buffer_size(), np.complex64)
+    blk.xcorrelate(x, out)
+    ref = oracle.xengine_ichar(N, F, npol, T, x, exact=True)
+    assert np.array_equal(out, ref)
+    if (N, F) == (130, 64):  # the accumulate form (pipeline integration) and a second integration through the same workspace
+        x2 = rng.integers(-128, 128, size=x.size, dtype=np.int64).astype(np.int8)
+        blk.xcorrelate(x2, out, accumulate=True)
+        assert np.array_equal(out, oracle.xengine_ichar(N, F, npol, T, x2, exact=True, acc=ref))
+
+
+def test_large_array_extremes_and_packed4(gpu, oracle):
+    """Every sample (-128, -128) at 200 stations: the ~Q / row-sum form of the imaginary part at its limits (re = 2 * 128^2 * T, im = 0);
+    packed 4-bit input at 160 rows (80 stations x 2) through the same correlator."""
+    N, F, T = 200, 64, 4096
+    blk = _xe(gpu, gpu.DTYPE_BYTE, 1, N, F, T)
+    out = np.empty(blk.get_output_buffer_size(), np.complex64)
+    blk.xcorrelate(np.full(T * N * F * 2, -128, np.int8), out)
+    kd = 0.007874015748031496063
+    assert np.array_equal(out, np.full(out.shape, np.float32(2.0 * 128 * 128 * T * kd * kd), np.complex64))
+    N, F, T = 80, 64, 96
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, 256, size=T * N * F * 2, dtype=np.int64).astype(np.uint8)
+    blk = _xe(gpu, gpu.DTYPE_PACKEDXY, 2, N, F, T)
+    out = np.empty(blk.get_output_buffer_size(), np.complex64)
+    blk.xcorrelate(x, out)
+    assert relerr(out, oracle.xengine_packed4(N, F, T, x)) <= TOL
+
+
 @pytest.mark.parametrize("tsplit", ["1", "4", None])
 def test_fused_full_range_extremes(gpu, oracle, monkeypatch, tsplit):
     """Every sample (-128, -128) over the longest integration: re = 2 * 128^2 * 65536 = 2^31 wraps the int32 accumulator of a single

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""X-engine rates for the large geometries (rows > 64) and the per-rank / batched forms; run under tools/prof_kernels.sh for the
+per-kernel split.  usage: xe_large.py [N,F,T,npol ...]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import __graft_entry__ as e  # noqa: E402
+
+pkg = e.load_package()
+ARGS = (1, 2, 0, 0)
+
+
+def ev_time(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e-3 / iters
+
+
+cases = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(96, 1024, 1024, 1), (128, 1024, 1024, 1), (64, 1024, 1024, 2), (256, 512, 1024, 1), (128, 512, 1024, 2)]
+for (Na, F, T, npol) in cases:
+    x = torch.randint(-127, 128, (T * Na * F * npol * 2,), dtype=torch.int8, device="cuda")
+    blk = pkg.clXEngine(*ARGS, False, pkg.DTYPE_BYTE, npol, Na, 1, 0, F, T, [])
+    out = torch.zeros(blk.get_output_buffer_size(), 2, device="cuda")
+    dt = ev_time(lambda: blk.xcorrelate_device(x, out))
+    nb = Na * (Na + 1) // 2
+    alg = x.numel() + out.numel() * 4
+    ops = 8.0 * F * nb * T * npol ** 2
+    print("clXEngine ichar N=%d F=%d T=%d npol=%d: %7.1f us  %6.1f Top/s (%.3f of 5 POPS)  algorithmic %.2f TB/s (%.1f %% of 8 TB/s)" % (
+        Na, F, T, npol, dt * 1e6, ops / dt / 1e12, ops / dt / 5e15, alg / dt / 1e12, alg / dt / 8e10), flush=True)
