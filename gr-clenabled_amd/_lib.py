@@ -105,6 +105,7 @@ def lib():
         "mi355_xengine_xcorrelate": (i, [vp, vp, vp, i]),
         "mi355_xengine_xcorrelate_dev": (i, [vp, vp, vp, i, vp]),
         "mi355_xengine_xcorrelate_grouped_dev": (i, [vp, vp, vp, i, i, vp]),
+        "mi355_xengine_xcorrelate_n_dev": (i, [vp, i, vp, vp, i, i, vp]),
         "mi355_pack3d_dev": (i, [vp, vp, vp, sz, sz, sz, sz, sz, sz, sz, vp]),
         "mi355_xengine_gather": (i, [vp, i, i, pp, vp]),
         "mi355_xengine_submit": (i, [vp, vp, vp]),

@@ -411,6 +411,15 @@ class clXEngine(_Block):
               "mi355_xengine_xcorrelate_dev")
         return self.get_output_buffer_size()
 
+    def xcorrelate_n_device(self, nint, input_matrices, cross_correlations, accumulate=False, stations_per_group=None):
+        """nint integration windows in one launch (the per-integration loop of lib/clXEngine_impl.cc:1234-1299, batched).  input_matrices:
+        nint windows back to back, or with stations_per_group the receive buffer of ONE all-to-all over nint windows,
+        [group][window][t][station in group][chan][pol]; cross_correlations: nint matrices back to back."""
+        check(self._L.mi355_xengine_xcorrelate_n_dev(self._h, int(nint), _dp(input_matrices), _dp(cross_correlations), 1 if accumulate else 0,
+                                                     int(stations_per_group or 0), _torch_stream(self.device)),
+              "mi355_xengine_xcorrelate_n_dev")
+        return nint * self.get_output_buffer_size()
+
     def pack3d_device(self, dst, src, width_bytes, rows, nblocks, src_pitch, src_block_stride, dst_pitch, dst_block_stride):
         """Strided device copy on this block's context (the send-side packing of the corner turn)."""
         check(self._L.mi355_pack3d_dev(self._ctx, _dp(dst), _dp(src), int(width_bytes), int(rows), int(nblocks), int(src_pitch),

@@ -1058,6 +1058,10 @@ struct mi355_xengine {
     int next_submit = 0, next_wait = 0, pending = 0;
     bool acquired = false;  // the next slot's pinned frame buffer is handed out (zero-copy gather)
     unsigned fused_epoch[2] = {0, 0};  // launches of the fused IChar path per tile workspace (slot 0 / the handle's, slot 1)
+    bool flags_stale[2] = {false, false};  // a non-fused launch wrote corner-turn tiles over the workspace: the in-launch reduction's counters are gone
+    // batched form (mi355_xengine_xcorrelate_n_dev): partial sums of nint windows, grown on demand
+    unsigned char *d_batch = nullptr;
+    size_t batch_bytes = 0;
     int pad = 0;            // one zero channel appended on the device (odd channel count of 2-byte samples)
     size_t pad_bytes = 0;
     unsigned char *d_pad = nullptr;
@@ -1158,10 +1162,18 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
     // (xengine_fused.hip); the tile workspace then only holds the int32 partial sums of the time ranges.
     if (g.mode == 0 && (reinterpret_cast<uintptr_t>(in) & 15u) == 0) {
         const XeFusedPlan fp = mi355_xe_fused_plan(g.N, g.F, g.Fout, g.npol, g.T, h->ctx->num_cus);
-        if (fp.ok && (fp.part_bytes == 0 || (tiles && fp.part_bytes <= h->tile_bytes)))
+        if (fp.ok && (fp.part_bytes == 0 || (tiles && fp.part_bytes <= h->tile_bytes))) {
+            const int ws = tiles == h->d_tiles ? 0 : 1;
+            if (h->flags_stale[ws] && fp.part_bytes > fp.flag_offset) {  // counters of the in-launch reduction restart from zero
+                MI355_HIP(hipMemsetAsync(tiles + fp.flag_offset, 0, fp.part_bytes - fp.flag_offset, st));
+                h->fused_epoch[ws] = 0;
+                h->flags_stale[ws] = false;
+            }
             return mi355_xe_fused_launch(fp, in, out, tiles, g.N, g.F, g.Fout, g.T, 0.007874015748031496063, accumulate, st, stations_per_group,
-                                         ++h->fused_epoch[tiles == h->d_tiles ? 0 : 1]);
+                                         ++h->fused_epoch[ws]);
+        }
     }
+    if (tiles) h->flags_stale[tiles == h->d_tiles ? 0 : 1] = true;  // the corner turn below writes over the whole workspace
     if (stations_per_group > 0 && stations_per_group < g.N) {
         mi355_set_error("antenna-group-major input needs the fused IChar path (<= 64 rows, whole 128-byte rows, integration %% 32 == 0)");
         return MI355_ERR_UNSUPPORTED;
@@ -1250,6 +1262,7 @@ extern "C" int mi355_xengine_destroy(mi355_xengine *h)
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     if (h->d_pad) (void)hipFree(h->d_pad);
+    if (h->d_batch) (void)hipFree(h->d_batch);
     delete h;
     return MI355_OK;
 }
@@ -1340,6 +1353,54 @@ extern "C" int mi355_xengine_xcorrelate_grouped_dev(mi355_xengine *h, const void
     MI355_REQUIRE(h->data_type == MI355_DTYPE_BYTE && !h->pad, "group-major input: IChar with an even channel count only");
     MI355_HIP(hipSetDevice(h->ctx->device));
     return launch_xe(h, in_dev, out_dev, accumulate, mi355_pick_stream(h->ctx, stream), h->d_tiles, h->d_pad, stations_per_group);
+}
+
+extern "C" int mi355_xengine_xcorrelate_n_dev(mi355_xengine *h, int nint, const void *in_dev, void *out_dev, int accumulate, int stations_per_group,
+                                              void *stream)
+{
+    MI355_REQUIRE(h && in_dev && out_dev, "NULL argument");
+    MI355_REQUIRE(nint >= 1, "nint must be >= 1");
+    MI355_REQUIRE(stations_per_group == 0 || (stations_per_group >= 1 && h->g.N % stations_per_group == 0),
+                  "stations_per_group must be 0 (reference layout) or divide the number of inputs");
+    MI355_REQUIRE((reinterpret_cast<uintptr_t>(in_dev) & (h->data_type == MI355_DTYPE_COMPLEX ? 7u : 3u)) == 0 &&
+                      (reinterpret_cast<uintptr_t>(out_dev) & 7u) == 0,
+                  "device buffers must be 4-byte (int8 / packed input) or 8-byte (complex input, output) aligned");
+    MI355_HIP(hipSetDevice(h->ctx->device));
+    hipStream_t st = mi355_pick_stream(h->ctx, stream);
+    const XeGeo &g = h->g;
+    const bool grouped = stations_per_group > 0 && stations_per_group < g.N;
+    // one launch for all windows: the fused IChar path (<= 64 rows, whole 128-byte rows, integration % 32 == 0, 16-byte aligned input)
+    if (h->data_type == MI355_DTYPE_BYTE && !h->pad && (reinterpret_cast<uintptr_t>(in_dev) & 15u) == 0) {
+        const XeFusedPlan fp = mi355_xe_fused_plan(g.N, g.F, g.Fout, g.npol, g.T, h->ctx->num_cus, nint);
+        if (fp.ok) {
+            if (fp.part_bytes > h->batch_bytes) {  // (first call at this batch size: the only allocation of the device path)
+                std::lock_guard<std::mutex> lk(h->ctx->lock);
+                MI355_HIP(hipStreamSynchronize(st));
+                if (h->d_batch) MI355_HIP(hipFree(h->d_batch));
+                h->d_batch = nullptr;
+                h->batch_bytes = 0;
+                if (hipMalloc((void **)&h->d_batch, fp.part_bytes) != hipSuccess) {
+                    mi355_set_error("cannot allocate %zu bytes of partial-sum workspace for %d integration windows", fp.part_bytes, nint);
+                    return MI355_ERR_NOMEM;
+                }
+                h->batch_bytes = fp.part_bytes;
+            }
+            return mi355_xe_fused_launch(fp, in_dev, out_dev, h->d_batch, g.N, g.F, g.Fout, g.T, 0.007874015748031496063, accumulate, st,
+                                         stations_per_group, 1, nint);
+        }
+    }
+    if (grouped && nint > 1) {
+        mi355_set_error("group-major input of several windows needs the fused IChar path (<= 64 rows, whole 128-byte rows, integration %% 32 == 0)");
+        return MI355_ERR_UNSUPPORTED;
+    }
+    // every other geometry / sample format: one window after the other through the handle's workspace (stream ordered)
+    const size_t out_bytes = h->out_items * 8;
+    for (int i = 0; i < nint; i++) {
+        const int rc = launch_xe(h, (const char *)in_dev + (size_t)i * h->in_bytes, (char *)out_dev + (size_t)i * out_bytes, accumulate, st, h->d_tiles,
+                                 h->d_pad, grouped ? stations_per_group : 0);
+        if (rc != MI355_OK) return rc;
+    }
+    return MI355_OK;
 }
 
 extern "C" int mi355_xengine_xcorrelate_dev(mi355_xengine *h, const void *in_dev, void *out_dev, int accumulate, void *stream)

@@ -42,6 +42,12 @@ struct FuArgs {
     int compact;       // partial matrices of the diagonal tile pairs as ONE record (re on and below the diagonal, im above it)
     int dbg;  // tuning aid (MI355_XE_DBG): 1 = no compute, 2 = no stores, 4 = no DMA
     double kd;
+    // batched form: nint integration windows per launch, wgs workgroups each
+    int wgs;                       // workgroups per window = units * tsplit
+    int nint_launch;               // windows of this launch
+    size_t in_window, in_group;    // bytes between windows / between antenna groups of the input
+    size_t out_window;             // output elements per window
+    size_t part_window;            // v4i elements of partial sums per window
 };
 
 __device__ __forceinline__ unsigned perm(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
@@ -106,31 +112,42 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // ---- which slice / time range: the 4 workgroups of a 128-byte line on one XCD, same time range
-    int slice, q;
+    // (the batched form adds the integration window to the combination: consecutive workgroups go to the eight XCDs round robin, so the
+    // four workgroups of a 128-byte line must be 8 apart to meet in one L2)
+    int slice, q, win;
     {
         const int b = blockIdx.x;
+        int combo, sector;
         if (a.pinned) {
-            const int xcd = b & 7, within = b >> 3, sector = within & 3, combo = xcd + 8 * (within >> 2);
-            slice = (combo % a.nlines) * 4 + sector;
-            q = combo / a.nlines;
+            const int xcd = b & 7, within = b >> 3;
+            sector = within & 3;
+            combo = xcd + 8 * (within >> 2);
         } else {
-            slice = b % (a.nlines * 4);
-            q = b / (a.nlines * 4);
+            sector = b & 3;
+            combo = b >> 2;
         }
+        slice = (combo % a.nlines) * 4 + sector;
+        const int rest = combo / a.nlines;
+        q = rest % a.tsplit;
+        win = rest / a.tsplit;
+        a.in += (size_t)win * a.in_window;
+        a.out += (size_t)win * a.out_window;
+        a.part += (size_t)win * a.part_window;
     }
     const size_t row_bytes = (size_t)a.nlines * 128;
     const int t_base = q * a.steps * 32;
     const unsigned lds0 = (unsigned)(size_t)lds;
 
     // ---- DMA of one 16-step stage: chunk = (time step, station half) = 32 stations x 32 B, 2 * NSH chunks per wave
-    // station s of time step t sits at ((s / ng) * T * ng + t * ng + s % ng) * row_bytes: the frames of antenna group s / ng
-    // are one contiguous block (what the all-to-all corner turn of shard.py delivers); ng == N is the reference's layout
+    // station s of time step t sits at (s / ng) * in_group + (t * ng + s % ng) * row_bytes: the frames of antenna group s / ng are one
+    // contiguous block (what the all-to-all corner turn of shard.py delivers; in_group = windows * T * ng rows); ng == N is the
+    // reference's layout
     const size_t t_stride = (size_t)a.ng * row_bytes;
     const unsigned char *src_lane[NSH];
 #pragma unroll
     for (int sh = 0; sh < NSH; sh++) {
         const int s = sh * 32 + (lane >> 1);
-        src_lane[sh] = a.in + ((size_t)(s / a.ng) * a.T * a.ng + (size_t)(s % a.ng)) * row_bytes + (size_t)slice * 32 + (lane & 1) * 16;
+        src_lane[sh] = a.in + (size_t)(s / a.ng) * a.in_group + (size_t)(s % a.ng) * row_bytes + (size_t)slice * 32 + (lane & 1) * 16;
     }
     auto issue_stage = [&](int sigma) {
         const int slot = sigma & (kRing - 1), t0 = t_base + sigma * kStageT;
@@ -422,10 +439,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
 // (the default form of the reduction; MI355_XE_INKERNEL_REDUCE=1 selects the tail of k_xe_i8_fused instead)
 template <int NPOL, int TS>  // TS > 0: the number of time ranges at compile time (all loads of an item issued back to back)
 __global__ __launch_bounds__(256) void k_xe_i8_reduce(const v4i *__restrict__ part, c32 *__restrict__ out, int N, int F, int Fout, int NP, int NTT,
-                                                      int tsplit_rt, double kd, int accumulate, int compact, int ipw)
+                                                      int tsplit_rt, double kd, int accumulate, int compact, int ipw, size_t part_window, size_t out_window)
 {
     const int tsplit = TS > 0 ? TS : tsplit_rt;
     const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+    part += (size_t)blockIdx.y * part_window;  // integration window of the batched form
+    out += (size_t)blockIdx.y * out_window;
     // ipw consecutive items per wave, one after the other: the grid is sized so that every wave is resident from the start
     for (int it = 0; it < ipw; it++) {
     size_t item = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * ipw + it;  // (f, p)
@@ -536,21 +555,22 @@ template <int NPOL, int NTT, bool SPLIT> int launch_fused_s(const XeFusedPlan &p
     constexpr int NSH = (NTT * 16 / NPOL > 32) ? 2 : 1;
     constexpr int lds_bytes = kRing * (kStageT * NSH * kChunk + 16);
     MI355_HIP(hipFuncSetAttribute((const void *)k_xe_i8_fused<NPOL, NTT, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    hipLaunchKernelGGL((k_xe_i8_fused<NPOL, NTT, SPLIT>), dim3(p.units * p.tsplit), dim3(kThreads), lds_bytes, st, a);
+    const int nint = a.nint_launch;
+    hipLaunchKernelGGL((k_xe_i8_fused<NPOL, NTT, SPLIT>), dim3((unsigned)(p.units * p.tsplit * nint)), dim3(kThreads), lds_bytes, st, a);
     MI355_HIP(hipGetLastError());
     if (SPLIT && !a.inkernel) {
         const int NP = NTT * (NTT + 1) / 2;
         const size_t items = (size_t)a.Fout * NP;
         int ipw = 1;  // items per wave: as many as it takes for all waves to be resident together (32 per CU)
         if (const char *e = getenv("MI355_XE_REDUCE_IPW")) ipw = atoi(e) > 0 ? atoi(e) : 1;
-        else while (items > (size_t)ipw * 8192 && ipw < 8) ipw++;
+        else while (items * nint > (size_t)ipw * 8192 && ipw < 8) ipw++;
         const unsigned grid = (unsigned)((items + (size_t)4 * ipw - 1) / ((size_t)4 * ipw));
         if (p.tsplit == 4)
-            hipLaunchKernelGGL((k_xe_i8_reduce<NPOL, 4>), dim3(grid), dim3(256), 0, st, (const v4i *)a.part, a.out, a.N, a.F,
-                               a.Fout, NP, NTT, p.tsplit, a.kd, a.accumulate, a.compact, ipw);
+            hipLaunchKernelGGL((k_xe_i8_reduce<NPOL, 4>), dim3(grid, nint), dim3(256), 0, st, (const v4i *)a.part, a.out, a.N, a.F,
+                               a.Fout, NP, NTT, p.tsplit, a.kd, a.accumulate, a.compact, ipw, a.part_window, a.out_window);
         else
-            hipLaunchKernelGGL((k_xe_i8_reduce<NPOL, 0>), dim3(grid), dim3(256), 0, st, (const v4i *)a.part, a.out, a.N, a.F,
-                               a.Fout, NP, NTT, p.tsplit, a.kd, a.accumulate, a.compact, ipw);
+            hipLaunchKernelGGL((k_xe_i8_reduce<NPOL, 0>), dim3(grid, nint), dim3(256), 0, st, (const v4i *)a.part, a.out, a.N, a.F,
+                               a.Fout, NP, NTT, p.tsplit, a.kd, a.accumulate, a.compact, ipw, a.part_window, a.out_window);
         MI355_HIP(hipGetLastError());
     }
     return MI355_OK;
@@ -562,7 +582,7 @@ template <int NPOL, int NTT> int launch_fused(const XeFusedPlan &p, const FuArgs
 
 }  // namespace
 
-XeFusedPlan mi355_xe_fused_plan(int N, int F, int Fout, int npol, int T, int num_cus)
+XeFusedPlan mi355_xe_fused_plan(int N, int F, int Fout, int npol, int T, int num_cus, int nint)
 {
     XeFusedPlan p;
     (void)Fout;
@@ -580,18 +600,19 @@ XeFusedPlan mi355_xe_fused_plan(int N, int F, int Fout, int npol, int T, int num
     else
         // (not below four K blocks per range: 128 / 256 channels x 1024 frames measure 27.4 / 31.3 us with 8 ranges, 28.6 / 33.9 with 16 --
         // the per-rank problem of the 8-GPU sharded form, where two dispatches and the first-load latency dominate)
-        while (p.units * s < cus && s < 16 && T / (32 * s * 2) >= 4) s *= 2;
+        while ((long)p.units * s * (nint > 0 ? nint : 1) < cus && s < 16 && T / (32 * s * 2) >= 4) s *= 2;
     while (s > 1 && (T % (32 * s) != 0)) s /= 2;
     p.tsplit = s;
     const int NP = p.ntt * (p.ntt + 1) / 2;
-    p.flag_offset = s > 1 ? (size_t)s * F * NP * 2 * 1024 : 0;
+    p.part_per_window = s > 1 ? (size_t)s * F * NP * 2 * 1024 : 0;
+    p.flag_offset = p.part_per_window * (nint > 0 ? nint : 1);
     p.part_bytes = s > 1 ? p.flag_offset + (((size_t)p.units * (s + 1) * 4 + 255) & ~(size_t)255) : 0;
     p.ok = true;
     return p;
 }
 
 int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void *part, int N, int F, int Fout, int T, double kd, int accumulate,
-                          hipStream_t st, int stations_per_group, unsigned epoch)
+                          hipStream_t st, int stations_per_group, unsigned epoch, int nint)
 {
     FuArgs a;
     a.in = (const unsigned char *)in;
@@ -602,17 +623,27 @@ int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void 
     // sums do not fit the XCD's L2 (10.5 MB per XCD against 4 MiB), so either way they are written to and read back from the
     // memory side at HBM-like rates (~28 us of the total); the second kernel streams them with every CU, the in-launch tail is
     // kept as an option (MI355_XE_INKERNEL_REDUCE=1) and for the tests.
-    a.inkernel = (getenv("MI355_XE_INKERNEL_REDUCE") && atoi(getenv("MI355_XE_INKERNEL_REDUCE")) != 0) ? 1 : 0;
+    a.inkernel = (nint <= 1 && getenv("MI355_XE_INKERNEL_REDUCE") && atoi(getenv("MI355_XE_INKERNEL_REDUCE")) != 0) ? 1 : 0;
     a.compact = (!a.inkernel && !getenv("MI355_XE_NO_COMPACT")) ? 1 : 0;
     // 24-bit planes: time ranges of at most 256 steps, at least two row tiles (a lone diagonal record has nothing to pair with)
     if (a.compact && p.tsplit > 1 && T / p.tsplit <= 256 && p.ntt >= 2 && !getenv("MI355_XE_NO_PACK24")) a.compact = 2;
     a.out = (c32 *)out;
     a.N = N; a.F = F; a.Fout = Fout; a.T = T;
     a.ng = (stations_per_group > 0 && stations_per_group < N) ? stations_per_group : N;
+    {
+        const size_t row_bytes = (size_t)p.units * 32;
+        a.nint_launch = nint > 0 ? nint : 1;
+        a.wgs = p.units * p.tsplit;
+        // reference layout: [window][t][station]; group-major: [group][window][t][station in group]
+        a.in_window = (size_t)T * a.ng * row_bytes;
+        a.in_group = (size_t)a.nint_launch * T * a.ng * row_bytes;
+        a.out_window = (size_t)Fout * ((size_t)N * (N + 1) / 2) * p.npol * p.npol;
+        a.part_window = p.part_per_window / 16;
+    }
     a.nlines = p.units / 4;
     a.tsplit = p.tsplit;
     a.steps = T / (32 * p.tsplit);
-    a.pinned = ((a.nlines * p.tsplit) % 8 == 0) ? 1 : 0;
+    a.pinned = (((long)a.nlines * p.tsplit * (nint > 0 ? nint : 1)) % 8 == 0) ? 1 : 0;
     a.accumulate = accumulate;
     a.kd = kd;
     const int dbg = getenv("MI355_XE_DBG") ? atoi(getenv("MI355_XE_DBG")) : 0;

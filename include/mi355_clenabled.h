@@ -238,6 +238,15 @@ int mi355_xengine_xcorrelate_dev(mi355_xengine *h, const void *in_dev, void *out
  * integration % 32 == 0), otherwise MI355_ERR_UNSUPPORTED. */
 int mi355_xengine_xcorrelate_grouped_dev(mi355_xengine *h, const void *in_dev, void *out_dev, int accumulate,
                                          int stations_per_group, void *stream);
+/* Batched form: nint integration windows in ONE launch -- what the worker thread of the reference does one window at a time
+ * (the per-integration loop of lib/clXEngine_impl.cc:1234-1299).  in_dev holds nint windows back to back, each in the reference's
+ * frame layout (stations_per_group == 0 or num_inputs), or -- the receive buffer of one all-to-all over nint windows --
+ * [group][window][t][station in group][chan][pol]; out_dev receives nint matrices back to back (accumulate: each += its window).
+ * With few channels per device (the channel slab of one rank of an 8-GPU X-engine) one window cannot fill the device and pays two
+ * dispatches; a batch runs (window x column slice x time range) workgroups, and once nint * slices >= CUs no partial sums at all.
+ * Other sample formats / geometries run the windows one after the other (group-major input of several windows: UNSUPPORTED). */
+int mi355_xengine_xcorrelate_n_dev(mi355_xengine *h, int nint, const void *in_dev, void *out_dev, int accumulate,
+                                   int stations_per_group, void *stream);
 /* Double-buffered asynchronous form of the host path: replaces the reference's pinned double
  * buffers + worker thread (lib/clXEngine_impl.cc:304-382 start(), :1234-1299 runThread()).
  * submit() copies the integration window into a pinned slot and enqueues H2D + kernels + D2H on that

@@ -382,3 +382,48 @@ def test_group_major_input_refused_outside_the_fused_path(gpu):
     out = torch.zeros(blk.get_output_buffer_size(), 2, device="cuda")
     with pytest.raises(gpu.Mi355Error):
         blk.xcorrelate_device(x, out, stations_per_group=4)
+
+
+@pytest.mark.parametrize("N,F,T,npol,nint,W", [(64, 128, 1024, 1, 1, 1), (64, 128, 1024, 1, 3, 1), (64, 128, 1024, 1, 8, 1),   # the per-rank problem of config 5
+                                              (64, 128, 256, 1, 8, 8), (16, 64, 128, 2, 3, 4), (64, 128, 128, 1, 40, 1),     # group-major; enough windows for no time split
+                                              (20, 64, 96, 1, 5, 1), (12, 7, 70, 1, 3, 1), (100, 64, 64, 1, 2, 1)])          # other tile counts; non-fused fallbacks
+def test_batched_integration_windows_bit_exact(gpu, oracle, N, F, T, npol, nint, W):
+    """mi355_xengine_xcorrelate_n_dev: nint integration windows per launch (reference: one window per pass of the worker thread's loop,
+    lib/clXEngine_impl.cc:1234-1299).  Every window bit-exact against the oracle, in the reference layout and in the group-major layout
+    one all-to-all over nint windows delivers; then once more with accumulate."""
+    import torch
+    rng = np.random.default_rng(N * 31 + nint)
+    wins = rng.integers(-128, 128, size=(nint, T, N, F, npol, 2), dtype=np.int64).astype(np.int8)
+    blk = _xe(gpu, gpu.DTYPE_BYTE, npol, N, F, T)
+    per = blk.get_output_buffer_size()
+    ref = np.concatenate([oracle.xengine_ichar(N, F, npol, T, wins[i].reshape(-1), exact=True) for i in range(nint)])
+    out = torch.zeros(nint * per, 2, device="cuda")
+    if W > 1:
+        Ng = N // W  # [window][t][group][station] -> [group][window][t][station in group]
+        x = torch.from_numpy(np.ascontiguousarray(wins.reshape(nint, T, W, Ng, F, npol, 2).transpose(2, 0, 1, 3, 4, 5, 6))).cuda()
+        blk.xcorrelate_n_device(nint, x, out, stations_per_group=Ng)
+    else:
+        x = torch.from_numpy(wins).cuda()
+        blk.xcorrelate_n_device(nint, x, out)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.complex64).reshape(-1)
+    assert np.array_equal(got, ref)
+    if W == 1:
+        blk.xcorrelate_n_device(nint, x, out, accumulate=True)
+        torch.cuda.synchronize()
+        ref2 = np.concatenate([oracle.xengine_ichar(N, F, npol, T, wins[i].reshape(-1), exact=True, acc=ref[i * per:(i + 1) * per].copy()) for i in range(nint)])
+        assert np.array_equal(out.cpu().numpy().view(np.complex64).reshape(-1), ref2)
+    # a single-window call through the same handle afterwards (its own workspace) is unaffected
+    one = torch.zeros(per, 2, device="cuda")
+    blk.xcorrelate_device(torch.from_numpy(wins[nint - 1]).cuda(), one)
+    torch.cuda.synchronize()
+    assert np.array_equal(one.cpu().numpy().view(np.complex64).reshape(-1), ref[(nint - 1) * per:])
+
+
+def test_batched_group_major_refused_outside_the_fused_path(gpu):
+    import torch
+    blk = _xe(gpu, gpu.DTYPE_BYTE, 1, 8, 16, 32)
+    x = torch.zeros(2 * 32 * 8 * 16 * 2, dtype=torch.int8, device="cuda")
+    out = torch.zeros(2 * blk.get_output_buffer_size(), 2, device="cuda")
+    with pytest.raises(gpu.Mi355Error):
+        blk.xcorrelate_n_device(2, x, out, stations_per_group=4)

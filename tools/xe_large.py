@@ -35,3 +35,19 @@ for (Na, F, T, npol) in cases:
     ops = 8.0 * F * nb * T * npol ** 2
     print("clXEngine ichar N=%d F=%d T=%d npol=%d: %7.1f us  %6.1f Top/s (%.3f of 5 POPS)  algorithmic %.2f TB/s (%.1f %% of 8 TB/s)" % (
         Na, F, T, npol, dt * 1e6, ops / dt / 1e12, ops / dt / 5e15, alg / dt / 1e12, alg / dt / 8e10), flush=True)
+
+# per-rank problem of the 8-GPU sharded config 5 (64 antennas x 128 channels x 1024 frames), one window and batched
+if not sys.argv[1:] or os.environ.get("XE_BATCH"):
+    Na, F, T = 64, 128, 1024
+    blk = pkg.clXEngine(*ARGS, False, pkg.DTYPE_BYTE, 1, Na, 1, 0, F, T, [])
+    per = blk.get_output_buffer_size()
+    for nint in (1, 2, 4, 8, 16, 32):
+        x = torch.randint(-127, 128, (nint * T * Na * F * 2,), dtype=torch.int8, device="cuda")
+        out = torch.zeros(nint * per, 2, device="cuda")
+        dt = ev_time(lambda: blk.xcorrelate_n_device(nint, x, out))
+        print("per-rank 64 ant x 128 ch x 1024 t, %2d windows per launch: %7.1f us per launch, %6.2f us per window" % (nint, dt * 1e6, dt * 1e6 / nint), flush=True)
+    blk1 = pkg.clXEngine(*ARGS, False, pkg.DTYPE_BYTE, 1, 64, 1, 0, 1024, 1024, [])
+    x = torch.randint(-127, 128, (1024 * 64 * 1024 * 2,), dtype=torch.int8, device="cuda")
+    out = torch.zeros(blk1.get_output_buffer_size(), 2, device="cuda")
+    dt = ev_time(lambda: blk1.xcorrelate_device(x, out))
+    print("single GPU 64 ant x 1024 ch x 1024 t: %7.1f us" % (dt * 1e6))
