@@ -203,6 +203,30 @@ def cpu_baseline_fft(o, window, budget_s=8.0, budget_all_s=4.0):
          "sample": "%d frames of %d-pt complex FFT (window+shift), oracle fft_block f32, %.1f s" % (reps * probe, FFT_N, dt),
          "all_cores": {"value": round(frames_all * FFT_N / dta / 1e6, 2), "unit": "MSamples/s", "cores": nthr,
                        "sample": "%d threads, %d frames in total, %.1f s (frames split over threads)" % (nthr, frames_all, dta)}}
+    # third column ("if an FFT library is discovered ... an optional third column"): FFTW / VOLK are not in this image;
+    # numpy's pocketfft is -- the same block (window multiply, single-precision transform, half swap) on one thread
+    try:
+        xl = x.reshape(probe, FFT_N)
+        w32 = window.astype(np.float32)
+
+        def lib_run():
+            return np.fft.fftshift(np.fft.fft(xl * w32, axis=1), axes=1)
+
+        yl = lib_run()
+        if yl.dtype == np.complex64 and np.abs(yl.reshape(-1) - y).max() <= 1e-4 * np.abs(y).max():
+            t2 = time.perf_counter()
+            nl = 0
+            while time.perf_counter() - t2 < 2.0:
+                lib_run()
+                nl += 1
+            dl = time.perf_counter() - t2
+            d["library"] = {"value": round(nl * probe * FFT_N / dl / 1e6, 2), "unit": "MSamples/s", "cores": 1, "kind": "library",
+                            "what": "numpy %s pocketfft, complex64: window multiply + fft + fftshift (not the reference's FFTW; checked against the port)" % np.__version__,
+                            "sample": "%d frames, %.1f s" % (nl * probe, dl)}
+        else:
+            d["library"] = {"skipped": "numpy.fft did not keep complex64 (%s)" % yl.dtype}
+    except Exception as exc:  # noqa: BLE001
+        d["library"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     d.update(host)
     return d
 
@@ -249,9 +273,10 @@ def cpu_extras(o, o_taps):
     out["clComplexFilter_fft_65ctaps"] = timed(lambda: o.fir_ccc(ct, a[:m + 64], m), m)                     # fir_filter_ccc (the reference has no FFT mode for complex taps)
     buf = 65536
     out["clPolyphaseChannelizer_64x32_stream"] = timed(lambda: o.pfb(taps2048, buf, 64, 64, list(range(64)), a[:buf + 2048 - 64]), buf)
-    N, F, T = 64, 2, 1024
+    N, F, T = 64, 8, 1024  # 8 of the 1024 channels (channels are independent: the rate per sample is the same); the key says so
     x8 = rng.integers(-127, 128, size=T * N * F * 2, dtype=np.int64).astype(np.int8)
-    out["clXEngine_64ant_1024ch_1024t_ichar"] = timed(lambda: o.xengine_ichar(N, F, 1, T, x8, exact=False), N * F * T)  # kernel text restated
+    out["clXEngine_64ant_1024ch_1024t_ichar"] = {"MSamples_per_s": timed(lambda: o.xengine_ichar(N, F, 1, T, x8, exact=False), N * F * T),  # kernel text restated
+                                                 "sample": "64 antennas x 8 channels x 1024 frames per call (8 of the 1024 channels)"}
     return out
 
 
@@ -504,21 +529,64 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank, out=None):
     r = rate(lambda: xe.xcorrelate_device(x8, vis), N * Fw * T, 2, xe_extra)
     r.pop("hbm_frac", None)
     out["clXEngine_64ant_1024ch_1024t_ichar"] = r
+    t_full = r["us_per_launch"]
+    del xe, x8, vis
+    # The per-rank problem of the 8-GPU antenna-group sharding: after the corner turn a rank correlates 64 antennas x 128
+    # channels.  One window per launch cannot fill the device; the batched entry point (mi355_xengine_xcorrelate_n_dev, what one
+    # all-to-all over `windows` integrations feeds) can.  predicted_8gpu_efficiency = t(1024 channels) / (8 x t(128 channels)).
+    if world == 1:
+        Fr = 128
+        xr = pkg.clXEngine(*args, False, pkg.DTYPE_BYTE, 1, N, 1, 0, Fr, T, [])
+        perw = xr.get_output_buffer_size()
+        row = {"channels": Fr, "antennas": N, "frames": T}
+        for nint in (1, 8, 32):
+            xb = torch.randint(-127, 128, (nint, T, N, Fr, 1, 2), dtype=torch.int8, device="cuda", generator=g)
+            vb = torch.zeros(nint * perw, 2, device="cuda")
+            rr = rate(lambda: xr.xcorrelate_n_device(nint, xb, vb), nint * N * Fr * T, 2)
+            tw = rr["us_per_launch"] / nint
+            row["windows_per_launch_%d" % nint] = {"us_per_launch": rr["us_per_launch"], "us_per_window": round(tw, 2),
+                                                  "predicted_8gpu_efficiency": round(t_full / (8 * tw), 3)}
+            del xb, vb
+        out["clXEngine_perrank_64ant_128ch_1024t_ichar"] = row
+        del xr
+        # Large arrays (more than 64 rows): corner turn + the persistent one-pass correlator k_xe_corr_sb.  Compute-bound by the
+        # algorithm's count (2 x rows operations per input byte), so the int8 matrix-core fraction is the yardstick; the two-kernel
+        # form moves input + tiles written + tiles read + output, which is what bounds it.
+        for (Na, Fa, npa, key) in ((128, 1024, 1, "clXEngine_128ant_1024ch_1024t_ichar"), (64, 1024, 2, "clXEngine_64ant_dualpol_1024ch_1024t_ichar"),
+                                   (256, 512, 1, "clXEngine_256ant_512ch_1024t_ichar")):
+            xl = pkg.clXEngine(*args, False, pkg.DTYPE_BYTE, npa, Na, 1, 0, Fa, T, [])
+            xin = torch.randint(-127, 128, (T, Na, Fa, npa, 2), dtype=torch.int8, device="cuda", generator=g)
+            vl = torch.zeros(xl.get_output_buffer_size(), 2, device="cuda")
+            ops = 8.0 * Fa * (Na * (Na + 1) // 2) * T * npa * npa
+            algb = xin.numel() + vl.numel() * 4
+            moved = 3 * xin.numel() + vl.numel() * 4  # input read, tiles written, tiles read, output written
+            rl = rate(lambda: xl.xcorrelate_device(xin, vl), Na * npa * Fa * T, 2,
+                      lambda dt: {"TOPs": round(ops / dt / 1e12, 1), "mfma_frac_i8_5POPS": round(ops / dt / 5e15, 4),
+                                  "hbm_frac_algorithmic": round(algb / dt / 1e9 / HBM_PEAK_GBS, 4),
+                                  "hbm_frac_bytes_moved": round(moved / dt / 1e9 / HBM_PEAK_GBS, 4)})
+            rl.pop("hbm_frac", None)
+            rl.pop("GBps", None)
+            out[key] = rl
+            del xl, xin, vl
+            torch.cuda.empty_cache()
     return out
 
 
-def sharded_xengine(pkg, dev, steps, world, rank):
+def sharded_xengine(pkg, dev, steps, world, rank, windows=8):
     """BASELINE configs[4] sharded the way SURVEY 8e describes: every rank ingests its antenna group, ONE all-to-all corner
     turn (RCCL over xGMI, gr-clenabled_amd/shard.py) hands every rank its channel slice of all antennas, then the local
-    correlation.  The send blocks are packed by one strided device copy, the receive buffer is read in place by the fused
-    kernel (stations_per_group), and the exchange of integration i+1 runs on a side stream under the correlation of i."""
+    correlation.  An exchange carries `windows` integration windows and the rank correlates them in ONE launch
+    (mi355_xengine_xcorrelate_n_dev): a rank's slice alone (128 channels at 8 GPUs) cannot fill a device.  The send blocks are
+    packed by one strided device copy, the receive buffer is read in place by the fused kernel (stations_per_group), and
+    exchange i+1 runs on a side stream under the correlation of i.  Timed with HIP events on the launch stream; the bare
+    correlation call of the same batch is timed beside it, the difference is what the pipeline costs."""
     import torch
     N, F, T = 64, 1024, 1024
     Fw, Ng = F // world, N // world
     g = torch.Generator(device="cuda").manual_seed(4242 + rank)
     xe = pkg.clXEngine(1, 2, 0, dev, False, pkg.DTYPE_BYTE, 1, N, 1, 0, Fw, T, [])
-    vis = torch.zeros(xe.get_output_buffer_size(), 2, device="cuda")
-    ctn = pkg.shard.XEngineCornerTurn(N, F, T, 1, block=xe)
+    vis = torch.zeros(windows * xe.get_output_buffer_size(), 2, device="cuda")
+    ctn = pkg.shard.XEngineCornerTurn(N, F, T, 1, block=xe, windows=windows)
     loc = [torch.randint(-127, 128, ctn.local_shape(), dtype=torch.int8, device="cuda", generator=g) for _ in range(2)]
 
     def run(k):
@@ -526,21 +594,23 @@ def sharded_xengine(pkg, dev, steps, world, rank):
         for i in range(k):
             nxt = ctn.start(loc[(i + 1) & 1], (i + 1) & 1) if i + 1 < k else None
             recv = ctn.finish(h)
-            xe.xcorrelate_device(recv, vis, stations_per_group=Ng)
+            xe.xcorrelate_n_device(windows, recv, vis, stations_per_group=Ng)
             h = nxt
 
+    nex = max(3, steps // windows)
     run(2)
-    barrier(world)
-    t0 = time.perf_counter()
-    run(steps)
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    barrier(world)
-    wall = max_over_ranks(wall, world)
-    dt = wall / steps
-    return {"us_per_integration": round(dt * 1e6, 1), "total_input_MSamples_per_s": round(N * F * T / dt / 1e6, 1),
-            "integrations": steps, "n_gpus": world, "channels_per_rank": Fw, "antennas_per_rank_ingest": Ng,
-            "alltoall_bytes_sent_per_rank": int(loc[0].numel() * (world - 1) // world),
+    _, ev = time_steps(lambda: run(nex), 1, 0, world)
+    ev = max_over_ranks(ev, world)
+    dt = ev / (nex * windows)
+    # the same batch without the pipeline around it (group-major input already in place)
+    recv = ctn.finish(ctn.start(loc[0], 0))
+    _, evb = time_steps(lambda: xe.xcorrelate_n_device(windows, recv, vis, stations_per_group=Ng), nex, 2, world)
+    bare = max_over_ranks(evb, world) / (nex * windows)
+    return {"us_per_integration": round(dt * 1e6, 2), "us_per_integration_bare_batched_call": round(bare * 1e6, 2),
+            "pipeline_overhead_us_per_integration": round((dt - bare) * 1e6, 2),
+            "total_input_MSamples_per_s": round(N * F * T / dt / 1e6, 1), "integrations": nex * windows, "windows_per_exchange": windows,
+            "n_gpus": world, "channels_per_rank": Fw, "antennas_per_rank_ingest": Ng,
+            "alltoall_bytes_sent_per_rank_per_exchange": int(loc[0].numel() * (world - 1) // world), "timing": "HIP events on the launch stream",
             "overlap": "exchange(i+1) on a side stream under correlate(i); receive buffer read in place"}
 
 
@@ -552,7 +622,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary per-block lines")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s back-to-back leg")
-    ap.add_argument("--sustain-s", type=float, default=2.0)
+    ap.add_argument("--sustain-s", type=float, default=5.0)
     ap.add_argument("--secondary-timeout", type=int, default=300, help="seconds the secondary legs may take before the line is printed without the rest")
     a = ap.parse_args()
 
@@ -666,7 +736,11 @@ def main():
         if not a.no_extra:
             for k, v in cpu_extras(entry.load_oracle(), taps_pair).items():
                 if k in extras and isinstance(extras[k], dict):
-                    extras[k]["cpu_1core_MSamples_per_s"] = v
+                    if isinstance(v, dict):
+                        extras[k]["cpu_1core_MSamples_per_s"] = v["MSamples_per_s"]
+                        extras[k]["cpu_1core_sample"] = v["sample"]
+                    else:
+                        extras[k]["cpu_1core_MSamples_per_s"] = v
     dog.cancel()
     emit()
     import torch.distributed as dist

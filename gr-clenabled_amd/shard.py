@@ -67,9 +67,14 @@ class XEngineCornerTurn:
     Two buffer pairs and a side stream: start(i+1) packs and exchanges the next integration while the caller's
     stream correlates integration i.  exchange() is the blocking one-shot form (and, for CPU tensors
     under gloo -- the world-size-2 tests -- the packing is the same index arithmetic done with torch views).
+
+    windows > 1: one exchange carries that many integration windows -- local frames [window][T][Ng][F].., receive buffer
+    [group][window][T][Ng][F/W].. -- which clXEngine.xcorrelate_n_device(windows, recv, out, stations_per_group=Ng) correlates
+    in ONE launch: after the corner turn a rank holds only F/W channels, too few to fill a device one window at a time (64
+    antennas x 128 channels: 28 us per window alone, 7 us in a batch of 8), and the all-to-all messages grow from 2 to 16 MiB.
     """
 
-    def __init__(self, num_inputs, num_channels, integration, npol, ncomp=2, group=None, block=None):
+    def __init__(self, num_inputs, num_channels, integration, npol, ncomp=2, group=None, block=None, windows=1):
         import torch.distributed as dist
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -79,19 +84,25 @@ class XEngineCornerTurn:
         self.slices = channel_slices(num_channels, self.world)
         self.Ng = num_inputs // self.world
         self.Fw = num_channels // self.world
+        self.windows = int(windows)
+        if self.windows < 1:
+            raise ValueError("windows must be >= 1")
         self.block = block      # any block of this rank's context (its pack3d_device runs the packing kernel)
         self._bufs = {}
         self._side = None
 
+    def _w(self):
+        return (self.windows,) if self.windows > 1 else ()
+
     def local_shape(self):
-        return (self.T, self.Ng, self.F, self.npol, self.ncomp)
+        return self._w() + (self.T, self.Ng, self.F, self.npol, self.ncomp)
 
     def grouped_shape(self):
-        """Receive buffer: [group][T][Ng][F/W][npol][ncomp]."""
-        return (self.world, self.T, self.Ng, self.Fw, self.npol, self.ncomp)
+        """Receive buffer: [group]([window])[T][Ng][F/W][npol][ncomp]."""
+        return (self.world,) + self._w() + (self.T, self.Ng, self.Fw, self.npol, self.ncomp)
 
     def slab_shape(self):
-        return (self.T, self.N, self.Fw, self.npol, self.ncomp)
+        return self._w() + (self.T, self.N, self.Fw, self.npol, self.ncomp)
 
     # ---- packing -------------------------------------------------------------------------------------------
     def pack(self, local_frames, send):
@@ -101,28 +112,32 @@ class XEngineCornerTurn:
         if x.is_cuda:
             if self.block is None:
                 raise RuntimeError("XEngineCornerTurn on GPU tensors needs block= (a gr-clenabled block of this rank) for the packing kernel")
-            rows = self.T * self.Ng
+            rows = self.windows * self.T * self.Ng
             self.block.pack3d_device(send, x, self.Fw * esz, rows, self.world, self.F * esz, self.Fw * esz, self.Fw * esz, rows * self.Fw * esz)
         else:  # gloo / CPU tensors (tests/test_multi_gpu_cpu.py): same index arithmetic through a strided view
-            send.reshape(self.world, self.T, self.Ng, self.Fw, self.npol, self.ncomp).copy_(
-                x.reshape(self.T, self.Ng, self.world, self.Fw, self.npol, self.ncomp).permute(2, 0, 1, 3, 4, 5))
+            rows = self.windows * self.T * self.Ng  # (window, t, station) rows: the packing does not look inside
+            send.reshape(self.world, rows, self.Fw, self.npol, self.ncomp).copy_(
+                x.reshape(rows, self.world, self.Fw, self.npol, self.ncomp).permute(1, 0, 2, 3, 4))
         return send
 
     def to_slab(self, grouped):
-        """[group][T][Ng][Fw].. -> the reference layout [T][N][Fw].. (a copy; only the parity tests and non-fused geometries need it)."""
-        return grouped.reshape(self.grouped_shape()).permute(1, 0, 2, 3, 4, 5).reshape(self.slab_shape()).contiguous()
+        """[group]([window])[T][Ng][Fw].. -> the reference layout ([window])[T][N][Fw].. (a copy; only the parity tests and non-fused geometries need it)."""
+        g = grouped.reshape(self.world, self.windows, self.T, self.Ng, self.Fw, self.npol, self.ncomp)
+        return g.permute(1, 2, 0, 3, 4, 5, 6).reshape(self.slab_shape()).contiguous()
 
     def _buffers(self, like, slot):
         import torch
         key = (slot, like.device, like.dtype)
         if key not in self._bufs:
-            n = self.T * self.Ng * self.F * self.npol * self.ncomp
+            n = self.windows * self.T * self.Ng * self.F * self.npol * self.ncomp
             self._bufs[key] = (torch.empty(n, dtype=like.dtype, device=like.device), torch.empty(n, dtype=like.dtype, device=like.device))
         return self._bufs[key]
 
     # ---- overlapped form -----------------------------------------------------------------------------------
     def start(self, local_frames, slot=0):
-        """Enqueue pack + all-to-all of one integration window (on the side stream for GPU tensors); returns a handle for finish()."""
+        """Enqueue pack + all-to-all of one exchange (`windows` integration windows) on the side stream for GPU tensors; returns a
+        handle for finish().  A slot's receive buffer is overwritten by the next start() on that slot: the caller's consumer of the
+        previous result must have been enqueued on the current stream before that start() (it waits for the current stream)."""
         import torch
         import torch.distributed as dist
         if self.world == 1:
@@ -133,6 +148,11 @@ class XEngineCornerTurn:
                 self._side = torch.cuda.Stream()
             cur = torch.cuda.current_stream()
             self._side.wait_stream(cur)  # the frames were produced on, and the slot's buffers last read by, the caller's stream
+            # the side stream reads the caller's tensor and the slot's buffers after this call returns: tell the caching allocator,
+            # or a tensor the caller drops right after start() could be handed out again while the packing kernel still reads it
+            local_frames.record_stream(self._side)
+            send.record_stream(self._side)
+            recv.record_stream(self._side)
             with torch.cuda.stream(self._side):
                 self.pack(local_frames, send)
                 work = dist.all_to_all_single(recv, send, group=self.group, async_op=True)

@@ -72,6 +72,20 @@ WORKER = textwrap.dedent('''
         assert np.array_equal(r0[gi], full[:, a0:a1, f0:f1])
         assert np.array_equal(r1[gi], full2[:, a0:a1, f0:f1])
     assert np.array_equal(ct.to_slab(torch.from_numpy(r0)).numpy(), slab)
+    # batched form: ONE exchange carries three integration windows; receive buffer [group][window][T][Ng][F/W].. (what
+    # clXEngine.xcorrelate_n_device(3, recv, out, stations_per_group=Ng) reads in place), every window's slab bit exact
+    wins = np.stack([full, full2, np.ascontiguousarray(np.roll(full, 3, axis=0))])
+    ctb = sh.XEngineCornerTurn(N, F, T, npol, windows=3)
+    assert ctb.local_shape() == (3, T, N // world, F, npol, 2) and ctb.grouped_shape() == (world, 3, T, N // world, F // world, npol, 2)
+    rb = ctb.exchange_grouped(torch.from_numpy(np.ascontiguousarray(wins[:, :, g0:g1]))).numpy().reshape(ctb.grouped_shape())
+    for gi, (a0, a1) in enumerate(ctb.groups):
+        assert np.array_equal(rb[gi], wins[:, :, a0:a1, f0:f1])
+    slabs = ctb.to_slab(torch.from_numpy(rb.copy())).numpy()
+    assert slabs.shape == (3, T, N, F // world, npol, 2) and np.array_equal(slabs, wins[:, :, :, f0:f1])
+    for w in range(3):  # each window of the batch == the rank's channel rows of that window's full result
+        refw = o.xengine_ichar(N, F, npol, T, wins[w].reshape(-1), exact=True).reshape(F, -1)
+        gotw = o.xengine_ichar(N, F // world, npol, T, slabs[w].reshape(-1), exact=True).reshape(F // world, -1)
+        assert np.array_equal(gotw, refw[f0:f1])
     # correlating the slab == the rank's channel rows of the full result
     ref = o.xengine_ichar(N, F, npol, T, full.reshape(-1), exact=True).reshape(F, -1)
     got = o.xengine_ichar(N, F // world, npol, T, slab.reshape(-1), exact=True).reshape(F // world, -1)
