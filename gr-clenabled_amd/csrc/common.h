@@ -102,22 +102,40 @@ hipError_t mi355_direct_sync(hipStream_t st);
 
 // Staging copy of the host path (caller's pageable buffer <-> pinned staging).  One thread moves ~13 GB/s, which bounded the
 // large host calls at 1.8 GS/s (PCIe would carry 3x that): copies of 2 MiB and more are split over a small persistent pool
-// (MI355_COPY_THREADS, default 4 helpers; 0 = plain memcpy).  If the pool is busy with another block's copy the caller just
+// (MI355_COPY_THREADS, default 7 helpers; 0 = the calling thread alone), streaming stores (MI355_COPY_STREAM=0: plain memcpy).  If the pool is busy with another block's copy the caller just
 // copies alone.
 void mi355_copy(void *dst, const void *src, size_t bytes);
+// Staging chunk of a large host call of `total` bytes per buffer: 8 MiB pieces keep both DMA directions busy (40 GB/s each way of
+// the 48 this link carries with unbounded transfers); a call of only a few MiB is cut into >= 6 pieces of >= 1 MiB so that its
+// copy-in, transfers and copy-out overlap at all (one 8 MiB piece ran them strictly one after the other).  MI355_CHUNK_MB overrides.
+static inline size_t mi355_chunk_bytes(size_t total)
+{
+    static const size_t forced = getenv("MI355_CHUNK_MB") ? (size_t)atoi(getenv("MI355_CHUNK_MB")) << 20 : 0;
+    if (forced) return forced;
+    size_t c = total / 6;
+    if (c > ((size_t)8 << 20)) c = (size_t)8 << 20;
+    if (c < ((size_t)1 << 20)) c = (size_t)1 << 20;
+    return c & ~(size_t)4095;
+}
+// two copies as one job of the pool (a staging slot's copy-out and copy-in side by side); either may be empty
+void mi355_copy2(void *dst0, const void *src0, size_t bytes0, void *dst1, const void *src1, size_t bytes1);
 // runs fn(arg, part, parts) for part = 0..parts-1 on the pool (part 0 on the caller); false = pool busy or disabled, nothing was run
 bool mi355_parallel(void (*fn)(void *, int part, int parts), void *arg);
 
 struct HostPipe {
     static constexpr int MAXIN = 2;
+    // Four slots on the context's two streams (slot s runs on stream s & 1).  A slot's cycle is copy-in -> H2D -> kernel -> D2H ->
+    // copy-out; with two slots the host copies of one slot and the DMAs of the other took turns (8 MiB per 0.49 ms = 34 GB/s each
+    // way on a link that carries 48); with four the DMA queues never run dry.
+    static constexpr int kSlots = 4;
     mi355_ctx *ctx = nullptr;
     size_t cap_in[MAXIN] = {0, 0};
     size_t cap_out = 0;
-    void *h_in[2][MAXIN] = {{nullptr, nullptr}, {nullptr, nullptr}};
-    void *d_in[2][MAXIN] = {{nullptr, nullptr}, {nullptr, nullptr}};
-    void *h_out[2] = {nullptr, nullptr};
-    void *d_out[2] = {nullptr, nullptr};
-    hipEvent_t done[2] = {nullptr, nullptr};
+    void *h_in[kSlots][MAXIN] = {};
+    void *d_in[kSlots][MAXIN] = {};
+    void *h_out[kSlots] = {};
+    void *d_out[kSlots] = {};
+    hipEvent_t done[kSlots] = {};
 
     int init(mi355_ctx *c);
     int ensure(int nin, const size_t *in_bytes, size_t out_bytes);

@@ -1220,7 +1220,7 @@ extern "C" int mi355_fft_work(mi355_fft *h, int nvec, const void *const *in_stre
     std::lock_guard<std::mutex> g(h->ctx->lock);
     MI355_HIP(hipSetDevice(h->ctx->device));
     const size_t isz = mi355_dtype_size(h->dtype), in_frame = isz * (size_t)h->n, out_frame = 8 * (size_t)h->n;
-    size_t chunk_frames = (8u << 20) / out_frame;
+    size_t chunk_frames = mi355_chunk_bytes((size_t)nvec * out_frame) / out_frame;
     if (chunk_frames < 1) chunk_frames = 1;
     size_t first = (size_t)nvec < chunk_frames ? (size_t)nvec : chunk_frames;
     size_t inb = first * in_frame;
@@ -1240,26 +1240,25 @@ extern "C" int mi355_fft_work(mi355_fft *h, int nvec, const void *const *in_stre
         }
         return MI355_OK;
     }
-    // all (stream, chunk) pairs run through the two staging slots back to back
+    // all (stream, chunk) pairs run through the staging slots back to back
     size_t nchunks = ((size_t)nvec + chunk_frames - 1) / chunk_frames;
-    char *pend_dst[2] = {nullptr, nullptr};
-    size_t pend_bytes[2] = {0, 0};
+    char *pend_dst[HostPipe::kSlots] = {};
+    size_t pend_bytes[HostPipe::kSlots] = {};
     size_t seq = 0;
+    const bool one_stream = h->m || h->n > 32768 || (h->n == 32768 && h->two_kernel);  // chirp-z / multi-pass sizes share work buffers: one stream
     for (int s_i = 0; s_i < h->nstreams; s_i++) {
         MI355_REQUIRE(in_streams[s_i] && out_streams[s_i], "NULL stream buffer");
         const char *pin = (const char *)in_streams[s_i];
         char *pout = (char *)out_streams[s_i];
         for (size_t ci = 0; ci < nchunks; ci++, seq++) {
-            int s = (int)(seq & 1);
-            hipStream_t st = h->ctx->stream[(h->m || h->n > 32768 || (h->n == 32768 && h->two_kernel)) ? 0 : s];  // chirp-z / two-kernel paths share work buffers: one stream
-            if (pend_bytes[s]) {
-                MI355_HIP(hipEventSynchronize(p.done[s]));
-                mi355_copy(pend_dst[s], p.h_out[s], pend_bytes[s]);
-                pend_bytes[s] = 0;
-            }
+            int s = (int)(seq % HostPipe::kSlots);
+            hipStream_t st = h->ctx->stream[one_stream ? 0 : (s & 1)];
             size_t f0 = ci * chunk_frames;
             size_t nf = (size_t)nvec - f0 < chunk_frames ? (size_t)nvec - f0 : chunk_frames;
-            mi355_copy(p.h_in[s][0], pin + f0 * in_frame, nf * in_frame);
+            if (pend_bytes[s]) MI355_HIP(hipEventSynchronize(p.done[s]));
+            // the slot's previous result out and its next input in, side by side
+            mi355_copy2(pend_dst[s], p.h_out[s], pend_bytes[s], p.h_in[s][0], pin + f0 * in_frame, nf * in_frame);
+            pend_bytes[s] = 0;
             MI355_HIP(hipMemcpyAsync(p.d_in[s][0], p.h_in[s][0], nf * in_frame, hipMemcpyHostToDevice, st));
             rc = launch_handle(h, p.d_in[s][0], p.d_out[s], (int)nf, st);
             if (rc) return rc;
@@ -1269,8 +1268,8 @@ extern "C" int mi355_fft_work(mi355_fft *h, int nvec, const void *const *in_stre
             pend_bytes[s] = nf * out_frame;
         }
     }
-    for (int q = 0; q < 2; q++) {
-        int s = (int)((seq + q) & 1);
+    for (int q = 0; q < HostPipe::kSlots; q++) {
+        int s = (int)((seq + q) % HostPipe::kSlots);  // oldest slot first
         if (pend_bytes[s]) {
             MI355_HIP(hipEventSynchronize(p.done[s]));
             mi355_copy(pend_dst[s], p.h_out[s], pend_bytes[s]);

@@ -1189,7 +1189,7 @@ extern "C" int mi355_filter_work(mi355_filter *h, size_t noutput_items, const vo
     MI355_HIP(hipSetDevice(h->ctx->device));
     // chunks of outputs; each chunk re-sends its ntaps-1 samples of history
     const size_t hist = (size_t)h->ntaps - 1;
-    size_t chunk_out = (1u << 20) / (size_t)h->decim;
+    size_t chunk_out = mi355_chunk_bytes(noutput_items * 8) / 8;
     if (chunk_out < 1) chunk_out = 1;
     size_t first = noutput_items < chunk_out ? noutput_items : chunk_out;
     size_t inb = (first * h->decim + hist) * 8;
@@ -1208,19 +1208,17 @@ extern "C" int mi355_filter_work(mi355_filter *h, size_t noutput_items, const vo
         return MI355_OK;
     }
     size_t nchunks = (noutput_items + chunk_out - 1) / chunk_out;
-    size_t pend_off[2] = {0, 0}, pend_bytes[2] = {0, 0};
+    size_t pend_off[HostPipe::kSlots] = {}, pend_bytes[HostPipe::kSlots] = {};
     for (size_t ci = 0; ci < nchunks; ci++) {
-        int s = (int)(ci & 1);
-        hipStream_t st = h->ctx->stream[s];
-        if (pend_bytes[s]) {
-            MI355_HIP(hipEventSynchronize(p.done[s]));
-            mi355_copy(pout + pend_off[s], p.h_out[s], pend_bytes[s]);
-            pend_bytes[s] = 0;
-        }
+        int s = (int)(ci % HostPipe::kSlots);
+        hipStream_t st = h->ctx->stream[s & 1];
+        if (pend_bytes[s]) MI355_HIP(hipEventSynchronize(p.done[s]));
         size_t o0 = ci * chunk_out;
         size_t no = noutput_items - o0 < chunk_out ? noutput_items - o0 : chunk_out;
         size_t in_bytes = (no * h->decim + hist) * 8;
-        mi355_copy(p.h_in[s][0], pin + o0 * h->decim * 8, in_bytes);
+        // the slot's previous result out and its next input in, side by side
+        mi355_copy2(pout + pend_off[s], p.h_out[s], pend_bytes[s], p.h_in[s][0], pin + o0 * h->decim * 8, in_bytes);
+        pend_bytes[s] = 0;
         MI355_HIP(hipMemcpyAsync(p.d_in[s][0], p.h_in[s][0], in_bytes, hipMemcpyHostToDevice, st));
         rc = launch_filter(h, no, p.d_in[s][0], p.d_out[s], st);
         if (rc) return rc;
@@ -1228,8 +1226,8 @@ extern "C" int mi355_filter_work(mi355_filter *h, size_t noutput_items, const vo
         MI355_HIP(hipEventRecord(p.done[s], st));
         pend_off[s] = o0 * 8; pend_bytes[s] = no * 8;
     }
-    for (int q = 0; q < 2; q++) {
-        int s = (int)((nchunks + q) & 1);
+    for (int q = 0; q < HostPipe::kSlots; q++) {
+        int s = (int)((nchunks + q) % HostPipe::kSlots);  // oldest slot first
         if (pend_bytes[s]) {
             MI355_HIP(hipEventSynchronize(p.done[s]));
             mi355_copy(pout + pend_off[s], p.h_out[s], pend_bytes[s]);

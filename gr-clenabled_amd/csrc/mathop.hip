@@ -300,7 +300,7 @@ extern "C" int mi355_mathop_work(mi355_mathop *h, size_t nitems, const void *a, 
     MI355_REQUIRE(a && b && c, "NULL buffer");
     std::lock_guard<std::mutex> g(h->ctx->lock);
     MI355_HIP(hipSetDevice(h->ctx->device));
-    const size_t chunk_items = kChunkBytes / h->isize;
+    const size_t chunk_items = mi355_chunk_bytes(nitems * h->isize) / h->isize;
     size_t first = nitems < chunk_items ? nitems : chunk_items;
     size_t inb[2] = {first * h->isize, first * h->isize};
     int rc = h->pipe.ensure(2, inb, first * h->isize);
@@ -322,19 +322,16 @@ extern "C" int mi355_mathop_work(mi355_mathop *h, size_t nitems, const void *a, 
         return MI355_OK;
     }
     size_t nchunks = (nitems + chunk_items - 1) / chunk_items;
-    size_t pend_off[2] = {0, 0}, pend_bytes[2] = {0, 0};
+    size_t pend_off[HostPipe::kSlots] = {}, pend_bytes[HostPipe::kSlots] = {};
     for (size_t ci = 0; ci < nchunks; ci++) {
-        int s = (int)(ci & 1);
-        hipStream_t st = h->ctx->stream[s];
-        if (pend_bytes[s]) {  // slot busy with chunk ci-2: drain it
-            MI355_HIP(hipEventSynchronize(p.done[s]));
-            mi355_copy(pc + pend_off[s], p.h_out[s], pend_bytes[s]);
-            pend_bytes[s] = 0;
-        }
+        int s = (int)(ci % HostPipe::kSlots);
+        hipStream_t st = h->ctx->stream[s & 1];
+        if (pend_bytes[s]) MI355_HIP(hipEventSynchronize(p.done[s]));  // slot busy with chunk ci - kSlots: drain it
         size_t off_items = ci * chunk_items;
         size_t n = nitems - off_items < chunk_items ? nitems - off_items : chunk_items;
         size_t bytes = n * h->isize, off = off_items * h->isize;
-        mi355_copy(p.h_in[s][0], pa + off, bytes);
+        mi355_copy2(pc + pend_off[s], p.h_out[s], pend_bytes[s], p.h_in[s][0], pa + off, bytes);  // previous result out, next input in, side by side
+        pend_bytes[s] = 0;
         mi355_copy(p.h_in[s][1], pb + off, bytes);
         MI355_HIP(hipMemcpyAsync(p.d_in[s][0], p.h_in[s][0], bytes, hipMemcpyHostToDevice, st));
         MI355_HIP(hipMemcpyAsync(p.d_in[s][1], p.h_in[s][1], bytes, hipMemcpyHostToDevice, st));
@@ -344,8 +341,8 @@ extern "C" int mi355_mathop_work(mi355_mathop *h, size_t nitems, const void *a, 
         MI355_HIP(hipEventRecord(p.done[s], st));
         pend_off[s] = off; pend_bytes[s] = bytes;
     }
-    for (int q = 0; q < 2; q++) {
-        int s = (int)((nchunks + q) & 1);  // older slot first
+    for (int q = 0; q < HostPipe::kSlots; q++) {
+        int s = (int)((nchunks + q) % HostPipe::kSlots);  // oldest slot first
         if (pend_bytes[s]) {
             MI355_HIP(hipEventSynchronize(p.done[s]));
             mi355_copy(pc + pend_off[s], p.h_out[s], pend_bytes[s]);
@@ -421,7 +418,7 @@ extern "C" int mi355_mathconst_work(mi355_mathconst *h, size_t nitems, const voi
     MI355_HIP(hipSetDevice(h->ctx->device));
     float k;
     { std::lock_guard<std::mutex> gk(h->klock); k = h->k; }
-    const size_t chunk_items = kChunkBytes / h->isize;
+    const size_t chunk_items = mi355_chunk_bytes(nitems * h->isize) / h->isize;
     size_t first = nitems < chunk_items ? nitems : chunk_items;
     size_t inb = first * h->isize;
     int rc = h->pipe.ensure(1, &inb, inb);
@@ -440,19 +437,17 @@ extern "C" int mi355_mathconst_work(mi355_mathconst *h, size_t nitems, const voi
         return MI355_OK;
     }
     size_t nchunks = (nitems + chunk_items - 1) / chunk_items;
-    size_t pend_off[2] = {0, 0}, pend_bytes[2] = {0, 0};
+    size_t pend_off[HostPipe::kSlots] = {}, pend_bytes[HostPipe::kSlots] = {};
     for (size_t ci = 0; ci < nchunks; ci++) {
-        int s = (int)(ci & 1);
-        hipStream_t st = h->ctx->stream[s];
-        if (pend_bytes[s]) {
-            MI355_HIP(hipEventSynchronize(p.done[s]));
-            if (h->op != MI355_OP_EMPTY) mi355_copy(pc + pend_off[s], p.h_out[s], pend_bytes[s]);
-            pend_bytes[s] = 0;
-        }
+        int s = (int)(ci % HostPipe::kSlots);
+        hipStream_t st = h->ctx->stream[s & 1];
+        if (pend_bytes[s]) MI355_HIP(hipEventSynchronize(p.done[s]));
         size_t off_items = ci * chunk_items;
         size_t n = nitems - off_items < chunk_items ? nitems - off_items : chunk_items;
         size_t bytes = n * h->isize, off = off_items * h->isize;
-        mi355_copy(p.h_in[s][0], pa + off, bytes);
+        // previous result out (nothing to deliver for MATHOP_EMPTY), next input in, side by side
+        mi355_copy2(pc + pend_off[s], p.h_out[s], h->op != MI355_OP_EMPTY ? pend_bytes[s] : 0, p.h_in[s][0], pa + off, bytes);
+        pend_bytes[s] = 0;
         MI355_HIP(hipMemcpyAsync(p.d_in[s][0], p.h_in[s][0], bytes, hipMemcpyHostToDevice, st));
         rc = dispatch1(h, n, p.d_in[s][0], p.d_out[s], k, st);
         if (rc) return rc;
@@ -460,8 +455,8 @@ extern "C" int mi355_mathconst_work(mi355_mathconst *h, size_t nitems, const voi
         MI355_HIP(hipEventRecord(p.done[s], st));
         pend_off[s] = off; pend_bytes[s] = bytes;
     }
-    for (int q = 0; q < 2; q++) {
-        int s = (int)((nchunks + q) & 1);
+    for (int q = 0; q < HostPipe::kSlots; q++) {
+        int s = (int)((nchunks + q) % HostPipe::kSlots);  // oldest slot first
         if (pend_bytes[s]) {
             MI355_HIP(hipEventSynchronize(p.done[s]));
             if (h->op != MI355_OP_EMPTY) mi355_copy(pc + pend_off[s], p.h_out[s], pend_bytes[s]);

@@ -260,7 +260,7 @@ int HostPipe::init(mi355_ctx *c)
 {
     ctx = c;
     MI355_HIP(hipSetDevice(c->device));
-    for (int s = 0; s < 2; s++) MI355_HIP(hipEventCreateWithFlags(&done[s], hipEventDisableTiming));
+    for (int s = 0; s < kSlots; s++) MI355_HIP(hipEventCreateWithFlags(&done[s], hipEventDisableTiming));
     return MI355_OK;
 }
 
@@ -269,7 +269,7 @@ int HostPipe::ensure(int nin, const size_t *in_bytes, size_t out_bytes)
     MI355_HIP(hipSetDevice(ctx->device));
     for (int i = 0; i < nin; i++) {
         if (in_bytes[i] <= cap_in[i]) continue;
-        for (int s = 0; s < 2; s++) {
+        for (int s = 0; s < kSlots; s++) {
             if (h_in[s][i]) MI355_HIP(hipHostFree(h_in[s][i]));
             if (d_in[s][i]) MI355_HIP(hipFree(d_in[s][i]));
             h_in[s][i] = d_in[s][i] = nullptr;
@@ -279,7 +279,7 @@ int HostPipe::ensure(int nin, const size_t *in_bytes, size_t out_bytes)
         cap_in[i] = in_bytes[i];
     }
     if (out_bytes > cap_out) {
-        for (int s = 0; s < 2; s++) {
+        for (int s = 0; s < kSlots; s++) {
             if (h_out[s]) MI355_HIP(hipHostFree(h_out[s]));
             if (d_out[s]) MI355_HIP(hipFree(d_out[s]));
             h_out[s] = d_out[s] = nullptr;
@@ -295,7 +295,7 @@ void HostPipe::release()
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    for (int s = 0; s < 2; s++) {
+    for (int s = 0; s < kSlots; s++) {
         for (int i = 0; i < MAXIN; i++) {
             if (h_in[s][i]) (void)hipHostFree(h_in[s][i]);
             if (d_in[s][i]) (void)hipFree(d_in[s][i]);
@@ -313,6 +313,8 @@ void HostPipe::release()
 // ---------------------------------------------------------------------------
 // small persistent helper pool for host-side data movement (see common.h): staging copies and the X-engine frame gather
 // ---------------------------------------------------------------------------
+#include <immintrin.h>
+
 #include <atomic>
 #include <condition_variable>
 #include <cstring>
@@ -374,17 +376,51 @@ JobPool *job_pool()
 {
     static JobPool *pool = [] {
         const char *e = getenv("MI355_COPY_THREADS");
-        const int n = e ? atoi(e) : 4;
+        const int n = e ? atoi(e) : 7;
         return n > 0 ? new JobPool(n > 16 ? 16 : n) : (JobPool *)nullptr;  // lives until process exit
     }();
     return pool;
 }
-struct CopyJob { char *dst; const char *src; size_t bytes; };
+// Large copies between the caller's (pageable) buffers and the pinned staging buffers.  Streaming stores: a regular memcpy of
+// a 1-2 MiB piece reads the destination lines before overwriting them (read-for-ownership), i.e. moves three bytes per byte
+// copied; the staging buffer is read next by the DMA engine, not by this core, so there is nothing to keep in the cache.
+__attribute__((target("avx2"))) void copy_stream_avx2(char *d, const char *s, size_t n)
+{
+    while ((reinterpret_cast<uintptr_t>(d) & 31u) && n) { *d++ = *s++; n--; }
+    size_t blocks = n / 128;
+    for (; blocks; blocks--, d += 128, s += 128) {
+        const __m256i a = _mm256_loadu_si256((const __m256i *)s), b = _mm256_loadu_si256((const __m256i *)(s + 32));
+        const __m256i c = _mm256_loadu_si256((const __m256i *)(s + 64)), e = _mm256_loadu_si256((const __m256i *)(s + 96));
+        _mm256_stream_si256((__m256i *)d, a);
+        _mm256_stream_si256((__m256i *)(d + 32), b);
+        _mm256_stream_si256((__m256i *)(d + 64), c);
+        _mm256_stream_si256((__m256i *)(d + 96), e);
+    }
+    _mm_sfence();
+    if (n & 127) memcpy(d, s, n & 127);
+}
+void copy_piece(char *d, const char *s, size_t n)
+{
+    static const bool stream = __builtin_cpu_supports("avx2") && !(getenv("MI355_COPY_STREAM") && atoi(getenv("MI355_COPY_STREAM")) == 0);
+    if (stream && n >= (1u << 20)) copy_stream_avx2(d, s, n);  // (scheduler-sized calls keep the cached memcpy: their data is re-read at once)
+    else memcpy(d, s, n);
+}
+// up to two copies as ONE job: the bytes of both are cut into `parts` runs, so a staging slot's copy-out (previous result) and
+// copy-in (next input) proceed side by side instead of one after the other on the calling thread's time line
+struct CopyJob { char *dst[2]; const char *src[2]; size_t bytes[2]; };
 void copy_part(void *a, int part, int parts)
 {
     const CopyJob *j = (const CopyJob *)a;
-    const size_t per = ((j->bytes + parts - 1) / parts + 4095) & ~(size_t)4095, off = (size_t)part * per;
-    if (off < j->bytes) memcpy(j->dst + off, j->src + off, j->bytes - off < per ? j->bytes - off : per);
+    const size_t total = j->bytes[0] + j->bytes[1];
+    const size_t per = ((total + parts - 1) / parts + 4095) & ~(size_t)4095;
+    size_t lo = (size_t)part * per, hi = lo + per < total ? lo + per : total;
+    if (lo >= total) return;
+    if (lo < j->bytes[0]) {
+        const size_t e = hi < j->bytes[0] ? hi : j->bytes[0];
+        copy_piece(j->dst[0] + lo, j->src[0] + lo, e - lo);
+        lo = e;
+    }
+    if (lo < hi) copy_piece(j->dst[1] + (lo - j->bytes[0]), j->src[1] + (lo - j->bytes[0]), hi - lo);
 }
 }  // namespace
 
@@ -399,8 +435,13 @@ bool mi355_parallel(void (*fn)(void *, int, int), void *arg)
     return false;
 }
 
-void mi355_copy(void *dst, const void *src, size_t bytes)
+void mi355_copy2(void *dst0, const void *src0, size_t bytes0, void *dst1, const void *src1, size_t bytes1)
 {
-    CopyJob j = {(char *)dst, (const char *)src, bytes};
-    if (bytes < (2u << 20) || !mi355_parallel(copy_part, &j)) memcpy(dst, src, bytes);
+    CopyJob j = {{(char *)dst0, (char *)dst1}, {(const char *)src0, (const char *)src1}, {bytes0, bytes1}};
+    if (bytes0 + bytes1 < (2u << 20) || !mi355_parallel(copy_part, &j)) {
+        if (bytes0) copy_piece((char *)dst0, (const char *)src0, bytes0);
+        if (bytes1) copy_piece((char *)dst1, (const char *)src1, bytes1);
+    }
 }
+
+void mi355_copy(void *dst, const void *src, size_t bytes) { mi355_copy2(dst, src, bytes, nullptr, nullptr, 0); }
