@@ -17,7 +17,16 @@ struct mi355_ctx {
     hipStream_t stream[2] = {nullptr, nullptr};  // [0] = compute stream handed out by mi355_ctx_stream
     int num_cus = 0;
     std::mutex lock;
+    // table uploads (create / set_taps): their own stream, so that only this stream is waited for -- a hipDeviceSynchronize() here
+    // would stall every other block working on the device while one filter is retuned
+    hipStream_t upload = nullptr;
+    std::mutex upload_lock;
 };
+
+// host -> device copy of a table on the context's upload stream, complete (on the device) when it returns; `src` may be freed at once
+hipError_t mi355_upload(mi355_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+// device-side fill on the upload stream, complete when it returns
+hipError_t mi355_fill(mi355_ctx *ctx, void *dst_dev, int value, size_t bytes);
 
 void mi355_set_error(const char *fmt, ...);
 // one diagnostics line to the registered sink (mi355_set_log_callback) or, by default, to stderr; DEBUG / INFO lines are

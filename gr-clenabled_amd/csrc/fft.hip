@@ -1037,10 +1037,10 @@ void host_fft_pow2(std::vector<double> &re, std::vector<double> &im, int sign)
     }
 }
 
-int upload(void **d, const void *src, size_t bytes)
+int upload(mi355_ctx *ctx, void **d, const void *src, size_t bytes)
 {
     if (hipMalloc(d, bytes) != hipSuccess) return MI355_ERR_NOMEM;
-    if (hipMemcpy(*d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return MI355_ERR_HIP;
+    if (mi355_upload(ctx, *d, src, bytes) != hipSuccess) return MI355_ERR_HIP;
     return MI355_OK;
 }
 
@@ -1101,13 +1101,13 @@ int setup_bluestein(mi355_fft *h, const float *window)
     memcpy(post_blob.data(), post.data(), (size_t)N * 8);
     memcpy(post_blob.data() + (size_t)N * 8, src.data(), (size_t)N * 4);
     int rc;
-    if ((rc = upload(&h->d_pre, pre.data(), pre.size() * 4))) return rc;
-    if ((rc = upload(&h->d_post, post_blob.data(), post_blob.size()))) return rc;
-    if ((rc = upload(&h->d_bspec, bs.data(), bs.size() * 4))) return rc;
+    if ((rc = upload(h->ctx, &h->d_pre, pre.data(), pre.size() * 4))) return rc;
+    if ((rc = upload(h->ctx, &h->d_post, post_blob.data(), post_blob.size()))) return rc;
+    if ((rc = upload(h->ctx, &h->d_bspec, bs.data(), bs.size() * 4))) return rc;
     std::vector<float> tf = twiddle_table(M, -1), ti = twiddle_table(M, 1), ones(M, 1.0f);
-    if ((rc = upload(&h->d_twm_f, tf.data(), tf.size() * 4))) return rc;
-    if ((rc = upload(&h->d_twm_i, ti.data(), ti.size() * 4))) return rc;
-    if ((rc = upload((void **)&h->d_ones, ones.data(), ones.size() * 4))) return rc;
+    if ((rc = upload(h->ctx, &h->d_twm_f, tf.data(), tf.size() * 4))) return rc;
+    if ((rc = upload(h->ctx, &h->d_twm_i, ti.data(), ti.size() * 4))) return rc;
+    if ((rc = upload(h->ctx, (void **)&h->d_ones, ones.data(), ones.size() * 4))) return rc;
     return MI355_OK;
 }
 
@@ -1150,7 +1150,7 @@ extern "C" int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, con
         }
     }
     if (hipMalloc(&h->d_tw, tw.size() * sizeof(float)) != hipSuccess) return fail(MI355_ERR_NOMEM);
-    if (hipMemcpy(h->d_tw, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail(MI355_ERR_HIP);
+    if (mi355_upload(ctx, h->d_tw, tw.data(), tw.size() * sizeof(float)) != hipSuccess) return fail(MI355_ERR_HIP);
     {
         std::vector<float> w(fft_size, 1.0f);  // no window == all ones: the kernel has a single code path
         if (window_len) memcpy(w.data(), window, sizeof(float) * (size_t)fft_size);
@@ -1166,7 +1166,7 @@ extern "C" int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, con
             w.swap(p);
         }
         if (hipMalloc((void **)&h->d_window, sizeof(float) * (size_t)fft_size) != hipSuccess) return fail(MI355_ERR_NOMEM);
-        if (hipMemcpy(h->d_window, w.data(), sizeof(float) * (size_t)fft_size, hipMemcpyHostToDevice) != hipSuccess)
+        if (mi355_upload(ctx, h->d_window, w.data(), sizeof(float) * (size_t)fft_size) != hipSuccess)
             return fail(MI355_ERR_HIP);
     }
     int rc = h->pipe.init(ctx);
@@ -1175,8 +1175,7 @@ extern "C" int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, con
         rc = setup_bluestein(h, window_len ? window : nullptr);
         if (rc) return fail(rc);
     }
-    // the table uploads ran on the null stream, which the context's non-blocking streams do not wait for
-    if (hipDeviceSynchronize() != hipSuccess) return fail(MI355_ERR_HIP);
+    // (the table uploads ran on the context's upload stream and were waited for there: mi355_upload; no device-wide wait)
     mi355_log(ctx, MI355_LOG_INFO, "clFFT: %d points, %s, %s input, %d stream(s), shift %d, window %s: %s", fft_size,
               h->sign < 0 ? "forward" : "reverse", dtype == MI355_DTYPE_COMPLEX ? "complex" : "float", num_streams, h->shift,
               window_len ? "given" : "none", !pow2 ? "chirp-z over a power-of-two transform" : h->two_kernel ? "multi-pass" : "one pass");

@@ -776,6 +776,8 @@ struct mi355_filter {
     void *d_H = nullptr, *d_twf = nullptr, *d_twi = nullptr;
     void *d_Hu = nullptr;  // uniformly partitioned long filter (k_ols_ups): spectra of the 2048-tap segments, [ups][4096]
     int ups = 0;           // number of those segments (0: not applicable)
+    std::vector<void *> retired;   // tables of earlier taps, kept alive for kernels still in flight (see retire_dev)
+    size_t retired_bytes = 0, table_bytes = 0;
     HostPipe pipe;
     std::mutex lock;
 };
@@ -812,8 +814,32 @@ int pick_fft_size(int ntaps)
     return nf;
 }
 
+// tables of the previous taps: possibly still read by kernels in flight on the caller's streams
+void retire_dev(mi355_filter *h)
+{
+    size_t held = 0;
+    for (void *p : {(void *)h->d_taps_rev, (void *)h->d_hb, (void *)h->d_H, (void *)h->d_Hu, (void *)h->d_twf, (void *)h->d_twi})
+        if (p) h->retired.push_back(p);
+    h->retired_bytes += h->table_bytes;
+    held = h->retired_bytes;
+    h->table_bytes = 0;
+    h->d_taps_rev = nullptr;
+    h->d_hb = nullptr;
+    h->d_H = h->d_Hu = h->d_twf = h->d_twi = nullptr;
+    h->ups = 0;
+    if (held > ((size_t)64 << 20)) {  // a long series of retunes: pay one device-wide wait and start over
+        (void)hipDeviceSynchronize();
+        for (void *p : h->retired) (void)hipFree(p);
+        h->retired.clear();
+        h->retired_bytes = 0;
+    }
+}
+
 void free_dev(mi355_filter *h)
 {
+    for (void *p : h->retired) (void)hipFree(p);
+    h->retired.clear();
+    h->retired_bytes = 0;
     (void)hipSetDevice(h->ctx->device);
     if (h->d_taps_rev) (void)hipFree(h->d_taps_rev);
     if (h->d_hb) (void)hipFree(h->d_hb);
@@ -848,9 +874,10 @@ int upload_taps_impl(mi355_filter *h, const void *taps, int ntaps)
         }
     }
     MI355_HIP(hipSetDevice(h->ctx->device));
-    // kernels of earlier device-path calls may still be reading the tables that are about to be freed
-    MI355_HIP(hipDeviceSynchronize());
-    free_dev(h);
+    // kernels of earlier device-path calls may still be reading the current tables: they are retired (kept until the handle goes,
+    // or until 64 MiB have piled up), not freed -- hipFree would wait for the whole device, as the hipDeviceSynchronize() that
+    // stood here did, stalling every other block in the flowgraph while one filter is retuned
+    retire_dev(h);
     h->ntaps = ntaps;
     h->nf = nf;
     h->nseg = nseg;
@@ -863,7 +890,8 @@ int upload_taps_impl(mi355_filter *h, const void *taps, int ntaps)
     for (int k = 0; k < ntaps; k++)
         for (int c = 0; c < per; c++) rev[(size_t)per * k + c] = h->taps_host[(size_t)per * (ntaps - 1 - k) + c];
     MI355_HIP(hipMalloc((void **)&h->d_taps_rev, rev.size() * sizeof(float)));
-    MI355_HIP(hipMemcpy(h->d_taps_rev, rev.data(), rev.size() * sizeof(float), hipMemcpyHostToDevice));
+        h->table_bytes += rev.size() * sizeof(float);
+    MI355_HIP(mi355_upload(h->ctx, h->d_taps_rev, rev.data(), rev.size() * sizeof(float)));
     h->mf_kk = 0;
     {
         const int kk = (ntaps + 15 + 3) / 4;
@@ -875,7 +903,8 @@ int upload_taps_impl(mi355_filter *h, const void *taps, int ntaps)
             for (int m = 0; m < ntaps; m++)
                 for (int cpt = 0; cpt < per; cpt++) hb[cpt * tl + m + 15] = h->taps_host[(size_t)per * (ntaps - 1 - m) + cpt];
             MI355_HIP(hipMalloc((void **)&h->d_hb, hb.size() * sizeof(float)));
-            MI355_HIP(hipMemcpy(h->d_hb, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice));
+        h->table_bytes += hb.size() * sizeof(float);
+            MI355_HIP(mi355_upload(h->ctx, h->d_hb, hb.data(), hb.size() * sizeof(float)));
             h->mf_kk = kk;
         }
     }
@@ -921,18 +950,21 @@ int upload_taps_impl(mi355_filter *h, const void *taps, int ntaps)
                 }
             }
             MI355_HIP(hipMalloc(&h->d_Hu, bytes * ups));
-            MI355_HIP(hipMemcpy(h->d_Hu, Hu.data(), bytes * ups, hipMemcpyHostToDevice));
+        h->table_bytes += bytes * ups;
+            MI355_HIP(mi355_upload(h->ctx, h->d_Hu, Hu.data(), bytes * ups));
             h->ups = ups;
         }
         MI355_HIP(hipMalloc(&h->d_H, bytes * nseg));
+        h->table_bytes += bytes * nseg;
         MI355_HIP(hipMalloc(&h->d_twf, bytes));
+        h->table_bytes += bytes;
         MI355_HIP(hipMalloc(&h->d_twi, bytes));
-        MI355_HIP(hipMemcpy(h->d_H, H.data(), bytes * nseg, hipMemcpyHostToDevice));
-        MI355_HIP(hipMemcpy(h->d_twf, twf.data(), bytes, hipMemcpyHostToDevice));
-        MI355_HIP(hipMemcpy(h->d_twi, twi.data(), bytes, hipMemcpyHostToDevice));
+        h->table_bytes += bytes;
+        MI355_HIP(mi355_upload(h->ctx, h->d_H, H.data(), bytes * nseg));
+        MI355_HIP(mi355_upload(h->ctx, h->d_twf, twf.data(), bytes));
+        MI355_HIP(mi355_upload(h->ctx, h->d_twi, twi.data(), bytes));
     }
-    // the uploads above run on the null stream, which the context's non-blocking streams do not wait for
-    MI355_HIP(hipDeviceSynchronize());
+    // (every upload above ran on the context's upload stream and was waited for there: mi355_upload)
     return MI355_OK;
 }
 
@@ -1151,7 +1183,6 @@ extern "C" int mi355_filter_set_taps(mi355_filter *h, const void *taps, int ntap
     MI355_REQUIRE(h != nullptr, "handle is NULL");
     std::lock_guard<std::mutex> g(h->lock);  // lib/clFilter_impl.cc:443 takes d_mutex here
     MI355_HIP(hipSetDevice(h->ctx->device));
-    MI355_HIP(hipDeviceSynchronize());
     return upload_taps(h, taps, ntaps);
 }
 

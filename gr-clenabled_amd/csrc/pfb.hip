@@ -765,13 +765,12 @@ extern "C" int mi355_pfb_create(mi355_ctx *ctx, const float *taps, int ntaps, in
     if (hipMalloc(&h->d_tw, tw.size() * sizeof(float)) != hipSuccess) return fail(MI355_ERR_NOMEM);
     if (hipMalloc((void **)&h->d_map, (size_t)nmap * sizeof(int)) != hipSuccess) return fail(MI355_ERR_NOMEM);
     if (!h->fast && hipMalloc(&h->d_filt, (size_t)h->nsteps * M * 8) != hipSuccess) return fail(MI355_ERR_NOMEM);
-    if (hipMemcpy(h->d_taps, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail(MI355_ERR_HIP);
-    if (hipMemcpy(h->d_tw, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return fail(MI355_ERR_HIP);
-    if (hipMemcpy(h->d_map, ch_map, (size_t)nmap * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return fail(MI355_ERR_HIP);
+    if (mi355_upload(ctx, h->d_taps, t.data(), t.size() * sizeof(float)) != hipSuccess) return fail(MI355_ERR_HIP);
+    if (mi355_upload(ctx, h->d_tw, tw.data(), tw.size() * sizeof(float)) != hipSuccess) return fail(MI355_ERR_HIP);
+    if (mi355_upload(ctx, h->d_map, ch_map, (size_t)nmap * sizeof(int)) != hipSuccess) return fail(MI355_ERR_HIP);
     int rc = h->pipe.init(ctx);
     if (rc) return fail(rc);
-    // the table uploads ran on the null stream, which the context's non-blocking streams do not wait for
-    if (hipDeviceSynchronize() != hipSuccess) return fail(MI355_ERR_HIP);
+    // (the table uploads ran on the context's upload stream and were waited for there: mi355_upload; no device-wide wait)
     mi355_log(ctx, MI355_LOG_INFO, "clPolyphaseChannelizer: %d channels, %d taps, %d inputs per step, %d of %d outputs mapped, %d items per call: %s kernel",
               num_channels, ntaps, ninputs_per_iter, nmap, num_channels, buf_items, h->fast ? "fused filter + transform" : "two-pass");
     *out = h;

@@ -140,6 +140,7 @@ extern "C" int mi355_ctx_create(int ocl_type, int dev_selector, int platform_id,
         (void)hipGetLastError();
     }
     for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipStreamCreateWithFlags(&c->stream[i], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->upload, hipStreamNonBlocking);
     if (e != hipSuccess) {
         mi355_set_error("creating the context's streams on device %d -> %s", dev, hipGetErrorString(e));
         mi355_ctx_destroy(c);
@@ -160,8 +161,30 @@ extern "C" int mi355_ctx_destroy(mi355_ctx *ctx)
             (void)hipStreamSynchronize(ctx->stream[i]);
             (void)hipStreamDestroy(ctx->stream[i]);
         }
+    if (ctx->upload) {
+        (void)hipStreamSynchronize(ctx->upload);
+        (void)hipStreamDestroy(ctx->upload);
+    }
     delete ctx;
     return MI355_OK;
+}
+
+hipError_t mi355_upload(mi355_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
+{
+    if (bytes == 0) return hipSuccess;
+    std::lock_guard<std::mutex> g(ctx->upload_lock);
+    hipError_t e = hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->upload);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->upload);
+    return e;
+}
+
+hipError_t mi355_fill(mi355_ctx *ctx, void *dst_dev, int value, size_t bytes)
+{
+    if (bytes == 0) return hipSuccess;
+    std::lock_guard<std::mutex> g(ctx->upload_lock);
+    hipError_t e = hipMemsetAsync(dst_dev, value, bytes, ctx->upload);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->upload);
+    return e;
 }
 
 extern "C" int mi355_ctx_device(const mi355_ctx *ctx) { return ctx ? ctx->device : MI355_ERR_INVALID_ARG; }

@@ -254,15 +254,14 @@ extern "C" int mi355_xcorr_fft_create(mi355_ctx *ctx, int fft_size, int num_inpu
     }
     const size_t bytes = 2 * (size_t)n * sizeof(float);
     if (hipMalloc(&h->d_twf, bytes) != hipSuccess || hipMalloc(&h->d_twi, bytes) != hipSuccess ||
-        hipMemcpy(h->d_twf, twf.data(), bytes, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(h->d_twi, twi.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        mi355_upload(ctx, h->d_twf, twf.data(), bytes) != hipSuccess ||
+        mi355_upload(ctx, h->d_twi, twi.data(), bytes) != hipSuccess) {
         if (h->d_twf) (void)hipFree(h->d_twf);
         if (h->d_twi) (void)hipFree(h->d_twi);
         delete h;
         mi355_set_error("device allocation of the twiddle tables failed");
         return MI355_ERR_NOMEM;
     }
-    (void)hipDeviceSynchronize();  // the uploads ran on the null stream, which the context's non-blocking streams do not wait for
     *out = h;
     return MI355_OK;
 }

@@ -1320,9 +1320,9 @@ extern "C" int mi355_xengine_create(mi355_ctx *ctx, int data_type, int npol, int
         delete h;
         return MI355_ERR_NOMEM;
     }
-    // (hipMemset of device memory may return before the fill has run, and the fill is on the null stream, which the context's
-    // non-blocking streams do not wait for: without the synchronisation the first integration's corner turn can be overwritten by it)
-    if (h->tile_bytes && (hipMemset(h->d_tiles, 0, h->tile_bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) {
+    // the fill runs on the context's upload stream and is waited for there (a null-stream hipMemset may return before the fill has run
+    // and is not ordered with the context's non-blocking streams: the first integration's corner turn could be overwritten by it)
+    if (h->tile_bytes && mi355_fill(ctx, h->d_tiles, 0, h->tile_bytes) != hipSuccess) {
         mi355_xengine_destroy(h);
         return MI355_ERR_HIP;
     }
