@@ -147,6 +147,8 @@ struct HostPipe {
     hipEvent_t done[kSlots] = {};
 
     int init(mi355_ctx *c);
-    int ensure(int nin, const size_t *in_bytes, size_t out_bytes);
+    // staging for `nslots` slots (the first nslots; a frame of 32 MiB and more is staged through two slots only)
+    int ensure(int nin, const size_t *in_bytes, size_t out_bytes, int nslots = kSlots);
+    int slots_ready = 0;
     void release();
 };

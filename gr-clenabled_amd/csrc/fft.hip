@@ -715,6 +715,7 @@ struct mi355_fft {
     void *d_pre = nullptr, *d_post = nullptr, *d_bspec = nullptr;  // window*chirp (n), chirp (n), spectrum of the conjugate chirp / m (m)
     void *d_twm_f = nullptr, *d_twm_i = nullptr;                    // twiddle tables of the size-m forward / inverse transforms
     float *d_ones = nullptr;                                        // all-ones window of size m
+    mi355_fft *sub_f = nullptr, *sub_i = nullptr;                   // m > 32768: the size-m transforms are handles of their own (multi-pass sizes)
     void *d_wa = nullptr, *d_wb = nullptr;                          // work buffers, cap_frames * m complex each
     size_t cap_frames = 0;
     // The two-kernel sizes (> 16384 points) and the unfused chirp-z path go through ONE workspace per handle.  Calls on
@@ -882,6 +883,8 @@ int ws_release(mi355_fft *h, hipStream_t st)
     return MI355_OK;
 }
 
+int launch_handle(mi355_fft *h, const void *in, void *out, int nvec, hipStream_t st);
+
 int launch_bluestein(mi355_fft *h, const void *in, void *out, int nframes, hipStream_t st)
 {
     const int N = h->n, M = h->m;
@@ -923,10 +926,10 @@ int launch_bluestein(mi355_fft *h, const void *in, void *out, int nframes, hipSt
         hipLaunchKernelGGL(k_blu_pre, dim3(grid_for(tm)), dim3(256), 0, st, (const char *)in + f0 * N * isz, (c32 *)h->d_wa,
                            (const c32 *)h->d_pre, (const int *)((const char *)h->d_post + (size_t)N * 8), N, M, tm,
                            h->dtype == MI355_DTYPE_FLOAT ? 1 : 0);
-        int rc = launch_fft(h->ctx, M, -1, h->d_wa, h->d_wb, h->d_ones, h->d_twm_f, nf, 0, 0, st);
+        int rc = h->sub_f ? launch_handle(h->sub_f, h->d_wa, h->d_wb, nf, st) : launch_fft(h->ctx, M, -1, h->d_wa, h->d_wb, h->d_ones, h->d_twm_f, nf, 0, 0, st);
         if (rc) return rc;
         hipLaunchKernelGGL(k_blu_mul, dim3(grid_for(tm)), dim3(256), 0, st, (c32 *)h->d_wb, (const c32 *)h->d_bspec, M, tm);
-        rc = launch_fft(h->ctx, M, 1, h->d_wb, h->d_wa, h->d_ones, h->d_twm_i, nf, 0, 0, st);
+        rc = h->sub_i ? launch_handle(h->sub_i, h->d_wb, h->d_wa, nf, st) : launch_fft(h->ctx, M, 1, h->d_wb, h->d_wa, h->d_ones, h->d_twm_i, nf, 0, 0, st);
         if (rc) return rc;
         hipLaunchKernelGGL(k_blu_post, dim3(grid_for(tn)), dim3(256), 0, st, (const c32 *)h->d_wa, (c32 *)out + f0 * N,
                            (const c32 *)h->d_post, N, M, tn, (h->sign < 0 && h->shift) ? len : 0);
@@ -946,7 +949,8 @@ int launch_big(mi355_fft *h, const void *in, void *out, int nframes, hipStream_t
         const int rc = ws_acquire(h, st, chunk > h->cap_frames);
         if (rc) return rc;
     }
-    const bool three_pass = S > 16;  // 131072 .. 1048576 points: a second workspace for the 65536-point intermediate transforms
+    const bool three_pass = S > 16;  // 131072 points and more: a second workspace for the intermediate transforms
+    const bool four_pass = S > 256;  // 2^21 .. 2^24 points = 4096 x 16 x 16 x S3: one more combine level
     if (chunk > h->cap_frames) {
         MI355_HIP(hipStreamSynchronize(st));
         if (h->d_wa) (void)hipFree(h->d_wa);
@@ -972,13 +976,46 @@ int launch_big(mi355_fft *h, const void *in, void *out, int nframes, hipStream_t
         else             { if (h->dtype == MI355_DTYPE_FLOAT) SUB(1, true);  else SUB(1, false); }
 #undef SUB
         c32 *dst = (c32 *)out + f0 * N;
+#define COMB2(SS, SG, GY, ...) hipLaunchKernelGGL((k_fft_combine2<SS, SG>), dim3((unsigned)blocks, GY), dim3(256), 0, st, __VA_ARGS__)
+        if (four_pass) {
+            // sub-frame s = 16 S3 a + S3 b + c (a, b < 16, c < S3):
+            //   H_(b,c) = radix-16 combine over a of E_s            (A -> B)   65536-point transforms of x[16 S3 m + S3 b + c]
+            //   G_c     = radix-16 combine over b of H_(b,c)        (B -> A)   2^20-point transforms of x[S3 m + c]
+            //   X       = radix-S3 combine over c of G_c            (A -> out)
+            const int S3 = S / 256, T2 = 16 * S3;  // T2 = number of 65536-point intermediate transforms
+            {
+                const long long total = (long long)nf * 4096;
+                long long blocks = (total + 255) / 256;
+                if (blocks > (long long)cus * 16 / T2 + 1) blocks = (long long)cus * 16 / T2 + 1;
+                if (h->sign < 0) COMB2(16, -1, T2, (const c32 *)h->d_wa, (c32 *)h->d_wb, (const c32 *)h->d_tw, total, 4096, (long long)N, (long long)T2 * 4096, 4096LL, 65536LL, T2, N - 1, 0);
+                else             COMB2(16, 1, T2, (const c32 *)h->d_wa, (c32 *)h->d_wb, (const c32 *)h->d_tw, total, 4096, (long long)N, (long long)T2 * 4096, 4096LL, 65536LL, T2, N - 1, 0);
+            }
+            {
+                const long long total = (long long)nf * 65536;
+                long long blocks = (total + 255) / 256;
+                if (blocks > (long long)cus * 16 / S3 + 1) blocks = (long long)cus * 16 / S3 + 1;
+                if (h->sign < 0) COMB2(16, -1, S3, (const c32 *)h->d_wb, (c32 *)h->d_wa, (const c32 *)h->d_tw, total, 65536, (long long)N, (long long)S3 * 65536, 65536LL, 1048576LL, S3, N - 1, 0);
+                else             COMB2(16, 1, S3, (const c32 *)h->d_wb, (c32 *)h->d_wa, (const c32 *)h->d_tw, total, 65536, (long long)N, (long long)S3 * 65536, 65536LL, 1048576LL, S3, N - 1, 0);
+            }
+            {
+                const long long total = (long long)nf * 1048576;
+                long long blocks = (total + 255) / 256;
+                if (blocks > (long long)cus * 16) blocks = (long long)cus * 16;
+                const int mx = (h->sign < 0 && h->shift) ? S3 / 2 : 0;
+#define COMB2G(SS) do { if (h->sign < 0) COMB2(SS, -1, 1, (const c32 *)h->d_wa, dst, (const c32 *)h->d_tw, total, 1048576, (long long)N, 1048576LL, 0LL, 0LL, 1, N - 1, mx); \
+                        else             COMB2(SS, 1, 1, (const c32 *)h->d_wa, dst, (const c32 *)h->d_tw, total, 1048576, (long long)N, 1048576LL, 0LL, 0LL, 1, N - 1, mx); } while (0)
+                if (S3 == 2) COMB2G(2); else if (S3 == 4) COMB2G(4); else if (S3 == 8) COMB2G(8); else COMB2G(16);
+#undef COMB2G
+            }
+            MI355_HIP(hipGetLastError());
+            continue;
+        }
         if (three_pass) {
             const int S2 = S / 16;
             {   // G_b = radix-16 combine of the sub-frames S2 a + b  (workspace A -> B), all b in one launch
                 const long long total = (long long)nf * 4096;
                 long long blocks = (total + 255) / 256;
                 if (blocks > (long long)cus * 16 / S2 + 1) blocks = (long long)cus * 16 / S2 + 1;
-#define COMB2(SS, SG, GY, ...) hipLaunchKernelGGL((k_fft_combine2<SS, SG>), dim3((unsigned)blocks, GY), dim3(256), 0, st, __VA_ARGS__)
                 if (h->sign < 0) COMB2(16, -1, S2, (const c32 *)h->d_wa, (c32 *)h->d_wb, (const c32 *)h->d_tw, total, 4096, (long long)N, (long long)S2 * 4096, 4096LL, 65536LL, S2, N - 1, 0);
                 else             COMB2(16, 1, S2, (const c32 *)h->d_wa, (c32 *)h->d_wb, (const c32 *)h->d_tw, total, 4096, (long long)N, (long long)S2 * 4096, 4096LL, 65536LL, S2, N - 1, 0);
             }
@@ -991,11 +1028,11 @@ int launch_big(mi355_fft *h, const void *in, void *out, int nframes, hipStream_t
                         else             COMB2(SS, 1, 1, (const c32 *)h->d_wb, dst, (const c32 *)h->d_tw, total, 65536, (long long)N, 65536LL, 0LL, 0LL, 1, N - 1, mx); } while (0)
                 if (S2 == 2) COMB2F(2); else if (S2 == 4) COMB2F(4); else if (S2 == 8) COMB2F(8); else COMB2F(16);
 #undef COMB2F
-#undef COMB2
             }
             MI355_HIP(hipGetLastError());
             continue;
         }
+#undef COMB2
         const long long total = (long long)nf * 4096;
         long long blocks = (total + 255) / 256;
         if (blocks > (long long)cus * 16) blocks = (long long)cus * 16;
@@ -1025,10 +1062,18 @@ void host_fft_pow2(std::vector<double> &re, std::vector<double> &im, int sign)
         j ^= bit;
         if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
     }
+    // one table of n/2 roots (a sincos per butterfly took seconds at the sizes the large chirp-z lengths need)
+    std::vector<double> cr(n / 2 > 0 ? n / 2 : 1), ci(n / 2 > 0 ? n / 2 : 1);
+    for (int k = 0; k < n / 2; k++) {
+        const double a = sign * 2.0 * M_PI * (double)k / (double)n;
+        cr[k] = cos(a);
+        ci[k] = sin(a);
+    }
     for (int len = 2; len <= n; len <<= 1) {
+        const int step = n / len;
         for (int i = 0; i < n; i += len)
             for (int k = 0; k < len / 2; k++) {
-                const double a = sign * 2.0 * M_PI * (double)k / (double)len, wr = cos(a), wi = sin(a);
+                const double wr = cr[(size_t)k * step], wi = ci[(size_t)k * step];
                 const int p = i + k, q = p + len / 2;
                 const double tr = re[q] * wr - im[q] * wi, ti = re[q] * wi + im[q] * wr;
                 re[q] = re[p] - tr; im[q] = im[p] - ti;
@@ -1104,6 +1149,10 @@ int setup_bluestein(mi355_fft *h, const float *window)
     if ((rc = upload(h->ctx, &h->d_pre, pre.data(), pre.size() * 4))) return rc;
     if ((rc = upload(h->ctx, &h->d_post, post_blob.data(), post_blob.size()))) return rc;
     if ((rc = upload(h->ctx, &h->d_bspec, bs.data(), bs.size() * 4))) return rc;
+    if (M > 32768) {  // the convolution's transforms are multi-pass sizes: handles of their own (tables, workspaces, launch plan)
+        if ((rc = mi355_fft_create(h->ctx, M, MI355_FFT_FORWARD, nullptr, 0, MI355_DTYPE_COMPLEX, 1, 0, &h->sub_f))) return rc;
+        return mi355_fft_create(h->ctx, M, MI355_FFT_BACKWARD, nullptr, 0, MI355_DTYPE_COMPLEX, 1, 0, &h->sub_i);
+    }
     std::vector<float> tf = twiddle_table(M, -1), ti = twiddle_table(M, 1), ones(M, 1.0f);
     if ((rc = upload(h->ctx, &h->d_twm_f, tf.data(), tf.size() * 4))) return rc;
     if ((rc = upload(h->ctx, &h->d_twm_i, ti.data(), ti.size() * 4))) return rc;
@@ -1119,8 +1168,8 @@ extern "C" int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, con
     MI355_REQUIRE(ctx && out, "NULL argument");
     *out = nullptr;
     const bool pow2 = fft_size >= 2 && (fft_size & (fft_size - 1)) == 0;
-    if (fft_size < 2 || (pow2 && fft_size > 1048576) || (!pow2 && fft_size > 16384)) {
-        mi355_set_error("fft size %d unsupported (powers of two 2..1048576, any other size 3..16384)", fft_size);
+    if (fft_size < 2 || (pow2 && fft_size > 16777216) || (!pow2 && fft_size > 8388608)) {
+        mi355_set_error("fft size %d unsupported (powers of two 2..16777216, any other size 3..8388608)", fft_size);
         return fft_size < 2 ? MI355_ERR_INVALID_ARG : MI355_ERR_UNSUPPORTED;
     }
     MI355_REQUIRE(window_len == 0 || window_len == fft_size, "window not the same length as fft_size");
@@ -1193,6 +1242,8 @@ extern "C" int mi355_fft_destroy(mi355_fft *h)
     for (void *p : {h->d_pre, h->d_post, h->d_bspec, h->d_twm_f, h->d_twm_i, (void *)h->d_ones, h->d_wa, h->d_wb})
         if (p) (void)hipFree(p);
     if (h->ws_done) (void)hipEventDestroy(h->ws_done);
+    if (h->sub_f) (void)mi355_fft_destroy(h->sub_f);
+    if (h->sub_i) (void)mi355_fft_destroy(h->sub_i);
     delete h;
     return MI355_OK;
 }
@@ -1223,7 +1274,8 @@ extern "C" int mi355_fft_work(mi355_fft *h, int nvec, const void *const *in_stre
     if (chunk_frames < 1) chunk_frames = 1;
     size_t first = (size_t)nvec < chunk_frames ? (size_t)nvec : chunk_frames;
     size_t inb = first * in_frame;
-    int rc = h->pipe.ensure(1, &inb, first * out_frame);
+    const int nslots = first * out_frame >= ((size_t)32 << 20) ? 2 : HostPipe::kSlots;  // (a 2^22-point frame is 32 MiB: two staging slots)
+    int rc = h->pipe.ensure(1, &inb, first * out_frame, nslots);
     if (rc) return rc;
     HostPipe &p = h->pipe;
     if ((size_t)nvec <= chunk_frames && mi355_direct_ok((size_t)nvec * out_frame)) {
@@ -1250,7 +1302,7 @@ extern "C" int mi355_fft_work(mi355_fft *h, int nvec, const void *const *in_stre
         const char *pin = (const char *)in_streams[s_i];
         char *pout = (char *)out_streams[s_i];
         for (size_t ci = 0; ci < nchunks; ci++, seq++) {
-            int s = (int)(seq % HostPipe::kSlots);
+            int s = (int)(seq % nslots);
             hipStream_t st = h->ctx->stream[one_stream ? 0 : (s & 1)];
             size_t f0 = ci * chunk_frames;
             size_t nf = (size_t)nvec - f0 < chunk_frames ? (size_t)nvec - f0 : chunk_frames;
@@ -1267,8 +1319,8 @@ extern "C" int mi355_fft_work(mi355_fft *h, int nvec, const void *const *in_stre
             pend_bytes[s] = nf * out_frame;
         }
     }
-    for (int q = 0; q < HostPipe::kSlots; q++) {
-        int s = (int)((seq + q) % HostPipe::kSlots);  // oldest slot first
+    for (int q = 0; q < nslots; q++) {
+        int s = (int)((seq + q) % nslots);  // oldest slot first
         if (pend_bytes[s]) {
             MI355_HIP(hipEventSynchronize(p.done[s]));
             mi355_copy(pend_dst[s], p.h_out[s], pend_bytes[s]);

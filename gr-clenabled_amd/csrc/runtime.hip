@@ -287,30 +287,38 @@ int HostPipe::init(mi355_ctx *c)
     return MI355_OK;
 }
 
-int HostPipe::ensure(int nin, const size_t *in_bytes, size_t out_bytes)
+int HostPipe::ensure(int nin, const size_t *in_bytes, size_t out_bytes, int nslots)
 {
     MI355_HIP(hipSetDevice(ctx->device));
-    for (int i = 0; i < nin; i++) {
-        if (in_bytes[i] <= cap_in[i]) continue;
-        for (int s = 0; s < kSlots; s++) {
+    if (nslots < 1) nslots = 1;
+    if (nslots > kSlots) nslots = kSlots;
+    bool grow = nslots > slots_ready || out_bytes > cap_out;
+    for (int i = 0; i < nin; i++) grow = grow || in_bytes[i] > cap_in[i];
+    if (!grow) return MI355_OK;
+    // (re)allocate every slot in use at the larger of the old and new sizes
+    size_t want_in[MAXIN] = {cap_in[0], cap_in[1]}, want_out = cap_out > out_bytes ? cap_out : out_bytes;
+    for (int i = 0; i < nin; i++) if (in_bytes[i] > want_in[i]) want_in[i] = in_bytes[i];
+    const int upto = nslots > slots_ready ? nslots : slots_ready;
+    for (int s = 0; s < upto; s++) {
+        for (int i = 0; i < MAXIN; i++) {
+            if (want_in[i] == 0 || (want_in[i] == cap_in[i] && s < slots_ready)) continue;
             if (h_in[s][i]) MI355_HIP(hipHostFree(h_in[s][i]));
             if (d_in[s][i]) MI355_HIP(hipFree(d_in[s][i]));
             h_in[s][i] = d_in[s][i] = nullptr;
-            MI355_HIP(hipHostMalloc(&h_in[s][i], in_bytes[i], hipHostMallocDefault));
-            MI355_HIP(hipMalloc(&d_in[s][i], in_bytes[i]));
+            MI355_HIP(hipHostMalloc(&h_in[s][i], want_in[i], hipHostMallocDefault));
+            MI355_HIP(hipMalloc(&d_in[s][i], want_in[i]));
         }
-        cap_in[i] = in_bytes[i];
-    }
-    if (out_bytes > cap_out) {
-        for (int s = 0; s < kSlots; s++) {
+        if (want_out && !(want_out == cap_out && s < slots_ready)) {
             if (h_out[s]) MI355_HIP(hipHostFree(h_out[s]));
             if (d_out[s]) MI355_HIP(hipFree(d_out[s]));
             h_out[s] = d_out[s] = nullptr;
-            MI355_HIP(hipHostMalloc(&h_out[s], out_bytes, hipHostMallocDefault));
-            MI355_HIP(hipMalloc(&d_out[s], out_bytes));
+            MI355_HIP(hipHostMalloc(&h_out[s], want_out, hipHostMallocDefault));
+            MI355_HIP(hipMalloc(&d_out[s], want_out));
         }
-        cap_out = out_bytes;
     }
+    for (int i = 0; i < MAXIN; i++) cap_in[i] = want_in[i];
+    cap_out = want_out;
+    slots_ready = upto;
     return MI355_OK;
 }
 
@@ -331,6 +339,7 @@ void HostPipe::release()
         done[s] = nullptr;
     }
     cap_in[0] = cap_in[1] = cap_out = 0;
+    slots_ready = 0;
 }
 
 // ---------------------------------------------------------------------------

@@ -106,8 +106,8 @@ BLOCKS.append(dict(
     imports="from gnuradio.fft import window\nimport clenabled",
     make=two_branch("clenabled.clFFT(${fft_size},${fft_dir},${window},${type.datatype},%s,${setDebug},${num_streams},${shift})" % dev_args(True),
                     "clenabled.clFFT(${fft_size},${fft_dir},${window},${type.datatype},%s,${setDebug},${num_streams},${shift})" % dev_args(False)),
-    doc="Vector FFT on the GPU: window multiply, transform and fftshift in one kernel (any power of two up to 1048576; other "
-        "lengths up to 16384 by chirp-z).  One item = one vector of `Points` samples."))
+    doc="Vector FFT on the GPU: window multiply, transform and fftshift in one kernel (any power of two up to 16777216; other "
+        "lengths up to 8388608 by chirp-z).  One item = one vector of `Points` samples."))
 BLOCKS.append(dict(
     id="clenabled_cltapfirfilter", file="clenabled_clFIRTapFilter", label="MI355X FIR filter (given taps)",
     params=DEV + [dict(id="taps", label="Taps", dtype="real_vector"), MODE, INT("decimation", "Decimation", "1"),

@@ -150,9 +150,10 @@ int mi355_mathconst_work_dev(mi355_mathconst *h, size_t nitems, const void *a, v
  * clFFT: per frame Y = [fftshift] FFT_N( x .* window ), unnormalised in both
  * directions.  Replaces the clFFT plan + MultiplyFloat kernel + host fftshift
  * of clFFT_impl (ctor lib/clFFT_impl.cc:65-151, processOpenCL :526-634).
- * fft_size: any power of two 2..32768 (single fused kernel), 65536 (two kernels) and 131072..1048576 (three passes),
- * any other size 3..16384 (chirp-z over the power-of-two kernels; the reference leaves those to clFFT's radix-3/5/7
- * plans); larger sizes return MI355_ERR_UNSUPPORTED.  The shift of an odd-sized frame follows
+ * fft_size: any power of two 2..32768 (single fused kernel), 65536 (two kernels), 131072..1048576 (three passes) and
+ * 2097152..16777216 (four passes; 2^24 is clFFT's own single-precision limit), any other size 3..8388608 (chirp-z over the
+ * power-of-two kernels; the reference leaves those to clFFT's radix-3/5/7/11/13 plans, which refuse other prime factors);
+ * larger sizes return MI355_ERR_UNSUPPORTED.  The shift of an odd-sized frame follows
  * clFFT_impl::testCPU (len = ceil(N/2), :503-507).  window: NULL/0 or exactly fft_size floats
  * (:74-76).  dtype COMPLEX or FLOAT (real input, complex output).
  * `nvec` = number of frames per stream (= noutput_items of work(), :637-654).
@@ -164,7 +165,7 @@ int mi355_fft_work(mi355_fft *h, int nvec, const void *const *in_streams, void *
 /* Concurrency: sizes up to 32768 are stateless (any number of work_dev calls of one handle may be in flight on any streams).
  * 65536 points and more, and the non-power-of-two sizes above 2048, go through ONE per-handle workspace: calls from different threads or
  * streams are accepted and serialised on it (the later stream waits for the earlier call's kernels); use one handle per
- * stream for overlap.  Sizes: powers of two 2 .. 1048576, any other length 2 .. 16384 (chirp-z); larger ones return
+ * stream for overlap.  Sizes: powers of two 2 .. 16777216, any other length 3 .. 8388608 (chirp-z); larger ones return
  * MI355_ERR_UNSUPPORTED. */
 int mi355_fft_work_dev(mi355_fft *h, int nvec, const void *in, void *out, void *stream);
 

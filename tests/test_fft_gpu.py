@@ -159,9 +159,9 @@ def test_zero_vectors_and_bad_sizes(gpu):
     e = np.empty(0, np.complex64)
     assert blk.work(0, [e], [e]) == 0
     with pytest.raises(gpu.Mi355Error):
-        _fft(gpu, 2097152, gpu.CLFFT_FORWARD)  # powers of two above 2^20 are refused, not emulated
+        _fft(gpu, 1 << 25, gpu.CLFFT_FORWARD)  # powers of two above 2^24 (the reference's clFFT limit for single precision) are refused, not emulated
     with pytest.raises(gpu.Mi355Error):
-        _fft(gpu, 16385, gpu.CLFFT_FORWARD)  # other sizes above 16384 too
+        _fft(gpu, (1 << 23) + 1, gpu.CLFFT_FORWARD)  # other sizes above 2^23 too (their chirp-z transform would exceed 2^24 points)
     with pytest.raises(gpu.Mi355Error):
         _fft(gpu, 1, gpu.CLFFT_FORWARD)
 
@@ -251,6 +251,69 @@ def test_sizes_above_65536(gpu, oracle, n, fwd, shift, win):
             xs = xd[f * n:(f + 1) * n].cpu().numpy().view(np.complex64).reshape(-1)
             ys = yd[f * n:(f + 1) * n].cpu().numpy().view(np.complex64).reshape(-1)
             assert relerr(ys, oracle.fft_block(n, True, None, False, oracle.DTYPE_COMPLEX, xs, f64=True)) <= TOL
+
+
+# 2^21 .. 2^24 (clFFT's single-precision limit): four passes (sub-transforms, two radix-16 combines, a radix-2/4/8/16 combine)
+@pytest.mark.parametrize("n,fwd,shift,win", [(1 << 21, True, True, True), (1 << 22, False, True, True), (1 << 23, True, False, False),
+                                             (1 << 24, True, True, True), (1 << 24, False, False, False)])
+def test_sizes_above_two_to_the_twenty(gpu, oracle, n, fwd, shift, win):
+    import torch
+    rng = np.random.default_rng(n % 1000 + 17)
+    w = oracle.window(oracle.WIN_HAMMING, n) if win else None
+    x = crandn(rng, n)
+    blk = _fft(gpu, n, gpu.CLFFT_FORWARD if fwd else gpu.CLFFT_BACKWARD, w, shift=shift)
+    xd = torch.from_numpy(x.view(np.float32).reshape(-1, 2)).cuda()
+    yd = torch.empty_like(xd)
+    blk.work_device(1, [xd], [yd])
+    torch.cuda.synchronize()
+    y = yd.cpu().numpy().view(np.complex64).reshape(-1)
+    assert relerr(y, oracle.fft_block(n, fwd, w, shift, oracle.DTYPE_COMPLEX, x, f64=True)) <= TOL
+    if n == 1 << 21:  # the host path (one frame per staging chunk) and a single tone
+        y2 = np.empty_like(x)
+        assert blk.work(1, [x], [y2]) == 1
+        assert np.array_equal(y2, y)
+        t = np.exp(2j * np.pi * 1234567 * np.arange(n) / n).astype(np.complex64)
+        z = np.empty_like(t)
+        _fft(gpu, n, gpu.CLFFT_FORWARD).work(1, [t], [z])
+        assert abs(z[1234567] - n) < 1e-5 * n * 8 and np.abs(np.delete(z, 1234567)).max() < 1e-5 * n * 8
+
+
+def _np_fft_block(n, fwd, w, shift, x):
+    """clFFT work() semantics (oracle/o_fft.c:140-188) on numpy's float64 pocketfft: the oracle's O(N^2) DFT for lengths that are not a
+    power of two cannot be run at 10^5 .. 10^7 points.  Tied to the oracle at a small length in the test below."""
+    x = x.astype(np.complex128).reshape(-1, n)
+    if w is not None:
+        x = x * np.asarray(w, np.float64)
+    if not fwd and shift:
+        half = n // 2
+        x = np.concatenate([x[:, half:], x[:, :half]], axis=1)  # original position i -> i + (n - half) for i < half
+    y = np.fft.fft(x, axis=1) if fwd else np.fft.ifft(x, axis=1) * n
+    if fwd and shift:
+        ln = (n + 1) // 2
+        y = np.concatenate([y[:, ln:], y[:, :ln]], axis=1)
+    return y.reshape(-1).astype(np.complex64)
+
+
+# lengths above 16384 that are not a power of two: chirp-z over the multi-pass power-of-two sizes (65536 .. 2^24 points)
+@pytest.mark.parametrize("n,fwd,shift,win", [(16385, True, True, True), (20000, False, True, True), (65537, True, False, False), (100000, True, True, True),
+                                             (1000003, True, False, False), (3000000, False, True, False), (8388608 - 1, True, True, False)])
+def test_long_sizes_that_are_not_a_power_of_two(gpu, oracle, n, fwd, shift, win):
+    rng = np.random.default_rng(n % 977)
+    for m, f, sh in ((1000, True, True), (1001, False, True)):  # the numpy reference against the oracle where the oracle can run
+        xs = crandn(rng, m)
+        ws = oracle.window(oracle.WIN_HAMMING, m)
+        assert relerr(_np_fft_block(m, f, ws, sh, xs), oracle.fft_block(m, f, ws, sh, oracle.DTYPE_COMPLEX, xs, f64=True)) <= 1e-6
+    w = oracle.window(oracle.WIN_HAMMING, n) if win else None
+    x = crandn(rng, n)
+    y = np.empty_like(x)
+    blk = _fft(gpu, n, gpu.CLFFT_FORWARD if fwd else gpu.CLFFT_BACKWARD, w, shift=shift)
+    assert blk.work(1, [x], [y]) == 1
+    assert relerr(y, _np_fft_block(n, fwd, w, shift, x)) <= TOL
+    if n == 20000:  # real input and two frames
+        xr = rng.standard_normal(2 * n).astype(np.float32)
+        yr = np.empty(2 * n, np.complex64)
+        _fft(gpu, n, gpu.CLFFT_FORWARD, dtype=gpu.DTYPE_FLOAT).work(2, [xr], [yr])
+        assert relerr(yr, _np_fft_block(n, True, None, False, xr.astype(np.complex64))) <= TOL
 
 
 def test_two_kernel_real_input_and_tone(gpu, oracle):
