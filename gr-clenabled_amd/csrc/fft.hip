@@ -629,6 +629,133 @@ __global__ __launch_bounds__(256) void k_fft_combine2(const c32 *__restrict__ sr
     }
 }
 
+// ------------------------------------------------------------------------------------
+// 65536 .. 1048576 points in TWO passes over whole 128-byte lines (N = N1 x N2, both 256 .. 1024; n = n1 N2 + n2, k = k2 N1 + k1):
+//   X[k2 N1 + k1] = sum_n2 W_N2^(n2 k2) { W_N^(n2 k1) sum_n1 x[n1 N2 + n2] W_N1^(n1 k1) }
+// Both passes are the same kernel: a workgroup takes a TILE of sixteen neighbouring columns (16 x 8 B = one 128-byte line per
+// row) of a matrix with NR rows, transforms the sixteen columns (NR-point transforms, the frame machinery of fft_core with sixteen
+// frames per workgroup) and stores
+//   pass A (x as N1 rows of N2):   column n2 as ROW n2 of the workspace, times W_N^(n2 k1)      -> ws[n2][k1], k1-contiguous stores
+//   pass B (ws as N2 rows of N1):  back into the tile's own columns of the output                -> out[k2][k1]
+// The decimation-in-time form before this (k_fft_sub / k_fft_combine: 4096-point sub-transforms of x[S n + s]) reads 32 bytes of every
+// 128-byte line per workgroup -- the L2 request rate of partial lines -- and needs three passes above 65536 points; here every
+// global access of both passes is a whole line and 2^20 points take two passes instead of three.
+// The tile goes through LDS once on the way in (lanes run along the columns for the global access, along the rows for the
+// transform; column stride NR + 1 slots keeps both sides conflict free) and, in pass B, once on the way out.
+// ------------------------------------------------------------------------------------
+template <int NR> struct GeoTile {
+    static constexpr int TH = NR, PTS = 16 * NR, F = 16, WPE = 1;
+};
+
+template <int NR, int SIGN, bool PASS_B, bool REAL>
+__global__ __launch_bounds__(NR) void k_fft_tile(const void *__restrict__ in, c32 *__restrict__ out, const float *__restrict__ window,
+                                                 const c32 *__restrict__ twN, const c32 *__restrict__ twR,  // W_N (N entries), W_NR (NR entries)
+                                                 int ld /* columns of the matrix = elements per row */, int nmask /* N - 1 */,
+                                                 long long nitems /* frames x tiles per frame */, int row_xor)
+{
+    using G = GeoTile<NR>;
+    // pass A runs the reversed radix plan (remainder radix first): its LAST pass is then radix 16 for every NR, i.e. a thread ends up
+    // with k1 = j + 16-step multiples of NR / 16 -- one twiddle base and one step per thread (see below) instead of one table gather per value
+    constexpr bool REV = !PASS_B;
+    using PL = Plan<NR, REV>;
+    constexpr int TH = NR, CS = NR + 1;  // staging: column c at slots [c * CS, c * CS + NR)
+    extern __shared__ __attribute__((aligned(16))) c32 tile_lds[];
+    const int tid0 = threadIdx.x;
+    TwRegs<NR> tw;
+    load_twiddles<NR, REV, G>(tw, tid0, twR);
+    const int tiles = ld / 16;
+    const size_t frame_elems = (size_t)NR * ld;
+    // (fetching the next item's tile into registers while the current one is transformed was measured: slower at every NR -- the
+    // 1024-thread workgroups have 128 registers per thread and spill, the smaller ones lose more occupancy than they gain)
+    for (long long item = blockIdx.x; item < nitems; item += gridDim.x) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const long long frame = item / tiles;
+        const int c0 = (int)(item - frame * tiles) * 16;
+        // ---- tile in: lanes along the columns (16 lanes = one 128-byte line of a row) ----
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int e = tid + TH * i, col = e & 15, row = e >> 4;
+            const size_t idx = (size_t)(PASS_B ? row : (row ^ row_xor)) * ld + c0 + col;  // pass A, reverse + shift: the halves of the frame are swapped on load
+            c32 x;
+            if constexpr (REAL) x = mk(((const float *)in)[(size_t)frame * frame_elems + idx], 0.f);
+            else {
+                const f2v t = __builtin_nontemporal_load((const f2v *)in + (size_t)frame * frame_elems + idx);
+                x = mk(t.x, t.y);
+            }
+            if constexpr (!PASS_B) {
+                const float w = window[idx];  // indexed by the ORIGINAL position, like the reference (lib/clFFT_impl.cc:477-493)
+                x = mk(x.x * w, x.y * w);
+            }
+            tile_lds[col * CS + row] = x;
+        }
+        __syncthreads();
+        // ---- registers in the layout transform_regs expects: v[q R0 + r] = column fr, row j + r B0 (g = tid + TH q, fr = g / B0, j = g % B0) ----
+        c32 v[16];
+        constexpr int R0 = PL::radix(0), B0 = NR / R0;
+#pragma unroll
+        for (int q = 0; q < 16 / R0; q++) {
+            const int g = tid + TH * q, fr = g / B0, j = g % B0;
+#pragma unroll
+            for (int r = 0; r < R0; r++) v[q * R0 + r] = tile_lds[fr * CS + j + r * B0];
+        }
+        __syncthreads();  // the staged tile has been read: transform_regs works in the same memory
+        transform_regs<NR, SIGN, REV, G>(v, tw, tile_lds, tid);
+        constexpr int NP = PL::NP, RL = PL::radix(NP - 1), BL = NR / RL;
+        if constexpr (!PASS_B) {
+            // ---- pass A: column n2 = c0 + fr becomes row n2 of the workspace, times W_N^(n2 k1); lanes run along k1 ----
+            static_assert(RL == 16, "reversed plan: the last pass is radix 16");
+            const int fr = tid / BL, j = tid % BL, n2 = c0 + fr;
+            // k1 = j + m BL, m = 0 .. 15:  W_N^(n2 k1) = W_N^(n2 j) (W_N^(n2 BL))^m -- two table reads per thread and tile; the sixteen
+            // powers by squaring (at most four products deep).  A gather per value (sixteen per thread, 64 distinct lines per wave
+            // instruction) made this pass run at 1.8 - 2.9 TB/s.
+            const c32 base = twN[(int)(((long long)n2 * j) & nmask)], g1 = twN[(int)(((long long)n2 * BL) & nmask)];
+            const c32 g2 = cmul(g1, g1), g4 = cmul(g2, g2), g8 = cmul(g4, g4);
+            c32 gp[16];
+            gp[0] = base;
+            gp[1] = cmul(base, g1);
+            gp[2] = cmul(base, g2);
+            gp[3] = cmul(gp[2], g1);
+            gp[4] = cmul(base, g4);
+            gp[5] = cmul(gp[4], g1);
+            gp[6] = cmul(gp[4], g2);
+            gp[7] = cmul(gp[6], g1);
+#pragma unroll
+            for (int m = 0; m < 8; m++) gp[8 + m] = cmul(gp[m], g8);
+            f2v *__restrict__ o = (f2v *)out + (size_t)frame * frame_elems + (size_t)n2 * NR + j;
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const c32 z = cmul(v[t], gp[orev<16>(t)]);
+                f2v zz;
+                zz.x = z.x;
+                zz.y = z.y;
+                o[orev<16>(t) * BL] = zz;  // plain store: pass B reads it back
+            }
+            __syncthreads();  // the next item's tile overwrites the memory the last pass of the transform read
+        } else {
+            // ---- pass B: back into the tile's own columns; lanes along the columns again ----
+            __syncthreads();  // every thread has finished the last pass' LDS reads
+#pragma unroll
+            for (int q = 0; q < 16 / RL; q++) {
+                const int g = tid + TH * q, fr = g / BL, j = g % BL;
+#pragma unroll
+                for (int t = 0; t < RL; t++) tile_lds[fr * CS + j + orev<RL>(t) * BL] = v[q * RL + t];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int e = tid + TH * i, col = e & 15, row = e >> 4;
+                const c32 z = tile_lds[col * CS + row];
+                f2v zz;
+                zz.x = z.x;
+                zz.y = z.y;
+                __builtin_nontemporal_store(zz, (f2v *)out + (size_t)frame * frame_elems + (size_t)(row ^ row_xor) * ld + c0 + col);  // forward + shift: halves swapped on store
+            }
+            __syncthreads();
+        }
+    }
+}
+
 template <int N, class G>
 int launch_g(mi355_ctx *ctx, int sign, const void *in, void *out, const float *window, const void *tw, int nframes, int shift,
              int real_in, hipStream_t st)
@@ -722,6 +849,7 @@ struct mi355_fft {
     // different streams / threads are serialised on it: the lock covers the enqueue, ws_done orders the streams (the next
     // user's stream waits for the previous user's kernels) and guards the re-allocation.
     bool two_kernel = false;  // workspace scheme (65536 points; 32768 only with MI355_FFT_32768_TWO_KERNELS)
+    int tile_n1 = 0, tile_n2 = 0;  // 65536 .. 1048576 points: the two-pass tile scheme N = n1 x n2 (k_fft_tile); 0 = not used
     std::mutex ws_lock;
     hipEvent_t ws_done = nullptr;
     bool ws_used = false;
@@ -938,10 +1066,48 @@ int launch_bluestein(mi355_fft *h, const void *in, void *out, int nframes, hipSt
     return ws_release(h, st);
 }
 
+template <int NR, bool PASS_B>
+int launch_tile(mi355_fft *h, const void *in, c32 *out, const c32 *twR, int ld, int nframes, int row_xor, bool real_in, hipStream_t st)
+{
+    constexpr int lds_bytes = 16 * (NR + 1) * 8;
+    const int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
+    const long long items = (long long)nframes * (ld / 16);
+    const int per_cu = (160 * 1024) / lds_bytes;
+    long long grid = (long long)cus * (per_cu < 1 ? 1 : per_cu);
+    if (grid > items) grid = items;
+    const int nmask = h->n - 1;
+#define TILE(SG, RL)                                                                                                            \
+    do {                                                                                                                        \
+        MI355_HIP(hipFuncSetAttribute((const void *)k_fft_tile<NR, SG, PASS_B, RL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
+        hipLaunchKernelGGL((k_fft_tile<NR, SG, PASS_B, RL>), dim3((unsigned)grid), dim3(NR), lds_bytes, st, in, out, h->d_window, (const c32 *)h->d_tw, \
+                           twR, ld, nmask, items, row_xor);                                                                     \
+    } while (0)
+    if constexpr (PASS_B) {
+        if (h->sign < 0) TILE(-1, false); else TILE(1, false);
+    } else {
+        if (h->sign < 0) { if (real_in) TILE(-1, true); else TILE(-1, false); }
+        else             { if (real_in) TILE(1, true);  else TILE(1, false); }
+    }
+#undef TILE
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+template <bool PASS_B>
+int launch_tile_nr(mi355_fft *h, int nr, const void *in, c32 *out, const c32 *twR, int ld, int nframes, int row_xor, bool real_in, hipStream_t st)
+{
+    switch (nr) {
+    case 256: return launch_tile<256, PASS_B>(h, in, out, twR, ld, nframes, row_xor, real_in, st);
+    case 512: return launch_tile<512, PASS_B>(h, in, out, twR, ld, nframes, row_xor, real_in, st);
+    default: return launch_tile<1024, PASS_B>(h, in, out, twR, ld, nframes, row_xor, real_in, st);
+    }
+}
+
 int launch_big(mi355_fft *h, const void *in, void *out, int nframes, hipStream_t st)
 {
     const int N = h->n, S = N / 4096;
-    size_t chunk = (256u << 20) / ((size_t)N * 8);  // workspace bounded to 256 MiB
+    static const size_t ws_mb = getenv("MI355_FFT_WS_MB") ? (size_t)atoi(getenv("MI355_FFT_WS_MB")) : 256;
+    size_t chunk = (ws_mb << 20) / ((size_t)N * 8);  // workspace bounded to 256 MiB
     if (chunk < 1) chunk = 1;
     if (chunk > (size_t)nframes) chunk = (size_t)nframes;
     std::lock_guard<std::mutex> ws_guard(h->ws_lock);
@@ -949,7 +1115,7 @@ int launch_big(mi355_fft *h, const void *in, void *out, int nframes, hipStream_t
         const int rc = ws_acquire(h, st, chunk > h->cap_frames);
         if (rc) return rc;
     }
-    const bool three_pass = S > 16;  // 131072 points and more: a second workspace for the intermediate transforms
+    const bool three_pass = S > 16 && !h->tile_n1;  // 131072 points and more (decimation-in-time scheme): a second workspace for the intermediate transforms
     const bool four_pass = S > 256;  // 2^21 .. 2^24 points = 4096 x 16 x 16 x S3: one more combine level
     if (chunk > h->cap_frames) {
         MI355_HIP(hipStreamSynchronize(st));
@@ -971,6 +1137,15 @@ int launch_big(mi355_fft *h, const void *in, void *out, int nframes, hipStream_t
         // against 494 with the two resident workgroups per CU walking four quads each
         const int grid = (mi355_balanced_grid(h->ctx, nsub, 8, 8) + 7) & ~7;
         const void *src = (const char *)in + f0 * N * isz;
+        if (h->tile_n1) {  // two passes over whole lines: x (n1 rows of n2) -> ws[n2][k1] -> out[k2][k1]
+            const int n1 = h->tile_n1, n2 = h->tile_n2;
+            const c32 *tw1 = (const c32 *)h->d_tw + N + 4096, *tw2 = tw1 + n1;
+            int rc = launch_tile_nr<false>(h, n1, src, (c32 *)h->d_wa, tw1, n2, nf, (h->sign > 0 && h->shift) ? n1 / 2 : 0, h->dtype == MI355_DTYPE_FLOAT, st);
+            if (rc) return rc;
+            rc = launch_tile_nr<true>(h, n2, h->d_wa, (c32 *)out + f0 * N, tw2, n1, nf, (h->sign < 0 && h->shift) ? n2 / 2 : 0, false, st);
+            if (rc) return rc;
+            continue;
+        }
 #define SUB(SG, RL) hipLaunchKernelGGL((k_fft_sub<SG, RL>), dim3(grid), dim3(256), 0, st, src, (c32 *)h->d_wa, h->d_window, tw4096, S, nsub, in_xor)
         if (h->sign < 0) { if (h->dtype == MI355_DTYPE_FLOAT) SUB(-1, true); else SUB(-1, false); }
         else             { if (h->dtype == MI355_DTYPE_FLOAT) SUB(1, true);  else SUB(1, false); }
@@ -1198,13 +1373,26 @@ extern "C" int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, con
             tw.push_back((float)sin(a));
         }
     }
+    if (pow2 && fft_size >= 65536 && fft_size <= 1048576 && !getenv("MI355_FFT_NO_TILE")) {
+        // two-pass tile scheme: N = n1 x n2, n1 >= n2, both 256 .. 1024; their twiddle tables follow the 4096-point one
+        int lg = 0;
+        while ((1 << lg) < fft_size) lg++;
+        h->tile_n1 = 1 << ((lg + 1) / 2);
+        h->tile_n2 = fft_size / h->tile_n1;
+        for (int nr : {h->tile_n1, h->tile_n2})
+            for (int k = 0; k < nr; k++) {
+                double a = h->sign * 2.0 * M_PI * (double)k / (double)nr;
+                tw.push_back((float)cos(a));
+                tw.push_back((float)sin(a));
+            }
+    }
     if (hipMalloc(&h->d_tw, tw.size() * sizeof(float)) != hipSuccess) return fail(MI355_ERR_NOMEM);
     if (mi355_upload(ctx, h->d_tw, tw.data(), tw.size() * sizeof(float)) != hipSuccess) return fail(MI355_ERR_HIP);
     {
         std::vector<float> w(fft_size, 1.0f);  // no window == all ones: the kernel has a single code path
         if (window_len) memcpy(w.data(), window, sizeof(float) * (size_t)fft_size);
         h->two_kernel = pow2 && (fft_size > 32768 || (fft_size == 32768 && getenv("MI355_FFT_32768_TWO_KERNELS") != nullptr));
-        if (h->two_kernel) {
+        if (h->two_kernel && !h->tile_n1) {
             // two-kernel sizes: k_fft_sub reads the window values of the sub-frames (s .. s+3) for every n -- stored
             // quad-major, [s/4][n][4], they are one contiguous 16-byte load per lane instead of 16 bytes out of every S*4
             const int S = fft_size / 4096;
@@ -1227,7 +1415,8 @@ extern "C" int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, con
     // (the table uploads ran on the context's upload stream and were waited for there: mi355_upload; no device-wide wait)
     mi355_log(ctx, MI355_LOG_INFO, "clFFT: %d points, %s, %s input, %d stream(s), shift %d, window %s: %s", fft_size,
               h->sign < 0 ? "forward" : "reverse", dtype == MI355_DTYPE_COMPLEX ? "complex" : "float", num_streams, h->shift,
-              window_len ? "given" : "none", !pow2 ? "chirp-z over a power-of-two transform" : h->two_kernel ? "multi-pass" : "one pass");
+              window_len ? "given" : "none",
+              !pow2 ? "chirp-z over a power-of-two transform" : h->tile_n1 ? "two passes over 16-column tiles" : h->two_kernel ? "multi-pass" : "one pass");
     *out = h;
     return MI355_OK;
 }
