@@ -383,6 +383,22 @@ def hostpath_blocks(pkg, o_taps, dev):
     out["clXEngine_64ant_1024ch_1024t_ichar_hostpath"] = {"us_per_integration": round(dt * 1e6, 1), "integrations": k,
                                                           "total_input_MSamples_per_s": round(N * F * T / dt / 1e6, 1),
                                                           "input_Gbit_per_s": round(N * F * T * 16 / dt / 1e9, 1)}
+    del xe
+    # the whole block path of the C++ layer: general_work()-style calls of the CLI (frame gather of every input stream into the pinned
+    # window, asynchronous correlation, result delivery) -- the counterpart of what lib/test-clxengine.cc:309-332 times
+    try:
+        import re
+        import subprocess
+        cli = os.path.join(ROOT, "gr-clenabled_amd", "test-clenabled-mi355")
+        r = subprocess.run([cli, "--device=%d" % dev, "--xengine-e2e=4"], capture_output=True, text=True, timeout=120)
+        rows = {}
+        for m in re.finditer(r"(\d+) frames? per work_test call: ([0-9.]+) ms per integration", r.stdout):
+            rows["frames_per_call_%s" % m.group(1)] = {"ms_per_integration": float(m.group(2)),
+                                                        "total_input_MSamples_per_s": round(N * F * T / (float(m.group(2)) * 1e-3) / 1e6, 1)}
+        rows["checked"] = r.stdout.strip().endswith("ok")
+        out["clXEngine_e2e_gather_hostpath"] = rows
+    except Exception as exc:  # noqa: BLE001
+        out["clXEngine_e2e_gather_hostpath"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     return out
 
 
@@ -452,7 +468,7 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank, out=None):
     out["clFilter_fft_3000taps"] = rate(lambda: lfl.work_device(nl, [a], [c]), nl, 16)
     # other transform sizes of the headline block: one smaller, the one-pass 16384 / 32768 kernels, the two-kernel and the
     # three-pass workspace schemes
-    for fn_ in (1024, 16384, 32768, 65536, 1048576):
+    for fn_ in (1024, 16384, 32768, 65536, 131072, 1048576):
         fb = pkg.clFFT(fn_, pkg.CLFFT_FORWARD, np.blackman(fn_).astype(np.float32), pkg.DTYPE_COMPLEX, *args, 0, 1, True)
         nv = n // fn_
         out["clFFT_%d" % fn_] = rate(lambda: fb.work_device(nv, [a], [c]), nv * fn_, 16)
