@@ -1170,7 +1170,7 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
                 h->flags_stale[ws] = false;
             }
             return mi355_xe_fused_launch(fp, in, out, tiles, g.N, g.F, g.Fout, g.T, 0.007874015748031496063, accumulate, st, stations_per_group,
-                                         ++h->fused_epoch[ws]);
+                                         &h->fused_epoch[ws]);
         }
     }
     if (tiles) h->flags_stale[tiles == h->d_tiles ? 0 : 1] = true;  // the corner turn below writes over the whole workspace
@@ -1386,7 +1386,7 @@ extern "C" int mi355_xengine_xcorrelate_n_dev(mi355_xengine *h, int nint, const 
                 h->batch_bytes = fp.part_bytes;
             }
             return mi355_xe_fused_launch(fp, in_dev, out_dev, h->d_batch, g.N, g.F, g.Fout, g.T, 0.007874015748031496063, accumulate, st,
-                                         stations_per_group, 1, nint);
+                                         stations_per_group, nullptr, nint);
         }
     }
     if (grouped && nint > 1) {

@@ -19,11 +19,13 @@ struct XeFusedPlan {
 XeFusedPlan mi355_xe_fused_plan(int N, int F, int Fout, int npol, int T, int num_cus, int nint = 1);
 
 // in: [t][station][chan][pol]{I,Q} int8 (16-byte aligned), out: [chan][baseline][pol^2] complex float.
-// part: workspace of plan.part_bytes, zeroed once (unused when tsplit == 1); epoch: 1, 2, 3, ... per launch on that workspace
-// (the in-kernel reduction's counters hold launch numbers; launches sharing a workspace must be stream-ordered).  kd: 1/127.
+// part: workspace of plan.part_bytes, zeroed once (unused when tsplit == 1; launches sharing a workspace must be stream-ordered).  kd: 1/127.
 // stations_per_group (0 or N: the reference layout): the input is [group][t][station in group][chan][pol]{I,Q}, the blocks an
 // all-to-all corner turn delivers (gr-clenabled_amd/shard.py) -- read in place, no re-layout pass.
 // nint > 1: `in` holds nint windows, [window][t][station].. (reference layout) or [group][window][t][station in group].. (group-major: what
 // ONE all-to-all of nint windows delivers); `out` holds nint matrices back to back; the plan must have been made for the same nint.
+// epoch: the workspace's launch counter for the in-launch reduction (MI355_XE_INKERNEL_REDUCE); it advances only
+// with launches that use the counters, so a process that mixes both forms of the reduction on one workspace stays consistent.
+// NULL (or nint > 1): the reduce kernel is used.
 int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void *part, int N, int F, int Fout, int T, double kd,
-                          int accumulate, hipStream_t st, int stations_per_group = 0, unsigned epoch = 1, int nint = 1);
+                          int accumulate, hipStream_t st, int stations_per_group = 0, unsigned *epoch = nullptr, int nint = 1);

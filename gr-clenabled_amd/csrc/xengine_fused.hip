@@ -612,18 +612,22 @@ XeFusedPlan mi355_xe_fused_plan(int N, int F, int Fout, int npol, int T, int num
 }
 
 int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void *part, int N, int F, int Fout, int T, double kd, int accumulate,
-                          hipStream_t st, int stations_per_group, unsigned epoch, int nint)
+                          hipStream_t st, int stations_per_group, unsigned *epoch, int nint)
 {
     FuArgs a;
     a.in = (const unsigned char *)in;
     a.part = (v4i *)part;
     a.flags = p.tsplit > 1 ? (int *)((char *)part + p.flag_offset) : nullptr;
-    a.epoch = epoch;
+    a.epoch = 1;
     // Measured at BASELINE config 5: 69-70 us with the reduction inside the launch, 67 us with k_xe_i8_reduce -- the 84 MB of partial
     // sums do not fit the XCD's L2 (10.5 MB per XCD against 4 MiB), so either way they are written to and read back from the
     // memory side at HBM-like rates (~28 us of the total); the second kernel streams them with every CU, the in-launch tail is
     // kept as an option (MI355_XE_INKERNEL_REDUCE=1) and for the tests.
-    a.inkernel = (nint <= 1 && getenv("MI355_XE_INKERNEL_REDUCE") && atoi(getenv("MI355_XE_INKERNEL_REDUCE")) != 0) ? 1 : 0;
+    // (read per launch: a tuning / test switch.  The workspace's epoch advances only with launches that use the counters, so switching
+    // between the two forms of the reduction mid-process leaves them consistent)
+    const bool inkernel_env = getenv("MI355_XE_INKERNEL_REDUCE") && atoi(getenv("MI355_XE_INKERNEL_REDUCE")) != 0;
+    a.inkernel = (nint <= 1 && epoch && inkernel_env && p.tsplit > 1) ? 1 : 0;
+    if (a.inkernel) a.epoch = ++*epoch;
     a.compact = (!a.inkernel && !getenv("MI355_XE_NO_COMPACT")) ? 1 : 0;
     // 24-bit planes: time ranges of at most 256 steps, at least two row tiles (a lone diagonal record has nothing to pair with)
     if (a.compact && p.tsplit > 1 && T / p.tsplit <= 256 && p.ntt >= 2 && !getenv("MI355_XE_NO_PACK24")) a.compact = 2;

@@ -170,6 +170,35 @@ def test_fused_in_launch_reduction(gpu, oracle, monkeypatch, N, F, T, npol, tspl
     assert np.array_equal(out, ref + ref)
 
 
+def test_in_launch_reduction_survives_mode_switches(gpu, oracle, monkeypatch):
+    """One handle, one workspace: reduce-kernel launches, in-launch-reduction launches and a non-fused launch (unaligned input: its corner
+    turn writes tiles over the workspace, counters included) in any order.  The counters' epoch advances only with launches that use
+    them and is reset after the workspace was overwritten -- otherwise no workgroup reaches its target and `out` keeps stale values."""
+    import torch
+    monkeypatch.setenv("MI355_XE_TSPLIT", "4")
+    N, F, T = 48, 64, 256
+    rng = np.random.default_rng(11)
+    blk = _xe(gpu, gpu.DTYPE_BYTE, 1, N, F, T)
+    per = blk.get_output_buffer_size()
+
+    def run(inkernel, misaligned=False):
+        if inkernel:
+            monkeypatch.setenv("MI355_XE_INKERNEL_REDUCE", "1")
+        else:
+            monkeypatch.delenv("MI355_XE_INKERNEL_REDUCE", raising=False)
+        x = rng.integers(-128, 128, size=T * N * F * 2, dtype=np.int64).astype(np.int8)
+        buf = torch.zeros(x.size + 16, dtype=torch.int8, device="cuda")
+        off = 4 if misaligned else 0  # 4-byte aligned only: not the fused path
+        buf[off:off + x.size] = torch.from_numpy(x).cuda()
+        out = torch.full((per, 2), 7.0, device="cuda")  # stale values must not survive
+        blk.xcorrelate_device(buf[off:off + x.size], out)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.complex64).reshape(-1), oracle.xengine_ichar(N, F, 1, T, x, exact=True)), (inkernel, misaligned)
+
+    for inkernel, mis in ((False, False), (False, False), (True, False), (False, False), (True, False), (True, True), (True, False), (False, True), (True, False)):
+        run(inkernel, mis)
+
+
 def test_closed_form_cases(gpu):
     N, F, T = 8, 6, 32
     blk = _xe(gpu, gpu.DTYPE_BYTE, 1, N, F, T)
