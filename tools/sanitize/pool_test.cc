@@ -8,6 +8,7 @@
 #include <vector>
 
 void mi355_copy(void *dst, const void *src, size_t bytes);
+void mi355_copy2(void *dst0, const void *src0, size_t bytes0, void *dst1, const void *src1, size_t bytes1);
 bool mi355_parallel(void (*fn)(void *, int part, int parts), void *arg);
 
 struct Job { std::vector<int> *v; std::atomic<int> calls{0}; };
@@ -29,6 +30,16 @@ int main()
             for (size_t i = 0; i < bytes; i += 4093) a[i] = (unsigned char)(i + rep + id);
             mi355_copy(b.data(), a.data(), bytes);
             if (memcmp(a.data(), b.data(), bytes)) bad++;
+            // two copies as one job (a staging slot's copy-out and copy-in), unaligned starts and lengths, streaming-store path included
+            {
+                const size_t o0 = 1 + (size_t)rep % 61, o1 = 3 + (size_t)id * 7, n0 = bytes / 2 - 97 - o0, n1 = bytes / 2 - 4099 - o1;
+                std::vector<unsigned char> c(bytes, 0xEE);
+                mi355_copy2(c.data() + o0, a.data() + 5, n0, c.data() + bytes / 2 + o1, a.data() + bytes / 2 + 11, n1);
+                if (memcmp(c.data() + o0, a.data() + 5, n0) || memcmp(c.data() + bytes / 2 + o1, a.data() + bytes / 2 + 11, n1)) bad++;
+                if (c[o0 - 1] != 0xEE || c[o0 + n0] != 0xEE || c[bytes / 2 + o1 - 1] != 0xEE || c[bytes / 2 + o1 + n1] != 0xEE) bad++;  // nothing outside the ranges
+                mi355_copy2(nullptr, nullptr, 0, c.data(), a.data(), 1000);  // an empty first copy, a small second one
+                if (memcmp(c.data(), a.data(), 1000)) bad++;
+            }
             std::vector<int> v(100000 + 1000 * id, 0);
             Job j;
             j.v = &v;
