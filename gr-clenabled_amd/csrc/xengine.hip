@@ -640,7 +640,7 @@ __device__ __forceinline__ void sb_wave(const SbArgs &a, unsigned char *lds, int
 template <int NT, int NPOL>
 __global__ __launch_bounds__(NT * 32, 2) void k_xe_corr_sb(SbArgs a)
 {
-    static_assert(NT % 2 == 0 && NT >= 10 && NT <= 16, "even row-tile counts 10 .. 16");
+    static_assert(NT % 2 == 0 && NT >= 6 && NT <= 16, "even row-tile counts 6 .. 16");
     extern __shared__ __attribute__((aligned(16))) unsigned char sb_lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -653,8 +653,8 @@ __global__ __launch_bounds__(NT * 32, 2) void k_xe_corr_sb(SbArgs a)
     case 0: sb_wave<NT, 0, NPOL>(a, sb_lds, c0, nblk, lane); break;
     case 1: sb_wave<NT, 1, NPOL>(a, sb_lds, c0, nblk, lane); break;
     case 2: sb_wave<NT, 2, NPOL>(a, sb_lds, c0, nblk, lane); break;
-    case 3: sb_wave<NT, 3, NPOL>(a, sb_lds, c0, nblk, lane); break;
-    case 4: sb_wave<NT, 4, NPOL>(a, sb_lds, c0, nblk, lane); break;
+    case 3: if constexpr (NT >= 8) sb_wave<NT, 3, NPOL>(a, sb_lds, c0, nblk, lane); break;
+    case 4: if constexpr (NT >= 10) sb_wave<NT, 4, NPOL>(a, sb_lds, c0, nblk, lane); break;
     case 5: if constexpr (NT >= 12) sb_wave<NT, 5, NPOL>(a, sb_lds, c0, nblk, lane); break;
     case 6: if constexpr (NT >= 14) sb_wave<NT, 6, NPOL>(a, sb_lds, c0, nblk, lane); break;
     default: if constexpr (NT >= 16) sb_wave<NT, 7, NPOL>(a, sb_lds, c0, nblk, lane); break;
@@ -1207,12 +1207,15 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
 #define CORR_LDS(NTT, WV, PPW)                                                                                               \
     hipLaunchKernelGGL((k_xe_corr_lds<NTT, WV, PPW>), dim3(gs.Fs, (npairs + WV * PPW - 1) / (WV * PPW)), dim3(WV * 64), 0, st,  \
                        (const unsigned char *)tiles, (c32 *)out, gs, npairs, kd, accumulate)
-        if (g.NT > 8 && g.NT <= 16 && g.NT % 2 == 0 && !getenv("MI355_XE_NO_SB")) {  // 129 .. 256 rows: the row-tile count was padded to an even number at create
+        if (g.NT >= 6 && g.NT <= 16 && g.NT % 2 == 0 && !getenv("MI355_XE_NO_SB") && !(g.NT <= 8 && getenv("MI355_XE_NO_SB8"))) {  // 65 .. 256 rows (the row-tile count was padded to an even number at create)
             SbArgs sa;
             sa.tiles = tiles; sa.out = (c32 *)out; sa.g = gs; sa.kd = kd; sa.accumulate = accumulate;
             sa.dbg = getenv("MI355_XE_DBG") ? atoi(getenv("MI355_XE_DBG")) : 0;
             const int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
-            sa.chan_per_wg = (gs.Fs + cus - 1) / cus;
+            // 8 row tiles: the ring is 64 KiB and a workgroup four waves, so two workgroups share a CU -- one stores its matrix while the
+            // other multiplies (what the 16-tile form cannot do: there one channel's accumulators fill half the CU's registers)
+            const int wgs = cus * (g.NT == 8 ? 2 : g.NT == 6 ? 3 : 1);  // (6 row tiles: 48 KiB rings, three workgroups of three waves)
+            sa.chan_per_wg = (gs.Fs + wgs - 1) / wgs;
             const unsigned grid = (unsigned)((gs.Fs + sa.chan_per_wg - 1) / sa.chan_per_wg);
 #define CORR_SB(NTT)                                                                                                          \
     do {                                                                                                                      \
@@ -1228,7 +1231,9 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
             if (g.NT == 16) CORR_SB(16);
             else if (g.NT == 14) CORR_SB(14);
             else if (g.NT == 12) CORR_SB(12);
-            else CORR_SB(10);
+            else if (g.NT == 10) CORR_SB(10);
+            else if (g.NT == 8) CORR_SB(8);
+            else CORR_SB(6);
 #undef CORR_SB
         }
         else if (lds_corr && g.NT == 2) CORR_LDS(2, 4, 1);        //  3 pairs
@@ -1290,7 +1295,7 @@ extern "C" int mi355_xengine_create(mi355_ctx *ctx, int data_type, int npol, int
     g.A = g.N * npol; g.NT = (g.A + kRowTile - 1) / kRowTile; g.KB = (g.T + kKBlock - 1) / kKBlock;
     // 129 .. 256 rows of int8 / 4-bit samples go to k_xe_corr_sb, whose waves own two tile rows each: an odd row-tile count gets one
     // zero tile row (written by the corner turn's grid, or left at the workspace's initial zero by the slow turn)
-    if (data_type != MI355_DTYPE_COMPLEX && g.NT > 8 && g.NT <= 16) g.NT = (g.NT + 1) / 2 * 2;
+    if (data_type != MI355_DTYPE_COMPLEX && g.NT > 4 && g.NT <= 16) g.NT = (g.NT + 1) / 2 * 2;
     g.mode = (data_type == MI355_DTYPE_PACKEDXY) ? 1 : 0;
     const size_t items = (size_t)g.N * g.Fout * npol * g.T;
     h->in_bytes = items * mi355_dtype_size(data_type);  // frame_size_times_integration_bytes, :198
