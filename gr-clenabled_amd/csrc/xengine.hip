@@ -383,7 +383,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_xe_corr_lds(const unsigned char 
     }
 }
 
-// (2c) Large arrays (129 .. 256 rows: 9 .. 16 row tiles, padded to an even count NT).  One PERSISTENT workgroup per CU walks a contiguous
+// (2c) Large arrays (65 .. 256 rows: 5 .. 16 row tiles, padded to an even count NT).  A PERSISTENT workgroup (one per CU at 16 tiles) walks a contiguous
 // run of channels; a channel's whole lower triangle is accumulated in the workgroup's registers in ONE pass over its K blocks (time
 // is not split, nothing is re-read):
 //   * the K-block stream of a channel run is one contiguous byte range of the tile workspace ([chan][kblock][plane][rowtile][1 KiB]):
@@ -1293,7 +1293,7 @@ extern "C" int mi355_xengine_create(mi355_ctx *ctx, int data_type, int npol, int
     g.N = num_inputs; g.F = num_channels + pad; g.Fout = num_channels; g.npol = npol; g.T = integration;
     h->pad = pad;
     g.A = g.N * npol; g.NT = (g.A + kRowTile - 1) / kRowTile; g.KB = (g.T + kKBlock - 1) / kKBlock;
-    // 129 .. 256 rows of int8 / 4-bit samples go to k_xe_corr_sb, whose waves own two tile rows each: an odd row-tile count gets one
+    // 65 .. 256 rows of int8 / 4-bit samples go to k_xe_corr_sb, whose waves own two tile rows each: an odd row-tile count gets one
     // zero tile row (written by the corner turn's grid, or left at the workspace's initial zero by the slow turn)
     if (data_type != MI355_DTYPE_COMPLEX && g.NT > 4 && g.NT <= 16) g.NT = (g.NT + 1) / 2 * 2;
     g.mode = (data_type == MI355_DTYPE_PACKEDXY) ? 1 : 0;
