@@ -298,9 +298,15 @@ static int xengine_e2e(int nint)
         gr_vector_const_void_star in2(N, frames.data());
         for (int t = 0; t < T; t += per_call) xe2->work_test(per_call, in2, out);
         auto t1 = std::chrono::steady_clock::now();
+        double pos_ms[4] = {0, 0, 0, 0};  // time by position of the call inside its window (the last one also submits and collects)
         for (int i = 0; i < nint; i++)
-            for (int t = 0; t < T; t += per_call) xe2->work_test(per_call, in2, out);
+            for (int t = 0; t < T; t += per_call) {
+                auto c0 = std::chrono::steady_clock::now();
+                xe2->work_test(per_call, in2, out);
+                pos_ms[(t / per_call) & 3] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count();
+            }
         xe2->stop();
+        printf("  ms per call by position in the window: %.2f %.2f %.2f %.2f\n", pos_ms[0] / nint, pos_ms[1] / nint, pos_ms[2] / nint, pos_ms[3] / nint);
         std::chrono::duration<double> d2 = std::chrono::steady_clock::now() - t1;
         const double per2 = d2.count() / nint;
         printf("clXEngine e2e 64 ant x 1024 ch x 1024 frames, %d frames per work_test call: %.2f ms per integration, "
