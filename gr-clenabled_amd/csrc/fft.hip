@@ -647,8 +647,8 @@ template <int NR> struct GeoTile {
     static constexpr int TH = NR, PTS = 16 * NR, F = 16, WPE = 1;
 };
 
-template <int NR, int SIGN, bool PASS_B, bool REAL>
-__global__ __launch_bounds__(NR) void k_fft_tile(const void *__restrict__ in, c32 *__restrict__ out, const float *__restrict__ window,
+template <int NR, int SIGN, bool PASS_B, bool REAL, bool WR>
+__global__ __launch_bounds__(NR, 4) void k_fft_tile(const void *__restrict__ in, c32 *__restrict__ out, const float *__restrict__ window,
                                                  const c32 *__restrict__ twN, const c32 *__restrict__ twR,  // W_N (N entries), W_NR (NR entries)
                                                  int ld /* columns of the matrix = elements per row */, int nmask /* N - 1 */,
                                                  long long nitems /* frames x tiles per frame */, int row_xor)
@@ -667,11 +667,28 @@ __global__ __launch_bounds__(NR) void k_fft_tile(const void *__restrict__ in, c3
     const size_t frame_elems = (size_t)NR * ld;
     // (fetching the next item's tile into registers while the current one is transformed was measured: slower at every NR -- the
     // 1024-thread workgroups have 128 registers per thread and spill, the smaller ones lose more occupancy than they gain)
+    // pass A's window values depend on the tile's place in the frame only: the grid is a multiple of the tiles per frame whenever it can be
+    // (launch_tile), so a workgroup meets the same tile in every frame and these sixteen registers are loaded once per launch, not once per
+    // item (a 4-byte load per value from L2 was 12 % of the 65536-point transform)
+    // (NR = 1024: sixteen waves leave 128 registers per thread and the sixteen values spill -- that size keeps the load per value)
+    constexpr bool WREG = !PASS_B && WR;
+    float wreg[16];
+    int c0_window = -1;
     for (long long item = blockIdx.x; item < nitems; item += gridDim.x) {
         int tid = tid0;
         asm volatile("" : "+v"(tid));
         const long long frame = item / tiles;
         const int c0 = (int)(item - frame * tiles) * 16;
+        if constexpr (WREG) {
+            if (c0 != c0_window) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int e = tid + TH * i, col = e & 15, row = e >> 4;
+                    wreg[i] = window[(size_t)(row ^ row_xor) * ld + c0 + col];  // indexed by the ORIGINAL position, like the reference (lib/clFFT_impl.cc:477-493)
+                }
+                c0_window = c0;
+            }
+        }
         // ---- tile in: lanes along the columns (16 lanes = one 128-byte line of a row) ----
 #pragma unroll
         for (int i = 0; i < 16; i++) {
@@ -684,7 +701,7 @@ __global__ __launch_bounds__(NR) void k_fft_tile(const void *__restrict__ in, c3
                 x = mk(t.x, t.y);
             }
             if constexpr (!PASS_B) {
-                const float w = window[idx];  // indexed by the ORIGINAL position, like the reference (lib/clFFT_impl.cc:477-493)
+                const float w = WREG ? wreg[i] : window[idx];
                 x = mk(x.x * w, x.y * w);
             }
             tile_lds[col * CS + row] = x;
@@ -1075,12 +1092,20 @@ int launch_tile(mi355_fft *h, const void *in, c32 *out, const c32 *twR, int ld, 
     const int per_cu = (160 * 1024) / lds_bytes;
     long long grid = (long long)cus * (per_cu < 1 ? 1 : per_cu);
     if (grid > items) grid = items;
+    if (grid > ld / 16) grid -= grid % (ld / 16);  // a workgroup then meets the same tile of every frame (its window values stay in registers)
     const int nmask = h->n - 1;
+    constexpr bool WRD = !PASS_B && NR == 256;  // window values of pass A in registers
+    const bool wr = !PASS_B && NR < 1024 && (getenv("MI355_FFT_TILE_WREG") ? atoi(getenv("MI355_FFT_TILE_WREG")) != 0 : WRD);
+#define TILE1(SG, RL, WR)                                                                                                       \
+    do {                                                                                                                        \
+        MI355_HIP(hipFuncSetAttribute((const void *)k_fft_tile<NR, SG, PASS_B, RL, WR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
+        hipLaunchKernelGGL((k_fft_tile<NR, SG, PASS_B, RL, WR>), dim3((unsigned)grid), dim3(NR), lds_bytes, st, in, out, h->d_window, (const c32 *)h->d_tw, \
+                           twR, ld, nmask, items, row_xor);                                                                     \
+    } while (0)
 #define TILE(SG, RL)                                                                                                            \
     do {                                                                                                                        \
-        MI355_HIP(hipFuncSetAttribute((const void *)k_fft_tile<NR, SG, PASS_B, RL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
-        hipLaunchKernelGGL((k_fft_tile<NR, SG, PASS_B, RL>), dim3((unsigned)grid), dim3(NR), lds_bytes, st, in, out, h->d_window, (const c32 *)h->d_tw, \
-                           twR, ld, nmask, items, row_xor);                                                                     \
+        if constexpr (!PASS_B && NR < 1024) { if (wr) TILE1(SG, RL, true); else TILE1(SG, RL, false); }                         \
+        else TILE1(SG, RL, false);                                                                                              \
     } while (0)
     if constexpr (PASS_B) {
         if (h->sign < 0) TILE(-1, false); else TILE(1, false);
@@ -1089,6 +1114,8 @@ int launch_tile(mi355_fft *h, const void *in, c32 *out, const c32 *twR, int ld, 
         else             { if (real_in) TILE(1, true);  else TILE(1, false); }
     }
 #undef TILE
+#undef TILE1
+    (void)wr;
     MI355_HIP(hipGetLastError());
     return MI355_OK;
 }
@@ -1374,10 +1401,15 @@ extern "C" int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, con
         }
     }
     if (pow2 && fft_size >= 65536 && fft_size <= 1048576 && !getenv("MI355_FFT_NO_TILE")) {
-        // two-pass tile scheme: N = n1 x n2, n1 >= n2, both 256 .. 1024; their twiddle tables follow the 4096-point one
+        // two-pass tile scheme: N = n1 x n2, both 256 .. 1024; their twiddle tables follow the 4096-point one
         int lg = 0;
         while ((1 << lg) < fft_size) lg++;
-        h->tile_n1 = 1 << ((lg + 1) / 2);
+        // 131072 = 256 x 512: the 256-row pass first (its window values stay in registers); 2^19 = 1024 x 512 measured 3 % faster than 512 x 1024
+        h->tile_n1 = lg == 17 ? 256 : 1 << ((lg + 1) / 2);
+        if (const char *e = getenv("MI355_FFT_TILE_N1")) {  // (tuning switch)
+            const int v = atoi(e);
+            if ((v == 256 || v == 512 || v == 1024) && fft_size / v >= 256 && fft_size / v <= 1024) h->tile_n1 = v;
+        }
         h->tile_n2 = fft_size / h->tile_n1;
         for (int nr : {h->tile_n1, h->tile_n2})
             for (int k = 0; k < nr; k++) {
