@@ -773,6 +773,133 @@ __global__ __launch_bounds__(NR, 4) void k_fft_tile(const void *__restrict__ in,
     }
 }
 
+// The same two passes with HALF the threads (NR / 2: thread t works on column t / (NR/16) of the tile's first eight columns and on the
+// same column of the last eight, two transforms in lockstep) -- sixteen waves of 128 registers become eight of 256, which leaves room to
+// fetch the NEXT tile into registers while this one is transformed: a 1024-row tile fills the CU's LDS, so no second workgroup can
+// cover the loads, and without this the pass alternates between loading and computing.
+template <int NR> struct GeoTileH {
+    static constexpr int TH = NR / 2, PTS = 8 * NR, F = 8, WPE = 1;
+};
+
+template <int NR, int SIGN, bool PASS_B, bool REAL>
+__global__ __launch_bounds__(NR / 2) void k_fft_tile_h(const void *__restrict__ in, c32 *__restrict__ out, const float *__restrict__ window,
+                                                       const c32 *__restrict__ twN, const c32 *__restrict__ twR, int ld, int nmask,
+                                                       long long nitems, int row_xor)
+{
+    using G = GeoTileH<NR>;
+    constexpr bool REV = !PASS_B;
+    using PL = Plan<NR, REV>;
+    constexpr int TH = NR / 2, CS = NR + 1;
+    extern __shared__ __attribute__((aligned(16))) c32 tile_lds[];
+    const int tid0 = threadIdx.x;
+    TwRegs<NR> tw;
+    load_twiddles<NR, REV, G>(tw, tid0, twR);
+    const int tiles = ld / 16;
+    const size_t frame_elems = (size_t)NR * ld;
+    // element i of a thread: e = tid + TH i (i < 32), column e & 15, row e >> 4
+    auto fetch = [&](long long item, c32 (&pf)[32], int tid) {
+        const long long frame = item / tiles;
+        const int c0 = (int)(item - frame * tiles) * 16;
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+            const int e = tid + TH * i, col = e & 15, row = e >> 4;
+            const size_t idx = (size_t)(PASS_B ? row : (row ^ row_xor)) * ld + c0 + col;
+            if constexpr (REAL) pf[i] = mk(((const float *)in)[(size_t)frame * frame_elems + idx], 0.f);
+            else {
+                const f2v t = __builtin_nontemporal_load((const f2v *)in + (size_t)frame * frame_elems + idx);
+                pf[i] = mk(t.x, t.y);
+            }
+        }
+    };
+    c32 pf[32];
+    if ((long long)blockIdx.x < nitems) fetch(blockIdx.x, pf, tid0);
+    for (long long item = blockIdx.x; item < nitems; item += gridDim.x) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const long long frame = item / tiles;
+        const int c0 = (int)(item - frame * tiles) * 16;
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+            const int e = tid + TH * i, col = e & 15, row = e >> 4;
+            c32 x = pf[i];
+            if constexpr (!PASS_B) {
+                const float w = window[(size_t)(row ^ row_xor) * ld + c0 + col];  // the ORIGINAL position (lib/clFFT_impl.cc:477-493)
+                x = mk(x.x * w, x.y * w);
+            }
+            tile_lds[col * CS + row] = x;
+        }
+        __syncthreads();
+        c32 va[16], vb[16];
+        constexpr int R0 = PL::radix(0), B0 = NR / R0;
+#pragma unroll
+        for (int q = 0; q < 16 / R0; q++) {
+            const int g = tid + TH * q, fr = g / B0, j = g % B0;
+#pragma unroll
+            for (int r = 0; r < R0; r++) {
+                va[q * R0 + r] = tile_lds[fr * CS + j + r * B0];
+                vb[q * R0 + r] = tile_lds[(fr + 8) * CS + j + r * B0];
+            }
+        }
+        __syncthreads();
+        if (item + gridDim.x < nitems) fetch(item + gridDim.x, pf, tid);  // in flight under the transform and the stores
+        transform_regs2<NR, SIGN, REV, G>(va, vb, tw, tile_lds, tile_lds + 8 * NR, tid);
+        constexpr int NP = PL::NP, RL = PL::radix(NP - 1), BL = NR / RL;
+        if constexpr (!PASS_B) {
+            static_assert(RL == 16, "reversed plan: the last pass is radix 16");
+            const int fr = tid / BL, j = tid % BL;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int n2 = c0 + fr + 8 * h;
+                const c32 base = twN[(int)(((long long)n2 * j) & nmask)], g1 = twN[(int)(((long long)n2 * BL) & nmask)];
+                const c32 g2 = cmul(g1, g1), g4 = cmul(g2, g2), g8 = cmul(g4, g4);
+                c32 gp[16];
+                gp[0] = base;
+                gp[1] = cmul(base, g1);
+                gp[2] = cmul(base, g2);
+                gp[3] = cmul(gp[2], g1);
+                gp[4] = cmul(base, g4);
+                gp[5] = cmul(gp[4], g1);
+                gp[6] = cmul(gp[4], g2);
+                gp[7] = cmul(gp[6], g1);
+#pragma unroll
+                for (int m = 0; m < 8; m++) gp[8 + m] = cmul(gp[m], g8);
+                f2v *__restrict__ o = (f2v *)out + (size_t)frame * frame_elems + (size_t)n2 * NR + j;
+#pragma unroll
+                for (int t = 0; t < 16; t++) {
+                    const c32 z = cmul(h ? vb[t] : va[t], gp[orev<16>(t)]);
+                    f2v zz;
+                    zz.x = z.x;
+                    zz.y = z.y;
+                    o[orev<16>(t) * BL] = zz;
+                }
+            }
+            __syncthreads();
+        } else {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 16 / RL; q++) {
+                const int g = tid + TH * q, fr = g / BL, j = g % BL;
+#pragma unroll
+                for (int t = 0; t < RL; t++) {
+                    tile_lds[fr * CS + j + orev<RL>(t) * BL] = va[q * RL + t];
+                    tile_lds[(fr + 8) * CS + j + orev<RL>(t) * BL] = vb[q * RL + t];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 32; i++) {
+                const int e = tid + TH * i, col = e & 15, row = e >> 4;
+                const c32 z = tile_lds[col * CS + row];
+                f2v zz;
+                zz.x = z.x;
+                zz.y = z.y;
+                __builtin_nontemporal_store(zz, (f2v *)out + (size_t)frame * frame_elems + (size_t)(row ^ row_xor) * ld + c0 + col);
+            }
+            __syncthreads();
+        }
+    }
+}
+
 template <int N, class G>
 int launch_g(mi355_ctx *ctx, int sign, const void *in, void *out, const float *window, const void *tw, int nframes, int shift,
              int real_in, hipStream_t st)
@@ -1107,6 +1234,28 @@ int launch_tile(mi355_fft *h, const void *in, c32 *out, const c32 *twR, int ld, 
         if constexpr (!PASS_B && NR < 1024) { if (wr) TILE1(SG, RL, true); else TILE1(SG, RL, false); }                         \
         else TILE1(SG, RL, false);                                                                                              \
     } while (0)
+    if constexpr (NR == 1024) {
+        // 1024 rows: half the threads, two transforms each, the next tile fetched under the transform (2^20 points 540 -> 517 us, 2^19 500 -> 485
+        // on one box; the same form at 512 rows, where two workgroups share the CU anyway, measured 3 % slower and is not instantiated)
+        static const bool half = getenv("MI355_FFT_TILE_HALF") ? atoi(getenv("MI355_FFT_TILE_HALF")) != 0 : true;
+        if (half) {
+#define TILEH(SG, RL)                                                                                                           \
+    do {                                                                                                                        \
+        MI355_HIP(hipFuncSetAttribute((const void *)k_fft_tile_h<NR, SG, PASS_B, RL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
+        hipLaunchKernelGGL((k_fft_tile_h<NR, SG, PASS_B, RL>), dim3((unsigned)grid), dim3(NR / 2), lds_bytes, st, in, out, h->d_window, (const c32 *)h->d_tw, \
+                           twR, ld, nmask, items, row_xor);                                                                     \
+    } while (0)
+            if constexpr (PASS_B) {
+                if (h->sign < 0) TILEH(-1, false); else TILEH(1, false);
+            } else {
+                if (h->sign < 0) { if (real_in) TILEH(-1, true); else TILEH(-1, false); }
+                else             { if (real_in) TILEH(1, true);  else TILEH(1, false); }
+            }
+#undef TILEH
+            MI355_HIP(hipGetLastError());
+            return MI355_OK;
+        }
+    }
     if constexpr (PASS_B) {
         if (h->sign < 0) TILE(-1, false); else TILE(1, false);
     } else {
