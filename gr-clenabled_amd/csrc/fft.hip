@@ -20,6 +20,7 @@
 
 #include "common.h"
 #include "fft_core.hpp"
+#include "fft_mr.h"
 
 using namespace fftc;
 #ifndef MI355_FFT_WPE
@@ -981,7 +982,9 @@ struct mi355_fft {
     float *d_window;  // n floats or NULL
     void *d_tw;       // n complex: exp(sign*2*pi*i*k/n), generated in double
     HostPipe pipe;
-    // sizes that are not a power of two: chirp-z (Bluestein) over power-of-two transforms of size m
+    // lengths 2^a 3^b 5^c 7^d that a workgroup holds: the mixed-radix kernel (fft_mr.hip); mr.n == 0: not used
+    MrPlan mr;
+    // every other size that is not a power of two: chirp-z (Bluestein) over power-of-two transforms of size m
     int m = 0;
     void *d_pre = nullptr, *d_post = nullptr, *d_bspec = nullptr;  // window*chirp (n), chirp (n), spectrum of the conjugate chirp / m (m)
     void *d_twm_f = nullptr, *d_twm_i = nullptr;                    // twiddle tables of the size-m forward / inverse transforms
@@ -1398,6 +1401,7 @@ int launch_big(mi355_fft *h, const void *in, void *out, int nframes, hipStream_t
 
 int launch_handle(mi355_fft *h, const void *in, void *out, int nvec, hipStream_t st)
 {
+    if (h->mr.n) return mi355_fft_mr_launch(h->mr, h->ctx, h->sign, in, out, h->d_window, nvec, h->shift, h->dtype == MI355_DTYPE_FLOAT, st);
     if (h->m) return launch_bluestein(h, in, out, nvec, st);
     if (h->n > 32768 || (h->n == 32768 && h->two_kernel)) return launch_big(h, in, out, nvec, st);
     return launch_fft(h->ctx, h->n, h->sign, in, out, h->d_window, h->d_tw, nvec, h->shift, h->dtype == MI355_DTYPE_FLOAT, st);
@@ -1590,14 +1594,21 @@ extern "C" int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, con
     int rc = h->pipe.init(ctx);
     if (rc) return fail(rc);
     if (!pow2) {
-        rc = setup_bluestein(h, window_len ? window : nullptr);
-        if (rc) return fail(rc);
+        std::vector<float> mtw;
+        if (!getenv("MI355_FFT_NO_MR") && mi355_fft_mr_plan(fft_size, h->sign, &h->mr, &mtw)) {
+            if (hipMalloc(&h->mr.d_tw, mtw.size() * sizeof(float)) != hipSuccess) return fail(MI355_ERR_NOMEM);
+            if (mi355_upload(ctx, h->mr.d_tw, mtw.data(), mtw.size() * sizeof(float)) != hipSuccess) return fail(MI355_ERR_HIP);
+        } else {
+            h->mr.n = 0;
+            rc = setup_bluestein(h, window_len ? window : nullptr);
+            if (rc) return fail(rc);
+        }
     }
     // (the table uploads ran on the context's upload stream and were waited for there: mi355_upload; no device-wide wait)
     mi355_log(ctx, MI355_LOG_INFO, "clFFT: %d points, %s, %s input, %d stream(s), shift %d, window %s: %s", fft_size,
               h->sign < 0 ? "forward" : "reverse", dtype == MI355_DTYPE_COMPLEX ? "complex" : "float", num_streams, h->shift,
               window_len ? "given" : "none",
-              !pow2 ? "chirp-z over a power-of-two transform" : h->tile_n1 ? "two passes over 16-column tiles" : h->two_kernel ? "multi-pass" : "one pass");
+              h->mr.n ? "mixed radix, one pass" : !pow2 ? "chirp-z over a power-of-two transform" : h->tile_n1 ? "two passes over 16-column tiles" : h->two_kernel ? "multi-pass" : "one pass");
     *out = h;
     return MI355_OK;
 }
@@ -1609,6 +1620,7 @@ extern "C" int mi355_fft_destroy(mi355_fft *h)
     h->pipe.release();
     if (h->d_window) (void)hipFree(h->d_window);
     if (h->d_tw) (void)hipFree(h->d_tw);
+    if (h->mr.d_tw) (void)hipFree(h->mr.d_tw);
     for (void *p : {h->d_pre, h->d_post, h->d_bspec, h->d_twm_f, h->d_twm_i, (void *)h->d_ones, h->d_wa, h->d_wb})
         if (p) (void)hipFree(p);
     if (h->ws_done) (void)hipEventDestroy(h->ws_done);

@@ -1,0 +1,30 @@
+// Mixed-radix clFFT path (fft_mr.hip): lengths 2^a 3^b 5^c 7^d that are not a power of two, one workgroup-resident Stockham pass
+// per radix.  The reference's clFFT library plans these lengths natively (lib/clFFT_impl.cc:91-128: clfftCreateDefaultPlan on any
+// length whose prime factors are 2, 3, 5, 7); everything else goes through the chirp-z path of fft.hip.
+#pragma once
+#include <vector>
+
+#include "common.h"
+
+struct MrPass {
+    int radix, ns, nb;          // butterflies of this pass are `radix` points wide, `ns` = product of the radices before it, nb = n / radix
+    unsigned m_nb, m_ns;        // ceil(2^32 / nb), ceil(2^32 / ns): exact quotients for operands below 2^16 (one multiply-high each)
+    int tw_off;                 // first entry of this pass' twiddle run exp(sign 2 pi i k / (ns radix)), k < ns
+};
+
+struct MrPlan {
+    int n = 0, npass = 0;
+    int threads = 0;            // workgroup size (256 / 512 / 1024)
+    int frames = 0;             // frames a workgroup transforms per iteration
+    int lds_bytes = 0;
+    MrPass pass[12];
+    void *d_tw = nullptr;       // the passes' twiddle runs, back to back
+};
+
+// false: n is not of this form (or does not fit a workgroup): use the chirp-z path.  tw receives the host copy of the twiddle runs.
+bool mi355_fft_mr_plan(int n, int sign, MrPlan *plan, std::vector<float> *tw);
+
+// in: nframes frames of n values (complex, or float when real_in); out: nframes x n complex.  window: n floats (all ones = no window).
+// shift as in oracle_fft_block: reverse = input halves swapped (window indexed by the original position), forward = output rotated by ceil(n/2).
+int mi355_fft_mr_launch(const MrPlan &plan, mi355_ctx *ctx, int sign, const void *in, void *out, const float *window, int nframes, int shift,
+                        int real_in, hipStream_t st);

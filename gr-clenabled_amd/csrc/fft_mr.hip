@@ -1,0 +1,294 @@
+// clFFT for lengths 2^a 3^b 5^c 7^d that are not a power of two (the reference plans them natively through the clFFT library,
+// lib/clFFT_impl.cc:91-128; block semantics -- window, shift, real input -- lib/clFFT_impl.cc:464-518, restated in oracle/o_fft.c).
+//
+// One kernel, the transform resident in a workgroup's LDS: a Stockham autosort pass per radix (odd radices first, then 16s, then the
+// remaining power of two), every thread holding at most sixteen values = 16 / R butterflies of R points per pass.
+//   pass with radix R, Ns = product of the radices before it, butterfly j < N / R, k = j mod Ns:
+//     v[r] = x[j + r N/R] W^(r k), W = exp(sign 2 pi i / (Ns R));  X = DFT_R(v);  y[(j / Ns) Ns R + k + r Ns] = X[r]
+// The first pass reads the frame straight from global memory (consecutive butterflies = consecutive addresses: coalesced), the last one
+// writes the spectrum straight back (in its last pass Ns R = N, so the output index is j + r Ns: coalesced again); in between the data
+// stays in LDS, in place (all reads of a pass, barrier, all writes).  Several short frames share a workgroup iteration (a butterfly
+// number runs over frames x N / R).  HBM traffic: the frame once in, once out.
+// j / (N/R) and j / Ns are one multiply-high each (ceil(2^32 / d), exact below 2^16).  One table read per butterfly (W^k, a
+// contiguous run per pass); the R - 1 powers by repeated squaring / one product.  LDS index i sits at slot i + i / 32 (the passes of
+// the power-of-two radices would otherwise put a wave's stores in a handful of banks).
+#include "fft_mr.h"
+
+#include "fft_core.hpp"
+
+using namespace fftc;
+
+namespace {
+
+typedef float f2v __attribute__((ext_vector_type(2)));
+constexpr int kVals = 16;  // complex values per thread and pass
+constexpr int kMaxPass = 12;
+
+struct MrArgs {
+    const void *in;
+    c32 *out;
+    const float *window;
+    const c32 *tw;
+    int n, nframes, frames, npass, in_rot, out_rot, real_in;
+    long long ngroups;
+    MrPass pass[kMaxPass];
+};
+
+__device__ __forceinline__ int slot(int i) { return i + (i >> 5); }
+
+template <int R> __host__ __device__ constexpr int out_index(int s) { return (R == 8 || R == 16) ? orev<R>(s) : s; }
+
+// DFT_R in place; slot s holds X[out_index<R>(s)] afterwards
+template <int R, int SIGN> __device__ __forceinline__ void dft(c32 *v)
+{
+    if constexpr (R == 2) bfly2<SIGN>(v[0], v[1]);
+    else if constexpr (R == 4) bfly4<SIGN>(v[0], v[1], v[2], v[3]);
+    else if constexpr (R == 8) bfly8<SIGN>(v);
+    else if constexpr (R == 16) bfly16<SIGN>(v);
+    else if constexpr (R == 3) {
+        constexpr float s3 = 0.86602540378443864676f;
+        const c32 t = v[1] + v[2], d = rot90<SIGN>(scale(v[1] - v[2], s3));  // i sign sin(2 pi / 3) (x1 - x2)
+        const c32 m = mk(v[0].x - 0.5f * t.x, v[0].y - 0.5f * t.y);
+        v[0] = v[0] + t;
+        v[1] = m + d;
+        v[2] = m - d;
+    } else if constexpr (R == 5) {
+        constexpr float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f, s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+        const c32 t1 = v[1] + v[4], t2 = v[2] + v[3], t3 = v[1] - v[4], t4 = v[2] - v[3];
+        const c32 a1 = mk(v[0].x + c1 * t1.x + c2 * t2.x, v[0].y + c1 * t1.y + c2 * t2.y);
+        const c32 a2 = mk(v[0].x + c2 * t1.x + c1 * t2.x, v[0].y + c2 * t1.y + c1 * t2.y);
+        const c32 b1 = rot90<SIGN>(mk(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y));
+        const c32 b2 = rot90<SIGN>(mk(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y));
+        v[0] = v[0] + t1 + t2;
+        v[1] = a1 + b1;
+        v[4] = a1 - b1;
+        v[2] = a2 + b2;
+        v[3] = a2 - b2;
+    } else {
+        static_assert(R == 7, "radix");
+        constexpr float c1 = 0.62348980185873353053f, c2 = -0.22252093395631440429f, c3 = -0.90096886790241912624f;
+        constexpr float s1 = 0.78183148246802980871f, s2 = 0.97492791218182360702f, s3 = 0.43388373911755812048f;
+        const c32 t1 = v[1] + v[6], t2 = v[2] + v[5], t3 = v[3] + v[4], u1 = v[1] - v[6], u2 = v[2] - v[5], u3 = v[3] - v[4];
+        // cos(2 pi j k / 7): k = 1: c1 c2 c3;  k = 2: c2 c3 c1;  k = 3: c3 c1 c2.   sin: k = 1: s1 s2 s3;  k = 2: s2 -s3 -s1;  k = 3: s3 -s1 s2
+        const c32 a1 = mk(v[0].x + c1 * t1.x + c2 * t2.x + c3 * t3.x, v[0].y + c1 * t1.y + c2 * t2.y + c3 * t3.y);
+        const c32 a2 = mk(v[0].x + c2 * t1.x + c3 * t2.x + c1 * t3.x, v[0].y + c2 * t1.y + c3 * t2.y + c1 * t3.y);
+        const c32 a3 = mk(v[0].x + c3 * t1.x + c1 * t2.x + c2 * t3.x, v[0].y + c3 * t1.y + c1 * t2.y + c2 * t3.y);
+        const c32 b1 = rot90<SIGN>(mk(s1 * u1.x + s2 * u2.x + s3 * u3.x, s1 * u1.y + s2 * u2.y + s3 * u3.y));
+        const c32 b2 = rot90<SIGN>(mk(s2 * u1.x - s3 * u2.x - s1 * u3.x, s2 * u1.y - s3 * u2.y - s1 * u3.y));
+        const c32 b3 = rot90<SIGN>(mk(s3 * u1.x - s1 * u2.x + s2 * u3.x, s3 * u1.y - s1 * u2.y + s2 * u3.y));
+        v[0] = v[0] + t1 + t2 + t3;
+        v[1] = a1 + b1;
+        v[6] = a1 - b1;
+        v[2] = a2 + b2;
+        v[5] = a2 - b2;
+        v[3] = a3 + b3;
+        v[4] = a3 - b3;
+    }
+}
+
+// MODE 0: first pass (global -> LDS), 1: LDS -> LDS, 2: last pass (LDS -> global)
+template <int R, int SIGN, int MODE, int TH>
+__device__ __forceinline__ void mr_pass(const MrArgs &a, const MrPass &ps, c32 *lds, int tid, long long group)
+{
+    constexpr int B = kVals / R;
+    c32 v[B][R];
+    int fr[B], bb[B];
+    const int n = a.n, nb = ps.nb, nbt = a.frames * nb;
+#pragma unroll
+    for (int i = 0; i < B; i++) {
+        const int b = tid + TH * i;
+        fr[i] = (int)__umulhi((unsigned)b, ps.m_nb);
+        bb[i] = b - fr[i] * nb;
+        if (b < nbt) {
+            if constexpr (MODE == 0) {
+                const long long frame = group * a.frames + fr[i];
+                const bool live = frame < a.nframes;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    int src = bb[i] + r * nb + a.in_rot;  // reverse + shift: the halves of the frame are swapped on load
+                    if (src >= n) src -= n;
+                    c32 x = mk(0.f, 0.f);
+                    if (live) {
+                        if (a.real_in) x = mk(((const float *)a.in)[(size_t)frame * n + src], 0.f);
+                        else {
+                            const f2v t = __builtin_nontemporal_load((const f2v *)a.in + (size_t)frame * n + src);
+                            x = mk(t.x, t.y);
+                        }
+                        const float w = a.window[src];  // indexed by the ORIGINAL position (lib/clFFT_impl.cc:477-493)
+                        x = mk(x.x * w, x.y * w);
+                    }
+                    v[i][r] = x;
+                }
+            } else {
+                const int base = fr[i] * n + bb[i];
+#pragma unroll
+                for (int r = 0; r < R; r++) v[i][r] = lds[slot(base + r * nb)];
+            }
+        }
+    }
+    if constexpr (MODE != 0) __syncthreads();  // every value of this pass is in registers: the writes below go to the same memory
+#pragma unroll
+    for (int i = 0; i < B; i++) {
+        const int b = tid + TH * i;
+        if (b < nbt) {
+            int g = bb[i], k = 0;
+            if constexpr (MODE != 0) {
+                g = (int)__umulhi((unsigned)bb[i], ps.m_ns);
+                k = bb[i] - g * ps.ns;
+                c32 pw[R];
+                pw[1] = a.tw[ps.tw_off + k];
+#pragma unroll
+                for (int r = 2; r < R; r++) pw[r] = (r & 1) ? cmul(pw[r - 1], pw[1]) : cmul(pw[r >> 1], pw[r >> 1]);
+#pragma unroll
+                for (int r = 1; r < R; r++) v[i][r] = cmul(v[i][r], pw[r]);
+            }
+            dft<R, SIGN>(v[i]);
+            if constexpr (MODE == 2) {
+                const long long frame = group * a.frames + fr[i];
+                if (frame < a.nframes) {
+#pragma unroll
+                    for (int s = 0; s < R; s++) {
+                        int p = k + out_index<R>(s) * ps.ns - a.out_rot;  // (g = 0 in the last pass); forward + shift: out[p] = X[(p + ceil(n/2)) mod n]
+                        if (p < 0) p += n;
+                        f2v z;
+                        z.x = v[i][s].x;
+                        z.y = v[i][s].y;
+                        __builtin_nontemporal_store(z, (f2v *)a.out + (size_t)frame * n + p);
+                    }
+                }
+            } else {
+                const int base = fr[i] * n + g * ps.ns * R + k;
+#pragma unroll
+                for (int s = 0; s < R; s++) lds[slot(base + out_index<R>(s) * ps.ns)] = v[i][s];
+            }
+        }
+    }
+    if constexpr (MODE != 2) __syncthreads();
+}
+
+template <int SIGN, int TH>
+__global__ __launch_bounds__(TH) void k_fft_mr(const MrArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) c32 mr_lds[];
+    const int tid0 = threadIdx.x;
+#define MR_PASS(MODE, P)                                                                        \
+    switch (a.pass[P].radix) {                                                                  \
+    case 2: mr_pass<2, SIGN, MODE, TH>(a, a.pass[P], mr_lds, tid, group); break;                \
+    case 3: mr_pass<3, SIGN, MODE, TH>(a, a.pass[P], mr_lds, tid, group); break;                \
+    case 4: mr_pass<4, SIGN, MODE, TH>(a, a.pass[P], mr_lds, tid, group); break;                \
+    case 5: mr_pass<5, SIGN, MODE, TH>(a, a.pass[P], mr_lds, tid, group); break;                \
+    case 7: mr_pass<7, SIGN, MODE, TH>(a, a.pass[P], mr_lds, tid, group); break;                \
+    case 8: mr_pass<8, SIGN, MODE, TH>(a, a.pass[P], mr_lds, tid, group); break;                \
+    default: mr_pass<16, SIGN, MODE, TH>(a, a.pass[P], mr_lds, tid, group); break;              \
+    }
+    for (long long group = blockIdx.x; group < a.ngroups; group += gridDim.x) {
+        // opaque per iteration: everything below depends on the thread number and the pass only, and hoisted out of this loop -- for every
+        // radix of the three switches at once -- it costs hundreds of registers (256 + 190 spilled before this line was here)
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        MR_PASS(0, 0)
+        for (int p = 1; p < a.npass - 1; p++) { MR_PASS(1, p) }
+        MR_PASS(2, a.npass - 1)
+    }
+#undef MR_PASS
+}
+
+unsigned magic(int d) { return (unsigned)((0x100000000ull + (unsigned long long)d - 1) / (unsigned long long)d); }
+
+}  // namespace
+
+bool mi355_fft_mr_plan(int n, int sign, MrPlan *plan, std::vector<float> *tw)
+{
+    if (n < 6 || (n & (n - 1)) == 0) return false;
+    int radix[kMaxPass], np = 0, m = n;
+    for (int f : {7, 5, 3})
+        while (m % f == 0) {
+            if (np == kMaxPass) return false;
+            radix[np++] = f;
+            m /= f;
+        }
+    if (m & (m - 1)) return false;  // a prime factor above 7
+    int lg = 0;
+    while ((1 << lg) < m) lg++;
+    for (; lg >= 4; lg -= 4) {
+        if (np == kMaxPass) return false;
+        radix[np++] = 16;
+    }
+    if (lg) {
+        if (np == kMaxPass) return false;
+        radix[np++] = 1 << lg;
+    }
+    if (np < 2) return false;
+    int per_thread = kVals;  // values a thread can hold in every pass of this plan
+    for (int p = 0; p < np; p++) {
+        const int v = (kVals / radix[p]) * radix[p];
+        if (v < per_thread) per_thread = v;
+    }
+    int th = 0;
+    for (int t : {256, 512, 1024})
+        if ((long long)t * per_thread >= n) { th = t; break; }
+    if (!th) return false;  // longer than a workgroup holds: chirp-z
+    plan->n = n;
+    plan->npass = np;
+    plan->threads = th;
+    plan->frames = th * per_thread / n;
+    plan->lds_bytes = (plan->frames * n + (plan->frames * n >> 5) + 1) * 8;
+    tw->clear();
+    int ns = 1;
+    for (int p = 0; p < np; p++) {
+        MrPass &ps = plan->pass[p];
+        ps.radix = radix[p];
+        ps.ns = ns;
+        ps.nb = n / radix[p];
+        ps.m_nb = magic(ps.nb);
+        ps.m_ns = ns > 1 ? magic(ns) : 0;
+        ps.tw_off = (int)(tw->size() / 2);
+        if (p > 0)
+            for (int k = 0; k < ns; k++) {
+                const double a = sign * 2.0 * M_PI * (double)k / ((double)ns * radix[p]);
+                tw->push_back((float)cos(a));
+                tw->push_back((float)sin(a));
+            }
+        ns *= radix[p];
+    }
+    return true;
+}
+
+int mi355_fft_mr_launch(const MrPlan &plan, mi355_ctx *ctx, int sign, const void *in, void *out, const float *window, int nframes, int shift,
+                        int real_in, hipStream_t st)
+{
+    if (nframes <= 0) return MI355_OK;
+    MrArgs a;
+    a.in = in;
+    a.out = (c32 *)out;
+    a.window = window;
+    a.tw = (const c32 *)plan.d_tw;
+    a.n = plan.n;
+    a.nframes = nframes;
+    a.frames = plan.frames;
+    a.npass = plan.npass;
+    a.in_rot = (sign > 0 && shift) ? plan.n / 2 : 0;         // floor(n/2), lib/clFFT_impl.cc:491
+    a.out_rot = (sign < 0 && shift) ? (plan.n + 1) / 2 : 0;  // ceil(n/2), lib/clFFT_impl.cc:503-507
+    a.real_in = real_in;
+    a.ngroups = ((long long)nframes + plan.frames - 1) / plan.frames;
+    for (int p = 0; p < plan.npass; p++) a.pass[p] = plan.pass[p];
+    const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+    int per_cu = (160 * 1024) / plan.lds_bytes;
+    if (per_cu > 2048 / plan.threads) per_cu = 2048 / plan.threads;
+    if (per_cu < 1) per_cu = 1;
+    long long grid = (long long)cus * per_cu;
+    if (grid > a.ngroups) grid = a.ngroups;
+#define MR_LAUNCH(SG, TH)                                                                                                                \
+    do {                                                                                                                                 \
+        MI355_HIP(hipFuncSetAttribute((const void *)k_fft_mr<SG, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, plan.lds_bytes));      \
+        hipLaunchKernelGGL((k_fft_mr<SG, TH>), dim3((unsigned)grid), dim3(TH), plan.lds_bytes, st, a);                                   \
+    } while (0)
+    if (sign < 0) {
+        if (plan.threads == 256) MR_LAUNCH(-1, 256); else if (plan.threads == 512) MR_LAUNCH(-1, 512); else MR_LAUNCH(-1, 1024);
+    } else {
+        if (plan.threads == 256) MR_LAUNCH(1, 256); else if (plan.threads == 512) MR_LAUNCH(1, 512); else MR_LAUNCH(1, 1024);
+    }
+#undef MR_LAUNCH
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}

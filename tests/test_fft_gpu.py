@@ -166,10 +166,16 @@ def test_zero_vectors_and_bad_sizes(gpu):
         _fft(gpu, 1, gpu.CLFFT_FORWARD)
 
 
-# sizes that are not a power of two (clFFT's radix-3/5/7 plans in the reference) run through the chirp-z path
+# sizes that are not a power of two (clFFT's radix-3/5/7 plans in the reference): lengths 2^a 3^b 5^c 7^d up to 15360 run through the
+# mixed-radix kernel (fft_mr.hip), everything else -- and every length when MI355_FFT_NO_MR is set -- through the chirp-z path
 @pytest.mark.parametrize("n", [3, 5, 12, 48, 100, 1000, 1536, 2000, 4095, 6000, 8191, 10000, 16383])
 @pytest.mark.parametrize("fwd,shift,win", [(True, False, False), (True, True, True), (False, True, True), (False, False, False)])
-def test_sizes_that_are_not_a_power_of_two(gpu, oracle, n, fwd, shift, win):
+@pytest.mark.parametrize("chirpz_only", [False, True])
+def test_sizes_that_are_not_a_power_of_two(gpu, oracle, monkeypatch, n, fwd, shift, win, chirpz_only):
+    if chirpz_only:
+        if n in (3, 5, 4095, 8191, 16383):
+            pytest.skip("not a 2-3-5-7 length: the chirp-z path either way")
+        monkeypatch.setenv("MI355_FFT_NO_MR", "1")  # read when the block is made
     rng = np.random.default_rng(n + 3)
     nvec = 3 if n > 2048 else 7
     w = oracle.window(oracle.WIN_HAMMING, n) if win else None
@@ -178,6 +184,54 @@ def test_sizes_that_are_not_a_power_of_two(gpu, oracle, n, fwd, shift, win):
     blk = _fft(gpu, n, gpu.CLFFT_FORWARD if fwd else gpu.CLFFT_BACKWARD, w, shift=shift)
     assert blk.work(nvec, [x], [y]) == nvec
     assert relerr(y, oracle.fft_block(n, fwd, w, shift, oracle.DTYPE_COMPLEX, x, f64=True)) <= TOL
+
+
+# the mixed-radix kernel: every radix, odd lengths (shift by floor / ceil of n / 2), the longest lengths per workgroup size
+# (256 threads: 3584 with a factor 7, else 3840; 512: 7168 / 7680; 1024: 14336 / 15360), ragged frame counts, real input, device path
+MR_SIZES = [6, 14, 15, 21, 35, 56, 96, 105, 112, 210, 360, 675, 1125, 1715, 2401, 3375, 3584, 3840, 4000, 4200, 5000, 5625, 7168, 7680, 9000,
+            12000, 12005, 14336, 15000, 15360]
+
+
+@pytest.mark.parametrize("n", MR_SIZES)
+def test_mixed_radix_lengths(gpu, oracle, n):
+    import torch
+    rng = np.random.default_rng(n)
+    nvec = 11 if n < 2000 else 3
+    w = oracle.window(oracle.WIN_BLACKMAN, n)
+    x = crandn(rng, nvec * n)
+    y = np.empty_like(x)
+    ref_fn = (lambda f, ww, sh, xx: oracle.fft_block(n, f, ww, sh, oracle.DTYPE_COMPLEX, xx, f64=True)) if n <= 2401 else \
+             (lambda f, ww, sh, xx: _np_fft_block(n, f, ww, sh, xx))
+    for fwd, shift, win in ((True, True, True), (False, True, True), (True, False, False), (False, False, False)):
+        blk = _fft(gpu, n, gpu.CLFFT_FORWARD if fwd else gpu.CLFFT_BACKWARD, w if win else None, shift=shift)
+        assert blk.work(nvec, [x], [y]) == nvec
+        err = relerr(y, ref_fn(fwd, w if win else None, shift, x))
+        assert err <= TOL and err <= 3e-6, (n, fwd, shift, err)
+    # real input, forward + shift, on device buffers
+    xr = rng.standard_normal(nvec * n).astype(np.float32)
+    blk = _fft(gpu, n, gpu.CLFFT_FORWARD, w, dtype=gpu.DTYPE_FLOAT, shift=True)
+    dx = torch.from_numpy(xr).cuda()
+    dy = torch.empty(nvec * n, 2, device="cuda")
+    blk.work_device(nvec, [dx], [dy])
+    torch.cuda.synchronize()
+    assert relerr(dy.cpu().numpy().view(np.complex64).reshape(-1), ref_fn(True, w, True, xr.astype(np.complex64))) <= TOL
+
+
+def test_mixed_radix_many_frames_and_tone(gpu, oracle):
+    # more frame groups than workgroups (grid-stride), a ragged last group, and a closed form: one cycle-k tone -> n in bin k
+    n, nvec = 1000, 20011
+    rng = np.random.default_rng(5)
+    x = crandn(rng, nvec * n)
+    y = np.empty_like(x)
+    _fft(gpu, n, gpu.CLFFT_FORWARD).work(nvec, [x], [y])
+    for f0 in (0, 777, nvec - 3):
+        sl = slice(f0 * n, (f0 + 3) * n)
+        assert relerr(y[sl], oracle.fft_block(n, True, None, False, oracle.DTYPE_COMPLEX, x[sl], f64=True)) <= TOL
+    n = 12000
+    t = np.exp(2j * np.pi * 4321 * np.arange(n) / n).astype(np.complex64)
+    z = np.empty_like(t)
+    _fft(gpu, n, gpu.CLFFT_FORWARD).work(1, [t], [z])
+    assert abs(z[4321] - n) < 0.05 and np.abs(np.delete(z, 4321)).max() < 0.05
 
 
 def test_chirpz_real_input_device_path_and_chunks(gpu, oracle):
