@@ -1598,6 +1598,8 @@ extern "C" int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, con
         if (!getenv("MI355_FFT_NO_MR") && mi355_fft_mr_plan(fft_size, h->sign, &h->mr, &mtw)) {
             if (hipMalloc(&h->mr.d_tw, mtw.size() * sizeof(float)) != hipSuccess) return fail(MI355_ERR_NOMEM);
             if (mi355_upload(ctx, h->mr.d_tw, mtw.data(), mtw.size() * sizeof(float)) != hipSuccess) return fail(MI355_ERR_HIP);
+            rc = mi355_fft_mr_tune(&h->mr, ctx, h->sign, h->d_window, h->mr.per_thread);
+            if (rc) return fail(rc);
         } else {
             h->mr.n = 0;
             rc = setup_bluestein(h, window_len ? window : nullptr);

@@ -14,15 +14,20 @@ struct MrPass {
 
 struct MrPlan {
     int n = 0, npass = 0;
-    int threads = 0;            // workgroup size (256 / 512 / 1024)
+    int threads = 0;            // workgroup size (a multiple of 64, at most 1024)
     int frames = 0;             // frames a workgroup transforms per iteration
     int lds_bytes = 0;
+    int per_thread = 0;         // values a thread holds in the tightest pass (14 with a radix 7, 15 with 3 or 5)
     MrPass pass[12];
     void *d_tw = nullptr;       // the passes' twiddle runs, back to back
 };
 
 // false: n is not of this form (or does not fit a workgroup): use the chirp-z path.  tw receives the host copy of the twiddle runs.
 bool mi355_fft_mr_plan(int n, int sign, MrPlan *plan, std::vector<float> *tw);
+
+// Measures (threads, frames) for this length once per process and keeps the fastest (MI355_FFT_MR_AUTOTUNE=0: the plan's rule stands).
+// plan->d_tw and window_dev (n floats on the device) must be in place.
+int mi355_fft_mr_tune(MrPlan *plan, mi355_ctx *ctx, int sign, const float *window_dev, int per_thread);
 
 // in: nframes frames of n values (complex, or float when real_in); out: nframes x n complex.  window: n floats (all ones = no window).
 // shift as in oracle_fft_block: reverse = input halves swapped (window indexed by the original position), forward = output rotated by ceil(n/2).

@@ -14,6 +14,12 @@
 // the power-of-two radices would otherwise put a wave's stores in a handful of banks).
 #include "fft_mr.h"
 
+#include <cmath>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "fft_core.hpp"
 
 using namespace fftc;
@@ -87,9 +93,10 @@ template <int R, int SIGN> __device__ __forceinline__ void dft(c32 *v)
 }
 
 // MODE 0: first pass (global -> LDS), 1: LDS -> LDS, 2: last pass (LDS -> global)
-template <int R, int SIGN, int MODE, int TH>
+template <int R, int SIGN, int MODE>
 __device__ __forceinline__ void mr_pass(const MrArgs &a, const MrPass &ps, c32 *lds, int tid, long long group)
 {
+    const int TH = blockDim.x;
     constexpr int B = kVals / R;
     c32 v[B][R];
     int fr[B], bb[B];
@@ -166,20 +173,20 @@ __device__ __forceinline__ void mr_pass(const MrArgs &a, const MrPass &ps, c32 *
     if constexpr (MODE != 2) __syncthreads();
 }
 
-template <int SIGN, int TH>
-__global__ __launch_bounds__(TH) void k_fft_mr(const MrArgs a)
+template <int SIGN>
+__global__ __launch_bounds__(1024) void k_fft_mr(const MrArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) c32 mr_lds[];
     const int tid0 = threadIdx.x;
 #define MR_PASS(MODE, P)                                                                        \
     switch (a.pass[P].radix) {                                                                  \
-    case 2: mr_pass<2, SIGN, MODE, TH>(a, a.pass[P], mr_lds, tid, group); break;                \
-    case 3: mr_pass<3, SIGN, MODE, TH>(a, a.pass[P], mr_lds, tid, group); break;                \
-    case 4: mr_pass<4, SIGN, MODE, TH>(a, a.pass[P], mr_lds, tid, group); break;                \
-    case 5: mr_pass<5, SIGN, MODE, TH>(a, a.pass[P], mr_lds, tid, group); break;                \
-    case 7: mr_pass<7, SIGN, MODE, TH>(a, a.pass[P], mr_lds, tid, group); break;                \
-    case 8: mr_pass<8, SIGN, MODE, TH>(a, a.pass[P], mr_lds, tid, group); break;                \
-    default: mr_pass<16, SIGN, MODE, TH>(a, a.pass[P], mr_lds, tid, group); break;              \
+    case 2: mr_pass<2, SIGN, MODE>(a, a.pass[P], mr_lds, tid, group); break;                \
+    case 3: mr_pass<3, SIGN, MODE>(a, a.pass[P], mr_lds, tid, group); break;                \
+    case 4: mr_pass<4, SIGN, MODE>(a, a.pass[P], mr_lds, tid, group); break;                \
+    case 5: mr_pass<5, SIGN, MODE>(a, a.pass[P], mr_lds, tid, group); break;                \
+    case 7: mr_pass<7, SIGN, MODE>(a, a.pass[P], mr_lds, tid, group); break;                \
+    case 8: mr_pass<8, SIGN, MODE>(a, a.pass[P], mr_lds, tid, group); break;                \
+    default: mr_pass<16, SIGN, MODE>(a, a.pass[P], mr_lds, tid, group); break;              \
     }
     for (long long group = blockIdx.x; group < a.ngroups; group += gridDim.x) {
         // opaque per iteration: everything below depends on the thread number and the pass only, and hoisted out of this loop -- for every
@@ -224,15 +231,35 @@ bool mi355_fft_mr_plan(int n, int sign, MrPlan *plan, std::vector<float> *tw)
         const int v = (kVals / radix[p]) * radix[p];
         if (v < per_thread) per_thread = v;
     }
-    int th = 0;
-    for (int t : {256, 512, 1024})
-        if ((long long)t * per_thread >= n) { th = t; break; }
+    // Workgroup size and frames per iteration (tools/fft_mr_sweep.py: every size x frame count, 12 ... 15360 points).  The fastest
+    // arrangements fill the CU's LDS with frames and give them about 1536 threads, 10 - 12 values per thread rather than the 15 - 16 a
+    // thread can hold: W workgroups per CU of 1536 / W threads, each with as many frames as its share of the LDS (and its threads) hold;
+    // the W with the most values resident per CU wins, the smaller workgroup on a tie.
+    int th = 0, frames = 0;
+    long long best = 0;
+    for (int w : {8, 6, 5, 4, 3, 2, 1}) {
+        int t = w == 1 ? 1024 : 1536 / w / 64 * 64;
+        long long f = (long long)t * per_thread / n;
+        const long long lds_vals = (160 * 1024 / w / 8 - 1) * 32 / 33;  // slots of an LDS share, minus the padding
+        if (f > lds_vals / n) f = lds_vals / n;
+        if (f < 1) continue;
+        if (w * f * n > best) {
+            best = w * f * n;
+            th = t;
+            frames = (int)f;
+        }
+    }
+    if (const char *e = getenv("MI355_FFT_MR_THREADS")) {  // (tuning switches, read at create: threads, frames per iteration)
+        const int t = atoi(e), f = getenv("MI355_FFT_MR_FRAMES") ? atoi(getenv("MI355_FFT_MR_FRAMES")) : 1;
+        if (t >= 64 && t <= 1024 && t % 64 == 0 && f >= 1 && (long long)f * n <= (long long)t * per_thread) { th = t; frames = f; }
+    }
     if (!th) return false;  // longer than a workgroup holds: chirp-z
     plan->n = n;
     plan->npass = np;
     plan->threads = th;
-    plan->frames = th * per_thread / n;
+    plan->frames = frames;
     plan->lds_bytes = (plan->frames * n + (plan->frames * n >> 5) + 1) * 8;
+    plan->per_thread = per_thread;
     tw->clear();
     int ns = 1;
     for (int p = 0; p < np; p++) {
@@ -254,10 +281,12 @@ bool mi355_fft_mr_plan(int n, int sign, MrPlan *plan, std::vector<float> *tw)
     return true;
 }
 
-int mi355_fft_mr_launch(const MrPlan &plan, mi355_ctx *ctx, int sign, const void *in, void *out, const float *window, int nframes, int shift,
-                        int real_in, hipStream_t st)
+namespace {
+int lds_bytes_for(int n, int frames) { return (frames * n + (frames * n >> 5) + 1) * 8; }
+
+int launch_with(const MrPlan &plan, int threads, int frames, mi355_ctx *ctx, int sign, const void *in, void *out, const float *window, int nframes,
+                int shift, int real_in, hipStream_t st)
 {
-    if (nframes <= 0) return MI355_OK;
     MrArgs a;
     a.in = in;
     a.out = (c32 *)out;
@@ -265,30 +294,122 @@ int mi355_fft_mr_launch(const MrPlan &plan, mi355_ctx *ctx, int sign, const void
     a.tw = (const c32 *)plan.d_tw;
     a.n = plan.n;
     a.nframes = nframes;
-    a.frames = plan.frames;
+    a.frames = frames;
     a.npass = plan.npass;
     a.in_rot = (sign > 0 && shift) ? plan.n / 2 : 0;         // floor(n/2), lib/clFFT_impl.cc:491
     a.out_rot = (sign < 0 && shift) ? (plan.n + 1) / 2 : 0;  // ceil(n/2), lib/clFFT_impl.cc:503-507
     a.real_in = real_in;
-    a.ngroups = ((long long)nframes + plan.frames - 1) / plan.frames;
+    a.ngroups = ((long long)nframes + frames - 1) / frames;
     for (int p = 0; p < plan.npass; p++) a.pass[p] = plan.pass[p];
     const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
-    int per_cu = (160 * 1024) / plan.lds_bytes;
-    if (per_cu > 2048 / plan.threads) per_cu = 2048 / plan.threads;
+    const int lds_bytes = lds_bytes_for(plan.n, frames);
+    int per_cu = (160 * 1024) / lds_bytes;
+    if (per_cu > 2048 / threads) per_cu = 2048 / threads;
     if (per_cu < 1) per_cu = 1;
     long long grid = (long long)cus * per_cu;
     if (grid > a.ngroups) grid = a.ngroups;
-#define MR_LAUNCH(SG, TH)                                                                                                                \
-    do {                                                                                                                                 \
-        MI355_HIP(hipFuncSetAttribute((const void *)k_fft_mr<SG, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, plan.lds_bytes));      \
-        hipLaunchKernelGGL((k_fft_mr<SG, TH>), dim3((unsigned)grid), dim3(TH), plan.lds_bytes, st, a);                                   \
+#define MR_LAUNCH(SG)                                                                                                     \
+    do {                                                                                                                  \
+        MI355_HIP(hipFuncSetAttribute((const void *)k_fft_mr<SG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
+        hipLaunchKernelGGL((k_fft_mr<SG>), dim3((unsigned)grid), dim3(threads), lds_bytes, st, a);                         \
     } while (0)
-    if (sign < 0) {
-        if (plan.threads == 256) MR_LAUNCH(-1, 256); else if (plan.threads == 512) MR_LAUNCH(-1, 512); else MR_LAUNCH(-1, 1024);
-    } else {
-        if (plan.threads == 256) MR_LAUNCH(1, 256); else if (plan.threads == 512) MR_LAUNCH(1, 512); else MR_LAUNCH(1, 1024);
-    }
+    if (sign < 0) MR_LAUNCH(-1); else MR_LAUNCH(1);
 #undef MR_LAUNCH
     MI355_HIP(hipGetLastError());
     return MI355_OK;
+}
+
+std::mutex g_tuned_lock;
+std::map<int, std::pair<int, int>> g_tuned;  // length -> (threads, frames) measured in this process
+}  // namespace
+
+int mi355_fft_mr_launch(const MrPlan &plan, mi355_ctx *ctx, int sign, const void *in, void *out, const float *window, int nframes, int shift,
+                        int real_in, hipStream_t st)
+{
+    if (nframes <= 0) return MI355_OK;
+    return launch_with(plan, plan.threads, plan.frames, ctx, sign, in, out, window, nframes, shift, real_in, st);
+}
+
+// The rate over (threads, frames per iteration) is irregular -- 4000 points: 320 threads 163 GS/s, 384 threads 107, 512 threads 131; the
+// rule of mi355_fft_mr_plan is within 5 % of the best for most lengths and 35 % off for some -- so the handle measures it once per
+// length and process: every workgroup size x a few frame counts on 2^23 zero samples, on the context's upload stream (no other
+// stream waits for it), about 10 ms.  MI355_FFT_MR_AUTOTUNE=0 keeps the rule.
+int mi355_fft_mr_tune(MrPlan *plan, mi355_ctx *ctx, int sign, const float *window_dev, int per_thread)
+{
+    if (const char *e = getenv("MI355_FFT_MR_AUTOTUNE"))
+        if (atoi(e) == 0) return MI355_OK;
+    if (getenv("MI355_FFT_MR_THREADS")) return MI355_OK;
+    {
+        std::lock_guard<std::mutex> g(g_tuned_lock);
+        auto it = g_tuned.find(plan->n);
+        if (it != g_tuned.end()) {
+            plan->threads = it->second.first;
+            plan->frames = it->second.second;
+            plan->lds_bytes = lds_bytes_for(plan->n, plan->frames);
+            return MI355_OK;
+        }
+    }
+    const int n = plan->n;
+    const size_t total = (size_t)1 << 23;
+    const int nframes = (int)(total / n);
+    void *din = nullptr, *dout = nullptr;
+    if (hipMalloc(&din, (size_t)nframes * n * 8) != hipSuccess) return MI355_OK;  // no room to measure: the rule stands
+    if (hipMalloc(&dout, (size_t)nframes * n * 8) != hipSuccess) { (void)hipFree(din); return MI355_OK; }
+    std::lock_guard<std::mutex> g(ctx->upload_lock);
+    hipStream_t st = ctx->upload;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = MI355_OK;
+    auto done = [&](int r) {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        (void)hipFree(din);
+        (void)hipFree(dout);
+        return r;
+    };
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return done(MI355_OK);
+    if (hipMemsetAsync(din, 0, (size_t)nframes * n * 8, st) != hipSuccess) return done(MI355_OK);
+    float best_ms = 1e30f;
+    int best_t = plan->threads, best_f = plan->frames;
+    auto trial = [&](int t, int f) {
+        if (f < 1 || (long long)f * n > (long long)t * per_thread || lds_bytes_for(n, f) > 160 * 1024) return;
+        if (launch_with(*plan, t, f, ctx, sign, din, dout, window_dev, nframes, 0, 0, st) != MI355_OK) { rc = MI355_ERR_HIP; return; }
+        float ms = 1e30f;
+        for (int rep = 0; rep < 2; rep++) {  // the faster of two bursts of three launches
+            (void)hipEventRecord(e0, st);
+            for (int k = 0; k < 3; k++)
+                if (launch_with(*plan, t, f, ctx, sign, din, dout, window_dev, nframes, 0, 0, st) != MI355_OK) { rc = MI355_ERR_HIP; return; }
+            (void)hipEventRecord(e1, st);
+            if (hipEventSynchronize(e1) != hipSuccess) { rc = MI355_ERR_HIP; return; }
+            float m = 0.f;
+            if (hipEventElapsedTime(&m, e0, e1) != hipSuccess) return;
+            if (m < ms) ms = m;
+        }
+        if (ms < best_ms * 0.98f) {  // (a later candidate has to be clearly faster: ties keep the smaller workgroup)
+            best_ms = ms;
+            best_t = t;
+            best_f = f;
+        }
+    };
+    trial(plan->threads, plan->frames);  // the rule's choice first: it stays unless something is 2 % faster
+    for (int t = 64; t <= 1024 && rc == MI355_OK; t += 64) {
+        const int fmax = (int)((long long)t * per_thread / n);
+        if (fmax < 1) continue;
+        int tried[4] = {fmax, (fmax * 3 + 3) / 4, (fmax + 1) / 2, 1}, ntried = 0;
+        for (int f : tried) {
+            bool dup = false;
+            for (int q = 0; q < ntried; q++) dup = dup || tried[q] == f;
+            if (!dup && rc == MI355_OK) trial(t, f);
+            tried[ntried++] = f;
+        }
+    }
+    if (rc != MI355_OK) return done(rc);
+    plan->threads = best_t;
+    plan->frames = best_f;
+    plan->lds_bytes = lds_bytes_for(n, best_f);
+    {
+        std::lock_guard<std::mutex> g2(g_tuned_lock);
+        g_tuned[n] = std::make_pair(best_t, best_f);
+    }
+    mi355_log(ctx, MI355_LOG_INFO, "clFFT %d points (mixed radix): %d threads x %d frame(s) per workgroup measured fastest", n, best_t, best_f);
+    return done(MI355_OK);
 }
