@@ -473,6 +473,12 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank, out=None):
         fb = pkg.clFFT(fn_, pkg.CLFFT_FORWARD, np.blackman(fn_).astype(np.float32), pkg.DTYPE_COMPLEX, *args, 0, 1, True)
         nv = n // fn_
         out["clFFT_%d" % fn_] = rate(lambda: fb.work_device(nv, [a], [c]), nv * fn_, 16)
+    # lengths that are not a power of two: 2^a 3^b 5^c 7^d through the mixed-radix kernel (one pass over HBM), a prime through chirp-z
+    for fn_ in (1000, 3000, 12000, 4099):
+        fb = pkg.clFFT(fn_, pkg.CLFFT_FORWARD, np.blackman(fn_).astype(np.float32), pkg.DTYPE_COMPLEX, *args, 0, 1, True)
+        nv = (n // 2) // fn_
+        path = "mixed radix" if fn_ != 4099 else "chirp-z (prime length)"
+        out["clFFT_%d" % fn_] = rate(lambda: fb.work_device(nv, [a], [c]), nv * fn_, 16, lambda dt, path=path: {"path": path})
     # BASELINE configs[3]: polyphase channelizer 64 ch x 32 taps/arm; streaming buffer and the 65536-item call
     for buf, key in (((1 << 26) - (1 << 16), "clPolyphaseChannelizer_64x32_stream"), (65536, "clPolyphaseChannelizer_64x32_buf65536")):
         pfb = pkg.clPolyphaseChannelizer(*args, taps2048, buf, 64, 64, list(range(64)))

@@ -98,14 +98,22 @@ __device__ __forceinline__ void mr_pass(const MrArgs &a, const MrPass &ps, c32 *
 {
     const int TH = blockDim.x;
     constexpr int B = kVals / R;
-    c32 v[B][R];
-    int fr[B], bb[B];
+    c32 v[B][R], w1[B];
+    int fr[B], bb[B], gq[B], kq[B];
     const int n = a.n, nb = ps.nb, nbt = a.frames * nb;
 #pragma unroll
     for (int i = 0; i < B; i++) {
         const int b = tid + TH * i;
         fr[i] = (int)__umulhi((unsigned)b, ps.m_nb);
         bb[i] = b - fr[i] * nb;
+        gq[i] = bb[i];
+        kq[i] = 0;
+        if constexpr (MODE != 0) {
+            gq[i] = (int)__umulhi((unsigned)bb[i], ps.m_ns);
+            kq[i] = bb[i] - gq[i] * ps.ns;
+            // the butterfly's twiddle comes from L1 / L2: asked for before the LDS reads and the barrier, not after them
+            w1[i] = b < nbt ? a.tw[ps.tw_off + kq[i]] : mk(1.f, 0.f);
+        }
         if (b < nbt) {
             if constexpr (MODE == 0) {
                 const long long frame = group * a.frames + fr[i];
@@ -138,12 +146,10 @@ __device__ __forceinline__ void mr_pass(const MrArgs &a, const MrPass &ps, c32 *
     for (int i = 0; i < B; i++) {
         const int b = tid + TH * i;
         if (b < nbt) {
-            int g = bb[i], k = 0;
+            const int g = gq[i], k = kq[i];
             if constexpr (MODE != 0) {
-                g = (int)__umulhi((unsigned)bb[i], ps.m_ns);
-                k = bb[i] - g * ps.ns;
                 c32 pw[R];
-                pw[1] = a.tw[ps.tw_off + k];
+                pw[1] = w1[i];
 #pragma unroll
                 for (int r = 2; r < R; r++) pw[r] = (r & 1) ? cmul(pw[r - 1], pw[1]) : cmul(pw[r >> 1], pw[r >> 1]);
 #pragma unroll
