@@ -1595,11 +1595,40 @@ extern "C" int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, con
     if (rc) return fail(rc);
     if (!pow2) {
         std::vector<float> mtw;
-        if (!getenv("MI355_FFT_NO_MR") && mi355_fft_mr_plan(fft_size, h->sign, &h->mr, &mtw)) {
-            if (hipMalloc(&h->mr.d_tw, mtw.size() * sizeof(float)) != hipSuccess) return fail(MI355_ERR_NOMEM);
-            if (mi355_upload(ctx, h->mr.d_tw, mtw.data(), mtw.size() * sizeof(float)) != hipSuccess) return fail(MI355_ERR_HIP);
-            rc = mi355_fft_mr_tune(&h->mr, ctx, h->sign, h->d_window, h->mr.per_thread);
-            if (rc) return fail(rc);
+        if (!getenv("MI355_FFT_NO_MR") && mi355_fft_mr_plan(fft_size, h->sign, 0, &h->mr, &mtw)) {
+            // Two factorisations (fewest passes / at least 14 values per thread), each with its workgroup size and frames per iteration
+            // measured once per length and process (fft_mr.hip); the faster one stays.  ~20 ms at the first handle of a length.
+            auto put = [&](MrPlan &pl, const std::vector<float> &t) {
+                if (hipMalloc(&pl.d_tw, t.size() * sizeof(float)) != hipSuccess) return (int)MI355_ERR_NOMEM;
+                return mi355_upload(ctx, pl.d_tw, t.data(), t.size() * sizeof(float)) != hipSuccess ? (int)MI355_ERR_HIP : (int)MI355_OK;
+            };
+            const int known = mi355_fft_mr_cached_variant(fft_size);
+            MrPlan alt;
+            std::vector<float> atw;
+            const bool have_alt = mi355_fft_mr_plan(fft_size, h->sign, 1, &alt, &atw) && (alt.npass != h->mr.npass || alt.per_thread != h->mr.per_thread);
+            if (known == 1 && have_alt) {
+                h->mr = alt;
+                mtw.swap(atw);
+            }
+            if ((rc = put(h->mr, mtw))) return fail(rc);
+            float ms0 = -1.f, ms1 = -1.f;
+            if ((rc = mi355_fft_mr_tune(&h->mr, ctx, h->sign, h->d_window, &ms0))) return fail(rc);
+            if (known < 0 && have_alt && ms0 > 0.f) {
+                if ((rc = put(alt, atw))) { if (alt.d_tw) (void)hipFree(alt.d_tw); return fail(rc); }
+                rc = mi355_fft_mr_tune(&alt, ctx, h->sign, h->d_window, &ms1);
+                if (rc) { (void)hipFree(alt.d_tw); return fail(rc); }
+                if (ms1 > 0.f && ms1 < ms0 * 0.98f) {
+                    (void)hipFree(h->mr.d_tw);
+                    h->mr = alt;
+                } else {
+                    (void)hipFree(alt.d_tw);
+                }
+            }
+            if (ms0 > 0.f) {
+                mi355_fft_mr_remember(h->mr);
+                mi355_log(ctx, MI355_LOG_INFO, "clFFT %d points (mixed radix): %d passes, %d threads x %d frame(s) per workgroup measured fastest", fft_size,
+                          h->mr.npass, h->mr.threads, h->mr.frames);
+            }
         } else {
             h->mr.n = 0;
             rc = setup_bluestein(h, window_len ? window : nullptr);

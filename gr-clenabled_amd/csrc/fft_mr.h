@@ -17,17 +17,21 @@ struct MrPlan {
     int threads = 0;            // workgroup size (a multiple of 64, at most 1024)
     int frames = 0;             // frames a workgroup transforms per iteration
     int lds_bytes = 0;
+    int variant = 0;            // 0: fewest passes; 1: at least 14 values per thread in every pass, then fewest passes
     int per_thread = 0;         // values a thread holds in the tightest pass (14 with a radix 7, 15 with 3 or 5)
     MrPass pass[12];
     void *d_tw = nullptr;       // the passes' twiddle runs, back to back
 };
 
 // false: n is not of this form (or does not fit a workgroup): use the chirp-z path.  tw receives the host copy of the twiddle runs.
-bool mi355_fft_mr_plan(int n, int sign, MrPlan *plan, std::vector<float> *tw);
+bool mi355_fft_mr_plan(int n, int sign, int variant, MrPlan *plan, std::vector<float> *tw);
 
-// Measures (threads, frames) for this length once per process and keeps the fastest (MI355_FFT_MR_AUTOTUNE=0: the plan's rule stands).
-// plan->d_tw and window_dev (n floats on the device) must be in place.
-int mi355_fft_mr_tune(MrPlan *plan, mi355_ctx *ctx, int sign, const float *window_dev, int per_thread);
+// Measures (threads, frames) for this plan and keeps the fastest; *best_ms = time of the fastest trial (-1: nothing was measured --
+// MI355_FFT_MR_AUTOTUNE=0, a forced size, no memory, or this length's result is remembered).  plan->d_tw and window_dev must be in place.
+int mi355_fft_mr_tune(MrPlan *plan, mi355_ctx *ctx, int sign, const float *window_dev, float *best_ms);
+// what a previous handle of this process found for length n: the variant it kept (-1: nothing yet) / store the winner
+int mi355_fft_mr_cached_variant(int n);
+void mi355_fft_mr_remember(const MrPlan &plan);
 
 // in: nframes frames of n values (complex, or float when real_in); out: nframes x n complex.  window: n floats (all ones = no window).
 // shift as in oracle_fft_block: reverse = input halves swapped (window indexed by the original position), forward = output rotated by ceil(n/2).

@@ -42,7 +42,41 @@ struct MrArgs {
 
 __device__ __forceinline__ int slot(int i) { return i + (i >> 5); }
 
-template <int R> __host__ __device__ constexpr int out_index(int s) { return (R == 8 || R == 16) ? orev<R>(s) : s; }
+// composite radices R = A x B (both with natural-order butterflies): DFT_A down the columns (stride B), W_R^(b k1), DFT_B along the rows
+template <int R> __host__ __device__ constexpr int fac_a() { return R == 6 ? 2 : R == 9 ? 3 : R == 10 ? 2 : R == 12 ? 4 : R == 14 ? 2 : R == 15 ? 3 : 1; }
+template <int R> __host__ __device__ constexpr int out_index(int s)
+{
+    if (R == 8 || R == 16) return orev<R>(s);
+    if (fac_a<R>() > 1) return s / (R / fac_a<R>()) + fac_a<R>() * (s % (R / fac_a<R>()));  // slot B k1 + k2 holds X[k1 + A k2]
+    return s;
+}
+
+// cos / sin of 2 pi m / R for the composite radices (the twiddles between the two factors of a butterfly)
+template <int R> struct Roots;
+template <> struct Roots<6> {
+    static constexpr float c[6] = {1.000000000e+00f, 5.000000000e-01f, -5.000000000e-01f, -1.000000000e+00f, -5.000000000e-01f, 5.000000000e-01f};
+    static constexpr float s[6] = {0.000000000e+00f, 8.660254038e-01f, 8.660254038e-01f, 1.224646799e-16f, -8.660254038e-01f, -8.660254038e-01f};
+};
+template <> struct Roots<9> {
+    static constexpr float c[9] = {1.000000000e+00f, 7.660444431e-01f, 1.736481777e-01f, -5.000000000e-01f, -9.396926208e-01f, -9.396926208e-01f, -5.000000000e-01f, 1.736481777e-01f, 7.660444431e-01f};
+    static constexpr float s[9] = {0.000000000e+00f, 6.427876097e-01f, 9.848077530e-01f, 8.660254038e-01f, 3.420201433e-01f, -3.420201433e-01f, -8.660254038e-01f, -9.848077530e-01f, -6.427876097e-01f};
+};
+template <> struct Roots<10> {
+    static constexpr float c[10] = {1.000000000e+00f, 8.090169944e-01f, 3.090169944e-01f, -3.090169944e-01f, -8.090169944e-01f, -1.000000000e+00f, -8.090169944e-01f, -3.090169944e-01f, 3.090169944e-01f, 8.090169944e-01f};
+    static constexpr float s[10] = {0.000000000e+00f, 5.877852523e-01f, 9.510565163e-01f, 9.510565163e-01f, 5.877852523e-01f, 1.224646799e-16f, -5.877852523e-01f, -9.510565163e-01f, -9.510565163e-01f, -5.877852523e-01f};
+};
+template <> struct Roots<12> {
+    static constexpr float c[12] = {1.000000000e+00f, 8.660254038e-01f, 5.000000000e-01f, 6.123233996e-17f, -5.000000000e-01f, -8.660254038e-01f, -1.000000000e+00f, -8.660254038e-01f, -5.000000000e-01f, -1.836970199e-16f, 5.000000000e-01f, 8.660254038e-01f};
+    static constexpr float s[12] = {0.000000000e+00f, 5.000000000e-01f, 8.660254038e-01f, 1.000000000e+00f, 8.660254038e-01f, 5.000000000e-01f, 1.224646799e-16f, -5.000000000e-01f, -8.660254038e-01f, -1.000000000e+00f, -8.660254038e-01f, -5.000000000e-01f};
+};
+template <> struct Roots<14> {
+    static constexpr float c[14] = {1.000000000e+00f, 9.009688679e-01f, 6.234898019e-01f, 2.225209340e-01f, -2.225209340e-01f, -6.234898019e-01f, -9.009688679e-01f, -1.000000000e+00f, -9.009688679e-01f, -6.234898019e-01f, -2.225209340e-01f, 2.225209340e-01f, 6.234898019e-01f, 9.009688679e-01f};
+    static constexpr float s[14] = {0.000000000e+00f, 4.338837391e-01f, 7.818314825e-01f, 9.749279122e-01f, 9.749279122e-01f, 7.818314825e-01f, 4.338837391e-01f, 1.224646799e-16f, -4.338837391e-01f, -7.818314825e-01f, -9.749279122e-01f, -9.749279122e-01f, -7.818314825e-01f, -4.338837391e-01f};
+};
+template <> struct Roots<15> {
+    static constexpr float c[15] = {1.000000000e+00f, 9.135454576e-01f, 6.691306064e-01f, 3.090169944e-01f, -1.045284633e-01f, -5.000000000e-01f, -8.090169944e-01f, -9.781476007e-01f, -9.781476007e-01f, -8.090169944e-01f, -5.000000000e-01f, -1.045284633e-01f, 3.090169944e-01f, 6.691306064e-01f, 9.135454576e-01f};
+    static constexpr float s[15] = {0.000000000e+00f, 4.067366431e-01f, 7.431448255e-01f, 9.510565163e-01f, 9.945218954e-01f, 8.660254038e-01f, 5.877852523e-01f, 2.079116908e-01f, -2.079116908e-01f, -5.877852523e-01f, -8.660254038e-01f, -9.945218954e-01f, -9.510565163e-01f, -7.431448255e-01f, -4.067366431e-01f};
+};
 
 // DFT_R in place; slot s holds X[out_index<R>(s)] afterwards
 template <int R, int SIGN> __device__ __forceinline__ void dft(c32 *v)
@@ -70,6 +104,26 @@ template <int R, int SIGN> __device__ __forceinline__ void dft(c32 *v)
         v[4] = a1 - b1;
         v[2] = a2 + b2;
         v[3] = a2 - b2;
+    } else if constexpr (fac_a<R>() > 1) {
+        constexpr int A = fac_a<R>(), B = R / A;
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            c32 t[A];
+#pragma unroll
+            for (int q = 0; q < A; q++) t[q] = v[B * q + b];
+            dft<A, SIGN>(t);
+#pragma unroll
+            for (int k1 = 0; k1 < A; k1++) {
+                c32 y = t[k1];
+                if (b * k1 != 0) {
+                    constexpr float sg = SIGN < 0 ? -1.f : 1.f;
+                    y = cmul(y, mk(Roots<R>::c[(b * k1) % R], sg * Roots<R>::s[(b * k1) % R]));
+                }
+                v[B * k1 + b] = y;
+            }
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < A; k1++) dft<B, SIGN>(&v[B * k1]);
     } else {
         static_assert(R == 7, "radix");
         constexpr float c1 = 0.62348980185873353053f, c2 = -0.22252093395631440429f, c3 = -0.90096886790241912624f;
@@ -191,6 +245,12 @@ __global__ __launch_bounds__(1024) void k_fft_mr(const MrArgs a)
     case 4: mr_pass<4, SIGN, MODE>(a, a.pass[P], mr_lds, tid, group); break;                \
     case 5: mr_pass<5, SIGN, MODE>(a, a.pass[P], mr_lds, tid, group); break;                \
     case 7: mr_pass<7, SIGN, MODE>(a, a.pass[P], mr_lds, tid, group); break;                \
+    case 6: mr_pass<6, SIGN, MODE>(a, a.pass[P], mr_lds, tid, group); break;                    \
+    case 9: mr_pass<9, SIGN, MODE>(a, a.pass[P], mr_lds, tid, group); break;                    \
+    case 10: mr_pass<10, SIGN, MODE>(a, a.pass[P], mr_lds, tid, group); break;                  \
+    case 12: mr_pass<12, SIGN, MODE>(a, a.pass[P], mr_lds, tid, group); break;                  \
+    case 14: mr_pass<14, SIGN, MODE>(a, a.pass[P], mr_lds, tid, group); break;                  \
+    case 15: mr_pass<15, SIGN, MODE>(a, a.pass[P], mr_lds, tid, group); break;                  \
     case 8: mr_pass<8, SIGN, MODE>(a, a.pass[P], mr_lds, tid, group); break;                \
     default: mr_pass<16, SIGN, MODE>(a, a.pass[P], mr_lds, tid, group); break;              \
     }
@@ -210,28 +270,52 @@ unsigned magic(int d) { return (unsigned)((0x100000000ull + (unsigned long long)
 
 }  // namespace
 
-bool mi355_fft_mr_plan(int n, int sign, MrPlan *plan, std::vector<float> *tw)
+namespace {
+// factorisation into the radices the kernel has: fewest passes first (every pass is a trip through LDS and two barriers), then the one
+// that leaves a thread the most values (16 / R butterflies of R points: 15 at R = 15, 10 at R = 10), provided 1024 threads hold a frame
+constexpr int kRadices[] = {16, 15, 14, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2};
+struct Factorisation {
+    int np = 99, per_thread = 0;
+    int r[kMaxPass];
+};
+void search(int n, int m, int depth, int first, int per_thread, int floor_pt, int *cur, Factorisation *best)
 {
-    if (n < 6 || (n & (n - 1)) == 0) return false;
-    int radix[kMaxPass], np = 0, m = n;
-    for (int f : {7, 5, 3})
-        while (m % f == 0) {
-            if (np == kMaxPass) return false;
-            radix[np++] = f;
-            m /= f;
+    if (m == 1) {
+        if (depth >= 2 && per_thread >= floor_pt && 1024LL * per_thread >= n && (depth < best->np || (depth == best->np && per_thread > best->per_thread))) {
+            best->np = depth;
+            best->per_thread = per_thread;
+            for (int i = 0; i < depth; i++) best->r[i] = cur[i];
         }
-    if (m & (m - 1)) return false;  // a prime factor above 7
-    int lg = 0;
-    while ((1 << lg) < m) lg++;
-    for (; lg >= 4; lg -= 4) {
-        if (np == kMaxPass) return false;
-        radix[np++] = 16;
+        return;
     }
-    if (lg) {
-        if (np == kMaxPass) return false;
-        radix[np++] = 1 << lg;
+    if (depth >= best->np || depth >= kMaxPass) return;
+    for (int i = first; i < (int)(sizeof kRadices / sizeof kRadices[0]); i++) {
+        const int r = kRadices[i];
+        if (m % r) continue;
+        cur[depth] = r;
+        const int v = (kVals / r) * r;
+        search(n, m / r, depth + 1, i, v < per_thread ? v : per_thread, floor_pt, cur, best);
     }
-    if (np < 2) return false;
+}
+}  // namespace
+
+bool mi355_fft_mr_plan(int n, int sign, int variant, MrPlan *plan, std::vector<float> *tw)
+{
+    if (n < 6 || n > 16 * 1024 || (n & (n - 1)) == 0) return false;
+    Factorisation fz;
+    {
+        int cur[kMaxPass];
+        search(n, n, 0, 0, kVals, variant ? 14 : 0, cur, &fz);
+    }
+    if (fz.np > kMaxPass) return false;  // a prime factor above 7, or longer than a workgroup holds: chirp-z
+    // order: radices with an odd factor first, largest first (the first pass stores with a stride of R slots between lanes: an odd stride
+    // is conflict free; a pass with a power-of-two radix wants a long run Ns of consecutive slots in front of it), then 16s, 8 / 4 / 2 last
+    int radix[kMaxPass], np = 0;
+    for (int pass = 0; pass < 2; pass++)
+        for (int i = 0; i < fz.np; i++) {
+            const bool pow2 = (fz.r[i] & (fz.r[i] - 1)) == 0;
+            if ((pass == 0) != pow2) radix[np++] = fz.r[i];  // (the search lists each group in descending order already)
+        }
     int per_thread = kVals;  // values a thread can hold in every pass of this plan
     for (int p = 0; p < np; p++) {
         const int v = (kVals / radix[p]) * radix[p];
@@ -266,6 +350,7 @@ bool mi355_fft_mr_plan(int n, int sign, MrPlan *plan, std::vector<float> *tw)
     plan->frames = frames;
     plan->lds_bytes = (plan->frames * n + (plan->frames * n >> 5) + 1) * 8;
     plan->per_thread = per_thread;
+    plan->variant = variant;
     tw->clear();
     int ns = 1;
     for (int p = 0; p < np; p++) {
@@ -326,7 +411,8 @@ int launch_with(const MrPlan &plan, int threads, int frames, mi355_ctx *ctx, int
 }
 
 std::mutex g_tuned_lock;
-std::map<int, std::pair<int, int>> g_tuned;  // length -> (threads, frames) measured in this process
+struct Tuned { int variant, threads, frames; };
+std::map<int, Tuned> g_tuned;  // length -> what was measured fastest in this process
 }  // namespace
 
 int mi355_fft_mr_launch(const MrPlan &plan, mi355_ctx *ctx, int sign, const void *in, void *out, const float *window, int nframes, int shift,
@@ -340,17 +426,19 @@ int mi355_fft_mr_launch(const MrPlan &plan, mi355_ctx *ctx, int sign, const void
 // rule of mi355_fft_mr_plan is within 5 % of the best for most lengths and 35 % off for some -- so the handle measures it once per
 // length and process: every workgroup size x a few frame counts on 2^23 zero samples, on the context's upload stream (no other
 // stream waits for it), about 10 ms.  MI355_FFT_MR_AUTOTUNE=0 keeps the rule.
-int mi355_fft_mr_tune(MrPlan *plan, mi355_ctx *ctx, int sign, const float *window_dev, int per_thread)
+int mi355_fft_mr_tune(MrPlan *plan, mi355_ctx *ctx, int sign, const float *window_dev, float *best_ms_out)
 {
+    const int per_thread = plan->per_thread;
+    if (best_ms_out) *best_ms_out = -1.f;
     if (const char *e = getenv("MI355_FFT_MR_AUTOTUNE"))
         if (atoi(e) == 0) return MI355_OK;
     if (getenv("MI355_FFT_MR_THREADS")) return MI355_OK;
     {
         std::lock_guard<std::mutex> g(g_tuned_lock);
         auto it = g_tuned.find(plan->n);
-        if (it != g_tuned.end()) {
-            plan->threads = it->second.first;
-            plan->frames = it->second.second;
+        if (it != g_tuned.end() && it->second.variant == plan->variant) {
+            plan->threads = it->second.threads;
+            plan->frames = it->second.frames;
             plan->lds_bytes = lds_bytes_for(plan->n, plan->frames);
             return MI355_OK;
         }
@@ -412,10 +500,19 @@ int mi355_fft_mr_tune(MrPlan *plan, mi355_ctx *ctx, int sign, const float *windo
     plan->threads = best_t;
     plan->frames = best_f;
     plan->lds_bytes = lds_bytes_for(n, best_f);
-    {
-        std::lock_guard<std::mutex> g2(g_tuned_lock);
-        g_tuned[n] = std::make_pair(best_t, best_f);
-    }
-    mi355_log(ctx, MI355_LOG_INFO, "clFFT %d points (mixed radix): %d threads x %d frame(s) per workgroup measured fastest", n, best_t, best_f);
+    if (best_ms_out) *best_ms_out = best_ms;
     return done(MI355_OK);
+}
+
+int mi355_fft_mr_cached_variant(int n)
+{
+    std::lock_guard<std::mutex> g(g_tuned_lock);
+    auto it = g_tuned.find(n);
+    return it == g_tuned.end() ? -1 : it->second.variant;
+}
+
+void mi355_fft_mr_remember(const MrPlan &plan)
+{
+    std::lock_guard<std::mutex> g(g_tuned_lock);
+    g_tuned[plan.n] = Tuned{plan.variant, plan.threads, plan.frames};
 }

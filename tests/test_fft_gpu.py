@@ -186,10 +186,10 @@ def test_sizes_that_are_not_a_power_of_two(gpu, oracle, monkeypatch, n, fwd, shi
     assert relerr(y, oracle.fft_block(n, fwd, w, shift, oracle.DTYPE_COMPLEX, x, f64=True)) <= TOL
 
 
-# the mixed-radix kernel: every radix, odd lengths (shift by floor / ceil of n / 2), the longest lengths per workgroup size
+# the mixed-radix kernel: every radix (2 ... 16 incl. the composite 6, 9, 10, 12, 14, 15), odd lengths (shift by floor / ceil of n / 2), the longest lengths per workgroup size
 # (256 threads: 3584 with a factor 7, else 3840; 512: 7168 / 7680; 1024: 14336 / 15360), ragged frame counts, real input, device path
-MR_SIZES = [6, 14, 15, 21, 35, 56, 96, 105, 112, 210, 360, 675, 1125, 1715, 2401, 3375, 3584, 3840, 4000, 4200, 5000, 5625, 7168, 7680, 9000,
-            12000, 12005, 14336, 15000, 15360]
+MR_SIZES = [6, 14, 15, 21, 35, 56, 81, 96, 105, 112, 144, 196, 210, 360, 675, 729, 1125, 1715, 1728, 2401, 2744, 3375, 3584, 3840, 4000, 4200,
+            5000, 5625, 7168, 7680, 9000, 10000, 10240 - 10, 12000, 12005, 14336, 15000, 15360]  # (81 = 9 x 9, 144 = 12 x 12, 196 = 14 x 14, 10000 = 10^4)
 
 
 @pytest.mark.parametrize("n", MR_SIZES)
