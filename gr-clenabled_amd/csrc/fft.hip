@@ -1043,7 +1043,7 @@ __global__ __launch_bounds__(256) void k_blu_post(const c32 *__restrict__ A, c32
     }
 }
 
-// Fused chirp-z for m <= 4096 (N <= 2048): one kernel per call, HBM traffic = the frame read once and written once.
+// Fused chirp-z for m <= 16384 (N <= 8192; round 3: m = 8192 / 16384, 2 x the five-launch path -- 3001 points 26 -> 52 GS/s, 8191 36 -> 56): one kernel per call, HBM traffic = the frame read once and written once.
 // Same structure as the overlap-save filter (filter.hip): forward FFT_m, spectrum multiply in registers, inverse FFT_m
 // through the reversed radix plan.  The chirp tables are read from L2 at the positions a thread holds (coalesced).
 template <int M, bool REAL>
@@ -1056,10 +1056,11 @@ __global__ __launch_bounds__(Geo<M>::TH, Geo<M>::WPE) void k_chirpz(const void *
     using G = Geo<M>;
     using PF = Plan<M, false>;
     using PI = Plan<M, true>;
-    constexpr int TH = G::TH, PTS = G::PTS, F = G::F, NP = PF::NP;
+    constexpr int TH = G::TH, F = G::F, NP = PF::NP;
     constexpr int RL = PF::radix(NP - 1), BL = M / RL;
     static_assert(PI::radix(0) == RL, "inverse plan must start with the forward plan's last radix");
-    __shared__ c32 lds[NP > 1 ? PTS : 1];
+    extern __shared__ __attribute__((aligned(16))) c32 chirp_lds[];  // PTS slots (64 / 128 KiB at m = 8192 / 16384)
+    c32 *lds = chirp_lds;
     const int tid0 = threadIdx.x;
     constexpr bool SHARE = (PF::L % 4) == 0;  // all-radix-16 sizes: inverse twiddles = conjugates of the forward ones
     TwRegs<M> twf, twi;
@@ -1131,12 +1132,16 @@ int launch_chirpz_m(mi355_fft *h, const void *in, void *out, int nframes, hipStr
     const int grid = mi355_balanced_grid(h->ctx, ngroups, 2, 3);
     const int lo = (h->sign < 0 && h->shift) ? (h->n + 1) / 2 : 0;
     const int *src = (const int *)((const char *)h->d_post + (size_t)h->n * 8);
-    if (h->dtype == MI355_DTYPE_FLOAT)
-        hipLaunchKernelGGL((k_chirpz<M, true>), dim3(grid), dim3(TH), 0, st, in, (c32 *)out, (const c32 *)h->d_pre, src, (const c32 *)h->d_post,
+    constexpr int lds_bytes = Geo<M>::PTS * 8;
+    if (h->dtype == MI355_DTYPE_FLOAT) {
+        if (lds_bytes > 64 * 1024) MI355_HIP(hipFuncSetAttribute((const void *)k_chirpz<M, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        hipLaunchKernelGGL((k_chirpz<M, true>), dim3(grid), dim3(TH), lds_bytes, st, in, (c32 *)out, (const c32 *)h->d_pre, src, (const c32 *)h->d_post,
                            (const c32 *)h->d_bspec, (const c32 *)h->d_twm_f, (const c32 *)h->d_twm_i, h->n, nframes, ngroups, lo);
-    else
-        hipLaunchKernelGGL((k_chirpz<M, false>), dim3(grid), dim3(TH), 0, st, in, (c32 *)out, (const c32 *)h->d_pre, src, (const c32 *)h->d_post,
+    } else {
+        if (lds_bytes > 64 * 1024) MI355_HIP(hipFuncSetAttribute((const void *)k_chirpz<M, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        hipLaunchKernelGGL((k_chirpz<M, false>), dim3(grid), dim3(TH), lds_bytes, st, in, (c32 *)out, (const c32 *)h->d_pre, src, (const c32 *)h->d_post,
                            (const c32 *)h->d_bspec, (const c32 *)h->d_twm_f, (const c32 *)h->d_twm_i, h->n, nframes, ngroups, lo);
+    }
     MI355_HIP(hipGetLastError());
     return MI355_OK;
 }
@@ -1171,6 +1176,8 @@ int launch_bluestein(mi355_fft *h, const void *in, void *out, int nframes, hipSt
         case 1024: return launch_chirpz_m<1024>(h, in, out, nframes, st);
         case 2048: return launch_chirpz_m<2048>(h, in, out, nframes, st);
         case 4096: return launch_chirpz_m<4096>(h, in, out, nframes, st);
+        case 8192: return launch_chirpz_m<8192>(h, in, out, nframes, st);
+        case 16384: return launch_chirpz_m<16384>(h, in, out, nframes, st);
         }
     }
     // bound the work buffers to 2 x 128 MiB
