@@ -399,11 +399,19 @@ int launch_with(const MrPlan &plan, int threads, int frames, mi355_ctx *ctx, int
     if (per_cu < 1) per_cu = 1;
     long long grid = (long long)cus * per_cu;
     if (grid > a.ngroups) grid = a.ngroups;
-#define MR_LAUNCH(SG)                                                                                                     \
-    do {                                                                                                                  \
-        MI355_HIP(hipFuncSetAttribute((const void *)k_fft_mr<SG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)); \
-        hipLaunchKernelGGL((k_fft_mr<SG>), dim3((unsigned)grid), dim3(threads), lds_bytes, st, a);                         \
-    } while (0)
+    // (the kernels may use the whole LDS: said once per device and direction, not per launch)
+    static std::map<int, bool> lds_ok;  // (device, direction)
+    static std::mutex lds_ok_lock;
+    {
+        std::lock_guard<std::mutex> g(lds_ok_lock);
+        const int which = ctx->device * 2 + (sign < 0 ? 0 : 1);
+        if (!lds_ok[which]) {
+            if (sign < 0) MI355_HIP(hipFuncSetAttribute((const void *)k_fft_mr<-1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            else MI355_HIP(hipFuncSetAttribute((const void *)k_fft_mr<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            lds_ok[which] = true;
+        }
+    }
+#define MR_LAUNCH(SG) hipLaunchKernelGGL((k_fft_mr<SG>), dim3((unsigned)grid), dim3(threads), lds_bytes, st, a)
     if (sign < 0) MR_LAUNCH(-1); else MR_LAUNCH(1);
 #undef MR_LAUNCH
     MI355_HIP(hipGetLastError());
