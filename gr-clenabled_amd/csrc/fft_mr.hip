@@ -153,28 +153,25 @@ __device__ __forceinline__ void mr_pass(const MrArgs &a, const MrPass &ps, c32 *
     const int TH = blockDim.x;
     constexpr int B = kVals / R;
     c32 v[B][R], w1[B];
-    int fr[B], bb[B], gq[B], kq[B];
     const int n = a.n, nb = ps.nb, nbt = a.frames * nb;
+    // (butterfly number -> frame, place in the frame, k: recomputed where they are needed -- four multiply-highs per butterfly cost less
+    // than the registers that would carry them across the barrier)
 #pragma unroll
     for (int i = 0; i < B; i++) {
         const int b = tid + TH * i;
-        fr[i] = (int)__umulhi((unsigned)b, ps.m_nb);
-        bb[i] = b - fr[i] * nb;
-        gq[i] = bb[i];
-        kq[i] = 0;
+        const int fr = (int)__umulhi((unsigned)b, ps.m_nb), bb = b - fr * nb;
         if constexpr (MODE != 0) {
-            gq[i] = (int)__umulhi((unsigned)bb[i], ps.m_ns);
-            kq[i] = bb[i] - gq[i] * ps.ns;
+            const int k = bb - (int)__umulhi((unsigned)bb, ps.m_ns) * ps.ns;
             // the butterfly's twiddle comes from L1 / L2: asked for before the LDS reads and the barrier, not after them
-            w1[i] = b < nbt ? a.tw[ps.tw_off + kq[i]] : mk(1.f, 0.f);
+            w1[i] = b < nbt ? a.tw[ps.tw_off + k] : mk(1.f, 0.f);
         }
         if (b < nbt) {
             if constexpr (MODE == 0) {
-                const long long frame = group * a.frames + fr[i];
+                const long long frame = group * a.frames + fr;
                 const bool live = frame < a.nframes;
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    int src = bb[i] + r * nb + a.in_rot;  // reverse + shift: the halves of the frame are swapped on load
+                    int src = bb + r * nb + a.in_rot;  // reverse + shift: the halves of the frame are swapped on load
                     if (src >= n) src -= n;
                     c32 x = mk(0.f, 0.f);
                     if (live) {
@@ -189,7 +186,7 @@ __device__ __forceinline__ void mr_pass(const MrArgs &a, const MrPass &ps, c32 *
                     v[i][r] = x;
                 }
             } else {
-                const int base = fr[i] * n + bb[i];
+                const int base = fr * n + bb;
 #pragma unroll
                 for (int r = 0; r < R; r++) v[i][r] = lds[slot(base + r * nb)];
             }
@@ -200,18 +197,33 @@ __device__ __forceinline__ void mr_pass(const MrArgs &a, const MrPass &ps, c32 *
     for (int i = 0; i < B; i++) {
         const int b = tid + TH * i;
         if (b < nbt) {
-            const int g = gq[i], k = kq[i];
+            const int fr = (int)__umulhi((unsigned)b, ps.m_nb), bb = b - fr * nb;
+            int g = bb, k = 0;
             if constexpr (MODE != 0) {
-                c32 pw[R];
-                pw[1] = w1[i];
+                g = (int)__umulhi((unsigned)bb, ps.m_ns);
+                k = bb - g * ps.ns;
+                // W^r from W, W^2, W^4, W^8 (at most three products per value): four stored powers instead of R - 1 -- the register
+                // count of the radix-14 ... 16 passes decides how many waves a SIMD holds, and this kernel lives on occupancy
+                c32 sq[4];
+                sq[0] = w1[i];
 #pragma unroll
-                for (int r = 2; r < R; r++) pw[r] = (r & 1) ? cmul(pw[r - 1], pw[1]) : cmul(pw[r >> 1], pw[r >> 1]);
+                for (int q = 1; q < 4; q++) sq[q] = (R > (1 << q)) ? cmul(sq[q - 1], sq[q - 1]) : sq[q - 1];
 #pragma unroll
-                for (int r = 1; r < R; r++) v[i][r] = cmul(v[i][r], pw[r]);
+                for (int r = 1; r < R; r++) {
+                    c32 t = mk(1.f, 0.f);
+                    bool first = true;
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if ((r >> q) & 1) {
+                            t = first ? sq[q] : cmul(t, sq[q]);
+                            first = false;
+                        }
+                    v[i][r] = cmul(v[i][r], t);
+                }
             }
             dft<R, SIGN>(v[i]);
             if constexpr (MODE == 2) {
-                const long long frame = group * a.frames + fr[i];
+                const long long frame = group * a.frames + fr;
                 if (frame < a.nframes) {
 #pragma unroll
                     for (int s = 0; s < R; s++) {
@@ -224,7 +236,7 @@ __device__ __forceinline__ void mr_pass(const MrArgs &a, const MrPass &ps, c32 *
                     }
                 }
             } else {
-                const int base = fr[i] * n + g * ps.ns * R + k;
+                const int base = fr * n + g * ps.ns * R + k;
 #pragma unroll
                 for (int s = 0; s < R; s++) lds[slot(base + out_index<R>(s) * ps.ns)] = v[i][s];
             }
