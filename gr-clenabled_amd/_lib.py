@@ -81,6 +81,7 @@ def lib():
         "mi355_mathconst_work_dev": (i, [vp, sz, vp, vp, vp]),
         "mi355_fft_create": (i, [vp, i, i, vp, i, i, i, i, pp]),
         "mi355_fft_destroy": (i, [vp]),
+        "mi355_fft_plan_text": (i, [i, C.c_char_p, i]),
         "mi355_fft_work": (i, [vp, i, pp, pp]),
         "mi355_fft_work_dev": (i, [vp, i, vp, vp, vp]),
         "mi355_filter_create": (i, [vp, i, vp, i, i, i, pp]),

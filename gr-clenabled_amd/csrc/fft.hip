@@ -1651,6 +1651,37 @@ extern "C" int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, con
     return MI355_OK;
 }
 
+extern "C" int mi355_fft_plan_text(int fft_size, char *buf, int buf_len)
+{
+    MI355_REQUIRE(buf && buf_len > 0, "NULL argument");
+    const bool pow2 = fft_size >= 2 && (fft_size & (fft_size - 1)) == 0;
+    if (fft_size < 2 || (pow2 && fft_size > 16777216) || (!pow2 && fft_size > 8388608)) {
+        snprintf(buf, (size_t)buf_len, "unsupported (powers of two 2..16777216, any other size 3..8388608)");
+        return MI355_ERR_UNSUPPORTED;
+    }
+    if (pow2) {
+        if (fft_size <= 32768) snprintf(buf, (size_t)buf_len, "one pass");
+        else if (fft_size <= 1048576) {
+            int lg = 0;
+            while ((1 << lg) < fft_size) lg++;
+            const int n1 = lg == 17 ? 256 : 1 << ((lg + 1) / 2);
+            snprintf(buf, (size_t)buf_len, "two tile passes %d x %d", n1, fft_size / n1);
+        } else snprintf(buf, (size_t)buf_len, "four passes");
+        return MI355_OK;
+    }
+    MrPlan mp;
+    std::vector<float> tw;
+    if (mi355_fft_mr_plan(fft_size, -1, 0, &mp, &tw)) {
+        int at = snprintf(buf, (size_t)buf_len, "mixed radix ");
+        for (int p = 0; p < mp.npass && at < buf_len; p++) at += snprintf(buf + at, (size_t)(buf_len - at), p ? " x %d" : "%d", mp.pass[p].radix);
+        return MI355_OK;
+    }
+    int m = 256;
+    while (m < 2 * fft_size - 1) m <<= 1;
+    snprintf(buf, (size_t)buf_len, "chirp-z, m = %d%s", m, m <= 16384 ? " (fused)" : "");
+    return MI355_OK;
+}
+
 extern "C" int mi355_fft_destroy(mi355_fft *h)
 {
     if (!h) return MI355_OK;

@@ -150,9 +150,11 @@ int mi355_mathconst_work_dev(mi355_mathconst *h, size_t nitems, const void *a, v
  * clFFT: per frame Y = [fftshift] FFT_N( x .* window ), unnormalised in both
  * directions.  Replaces the clFFT plan + MultiplyFloat kernel + host fftshift
  * of clFFT_impl (ctor lib/clFFT_impl.cc:65-151, processOpenCL :526-634).
- * fft_size: any power of two 2..32768 (single fused kernel), 65536 (two kernels), 131072..1048576 (three passes) and
- * 2097152..16777216 (four passes; 2^24 is clFFT's own single-precision limit), any other size 3..8388608 (chirp-z over the
- * power-of-two kernels; the reference leaves those to clFFT's radix-3/5/7/11/13 plans, which refuse other prime factors);
+ * fft_size: any power of two 2..32768 (one fused kernel), 65536..1048576 (two passes over 16-column tiles), 2097152..16777216
+ * (four passes; 2^24 is clFFT's own single-precision limit); lengths 2^a 3^b 5^c 7^d up to 15360 (14336 with a factor 7) that are not a power of two in
+ * one pass by a mixed-radix kernel (the lengths clFFT's radix-3/5/7 plans cover; its workgroup shape is measured once per length
+ * and process at create, about 20 ms); any other size 3..8388608 by chirp-z over the power-of-two kernels (the reference
+ * leaves those to clFFT, which refuses prime factors above 13);
  * larger sizes return MI355_ERR_UNSUPPORTED.  The shift of an odd-sized frame follows
  * clFFT_impl::testCPU (len = ceil(N/2), :503-507).  window: NULL/0 or exactly fft_size floats
  * (:74-76).  dtype COMPLEX or FLOAT (real input, complex output).
@@ -161,6 +163,10 @@ int mi355_mathconst_work_dev(mi355_mathconst *h, size_t nitems, const void *a, v
 int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, const float *window, int window_len,
                      int dtype, int num_streams, int shift, mi355_fft **out);
 int mi355_fft_destroy(mi355_fft *h);
+/* Which path a length takes, as text ("one pass", "two tile passes 256 x 512", "mixed radix 10 x 10 x 10",
+ * "chirp-z, m = 8192 (fused)", ...): planning only, no device is touched.  Returns MI355_OK, or MI355_ERR_UNSUPPORTED with the
+ * reason in buf for a length mi355_fft_create would refuse. */
+int mi355_fft_plan_text(int fft_size, char *buf, int buf_len);
 int mi355_fft_work(mi355_fft *h, int nvec, const void *const *in_streams, void *const *out_streams);
 /* Concurrency: sizes up to 32768 are stateless (any number of work_dev calls of one handle may be in flight on any streams).
  * 65536 points and more, and the non-power-of-two sizes above 2048, go through ONE per-handle workspace: calls from different threads or

@@ -32,6 +32,51 @@ def test_version_and_strerror(pkg):
     assert L.mi355_strerror(-3) == b"unsupported configuration"
 
 
+def test_fft_plan_text_covers_every_length_class(pkg):
+    """mi355_fft_plan_text: the path a clFFT length takes (planning only -- runs without a device).  Every 2-3-5-7 length up to 15360 (14336 with a factor 7)
+    that is not a power of two gets a mixed-radix plan whose radices multiply to the length and fit 1024 threads of <= 16 values;
+    lengths with a larger prime factor, or longer ones, are chirp-z (the reference's clFFT plans: lib/clFFT_impl.cc:91-128)."""
+    import ctypes as C
+    L = pkg._lib.lib()
+    buf = C.create_string_buffer(256)
+
+    def plan(n):
+        rc = L.mi355_fft_plan_text(n, buf, 256)
+        return rc, buf.value.decode()
+
+    assert plan(4096) == (0, "one pass")
+    assert plan(65536) == (0, "two tile passes 256 x 256")
+    assert plan(131072) == (0, "two tile passes 256 x 512")
+    assert plan(1 << 22) == (0, "four passes")
+    assert plan(1000) == (0, "mixed radix 10 x 10 x 10")
+    assert plan(4099) == (0, "chirp-z, m = 16384 (fused)")  # a prime
+    assert plan(20000) == (0, "chirp-z, m = 65536")         # 2-5 smooth but longer than a workgroup holds
+    assert plan(11 * 1024)[1].startswith("chirp-z")          # a prime factor above 7
+    assert plan(1)[0] != 0 and plan((1 << 24) + 2)[0] != 0 and plan((1 << 23) + 1)[0] != 0
+    allowed = {2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 15, 16}
+    count = 0
+    for n in range(6, 15361):
+        m = n
+        for f in (2, 3, 5, 7):
+            while m % f == 0:
+                m //= f
+        if m != 1 or n & (n - 1) == 0 or n == 7:  # (7 alone has no two-pass factorisation: chirp-z)
+            continue
+        rc, text = plan(n)
+        if n % 7 == 0 and n > 14 * 1024:  # a radix-7 (or 14) pass leaves a thread 14 values: 1024 threads hold 14336
+            assert rc == 0 and text.startswith("chirp-z"), (n, text)
+            continue
+        assert rc == 0 and text.startswith("mixed radix "), (n, text)
+        radices = [int(v) for v in text[len("mixed radix "):].split(" x ")]
+        prod = 1
+        for r in radices:
+            prod *= r
+        assert prod == n and set(radices) <= allowed and len(radices) >= 2, (n, radices)
+        assert min((16 // r) * r for r in radices) * 1024 >= n, (n, radices)
+        count += 1
+    assert count > 350
+
+
 def test_cpu_device_type_is_refused_not_emulated(pkg):
     """OCLTYPE_CPU (3) must NOT fall back to a host implementation."""
     L = pkg.lib()
