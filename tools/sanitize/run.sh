@@ -1,6 +1,7 @@
 #!/bin/bash
 # Sanitizer builds of the host side (SURVEY 5.2 counterpart).  usage: tools/sanitize/run.sh [gpu]
-#   always: the helper pool of runtime.hip under ThreadSanitizer and Address+UB sanitizers (no GPU needed)
+#   always: the helper pool of runtime.hip under ThreadSanitizer and Address+UB sanitizers, the mixed-radix clFFT planner under
+#           Address+UB sanitizers (no GPU needed)
 #   gpu:    the C++ block layer + CLI rebuilt with AddressSanitizer and run against the scheduler-contract, X-engine streaming and
 #           per-block known-answer tests on the device (the HIP library itself stays uninstrumented)
 set -u
@@ -16,6 +17,11 @@ for san in thread address,undefined; do
     echo "== pool stress under -fsanitize=$san"
     TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0" ASAN_OPTIONS="detect_leaks=0" $out 2>&1 | tail -15 || fail=1
 done
+echo "== mixed-radix clFFT planner under -fsanitize=address,undefined"
+$HIPCC -O1 -g -std=c++17 --offload-arch=gfx950 -fsanitize=address,undefined -fno-omit-frame-pointer -I$R/include -I$R/gr-clenabled_amd/csrc \
+    $R/gr-clenabled_amd/csrc/runtime.hip $R/gr-clenabled_amd/csrc/fft_mr.hip $R/tools/sanitize/plan_test.cc -o $B/plan_test -lpthread 2> $B/build_plan.log \
+    || { echo "build failed (planner)"; tail -5 $B/build_plan.log; fail=1; }
+[ -x $B/plan_test ] && { ASAN_OPTIONS="detect_leaks=0" $B/plan_test 2>&1 | tail -5 || fail=1; }
 if [ "${1:-}" = gpu ]; then
     echo "== block layer + CLI under AddressSanitizer (device run)"
     g++ -O1 -g -std=c++17 -fPIC -fsanitize=address -fno-omit-frame-pointer -I$R/gr-clenabled_amd/host/include -I$R/include -shared \
