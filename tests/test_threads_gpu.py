@@ -86,8 +86,19 @@ def test_blocks_work_concurrently_from_threads(gpu, oracle):
             if not np.array_equal(c, np.float32(3.0) * a):
                 errs.append("large copy")
 
+    def run_mixed_radix():  # two threads make a block of the same 2-3-5-7 length at once: its workgroup shape is being measured meanwhile
+        n = 1500
+        x = crandn(np.random.default_rng(10), 5 * n)
+        y = np.empty_like(x)
+        blk = gpu.clFFT(n, gpu.CLFFT_FORWARD, [], gpu.DTYPE_COMPLEX, *GPU_ARGS)
+        ref = oracle.fft_block(n, True, None, False, oracle.DTYPE_COMPLEX, x, f64=True)
+        for _ in range(50):
+            blk.work(5, [x], [y])
+            if relerr(y, ref) > 1e-5:
+                errs.append("fft1500")
+
     ts = [threading.Thread(target=f) for f in (run_fft, run_filter, run_math, run_xe, run_fft, run_math, run_pfb, run_big_fft, run_big_fft,
-                                               run_large_copy, run_large_copy)]
+                                               run_large_copy, run_large_copy, run_mixed_radix, run_mixed_radix)]
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errs, errs[:5]
