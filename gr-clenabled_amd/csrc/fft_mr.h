@@ -1,6 +1,6 @@
-// Mixed-radix clFFT path (fft_mr.hip): lengths 2^a 3^b 5^c 7^d that are not a power of two, one workgroup-resident Stockham pass
+// Mixed-radix clFFT path (fft_mr.hip): lengths 2^a 3^b 5^c 7^d 11^e 13^f that are not a power of two, one workgroup-resident Stockham pass
 // per radix.  The reference's clFFT library plans these lengths natively (lib/clFFT_impl.cc:91-128: clfftCreateDefaultPlan on any
-// length whose prime factors are 2, 3, 5, 7); everything else goes through the chirp-z path of fft.hip.
+// length whose prime factors are 2, 3, 5, 7, 11, 13); everything else goes through the chirp-z path of fft.hip.
 #pragma once
 #include <vector>
 

@@ -1,4 +1,4 @@
-// clFFT for lengths 2^a 3^b 5^c 7^d that are not a power of two (the reference plans them natively through the clFFT library,
+// clFFT for lengths 2^a 3^b 5^c 7^d 11^e 13^f that are not a power of two (the reference plans them natively through the clFFT library,
 // lib/clFFT_impl.cc:91-128; block semantics -- window, shift, real input -- lib/clFFT_impl.cc:464-518, restated in oracle/o_fft.c).
 //
 // One kernel, the transform resident in a workgroup's LDS: a Stockham autosort pass per radix (odd radices first, then 16s, then the
@@ -78,6 +78,15 @@ template <> struct Roots<15> {
     static constexpr float s[15] = {0.000000000e+00f, 4.067366431e-01f, 7.431448255e-01f, 9.510565163e-01f, 9.945218954e-01f, 8.660254038e-01f, 5.877852523e-01f, 2.079116908e-01f, -2.079116908e-01f, -5.877852523e-01f, -8.660254038e-01f, -9.945218954e-01f, -9.510565163e-01f, -7.431448255e-01f, -4.067366431e-01f};
 };
 
+template <> struct Roots<11> {
+    static constexpr float c[11] = {1.000000000e+00f, 8.412535328e-01f, 4.154150130e-01f, -1.423148383e-01f, -6.548607339e-01f, -9.594929736e-01f, -9.594929736e-01f, -6.548607339e-01f, -1.423148383e-01f, 4.154150130e-01f, 8.412535328e-01f};
+    static constexpr float s[11] = {0.000000000e+00f, 5.406408175e-01f, 9.096319954e-01f, 9.898214419e-01f, 7.557495744e-01f, 2.817325568e-01f, -2.817325568e-01f, -7.557495744e-01f, -9.898214419e-01f, -9.096319954e-01f, -5.406408175e-01f};
+};
+template <> struct Roots<13> {
+    static constexpr float c[13] = {1.000000000e+00f, 8.854560257e-01f, 5.680647467e-01f, 1.205366803e-01f, -3.546048870e-01f, -7.485107482e-01f, -9.709418174e-01f, -9.709418174e-01f, -7.485107482e-01f, -3.546048870e-01f, 1.205366803e-01f, 5.680647467e-01f, 8.854560257e-01f};
+    static constexpr float s[13] = {0.000000000e+00f, 4.647231720e-01f, 8.229838659e-01f, 9.927088741e-01f, 9.350162427e-01f, 6.631226582e-01f, 2.393156643e-01f, -2.393156643e-01f, -6.631226582e-01f, -9.350162427e-01f, -9.927088741e-01f, -8.229838659e-01f, -4.647231720e-01f};
+};
+
 // DFT_R in place; slot s holds X[out_index<R>(s)] afterwards
 template <int R, int SIGN> __device__ __forceinline__ void dft(c32 *v)
 {
@@ -124,6 +133,33 @@ template <int R, int SIGN> __device__ __forceinline__ void dft(c32 *v)
         }
 #pragma unroll
         for (int k1 = 0; k1 < A; k1++) dft<B, SIGN>(&v[B * k1]);
+    } else if constexpr (R == 11 || R == 13) {
+        // a prime radix as (R - 1) / 2 symmetric pairs: X[k], X[R - k] = a_k +- i sign b_k, a_k = x0 + sum_j cos(2 pi j k / R) (x_j + x_(R-j)),
+        // b_k = sum_j sin(2 pi j k / R) (x_j - x_(R-j))   (clFFT's remaining radices, lib/clFFT_impl.cc:91-128: lengths with factors 11 and 13)
+        constexpr int H = (R - 1) / 2;
+        c32 t[H], u[H];
+#pragma unroll
+        for (int j = 0; j < H; j++) {
+            t[j] = v[j + 1] + v[R - 1 - j];
+            u[j] = v[j + 1] - v[R - 1 - j];
+        }
+        c32 x0 = v[0], sum = v[0];
+#pragma unroll
+        for (int j = 0; j < H; j++) sum = sum + t[j];
+        v[0] = sum;
+#pragma unroll
+        for (int k = 1; k <= H; k++) {
+            c32 ak = x0, bk = mk(0.f, 0.f);
+#pragma unroll
+            for (int j = 1; j <= H; j++) {
+                const float c = Roots<R>::c[(j * k) % R], sn = Roots<R>::s[(j * k) % R];
+                ak = mk(ak.x + c * t[j - 1].x, ak.y + c * t[j - 1].y);
+                bk = mk(bk.x + sn * u[j - 1].x, bk.y + sn * u[j - 1].y);
+            }
+            const c32 jb = rot90<SIGN>(bk);
+            v[k] = ak + jb;
+            v[R - k] = ak - jb;
+        }
     } else {
         static_assert(R == 7, "radix");
         constexpr float c1 = 0.62348980185873353053f, c2 = -0.22252093395631440429f, c3 = -0.90096886790241912624f;
@@ -260,6 +296,8 @@ __global__ __launch_bounds__(1024) void k_fft_mr(const MrArgs a)
     case 6: mr_pass<6, SIGN, MODE>(a, a.pass[P], mr_lds, tid, group); break;                    \
     case 9: mr_pass<9, SIGN, MODE>(a, a.pass[P], mr_lds, tid, group); break;                    \
     case 10: mr_pass<10, SIGN, MODE>(a, a.pass[P], mr_lds, tid, group); break;                  \
+    case 11: mr_pass<11, SIGN, MODE>(a, a.pass[P], mr_lds, tid, group); break;                  \
+    case 13: mr_pass<13, SIGN, MODE>(a, a.pass[P], mr_lds, tid, group); break;                  \
     case 12: mr_pass<12, SIGN, MODE>(a, a.pass[P], mr_lds, tid, group); break;                  \
     case 14: mr_pass<14, SIGN, MODE>(a, a.pass[P], mr_lds, tid, group); break;                  \
     case 15: mr_pass<15, SIGN, MODE>(a, a.pass[P], mr_lds, tid, group); break;                  \
@@ -285,7 +323,7 @@ unsigned magic(int d) { return (unsigned)((0x100000000ull + (unsigned long long)
 namespace {
 // factorisation into the radices the kernel has: fewest passes first (every pass is a trip through LDS and two barriers), then the one
 // that leaves a thread the most values (16 / R butterflies of R points: 15 at R = 15, 10 at R = 10), provided 1024 threads hold a frame
-constexpr int kRadices[] = {16, 15, 14, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2};
+constexpr int kRadices[] = {16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
 struct Factorisation {
     int np = 99, per_thread = 0;
     int r[kMaxPass];
@@ -319,7 +357,7 @@ bool mi355_fft_mr_plan(int n, int sign, int variant, MrPlan *plan, std::vector<f
         int cur[kMaxPass];
         search(n, n, 0, 0, kVals, variant ? 14 : 0, cur, &fz);
     }
-    if (fz.np > kMaxPass) return false;  // a prime factor above 7, or longer than a workgroup holds: chirp-z
+    if (fz.np > kMaxPass) return false;  // a prime factor above 13, or longer than a workgroup holds: chirp-z
     // order: radices with an odd factor first, largest first (the first pass stores with a stride of R slots between lanes: an odd stride
     // is conflict free; a pass with a power-of-two radix wants a long run Ns of consecutive slots in front of it), then 16s, 8 / 4 / 2 last
     int radix[kMaxPass], np = 0;

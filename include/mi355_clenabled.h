@@ -151,7 +151,7 @@ int mi355_mathconst_work_dev(mi355_mathconst *h, size_t nitems, const void *a, v
  * directions.  Replaces the clFFT plan + MultiplyFloat kernel + host fftshift
  * of clFFT_impl (ctor lib/clFFT_impl.cc:65-151, processOpenCL :526-634).
  * fft_size: any power of two 2..32768 (one fused kernel), 65536..1048576 (two passes over 16-column tiles), 2097152..16777216
- * (four passes; 2^24 is clFFT's own single-precision limit); lengths 2^a 3^b 5^c 7^d up to 15360 (14336 with a factor 7) that are not a power of two in
+ * (four passes; 2^24 is clFFT's own single-precision limit); lengths 2^a 3^b 5^c 7^d 11^e 13^f up to 15360 (14336 / 13312 / 11264 with a factor 7 / 13 / 11) that are not a power of two in
  * one pass by a mixed-radix kernel (the lengths clFFT's radix-3/5/7 plans cover; its workgroup shape is measured once per length
  * and process at create, about 20 ms); any other size 3..8388608 by chirp-z over the power-of-two kernels (the reference
  * leaves those to clFFT, which refuses prime factors above 13);

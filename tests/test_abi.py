@@ -51,9 +51,11 @@ def test_fft_plan_text_covers_every_length_class(pkg):
     assert plan(1000) == (0, "mixed radix 10 x 10 x 10")
     assert plan(4099) == (0, "chirp-z, m = 16384 (fused)")  # a prime
     assert plan(20000) == (0, "chirp-z, m = 65536")         # 2-5 smooth but longer than a workgroup holds
-    assert plan(11 * 1024)[1].startswith("chirp-z")          # a prime factor above 7
+    assert plan(11 * 1024) == (0, "mixed radix 11 x 16 x 16 x 4") and plan(13 * 1024)[1].startswith("mixed radix 13")
+    assert plan(17 * 1024)[1].startswith("chirp-z")          # a prime factor above 13 (clFFT itself refuses those)
+    assert plan(11 * 1024 + 11)[1].startswith("chirp-z")     # 11 values per thread with a radix 11: 1024 threads hold 11264
     assert plan(1)[0] != 0 and plan((1 << 24) + 2)[0] != 0 and plan((1 << 23) + 1)[0] != 0
-    allowed = {2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 15, 16}
+    allowed = {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16}
     count = 0
     for n in range(6, 15361):
         m = n

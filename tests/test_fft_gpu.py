@@ -166,15 +166,15 @@ def test_zero_vectors_and_bad_sizes(gpu):
         _fft(gpu, 1, gpu.CLFFT_FORWARD)
 
 
-# sizes that are not a power of two (clFFT's radix-3/5/7 plans in the reference): lengths 2^a 3^b 5^c 7^d up to 15360 run through the
+# sizes that are not a power of two (clFFT's radix-3/5/7 plans in the reference): lengths 2^a 3^b 5^c 7^d 11^e 13^f up to 15360 run through the
 # mixed-radix kernel (fft_mr.hip), everything else -- and every length when MI355_FFT_NO_MR is set -- through the chirp-z path
 @pytest.mark.parametrize("n", [3, 5, 12, 48, 100, 1000, 1536, 2000, 4095, 6000, 8191, 10000, 16383])
 @pytest.mark.parametrize("fwd,shift,win", [(True, False, False), (True, True, True), (False, True, True), (False, False, False)])
 @pytest.mark.parametrize("chirpz_only", [False, True])
 def test_sizes_that_are_not_a_power_of_two(gpu, oracle, monkeypatch, n, fwd, shift, win, chirpz_only):
     if chirpz_only:
-        if n in (3, 5, 4095, 8191, 16383):
-            pytest.skip("not a 2-3-5-7 length: the chirp-z path either way")
+        if n in (3, 5, 8191, 16383):
+            pytest.skip("not a 2-3-5-7-11-13 length (or too short): the chirp-z path either way")
         monkeypatch.setenv("MI355_FFT_NO_MR", "1")  # read when the block is made
     rng = np.random.default_rng(n + 3)
     nvec = 3 if n > 2048 else 7
@@ -186,10 +186,11 @@ def test_sizes_that_are_not_a_power_of_two(gpu, oracle, monkeypatch, n, fwd, shi
     assert relerr(y, oracle.fft_block(n, fwd, w, shift, oracle.DTYPE_COMPLEX, x, f64=True)) <= TOL
 
 
-# the mixed-radix kernel: every radix (2 ... 16 incl. the composite 6, 9, 10, 12, 14, 15), odd lengths (shift by floor / ceil of n / 2), the longest lengths per workgroup size
+# the mixed-radix kernel: every radix (2 ... 16 incl. the primes 11, 13 and the composite 6, 9, 10, 12, 14, 15), odd lengths (shift by floor / ceil of n / 2), the longest lengths per workgroup size
 # (256 threads: 3584 with a factor 7, else 3840; 512: 7168 / 7680; 1024: 14336 / 15360), ragged frame counts, real input, device path
 MR_SIZES = [6, 14, 15, 21, 35, 56, 81, 96, 105, 112, 144, 196, 210, 360, 675, 729, 1125, 1715, 1728, 2401, 2744, 3375, 3584, 3840, 4000, 4200,
-            5000, 5625, 7168, 7680, 9000, 10000, 10240 - 10, 12000, 12005, 14336, 15000, 15360]  # (81 = 9 x 9, 144 = 12 x 12, 196 = 14 x 14, 10000 = 10^4)
+            5000, 5625, 7168, 7680, 9000, 10000, 10240 - 10, 12000, 12005, 14336, 15000, 15360,  # (81 = 9 x 9, 144 = 12 x 12, 196 = 14 x 14, 10000 = 10^4)
+            22, 143, 1100, 1331, 2197, 2860, 11264, 13312]  # radices 11 and 13 (11 / 13 values per thread: 11264 and 13312 are the longest)
 
 
 @pytest.mark.parametrize("n", MR_SIZES)
