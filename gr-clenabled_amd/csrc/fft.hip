@@ -984,6 +984,7 @@ struct mi355_fft {
     HostPipe pipe;
     // lengths 2^a 3^b 5^c 7^d that a workgroup holds: the mixed-radix kernel (fft_mr.hip); mr.n == 0: not used
     MrPlan mr;
+    MrTilePlan mrt;  // the same lengths above 15360 points: two passes (mrt.n == 0: not used); the workspace is d_wa
     // every other size that is not a power of two: chirp-z (Bluestein) over power-of-two transforms of size m
     int m = 0;
     void *d_pre = nullptr, *d_post = nullptr, *d_bspec = nullptr;  // window*chirp (n), chirp (n), spectrum of the conjugate chirp / m (m)
@@ -1406,8 +1407,37 @@ int launch_big(mi355_fft *h, const void *in, void *out, int nframes, hipStream_t
     return ws_release(h, st);
 }
 
+int launch_mr_tile(mi355_fft *h, const void *in, void *out, int nframes, hipStream_t st)
+{
+    const size_t N = (size_t)h->n;
+    size_t chunk = ((size_t)256 << 20) / (N * 8);  // workspace bounded to 256 MiB
+    if (chunk < 1) chunk = 1;
+    if (chunk > (size_t)nframes) chunk = (size_t)nframes;
+    std::lock_guard<std::mutex> ws_guard(h->ws_lock);
+    {
+        const int rc = ws_acquire(h, st, chunk > h->cap_frames);
+        if (rc) return rc;
+    }
+    if (chunk > h->cap_frames) {
+        MI355_HIP(hipStreamSynchronize(st));
+        if (h->d_wa) (void)hipFree(h->d_wa);
+        h->d_wa = nullptr; h->cap_frames = 0;
+        MI355_HIP(hipMalloc(&h->d_wa, chunk * N * 8));
+        h->cap_frames = chunk;
+    }
+    const size_t isz = h->dtype == MI355_DTYPE_FLOAT ? 4 : 8;
+    for (size_t f0 = 0; f0 < (size_t)nframes; f0 += chunk) {
+        const int nf = (int)((size_t)nframes - f0 < chunk ? (size_t)nframes - f0 : chunk);
+        const int rc = mi355_fft_mr_tile_launch(h->mrt, h->ctx, h->sign, (const char *)in + f0 * N * isz, h->d_wa, (char *)out + f0 * N * 8, h->d_window, nf,
+                                                h->shift, h->dtype == MI355_DTYPE_FLOAT, st);
+        if (rc) return rc;
+    }
+    return ws_release(h, st);
+}
+
 int launch_handle(mi355_fft *h, const void *in, void *out, int nvec, hipStream_t st)
 {
+    if (h->mrt.n) return launch_mr_tile(h, in, out, nvec, st);
     if (h->mr.n) return mi355_fft_mr_launch(h->mr, h->ctx, h->sign, in, out, h->d_window, nvec, h->shift, h->dtype == MI355_DTYPE_FLOAT, st);
     if (h->m) return launch_bluestein(h, in, out, nvec, st);
     if (h->n > 32768 || (h->n == 32768 && h->two_kernel)) return launch_big(h, in, out, nvec, st);
@@ -1638,15 +1668,27 @@ extern "C" int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, con
             }
         } else {
             h->mr.n = 0;
-            rc = setup_bluestein(h, window_len ? window : nullptr);
-            if (rc) return fail(rc);
+            std::vector<float> twa, twb;
+            if (!getenv("MI355_FFT_NO_MR") && mi355_fft_mr_tile_plan(fft_size, h->sign, &h->mrt, &twa, &twb)) {
+                // two passes with the mixed-radix passes inside (fft_mr.hip); W_N^k is the table this handle already has
+                h->mrt.a.d_tw = h->mrt.b.d_tw = nullptr;
+                if (hipMalloc(&h->mrt.a.d_tw, twa.size() * sizeof(float) + 8) != hipSuccess) return fail(MI355_ERR_NOMEM);
+                if (hipMalloc(&h->mrt.b.d_tw, twb.size() * sizeof(float) + 8) != hipSuccess) return fail(MI355_ERR_NOMEM);
+                if (!twa.empty() && mi355_upload(ctx, h->mrt.a.d_tw, twa.data(), twa.size() * sizeof(float)) != hipSuccess) return fail(MI355_ERR_HIP);
+                if (!twb.empty() && mi355_upload(ctx, h->mrt.b.d_tw, twb.data(), twb.size() * sizeof(float)) != hipSuccess) return fail(MI355_ERR_HIP);
+                h->mrt.d_twn = h->d_tw;
+            } else {
+                h->mrt.n = 0;
+                rc = setup_bluestein(h, window_len ? window : nullptr);
+                if (rc) return fail(rc);
+            }
         }
     }
     // (the table uploads ran on the context's upload stream and were waited for there: mi355_upload; no device-wide wait)
     mi355_log(ctx, MI355_LOG_INFO, "clFFT: %d points, %s, %s input, %d stream(s), shift %d, window %s: %s", fft_size,
               h->sign < 0 ? "forward" : "reverse", dtype == MI355_DTYPE_COMPLEX ? "complex" : "float", num_streams, h->shift,
               window_len ? "given" : "none",
-              h->mr.n ? "mixed radix, one pass" : !pow2 ? "chirp-z over a power-of-two transform" : h->tile_n1 ? "two passes over 16-column tiles" : h->two_kernel ? "multi-pass" : "one pass");
+              h->mr.n ? "mixed radix, one pass" : h->mrt.n ? "mixed radix, two passes over sixteen-column tiles" : !pow2 ? "chirp-z over a power-of-two transform" : h->tile_n1 ? "two passes over 16-column tiles" : h->two_kernel ? "multi-pass" : "one pass");
     *out = h;
     return MI355_OK;
 }
@@ -1676,6 +1718,12 @@ extern "C" int mi355_fft_plan_text(int fft_size, char *buf, int buf_len)
         for (int p = 0; p < mp.npass && at < buf_len; p++) at += snprintf(buf + at, (size_t)(buf_len - at), p ? " x %d" : "%d", mp.pass[p].radix);
         return MI355_OK;
     }
+    MrTilePlan tp;
+    std::vector<float> twb;
+    if (mi355_fft_mr_tile_plan(fft_size, -1, &tp, &tw, &twb)) {
+        snprintf(buf, (size_t)buf_len, "mixed radix, two passes %d x %d", tp.n1, tp.n2);
+        return MI355_OK;
+    }
     int m = 256;
     while (m < 2 * fft_size - 1) m <<= 1;
     snprintf(buf, (size_t)buf_len, "chirp-z, m = %d%s", m, m <= 16384 ? " (fused)" : "");
@@ -1690,6 +1738,8 @@ extern "C" int mi355_fft_destroy(mi355_fft *h)
     if (h->d_window) (void)hipFree(h->d_window);
     if (h->d_tw) (void)hipFree(h->d_tw);
     if (h->mr.d_tw) (void)hipFree(h->mr.d_tw);
+    if (h->mrt.a.d_tw) (void)hipFree(h->mrt.a.d_tw);
+    if (h->mrt.b.d_tw) (void)hipFree(h->mrt.b.d_tw);
     for (void *p : {h->d_pre, h->d_post, h->d_bspec, h->d_twm_f, h->d_twm_i, (void *)h->d_ones, h->d_wa, h->d_wb})
         if (p) (void)hipFree(p);
     if (h->ws_done) (void)hipEventDestroy(h->ws_done);
@@ -1747,7 +1797,7 @@ extern "C" int mi355_fft_work(mi355_fft *h, int nvec, const void *const *in_stre
     char *pend_dst[HostPipe::kSlots] = {};
     size_t pend_bytes[HostPipe::kSlots] = {};
     size_t seq = 0;
-    const bool one_stream = h->m || h->n > 32768 || (h->n == 32768 && h->two_kernel);  // chirp-z / multi-pass sizes share work buffers: one stream
+    const bool one_stream = h->m || h->mrt.n || h->n > 32768 || (h->n == 32768 && h->two_kernel);  // chirp-z / multi-pass sizes share work buffers: one stream
     for (int s_i = 0; s_i < h->nstreams; s_i++) {
         MI355_REQUIRE(in_streams[s_i] && out_streams[s_i], "NULL stream buffer");
         const char *pin = (const char *)in_streams[s_i];

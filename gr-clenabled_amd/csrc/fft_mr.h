@@ -37,3 +37,15 @@ void mi355_fft_mr_remember(const MrPlan &plan);
 // shift as in oracle_fft_block: reverse = input halves swapped (window indexed by the original position), forward = output rotated by ceil(n/2).
 int mi355_fft_mr_launch(const MrPlan &plan, mi355_ctx *ctx, int sign, const void *in, void *out, const float *window, int nframes, int shift,
                         int real_in, hipStream_t st);
+
+// Two-pass form for longer lengths of the same kind (15361 ... 921600 points): n = n1 x n2, both 4 ... 960, every pass the mixed-radix
+// passes over sixteen columns of a matrix (fft_mr.hip).  The caller uploads a.d_tw / b.d_tw (twa / twb) and d_twn = W_n^k, k < n.
+struct MrTilePlan {
+    int n = 0, n1 = 0, n2 = 0;
+    MrPlan a, b;           // the n1-point transforms of pass A, the n2-point transforms of pass B
+    void *d_twn = nullptr;
+};
+bool mi355_fft_mr_tile_plan(int n, int sign, MrTilePlan *tp, std::vector<float> *twa, std::vector<float> *twb);
+// ws: nframes x n complex workspace
+int mi355_fft_mr_tile_launch(const MrTilePlan &tp, mi355_ctx *ctx, int sign, const void *in, void *ws, void *out, const float *window, int nframes,
+                             int shift, int real_in, hipStream_t st);

@@ -316,6 +316,184 @@ __global__ __launch_bounds__(1024) void k_fft_mr(const MrArgs a)
 #undef MR_PASS
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Longer lengths of the same kind (15361 ... 921600 points, N = N1 x N2 with both factors 6 ... 960): two passes over HBM, the scheme of
+// k_fft_tile in fft.hip with the mixed-radix passes inside.  A workgroup takes sixteen neighbouring columns of a matrix with n rows
+// (one 128-byte piece per row), transforms the sixteen columns in LDS and stores
+//   pass A (x as N1 rows of N2):  column n2 as row n2 of the workspace, times W_N^(n2 k1)       -> ws[n2][k1]
+//   pass B (ws as N2 rows of N1): column k1 back into column k1 of the output                    -> out[k2][k1]
+// First pass of either: lanes run along the sixteen columns (coalesced gather), then the passes of mr_pass per column, last pass of
+// B: lanes along the columns again (coalesced scatter).  The shifts of clFFT_impl are rotations of the linear index (by floor(N/2)
+// on the way in, ceil(N/2) on the way out): a sixteen-column piece stays one contiguous run.  Columns beyond the matrix (N1 or N2
+// not a multiple of 16) are idle lanes.
+struct TileArgs {
+    const void *in;
+    c32 *out;
+    const float *window;
+    const c32 *tw;    // this pass' twiddle runs
+    const c32 *twn;   // W_N^k, k < N (pass A)
+    int n, ld, big, nframes, npass, in_rot, out_rot, real_in, fs /* LDS slots between the sixteen columns */;
+    long long nitems; // frames x tiles
+    MrPass pass[kMaxPass];
+};
+
+// MODE 0: first pass (gather).  1: LDS -> LDS.  2: last pass of A (column -> workspace row, big twiddle).  3: last pass of B (scatter)
+template <int R, int SIGN, int MODE>
+__device__ __forceinline__ void tile_pass(const TileArgs &a, const MrPass &ps, c32 *lds, int tid, long long frame, int c0)
+{
+    constexpr int B = kVals / R;
+    constexpr bool COLS = MODE == 0 || MODE == 3;  // lanes along the sixteen columns
+    const int TH = blockDim.x, n = a.n, nb = ps.nb, nbt = 16 * nb, ld = a.ld;
+    const size_t fbase = (size_t)frame * a.big;
+    c32 v[B][R], w1[B];
+#pragma unroll
+    for (int i = 0; i < B; i++) {
+        const int b = tid + TH * i;
+        const int fr = COLS ? (b & 15) : (int)__umulhi((unsigned)b, ps.m_nb), bb = COLS ? (b >> 4) : b - fr * nb;
+        if constexpr (MODE != 0) {
+            const int k = bb - (int)__umulhi((unsigned)bb, ps.m_ns) * ps.ns;
+            w1[i] = b < nbt ? a.tw[ps.tw_off + k] : mk(1.f, 0.f);
+        }
+        if (b < nbt) {
+            if constexpr (MODE == 0) {
+                const bool live = c0 + fr < ld;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    c32 x = mk(0.f, 0.f);
+                    if (live) {
+                        long long src = (long long)(bb + r * nb) * ld + c0 + fr + a.in_rot;
+                        if (src >= a.big) src -= a.big;
+                        if (a.real_in) x = mk(((const float *)a.in)[fbase + src], 0.f);
+                        else {
+                            const f2v t = ((const f2v *)a.in)[fbase + src];
+                            x = mk(t.x, t.y);
+                        }
+                        if (a.window) {
+                            const float w = a.window[src];  // the ORIGINAL position (lib/clFFT_impl.cc:477-493)
+                            x = mk(x.x * w, x.y * w);
+                        }
+                    }
+                    v[i][r] = x;
+                }
+            } else {
+                const int base = fr * a.fs + bb;
+#pragma unroll
+                for (int r = 0; r < R; r++) v[i][r] = lds[slot(base + r * nb)];
+            }
+        }
+    }
+    if constexpr (MODE != 0) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < B; i++) {
+        const int b = tid + TH * i;
+        if (b < nbt) {
+            const int fr = COLS ? (b & 15) : (int)__umulhi((unsigned)b, ps.m_nb), bb = COLS ? (b >> 4) : b - fr * nb;
+            int g = bb, k = 0;
+            if constexpr (MODE != 0) {
+                g = (int)__umulhi((unsigned)bb, ps.m_ns);
+                k = bb - g * ps.ns;
+                c32 sq[4];
+                sq[0] = w1[i];
+#pragma unroll
+                for (int q = 1; q < 4; q++) sq[q] = (R > (1 << q)) ? cmul(sq[q - 1], sq[q - 1]) : sq[q - 1];
+#pragma unroll
+                for (int r = 1; r < R; r++) {
+                    c32 t = mk(1.f, 0.f);
+                    bool first = true;
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if ((r >> q) & 1) {
+                            t = first ? sq[q] : cmul(t, sq[q]);
+                            first = false;
+                        }
+                    v[i][r] = cmul(v[i][r], t);
+                }
+            }
+            dft<R, SIGN>(v[i]);
+            if constexpr (MODE == 2) {
+                const int n2 = c0 + fr;
+                if (n2 < ld) {
+                    // W_N^(n2 k1), k1 = k + r ns: one base and one step from the table, the step's powers from four squares
+                    const c32 base = a.twn[(long long)n2 * k];
+                    c32 sq[4];
+                    sq[0] = a.twn[(long long)n2 * ps.ns];
+#pragma unroll
+                    for (int q = 1; q < 4; q++) sq[q] = (R > (1 << q)) ? cmul(sq[q - 1], sq[q - 1]) : sq[q - 1];
+                    f2v *o = (f2v *)a.out + fbase + (size_t)n2 * n + k;
+#pragma unroll
+                    for (int s = 0; s < R; s++) {
+                        const int r = out_index<R>(s);
+                        c32 t = base;
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            if ((r >> q) & 1) t = cmul(t, sq[q]);
+                        const c32 z = cmul(v[i][s], t);
+                        f2v zz;
+                        zz.x = z.x;
+                        zz.y = z.y;
+                        o[r * ps.ns] = zz;
+                    }
+                }
+            } else if constexpr (MODE == 3) {
+                if (c0 + fr < ld) {
+#pragma unroll
+                    for (int s = 0; s < R; s++) {
+                        long long p = (long long)(k + out_index<R>(s) * ps.ns) * ld + c0 + fr - a.out_rot;  // forward + shift: X[k] -> position k - ceil(N/2)
+                        if (p < 0) p += a.big;
+                        f2v zz;
+                        zz.x = v[i][s].x;
+                        zz.y = v[i][s].y;
+                        ((f2v *)a.out)[fbase + p] = zz;
+                    }
+                }
+            } else {
+                const int base = fr * a.fs + g * ps.ns * R + k;
+#pragma unroll
+                for (int s = 0; s < R; s++) lds[slot(base + out_index<R>(s) * ps.ns)] = v[i][s];
+            }
+        }
+    }
+    if constexpr (MODE < 2) __syncthreads();
+}
+
+template <int SIGN, bool PASS_B>
+__global__ __launch_bounds__(1024) void k_fft_mr_tile(const TileArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) c32 mr_lds[];
+    const int tid0 = threadIdx.x;
+    const int tiles = (a.ld + 15) / 16;
+#define TL_PASS(MODE, P)                                                                       \
+    switch (a.pass[P].radix) {                                                                 \
+    case 2: tile_pass<2, SIGN, MODE>(a, a.pass[P], mr_lds, tid, frame, c0); break;             \
+    case 3: tile_pass<3, SIGN, MODE>(a, a.pass[P], mr_lds, tid, frame, c0); break;             \
+    case 4: tile_pass<4, SIGN, MODE>(a, a.pass[P], mr_lds, tid, frame, c0); break;             \
+    case 5: tile_pass<5, SIGN, MODE>(a, a.pass[P], mr_lds, tid, frame, c0); break;             \
+    case 6: tile_pass<6, SIGN, MODE>(a, a.pass[P], mr_lds, tid, frame, c0); break;             \
+    case 7: tile_pass<7, SIGN, MODE>(a, a.pass[P], mr_lds, tid, frame, c0); break;             \
+    case 8: tile_pass<8, SIGN, MODE>(a, a.pass[P], mr_lds, tid, frame, c0); break;             \
+    case 9: tile_pass<9, SIGN, MODE>(a, a.pass[P], mr_lds, tid, frame, c0); break;             \
+    case 10: tile_pass<10, SIGN, MODE>(a, a.pass[P], mr_lds, tid, frame, c0); break;           \
+    case 11: tile_pass<11, SIGN, MODE>(a, a.pass[P], mr_lds, tid, frame, c0); break;           \
+    case 12: tile_pass<12, SIGN, MODE>(a, a.pass[P], mr_lds, tid, frame, c0); break;           \
+    case 13: tile_pass<13, SIGN, MODE>(a, a.pass[P], mr_lds, tid, frame, c0); break;           \
+    case 14: tile_pass<14, SIGN, MODE>(a, a.pass[P], mr_lds, tid, frame, c0); break;           \
+    case 15: tile_pass<15, SIGN, MODE>(a, a.pass[P], mr_lds, tid, frame, c0); break;           \
+    default: tile_pass<16, SIGN, MODE>(a, a.pass[P], mr_lds, tid, frame, c0); break;           \
+    }
+    for (long long item = blockIdx.x; item < a.nitems; item += gridDim.x) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));  // (see k_fft_mr)
+        const long long frame = item / tiles;
+        const int c0 = (int)(item - frame * tiles) * 16;
+        TL_PASS(0, 0)
+        for (int p = 1; p < a.npass - 1; p++) { TL_PASS(1, p) }
+        if constexpr (PASS_B) { TL_PASS(3, a.npass - 1) } else { TL_PASS(2, a.npass - 1) }
+        __syncthreads();  // the next item's first pass writes the memory this one's last pass read
+    }
+#undef TL_PASS
+}
+
 unsigned magic(int d) { return (unsigned)((0x100000000ull + (unsigned long long)d - 1) / (unsigned long long)d); }
 
 }  // namespace
@@ -349,9 +527,21 @@ void search(int n, int m, int depth, int first, int per_thread, int floor_pt, in
 }
 }  // namespace
 
+namespace {
+bool plan_len(int n, int sign, int variant, bool column_of_a_tile, MrPlan *plan, std::vector<float> *tw);
+}
+
 bool mi355_fft_mr_plan(int n, int sign, int variant, MrPlan *plan, std::vector<float> *tw)
 {
-    if (n < 6 || n > 16 * 1024 || (n & (n - 1)) == 0) return false;
+    if ((n & (n - 1)) == 0) return false;  // powers of two have kernels of their own (fft.hip)
+    return plan_len(n, sign, variant, false, plan, tw);
+}
+
+namespace {
+// column_of_a_tile: the plan of one factor of a two-pass length -- sixteen columns per workgroup, any length incl. powers of two
+bool plan_len(int n, int sign, int variant, bool column_of_a_tile, MrPlan *plan, std::vector<float> *tw)
+{
+    if (n < 4 || n > 16 * 1024) return false;
     Factorisation fz;
     {
         int cur[kMaxPass];
@@ -389,6 +579,11 @@ bool mi355_fft_mr_plan(int n, int sign, int variant, MrPlan *plan, std::vector<f
             frames = (int)f;
         }
     }
+    if (column_of_a_tile) {
+        th = (int)((16LL * n + per_thread - 1) / per_thread + 63) / 64 * 64;
+        frames = 16;
+        if (th > 1024) return false;
+    } else
     if (const char *e = getenv("MI355_FFT_MR_THREADS")) {  // (tuning switches, read at create: threads, frames per iteration)
         const int t = atoi(e), f = getenv("MI355_FFT_MR_FRAMES") ? atoi(getenv("MI355_FFT_MR_FRAMES")) : 1;
         if (t >= 64 && t <= 1024 && t % 64 == 0 && f >= 1 && (long long)f * n <= (long long)t * per_thread) { th = t; frames = f; }
@@ -421,6 +616,7 @@ bool mi355_fft_mr_plan(int n, int sign, int variant, MrPlan *plan, std::vector<f
     }
     return true;
 }
+}  // namespace
 
 namespace {
 int lds_bytes_for(int n, int frames) { return (frames * n + (frames * n >> 5) + 1) * 8; }
@@ -573,4 +769,100 @@ void mi355_fft_mr_remember(const MrPlan &plan)
 {
     std::lock_guard<std::mutex> g(g_tuned_lock);
     g_tuned[plan.n] = Tuned{plan.variant, plan.threads, plan.frames};
+}
+
+// ---- two-pass lengths ------------------------------------------------------------------------------------------------------
+namespace {
+int tile_fs(int n) { return n | 1; }  // LDS slots between the sixteen columns: odd, so that lanes along the columns meet different banks
+int tile_lds_bytes(int n) { const int v = 16 * tile_fs(n); return (v + (v >> 5) + 1) * 8; }
+}  // namespace
+
+bool mi355_fft_mr_tile_plan(int n, int sign, MrTilePlan *tp, std::vector<float> *twa, std::vector<float> *twb)
+{
+    if (n <= 15360 || n > 960 * 960) return false;
+    double best = 1e30;
+    MrPlan pa, pb;
+    std::vector<float> ta, tb;
+    for (int n1 = 4; n1 <= 960; n1++) {
+        if (n % n1) continue;
+        const int n2 = n / n1;
+        if (n2 < 4 || n2 > 960) continue;
+        bool ok = false;
+        for (int va = 0; va < 2 && !ok; va++)
+            for (int vb = 0; vb < 2 && !ok; vb++)
+                ok = plan_len(n1, sign, va, true, &pa, &ta) && plan_len(n2, sign, vb, true, &pb, &tb) && tile_lds_bytes(n1) <= 160 * 1024 &&
+                     tile_lds_bytes(n2) <= 160 * 1024;
+        if (!ok) continue;
+        // fewest passes; rows that start on a 128-byte line (the row length a multiple of 16 values) count as half a pass each; near-square
+        double cost = pa.npass + pb.npass + (n2 % 16 ? 0.5 : 0.0) + (n1 % 16 ? 0.5 : 0.0) + 0.25 * fabs(log2((double)n1 / n2));
+        if (cost < best) {
+            best = cost;
+            tp->n = n;
+            tp->n1 = n1;
+            tp->n2 = n2;
+            tp->a = pa;
+            tp->b = pb;
+            *twa = ta;
+            *twb = tb;
+        }
+    }
+    return best < 1e29;
+}
+
+int mi355_fft_mr_tile_launch(const MrTilePlan &tp, mi355_ctx *ctx, int sign, const void *in, void *ws, void *out, const float *window, int nframes,
+                             int shift, int real_in, hipStream_t st)
+{
+    if (nframes <= 0) return MI355_OK;
+    static std::map<int, bool> lds_ok;  // (device, direction)
+    static std::mutex lds_ok_lock;
+    {
+        std::lock_guard<std::mutex> g(lds_ok_lock);
+        const int which = ctx->device * 2 + (sign < 0 ? 0 : 1);
+        if (!lds_ok[which]) {
+            if (sign < 0) {
+                MI355_HIP(hipFuncSetAttribute((const void *)k_fft_mr_tile<-1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                MI355_HIP(hipFuncSetAttribute((const void *)k_fft_mr_tile<-1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            } else {
+                MI355_HIP(hipFuncSetAttribute((const void *)k_fft_mr_tile<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                MI355_HIP(hipFuncSetAttribute((const void *)k_fft_mr_tile<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            }
+            lds_ok[which] = true;
+        }
+    }
+    const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+    for (int pass = 0; pass < 2; pass++) {
+        const MrPlan &pl = pass ? tp.b : tp.a;
+        TileArgs a;
+        a.in = pass ? ws : in;
+        a.out = (c32 *)(pass ? out : ws);
+        a.window = pass ? nullptr : window;
+        a.tw = (const c32 *)pl.d_tw;
+        a.twn = (const c32 *)tp.d_twn;
+        a.n = pl.n;
+        a.ld = pass ? tp.n1 : tp.n2;
+        a.big = tp.n;
+        a.nframes = nframes;
+        a.npass = pl.npass;
+        a.in_rot = (!pass && sign > 0 && shift) ? tp.n / 2 : 0;
+        a.out_rot = (pass && sign < 0 && shift) ? (tp.n + 1) / 2 : 0;
+        a.real_in = pass ? 0 : real_in;
+        a.fs = tile_fs(pl.n);
+        a.nitems = (long long)nframes * ((a.ld + 15) / 16);
+        for (int p = 0; p < pl.npass; p++) a.pass[p] = pl.pass[p];
+        const int lds_bytes = tile_lds_bytes(pl.n);
+        int per_cu = (160 * 1024) / lds_bytes;
+        if (per_cu > 2048 / pl.threads) per_cu = 2048 / pl.threads;
+        if (per_cu < 1) per_cu = 1;
+        long long grid = (long long)cus * per_cu;
+        if (grid > a.nitems) grid = a.nitems;
+        if (sign < 0) {
+            if (pass) hipLaunchKernelGGL((k_fft_mr_tile<-1, true>), dim3((unsigned)grid), dim3(pl.threads), lds_bytes, st, a);
+            else hipLaunchKernelGGL((k_fft_mr_tile<-1, false>), dim3((unsigned)grid), dim3(pl.threads), lds_bytes, st, a);
+        } else {
+            if (pass) hipLaunchKernelGGL((k_fft_mr_tile<1, true>), dim3((unsigned)grid), dim3(pl.threads), lds_bytes, st, a);
+            else hipLaunchKernelGGL((k_fft_mr_tile<1, false>), dim3((unsigned)grid), dim3(pl.threads), lds_bytes, st, a);
+        }
+        MI355_HIP(hipGetLastError());
+    }
+    return MI355_OK;
 }

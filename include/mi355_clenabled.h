@@ -153,7 +153,7 @@ int mi355_mathconst_work_dev(mi355_mathconst *h, size_t nitems, const void *a, v
  * fft_size: any power of two 2..32768 (one fused kernel), 65536..1048576 (two passes over 16-column tiles), 2097152..16777216
  * (four passes; 2^24 is clFFT's own single-precision limit); lengths 2^a 3^b 5^c 7^d 11^e 13^f up to 15360 (14336 / 13312 / 11264 with a factor 7 / 13 / 11) that are not a power of two in
  * one pass by a mixed-radix kernel (the lengths clFFT's radix-3/5/7 plans cover; its workgroup shape is measured once per length
- * and process at create, about 20 ms); any other size 3..8388608 by chirp-z over the power-of-two kernels (the reference
+ * and process at create, about 20 ms), such lengths up to 921600 (= N1 x N2, both at most 960) in two passes; any other size 3..8388608 by chirp-z over the power-of-two kernels (the reference
  * leaves those to clFFT, which refuses prime factors above 13);
  * larger sizes return MI355_ERR_UNSUPPORTED.  The shift of an odd-sized frame follows
  * clFFT_impl::testCPU (len = ceil(N/2), :503-507).  window: NULL/0 or exactly fft_size floats

@@ -371,6 +371,40 @@ def test_long_sizes_that_are_not_a_power_of_two(gpu, oracle, n, fwd, shift, win)
         assert relerr(yr, _np_fft_block(n, True, None, False, xr.astype(np.complex64))) <= TOL
 
 
+# 2-3-5-7-11-13 lengths above 15360 points: two passes with the mixed-radix passes inside (k_fft_mr_tile); row lengths that are / are not a
+# multiple of sixteen values, an odd length (shift by floor / ceil), the longest length (960 x 960), real input, several frames
+@pytest.mark.parametrize("n,nvec", [(16000, 5), (20000, 3), (22050, 2), (30030, 2), (44100, 2), (48000, 3), (50625, 2), (100000, 2), (250000, 1),
+                                    (921600, 1)])
+def test_mixed_radix_two_pass_lengths(gpu, oracle, n, nvec):
+    import torch
+    rng = np.random.default_rng(n % 1009)
+    w = oracle.window(oracle.WIN_HAMMING, n)
+    x = crandn(rng, nvec * n)
+    y = np.empty_like(x)
+    for fwd, shift, win in ((True, True, True), (False, True, True), (True, False, False), (False, False, False)):
+        blk = _fft(gpu, n, gpu.CLFFT_FORWARD if fwd else gpu.CLFFT_BACKWARD, w if win else None, shift=shift)
+        assert blk.work(nvec, [x], [y]) == nvec
+        err = relerr(y, _np_fft_block(n, fwd, w if win else None, shift, x))
+        assert err <= TOL and err <= 3e-6, (n, fwd, shift, err)
+    xr = rng.standard_normal(nvec * n).astype(np.float32)
+    blk = _fft(gpu, n, gpu.CLFFT_FORWARD, w, dtype=gpu.DTYPE_FLOAT, shift=True)
+    dx = torch.from_numpy(xr).cuda()
+    dy = torch.empty(nvec * n, 2, device="cuda")
+    blk.work_device(nvec, [dx], [dy])
+    torch.cuda.synchronize()
+    assert relerr(dy.cpu().numpy().view(np.complex64).reshape(-1), _np_fft_block(n, True, w, True, xr.astype(np.complex64))) <= TOL
+
+
+def test_two_pass_length_through_chirpz_too(gpu, oracle, monkeypatch):
+    monkeypatch.setenv("MI355_FFT_NO_MR", "1")  # the chirp-z path keeps its coverage at a length the mixed-radix form now takes
+    n = 20000
+    rng = np.random.default_rng(3)
+    x = crandn(rng, 2 * n)
+    y = np.empty_like(x)
+    _fft(gpu, n, gpu.CLFFT_FORWARD, shift=True).work(2, [x], [y])
+    assert relerr(y, _np_fft_block(n, True, None, True, x)) <= TOL
+
+
 def test_two_kernel_real_input_and_tone(gpu, oracle):
     n = 32768
     rng = np.random.default_rng(2)
