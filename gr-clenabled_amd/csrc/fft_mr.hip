@@ -334,6 +334,7 @@ struct TileArgs {
     const c32 *tw;    // this pass' twiddle runs
     const c32 *twn;   // W_N^k, k < N (pass A)
     int n, ld, big, nframes, npass, in_rot, out_rot, real_in, fs /* LDS slots between the sixteen columns */;
+    int nt;  // the sixteen-column pieces are whole 128-byte lines nobody else touches: nontemporal loads / stores (measured equal to plain ones on one box, A/B)
     long long nitems; // frames x tiles
     MrPass pass[kMaxPass];
 };
@@ -366,7 +367,7 @@ __device__ __forceinline__ void tile_pass(const TileArgs &a, const MrPass &ps, c
                         if (src >= a.big) src -= a.big;
                         if (a.real_in) x = mk(((const float *)a.in)[fbase + src], 0.f);
                         else {
-                            const f2v t = ((const f2v *)a.in)[fbase + src];
+                            const f2v t = a.nt ? __builtin_nontemporal_load((const f2v *)a.in + fbase + src) : ((const f2v *)a.in)[fbase + src];
                             x = mk(t.x, t.y);
                         }
                         if (a.window) {
@@ -444,7 +445,8 @@ __device__ __forceinline__ void tile_pass(const TileArgs &a, const MrPass &ps, c
                         f2v zz;
                         zz.x = v[i][s].x;
                         zz.y = v[i][s].y;
-                        ((f2v *)a.out)[fbase + p] = zz;
+                        if (a.nt) __builtin_nontemporal_store(zz, (f2v *)a.out + fbase + p);
+                        else ((f2v *)a.out)[fbase + p] = zz;
                     }
                 }
             } else {
@@ -847,6 +849,7 @@ int mi355_fft_mr_tile_launch(const MrTilePlan &tp, mi355_ctx *ctx, int sign, con
         a.out_rot = (pass && sign < 0 && shift) ? (tp.n + 1) / 2 : 0;
         a.real_in = pass ? 0 : real_in;
         a.fs = tile_fs(pl.n);
+        a.nt = a.ld % 16 == 0 && a.in_rot % 16 == 0 && a.out_rot % 16 == 0;
         a.nitems = (long long)nframes * ((a.ld + 15) / 16);
         for (int p = 0; p < pl.npass; p++) a.pass[p] = pl.pass[p];
         const int lds_bytes = tile_lds_bytes(pl.n);
