@@ -189,6 +189,13 @@ struct mi355_xcorr_fft {
     // device staging for the host-pointer path (grow only)
     void *d_in = nullptr, *d_out = nullptr;
     size_t cap_frames = 0;
+    // every other even size clFFT plans (8192, 16384, ... and lengths that are not a power of two): the steps of the reference's work()
+    // one after the other over clFFT handles -- forward transforms, X0 conj(Xs), backward transform, |.| with the half swap
+    bool composed = false;
+    mi355_fft *fwd = nullptr, *inv = nullptr;
+    void *d_ws[3] = {nullptr, nullptr, nullptr};  // reference spectrum, signal spectrum / magnitude source, product
+    size_t ws_frames = 0;
+    std::mutex ws_lock;
 };
 
 namespace {
@@ -208,8 +215,76 @@ template <int N> int launch_xcorr_n(mi355_xcorr_fft *h, const XcArgs &a, int nfr
     return MI355_OK;
 }
 
+// MultConj of the reference (lib/clxcorrelate_fft_vcf_impl.cc:886-910): p = a * conj(b), same operation order
+__global__ __launch_bounds__(256) void k_xc_mulconj(const c32 *__restrict__ a, const c32 *__restrict__ b, c32 *__restrict__ p, long long total)
+{
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const c32 x = a[e], y = b[e];
+        const float b_r = y.x, b_i = -y.y;
+        p[e] = mk((x.x * b_r) - (x.y * b_i), (x.x * b_i) + (x.y * b_r));
+    }
+}
+// ComplexToMag (:912-935) and the host's exchange of the two halves (:1133-1140) in one store
+__global__ __launch_bounds__(256) void k_xc_mag_swap(const c32 *__restrict__ p, float *__restrict__ out, int n, long long total)
+{
+    const int half = n / 2;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long f = e / n;
+        const int k = (int)(e - f * n);
+        const c32 z = p[e];
+        out[f * n + (k < half ? k + half : k - half)] = sqrtf(fmaf(z.x, z.x, z.y * z.y));
+    }
+}
+
+int launch_composed(mi355_xcorr_fft *h, const XcArgs &a, int nframes, hipStream_t st)
+{
+    const size_t n = (size_t)h->n;
+    size_t chunk = ((size_t)128 << 20) / (n * 8);  // three work buffers of at most 128 MiB
+    if (chunk < 1) chunk = 1;
+    if (chunk > (size_t)nframes) chunk = (size_t)nframes;
+    std::lock_guard<std::mutex> g(h->ws_lock);
+    if (chunk > h->ws_frames) {
+        MI355_HIP(hipStreamSynchronize(st));
+        for (void *&w : h->d_ws) {
+            if (w) (void)hipFree(w);
+            w = nullptr;
+        }
+        h->ws_frames = 0;
+        for (void *&w : h->d_ws) MI355_HIP(hipMalloc(&w, chunk * n * 8));
+        h->ws_frames = chunk;
+    }
+    const int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
+    for (size_t f0 = 0; f0 < (size_t)nframes; f0 += chunk) {
+        const int nf = (int)((size_t)nframes - f0 < chunk ? (size_t)nframes - f0 : chunk);
+        const long long total = (long long)nf * (long long)n;
+        long long blocks = (total + 255) / 256;
+        if (blocks > (long long)cus * 16) blocks = (long long)cus * 16;
+        const c32 *ref = a.in[0] + f0 * n;
+        int rc;
+        if (h->time_series) {
+            if ((rc = mi355_fft_work_dev(h->fwd, nf, ref, h->d_ws[0], st))) return rc;
+            ref = (const c32 *)h->d_ws[0];
+        }
+        for (int s = 1; s < h->num_inputs; s++) {
+            const c32 *sig = a.in[s] + f0 * n;
+            if (h->time_series) {
+                if ((rc = mi355_fft_work_dev(h->fwd, nf, sig, h->d_ws[1], st))) return rc;
+                sig = (const c32 *)h->d_ws[1];
+            }
+            hipLaunchKernelGGL(k_xc_mulconj, dim3((unsigned)blocks), dim3(256), 0, st, ref, sig, (c32 *)h->d_ws[2], total);
+            if ((rc = mi355_fft_work_dev(h->inv, nf, h->d_ws[2], h->d_ws[1], st))) return rc;
+            hipLaunchKernelGGL(k_xc_mag_swap, dim3((unsigned)blocks), dim3(256), 0, st, (const c32 *)h->d_ws[1], a.out[s] + f0 * n, (int)n, total);
+            MI355_HIP(hipGetLastError());
+        }
+    }
+    // the buffers are shared by the calls on this handle: the next caller's stream has to see these kernels finished
+    MI355_HIP(hipStreamSynchronize(st));
+    return MI355_OK;
+}
+
 int launch_xcorr(mi355_xcorr_fft *h, const XcArgs &a, int nframes, hipStream_t st)
 {
+    if (h->composed) return launch_composed(h, a, nframes, st);
     switch (h->n) {
     case 16: return launch_xcorr_n<16>(h, a, nframes, st);
     case 32: return launch_xcorr_n<32>(h, a, nframes, st);
@@ -237,14 +312,29 @@ extern "C" int mi355_xcorr_fft_create(mi355_ctx *ctx, int fft_size, int num_inpu
         return MI355_ERR_UNSUPPORTED;
     }
     MI355_REQUIRE(input_type == 1 || input_type == 2, "input_type must be 1 (spectra) or 2 (time series)");
-    if (fft_size < 16 || fft_size > 4096 || (fft_size & (fft_size - 1))) {
-        mi355_set_error("cross-correlator FFT size %d not supported (power of two, 16..4096)", fft_size);
+    const bool fused = fft_size >= 16 && fft_size <= 4096 && (fft_size & (fft_size - 1)) == 0;
+    if (!fused && (fft_size < 2 || (fft_size & 1) || fft_size > (1 << 22))) {
+        // (an odd size would leave the last output of every vector unwritten in the reference: vlen_2 = fftSize / 2, :1133-1140)
+        mi355_set_error("cross-correlator FFT size %d not supported (even sizes 2..4194304; powers of two 16..4096 run as one fused kernel)", fft_size);
         return MI355_ERR_UNSUPPORTED;
     }
     mi355_xcorr_fft *h = new (std::nothrow) mi355_xcorr_fft();
     if (!h) return MI355_ERR_NOMEM;
     h->ctx = ctx; h->n = fft_size; h->num_inputs = num_inputs; h->time_series = input_type == 2;
     if (hipSetDevice(ctx->device) != hipSuccess) { delete h; mi355_set_error("hipSetDevice failed"); return MI355_ERR_HIP; }
+    if (!fused) {
+        h->composed = true;
+        int rc = h->time_series ? mi355_fft_create(ctx, fft_size, MI355_FFT_FORWARD, nullptr, 0, MI355_DTYPE_COMPLEX, 1, 0, &h->fwd) : MI355_OK;
+        if (rc == MI355_OK) rc = mi355_fft_create(ctx, fft_size, MI355_FFT_BACKWARD, nullptr, 0, MI355_DTYPE_COMPLEX, 1, 0, &h->inv);
+        if (rc != MI355_OK) {
+            if (h->fwd) (void)mi355_fft_destroy(h->fwd);
+            delete h;
+            return rc;
+        }
+        mi355_log(ctx, MI355_LOG_INFO, "clxcorrelate_fft_vcf: %d points, %d inputs: clFFT transforms and two elementwise kernels per signal", fft_size, num_inputs);
+        *out = h;
+        return MI355_OK;
+    }
     const int n = fft_size;
     std::vector<float> twf(2 * (size_t)n), twi(2 * (size_t)n);
     for (int k = 0; k < n; k++) {
@@ -274,6 +364,10 @@ extern "C" int mi355_xcorr_fft_destroy(mi355_xcorr_fft *h)
     if (h->d_twi) (void)hipFree(h->d_twi);
     if (h->d_in) (void)hipFree(h->d_in);
     if (h->d_out) (void)hipFree(h->d_out);
+    if (h->fwd) (void)mi355_fft_destroy(h->fwd);
+    if (h->inv) (void)mi355_fft_destroy(h->inv);
+    for (void *w : h->d_ws)
+        if (w) (void)hipFree(w);
     delete h;
     return MI355_OK;
 }

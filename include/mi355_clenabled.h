@@ -308,7 +308,9 @@ int mi355_elem_work_dev(mi355_elem *h, size_t n, const void *in0, const void *in
  * where X = the input itself (input_type 1, spectra) or its forward FFT (input_type 2, time series) and
  * halfswap exchanges the two halves of the vector (:1133-1140).  inputs[] holds num_inputs pointers to
  * [nframes][fft_size] complex, outputs[] num_inputs-1 pointers to [nframes][fft_size] float.
- * fft_size: power of two 16..4096, num_inputs 2..32, otherwise MI355_ERR_UNSUPPORTED.
+ * fft_size: powers of two 16..4096 run as ONE fused kernel; every other even size up to 4194304 (the reference hands fftSize to
+ * clFFT, lib/clxcorrelate_fft_vcf_impl.cc:711-737) runs the reference's steps one after the other over the clFFT transforms of
+ * this library; an odd size is refused (the reference would leave the last output of every vector unwritten).  num_inputs 2..32.
  * ------------------------------------------------------------------------------------------------ */
 int mi355_xcorr_fft_create(mi355_ctx *ctx, int fft_size, int num_inputs, int input_type, mi355_xcorr_fft **out);
 int mi355_xcorr_fft_destroy(mi355_xcorr_fft *h);

@@ -59,9 +59,49 @@ def test_many_inputs_and_device_path(gpu, oracle):
         assert relerr(o.cpu().numpy(), r) <= TOL
 
 
+def _np_xcorr(n, itype, ins):
+    """The block's definition on numpy's float64 pocketfft (the oracle's O(N^2) DFT cannot run lengths that are not a power of two
+    at these sizes); tied to the oracle at a small length in the test below."""
+    x = [v.astype(np.complex128).reshape(-1, n) for v in ins]
+    spec = x if itype == 1 else [np.fft.fft(v, axis=1) for v in x]
+    outs = []
+    for sp in spec[1:]:
+        r = np.abs(np.fft.ifft(spec[0] * np.conj(sp), axis=1) * n)
+        outs.append(np.concatenate([r[:, n // 2:], r[:, :n // 2]], axis=1).reshape(-1).astype(np.float32))
+    return outs
+
+
+# sizes outside the fused kernel's (powers of two 16 ... 4096): the reference's steps over the clFFT transforms -- powers of two below 16
+# and above 4096 (one pass, two tile passes), 2-3-5-7 lengths (mixed radix, one and two passes), a length with a large prime factor (chirp-z)
+@pytest.mark.parametrize("n", [2, 6, 14, 1000, 6000, 8192, 16384, 20000, 65536, 2 * 4099])
+@pytest.mark.parametrize("itype", [1, 2])
+def test_other_even_sizes(gpu, oracle, n, itype):
+    import torch
+    rng = np.random.default_rng(n + itype)
+    nframes, nin = (7 if n < 5000 else 2), 3
+    ins = [crandn(rng, nframes * n) for _ in range(nin)]
+    outs = [np.empty(nframes * n, np.float32) for _ in range(nin - 1)]
+    if n == 1000:  # the numpy reference against the oracle where the oracle can run
+        for r, o in zip(_np_xcorr(n, itype, ins), oracle.xcorr_fft(n, itype, ins, use_f64=True)):
+            assert relerr(r, o) <= 1e-6
+    blk = _blk(gpu, n, nin, itype)
+    assert blk.work(nframes, ins, outs) == nframes
+    ref = _np_xcorr(n, itype, ins)
+    for o, r in zip(outs, ref):
+        assert relerr(o, r) <= TOL
+    d_in = [torch.from_numpy(x.view(np.float32).reshape(-1, 2)).cuda() for x in ins]
+    d_out = [torch.empty(nframes * n, device="cuda") for _ in range(nin - 1)]
+    blk.work_device(nframes, d_in, d_out)
+    torch.cuda.synchronize()
+    for o, r in zip(d_out, ref):
+        assert relerr(o.cpu().numpy(), r) <= TOL
+
+
 def test_errors(gpu):
     with pytest.raises(gpu.Mi355Error):
-        _blk(gpu, 1000, 2, 1)      # not a power of two
+        _blk(gpu, 1001, 2, 1)      # odd: the reference's half swap (vlen_2 = fftSize / 2) leaves the last output unwritten
+    with pytest.raises(gpu.Mi355Error):
+        _blk(gpu, (1 << 22) + 2, 2, 1)
     with pytest.raises(gpu.Mi355Error):
         _blk(gpu, 1024, 1, 1)      # needs a reference and one more input
     with pytest.raises(gpu.Mi355Error):
