@@ -739,6 +739,51 @@ __global__ __launch_bounds__(kMfThreads, 2) void k_fir_mfma(const c32 *__restric
     }
 }
 
+// Decimations above 8 in the time domain.  The per-output kernel below (k_fir_td_dec) lets lane m read x[m D + k]: lanes D samples apart,
+// every load instruction 64 different lines, K times over -- 65 taps at decimation 16 ran at 16 GS/s of input.  Here the span of a tile of
+// outputs is staged in LDS with coalesced loads (slot i + i/32: a wave's reads, D slots apart, meet different banks for every D) and
+// each thread forms its outputs from there: the input is read from HBM once, whatever D.
+constexpr int kDlThreads = 256, kDlSpan = 8192;  // samples of input per tile (64 KiB: two workgroups per CU)
+__host__ __device__ inline int dl_slot(int i) { return i + (i >> 5); }
+
+template <bool CTAPS>
+__global__ __launch_bounds__(kDlThreads) void k_fir_dec_lds(const c32 *__restrict__ in, c32 *__restrict__ out, const float *__restrict__ taps_rev, int K,
+                                                            int decim, long long n_out, int tile_out)
+{
+    extern __shared__ __attribute__((aligned(16))) c32 dl_x[];
+    const int tid = threadIdx.x;
+    const long long ntiles = (n_out + tile_out - 1) / tile_out;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long o0 = tile * tile_out, left = n_out - o0;
+        const int no = left < tile_out ? (int)left : tile_out;
+        const c32 *__restrict__ src = in + o0 * decim;
+        const int span = (no - 1) * decim + K;
+        __syncthreads();  // the previous tile's reads are done
+        for (int i = tid; i < span; i += kDlThreads) {
+            const f2v t = __builtin_nontemporal_load((const f2v *)src + i);
+            dl_x[dl_slot(i)] = mk(t.x, t.y);
+        }
+        __syncthreads();
+        for (int o = tid; o < no; o += kDlThreads) {
+            const int base = o * decim;
+            c32 acc = mk(0.f, 0.f);
+            for (int k = 0; k < K; k++) {
+                const c32 v = dl_x[dl_slot(base + k)];
+                if constexpr (CTAPS) {
+                    const float hr = taps_rev[2 * k], hi = taps_rev[2 * k + 1];
+                    acc.x += hr * v.x - hi * v.y;
+                    acc.y += hr * v.y + hi * v.x;
+                } else {
+                    const float h = taps_rev[k];
+                    acc.x += h * v.x;
+                    acc.y += h * v.y;
+                }
+            }
+            out[o0 + o] = acc;
+        }
+    }
+}
+
 template <bool CTAPS>
 __global__ __launch_bounds__(256) void k_fir_td_dec(const c32 *__restrict__ in, c32 *__restrict__ out,
                                                     const float *__restrict__ taps_rev, int K, int decim, long long n_out)
@@ -1089,7 +1134,16 @@ int launch_filter(mi355_filter *h, size_t nout, const void *in, void *out, hipSt
     static const bool mf_on = !getenv("MI355_FIR_MFMA") || atoi(getenv("MI355_FIR_MFMA")) != 0;
     // decimations 2-8 keep every decim-th output of the same product; that variant needs more registers (2 workgroups per CU)
     // and only pays from ~100 taps (129 taps, decimation 2: 137 -> 148 GS/s; 65 taps: equal)
-    if (mf_on && h->mf_kk && ((h->decim == 1 && h->ntaps >= 16) || (h->decim >= 2 && h->decim <= 8 && h->ntaps >= 96))) {  // fewer taps: the vector kernel's short loop wins (9 taps: 350 vs 330 GS/s)
+    static const int dl_min = getenv("MI355_FIR_DEC_LDS_MIN") ? atoi(getenv("MI355_FIR_DEC_LDS_MIN")) : 9;  // smallest decimation of the LDS-staged kernel
+    const int dmax = dl_min - 1 < 8 ? dl_min - 1 : 8;  // largest decimation of the kernels that compute every undecimated output
+    // decimations above 8: either every undecimated output on the matrix cores (rate ~ 17500 / (K + 15) GS/s of input whatever D: 33 taps
+    // 280, 65 taps 205, 200 taps 97, 400 taps 58) or the LDS-staged kernel below (time per output ~ 0.65 K + 2.55 D ns: 65 taps 148 / 193 /
+    // 223 GS/s at D = 10 / 16 / 50, 200 taps 80 / 122 / 171) -- whichever this model puts ahead
+    double r_all = 17500.0 / (h->ntaps + 15), r_lds = h->decim / (0.00065 * h->ntaps + 0.00255 * h->decim);
+    if (r_all > 300.0) r_all = 300.0;
+    if (r_lds > 250.0) r_lds = 250.0;
+    const bool all_outputs_above_8 = h->decim > dmax && h->decim >= dl_min && r_all >= r_lds;
+    if (mf_on && h->mf_kk && ((h->decim == 1 && h->ntaps >= 16) || (h->decim >= 2 && h->decim <= dmax && h->ntaps >= 96) || (all_outputs_above_8 && h->ntaps >= 16))) {  // fewer taps: the vector kernel's short loop wins (9 taps: 350 vs 330 GS/s)
         const int span = kMfTile + 4 * h->mf_kk;
         const int nq = (span + kMfThreads - 1) / kMfThreads;
         const size_t smem = ((size_t)2 * (mf_pad(nq * kMfThreads + 16) + 1) + (size_t)(h->complex_taps ? 2 : 1) * (4 * h->mf_kk + 24)) * sizeof(float);
@@ -1113,7 +1167,7 @@ int launch_filter(mi355_filter *h, size_t nout, const void *in, void *out, hipSt
     }
     const int kpad0 = (h->ntaps + kTdU - 1) / kTdU * kTdU;
     // the register-tiled kernel computes every undecimated output: worth it up to a decimation of 8
-    if (h->decim == 1 || (h->decim <= 8 && (size_t)td_rows(kpad0) * kTdU * sizeof(c32) <= 160 * 1024)) {
+    if (h->decim == 1 || ((h->decim <= dmax || (h->ntaps < 16 && h->decim <= 64 && h->decim >= dl_min)) && (size_t)td_rows(kpad0) * kTdU * sizeof(c32) <= 160 * 1024)) {  // (fewer than 16 taps: this kernel runs at 400 GS/s of input whatever the decimation)
         const int kpad = kpad0;
         const size_t smem = (size_t)td_rows(kpad) * kTdU * sizeof(c32);
         if (smem > 160 * 1024) { mi355_set_error("time-domain mode supports up to ~18000 taps"); return MI355_ERR_UNSUPPORTED; }
@@ -1134,6 +1188,22 @@ int launch_filter(mi355_filter *h, size_t nout, const void *in, void *out, hipSt
         if (h->complex_taps) LAUNCH_TD(true);
         else LAUNCH_TD(false);
 #undef LAUNCH_TD
+    } else if (h->ntaps <= kDlSpan / 2 && h->decim <= 8 * h->ntaps && !getenv("MI355_FIR_DEC_LDS_OFF")) {
+        // (a decimation far above the filter length skips most of the input: the per-output kernel reads only what it needs)
+        int tile_out = (kDlSpan - h->ntaps) / h->decim + 1;
+        if (tile_out > 2048) tile_out = 2048;
+        const size_t smem = (size_t)(dl_slot(kDlSpan) + 1) * sizeof(c32);
+        const long long ntiles = ((long long)nout + tile_out - 1) / tile_out;
+        const long long grid = ntiles < (long long)cus * 8 ? ntiles : (long long)cus * 8;
+#define LAUNCH_DL(CT)                                                                                                          \
+    do {                                                                                                                       \
+        MI355_HIP(hipFuncSetAttribute((const void *)k_fir_dec_lds<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL((k_fir_dec_lds<CT>), dim3((unsigned)grid), dim3(kDlThreads), smem, st, (const c32 *)in, (c32 *)out, \
+                           h->d_taps_rev, h->ntaps, h->decim, (long long)nout, tile_out);                                      \
+    } while (0)
+        if (h->complex_taps) LAUNCH_DL(true);
+        else LAUNCH_DL(false);
+#undef LAUNCH_DL
     } else {
         long long blocks = ((long long)nout + 255) / 256;
         long long grid = blocks < (long long)cus * 8 ? blocks : (long long)cus * 8;

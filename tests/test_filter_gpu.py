@@ -215,10 +215,10 @@ def test_device_path_full_size_two_kernels_agree(gpu, oracle):
 
 
 @pytest.mark.parametrize("use_time", [False, True])
-@pytest.mark.parametrize("decim", [2, 4, 7, 8, 9, 16])
+@pytest.mark.parametrize("decim", [2, 4, 7, 8, 9, 16, 20, 50, 100, 700])
 def test_decimations_both_modes(gpu, oracle, decim, use_time):
-    """decimation <= 8 runs in the tiled direct-form kernel, larger ones one output per thread; the FFT mode decimates on
-    the store.  y[m] = (h * x)[m * decim]."""
+    """decimation <= 8 runs in the tiled direct-form kernel, larger ones from a span staged in LDS (k_fir_dec_lds), a decimation above
+    eight filter lengths (700) one output per thread; the FFT mode decimates on the store.  y[m] = (h * x)[m * decim]."""
     rng = np.random.default_rng(decim)
     ntaps = 77
     taps = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
@@ -229,6 +229,28 @@ def test_decimations_both_modes(gpu, oracle, decim, use_time):
     assert blk.work(nout, [xh], [y]) == nout
     full = oracle.fir_ccf(taps, xh, nout * decim)
     assert relerr(y, full[::decim][:nout]) <= TOL
+
+
+@pytest.mark.parametrize("ntaps,decim,ctaps", [(33, 12, True), (1000, 12, False), (1500, 25, True), (4000, 10, False), (5000, 9, False)])
+def test_large_decimations_time_domain_shapes(gpu, oracle, monkeypatch, ntaps, decim, ctaps):
+    """The LDS-staged decimating kernel: complex taps, filters that fill most of a tile's span (4000 of 8192 samples), one that does not
+    fit (5000 taps: the per-output kernel), a ragged last tile -- and the per-output kernel on the same inputs (MI355_FIR_DEC_LDS_OFF)."""
+    rng = np.random.default_rng(ntaps + decim)
+    nout = 2777
+    xh = crandn(rng, nout * decim + ntaps - 1)
+    if ctaps:
+        taps = (crandn(rng, ntaps) / np.sqrt(ntaps)).astype(np.complex64)
+        ref = oracle.fir_ccc(taps, xh, nout * decim)[::decim][:nout]
+    else:
+        taps = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+        ref = oracle.fir_ccf(taps, xh, nout * decim)[::decim][:nout]
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("MI355_FIR_DEC_LDS_OFF", "1")  # read per call
+        blk = gpu.clComplexFilter(*GPU_ARGS, decim, taps, 1, 0, use_time=True) if ctaps else gpu.clFilter(*GPU_ARGS, decim, taps, 1, 0, True)
+        y = np.empty(nout, np.complex64)
+        assert blk.work(nout, [xh], [y]) == nout
+        assert relerr(y, ref) <= TOL, (ntaps, decim, ctaps, off)
 
 
 def test_zero_outputs_and_bad_args(gpu):
