@@ -540,6 +540,51 @@ __global__ __launch_bounds__(256) void k_pfb_branches(const c32 *__restrict__ in
     }
 }
 
+// The same branch filters for R = M (every step consumes one new sample per arm): y_j[i] = sum_p h[j + M p] x_j[i - p] with
+// x_j[n] = in[n M - j + K - 1] is an ordinary FIR per arm.  A thread takes one arm and T consecutive steps and walks the taps in chunks
+// of PC: PC taps and a window of T + PC - 1 samples in registers feed T x PC multiply-adds -- (2 PC + T - 1) / (T PC) = 0.3 loads per
+// multiply-add instead of 2 (the per-output kernel above ran 32 taps per arm at 40 GS/s whatever the channel count).  Lanes run along
+// the arms: every load is a run of consecutive samples.  Same operation order per output (fma, taps ascending).
+template <int T, int PC>
+__global__ __launch_bounds__(256) void k_pfb_branches_t(const c32 *__restrict__ in, c32 *__restrict__ filt, const float *__restrict__ taps, int K,
+                                                        int M, int nsteps, long long total /* blocks of T steps x M */)
+{
+    const int P = (K + M - 1) / M;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long tb = e / M;
+        const int j = (int)(e - tb * M);
+        const long long i0 = tb * T;
+        float ar[T], ai[T];
+#pragma unroll
+        for (int t = 0; t < T; t++) ar[t] = ai[t] = 0.f;
+        for (int c0 = 0; c0 < P; c0 += PC) {
+            float h[PC];
+#pragma unroll
+            for (int q = 0; q < PC; q++) {
+                const long long k = (long long)j + (long long)M * (c0 + q);
+                h[q] = k < K ? taps[k] : 0.f;
+            }
+            const long long rb = i0 - c0 - PC + 1;  // first row of the window
+            c32 xw[T + PC - 1];
+#pragma unroll
+            for (int u = 0; u < T + PC - 1; u++) {
+                const long long row = rb + u, idx = row * M - j + K - 1;
+                xw[u] = (idx >= 0 && row < nsteps) ? in[idx] : mk(0.f, 0.f);
+            }
+#pragma unroll
+            for (int q = 0; q < PC; q++)  // taps ascending, as the reference kernel accumulates (lib/clPolyphaseChannelizer_impl.cc:156-167)
+#pragma unroll
+                for (int t = 0; t < T; t++) {
+                    ar[t] = fmaf(xw[t - q + PC - 1].x, h[q], ar[t]);
+                    ai[t] = fmaf(xw[t - q + PC - 1].y, h[q], ai[t]);
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < T; t++)
+            if (i0 + t < nsteps) filt[(i0 + t) * M + j] = mk(ar[t], ai[t]);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_pfb_dft_map(const c32 *__restrict__ filt, c32 *__restrict__ out,
                                                      const c32 *__restrict__ twM,  // exp(+2 pi i t / M), t < M
                                                      const int *__restrict__ ch_map, int nmap, int M, long long total)
@@ -561,6 +606,16 @@ __global__ __launch_bounds__(256) void k_pfb_dft_map(const c32 *__restrict__ fil
     }
 }
 
+// channel_map after the transform (lib/clPolyphaseChannelizer_impl.cc:169-177): out[i nmap + q] = u_i[ch_map[q]]
+__global__ __launch_bounds__(256) void k_pfb_map(const c32 *__restrict__ u, c32 *__restrict__ out, const int *__restrict__ ch_map, int nmap, int M,
+                                                 long long total)
+{
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long i = e / nmap;
+        out[e] = u[i * M + ch_map[(int)(e - i * nmap)]];
+    }
+}
+
 }  // namespace
 
 struct mi355_pfb {
@@ -572,6 +627,11 @@ struct mi355_pfb {
     void *d_tw = nullptr;         // M complex, exp(+2 pi i t / M)
     int *d_map = nullptr;
     void *d_filt = nullptr;       // generic path scratch: nsteps*M complex
+    // generic path, 8 channels and more with 16 and more of them mapped: the M-point backward DFT of every step as a clFFT transform of
+    // this library (the reference calls clFFT for it, lib/clPolyphaseChannelizer_impl.cc:100,208-225) instead of M products per output
+    mi355_fft *dft = nullptr;
+    void *d_filt2 = nullptr;      // the transforms' output when a channel map follows
+    bool whole_map = false;       // ch_map = 0 .. M-1: the transform writes the output itself
     HostPipe pipe;
 };
 
@@ -696,12 +756,29 @@ int launch_pfb(mi355_pfb *h, const void *in, void *out, hipStream_t st, int nste
     long long total = (long long)nsteps * h->M;
     long long blocks = (total + 255) / 256;
     long long grid = blocks < (long long)cus * 8 ? blocks : (long long)cus * 8;
+    if (h->R == h->M && !getenv("MI355_PFB_BRANCHES_PER_OUTPUT")) {
+        constexpr int T = 8, PC = 16;
+        const long long tt = ((long long)nsteps + T - 1) / T * h->M, tb = (tt + 255) / 256;
+        const long long g2 = tb < (long long)cus * 16 ? tb : (long long)cus * 16;
+        hipLaunchKernelGGL((k_pfb_branches_t<T, PC>), dim3((unsigned)(g2 < 1 ? 1 : g2)), dim3(256), 0, st, (const c32 *)in, (c32 *)h->d_filt, h->d_taps, h->K,
+                           h->M, nsteps, tt);
+    } else
     hipLaunchKernelGGL(k_pfb_branches, dim3((unsigned)grid), dim3(256), 0, st, (const c32 *)in, (c32 *)h->d_filt, h->d_taps, h->K,
                        h->M, h->R, total);
     total = (long long)nsteps * h->nmap;
     blocks = (total + 255) / 256;
     grid = blocks < (long long)cus * 8 ? blocks : (long long)cus * 8;
     if (grid < 1) grid = 1;
+    if (h->dft) {
+        MI355_HIP(hipGetLastError());
+        const int rc = mi355_fft_work_dev(h->dft, nsteps, h->d_filt, h->whole_map ? out : h->d_filt2, st);
+        if (rc) return rc;
+        if (!h->whole_map) {
+            hipLaunchKernelGGL(k_pfb_map, dim3((unsigned)grid), dim3(256), 0, st, (const c32 *)h->d_filt2, (c32 *)out, h->d_map, h->nmap, h->M, total);
+            MI355_HIP(hipGetLastError());
+        }
+        return MI355_OK;
+    }
     hipLaunchKernelGGL(k_pfb_dft_map, dim3((unsigned)grid), dim3(256), 0, st, (const c32 *)h->d_filt, (c32 *)out,
                        (const c32 *)h->d_tw, h->d_map, h->nmap, h->M, total);
     MI355_HIP(hipGetLastError());
@@ -719,6 +796,8 @@ extern "C" int mi355_pfb_destroy(mi355_pfb *h)
     if (h->d_tw) (void)hipFree(h->d_tw);
     if (h->d_map) (void)hipFree(h->d_map);
     if (h->d_filt) (void)hipFree(h->d_filt);
+    if (h->d_filt2) (void)hipFree(h->d_filt2);
+    if (h->dft) (void)mi355_fft_destroy(h->dft);
     delete h;
     return MI355_OK;
 }
@@ -765,6 +844,13 @@ extern "C" int mi355_pfb_create(mi355_ctx *ctx, const float *taps, int ntaps, in
     if (hipMalloc(&h->d_tw, tw.size() * sizeof(float)) != hipSuccess) return fail(MI355_ERR_NOMEM);
     if (hipMalloc((void **)&h->d_map, (size_t)nmap * sizeof(int)) != hipSuccess) return fail(MI355_ERR_NOMEM);
     if (!h->fast && hipMalloc(&h->d_filt, (size_t)h->nsteps * M * 8) != hipSuccess) return fail(MI355_ERR_NOMEM);
+    if (!h->fast && M >= 8 && nmap >= 16 && !getenv("MI355_PFB_DIRECT_DFT")) {
+        h->whole_map = nmap == M;
+        for (int q = 0; q < nmap && h->whole_map; q++) h->whole_map = ch_map[q] == q;
+        const int rc = mi355_fft_create(ctx, M, MI355_FFT_BACKWARD, nullptr, 0, MI355_DTYPE_COMPLEX, 1, 0, &h->dft);
+        if (rc != MI355_OK) return fail(rc);
+        if (!h->whole_map && hipMalloc(&h->d_filt2, (size_t)h->nsteps * M * 8) != hipSuccess) return fail(MI355_ERR_NOMEM);
+    }
     if (mi355_upload(ctx, h->d_taps, t.data(), t.size() * sizeof(float)) != hipSuccess) return fail(MI355_ERR_HIP);
     if (mi355_upload(ctx, h->d_tw, tw.data(), tw.size() * sizeof(float)) != hipSuccess) return fail(MI355_ERR_HIP);
     if (mi355_upload(ctx, h->d_map, ch_map, (size_t)nmap * sizeof(int)) != hipSuccess) return fail(MI355_ERR_HIP);
