@@ -540,15 +540,16 @@ __global__ __launch_bounds__(256) void k_pfb_branches(const c32 *__restrict__ in
     }
 }
 
-// The same branch filters for R = M (every step consumes one new sample per arm): y_j[i] = sum_p h[j + M p] x_j[i - p] with
+// The same branch filters for R = M (every step consumes one new sample per arm) and for 2- / 4-fold oversampling (R = M / 2, M / 4): y_j[i] = sum_p h[j + M p] x_j[i - p] with
 // x_j[n] = in[n M - j + K - 1] is an ordinary FIR per arm.  A thread takes one arm and T consecutive steps and walks the taps in chunks
 // of PC: PC taps and a window of T + PC - 1 samples in registers feed T x PC multiply-adds -- (2 PC + T - 1) / (T PC) = 0.3 loads per
 // multiply-add instead of 2 (the per-output kernel above ran 32 taps per arm at 40 GS/s whatever the channel count).  Lanes run along
 // the arms: every load is a run of consecutive samples.  Same operation order per output (fma, taps ascending).
-template <int T, int PC>
+template <int T, int PC, int S>
 __global__ __launch_bounds__(256) void k_pfb_branches_t(const c32 *__restrict__ in, c32 *__restrict__ filt, const float *__restrict__ taps, int K,
                                                         int M, int nsteps, long long total /* blocks of T steps x M */)
 {
+    const int R = M / S;  // S-fold oversampling (R = M / S new samples per step): x_j[n] = in[n R - j + K - 1], y_j[i] = sum_p h[j + M p] x_j[i - S p]
     const int P = (K + M - 1) / M;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         const long long tb = e / M;
@@ -564,24 +565,29 @@ __global__ __launch_bounds__(256) void k_pfb_branches_t(const c32 *__restrict__ 
                 const long long k = (long long)j + (long long)M * (c0 + q);
                 h[q] = k < K ? taps[k] : 0.f;
             }
-            const long long rb = i0 - c0 - PC + 1;  // first row of the window
-            c32 xw[T + PC - 1];
+            constexpr int W = T + S * (PC - 1);
+            const long long rb = i0 - (long long)S * (c0 + PC - 1);  // first row of the window
+            c32 xw[W];
 #pragma unroll
-            for (int u = 0; u < T + PC - 1; u++) {
-                const long long row = rb + u, idx = row * M - j + K - 1;
+            for (int u = 0; u < W; u++) {
+                const long long row = rb + u, idx = row * R - j + K - 1;
                 xw[u] = (idx >= 0 && row < nsteps) ? in[idx] : mk(0.f, 0.f);
             }
 #pragma unroll
             for (int q = 0; q < PC; q++)  // taps ascending, as the reference kernel accumulates (lib/clPolyphaseChannelizer_impl.cc:156-167)
 #pragma unroll
                 for (int t = 0; t < T; t++) {
-                    ar[t] = fmaf(xw[t - q + PC - 1].x, h[q], ar[t]);
-                    ai[t] = fmaf(xw[t - q + PC - 1].y, h[q], ai[t]);
+                    ar[t] = fmaf(xw[t + S * (PC - 1 - q)].x, h[q], ar[t]);
+                    ai[t] = fmaf(xw[t + S * (PC - 1 - q)].y, h[q], ai[t]);
                 }
         }
 #pragma unroll
         for (int t = 0; t < T; t++)
-            if (i0 + t < nsteps) filt[(i0 + t) * M + j] = mk(ar[t], ai[t]);
+            if (i0 + t < nsteps) {
+                const long long i = i0 + t;
+                const int slot = S == 1 ? j : (int)((j + i * (long long)(M - R)) % M);  // (:164: the branch outputs rotate with the step when R != M)
+                filt[i * M + slot] = mk(ar[t], ai[t]);
+            }
     }
 }
 
@@ -756,12 +762,18 @@ int launch_pfb(mi355_pfb *h, const void *in, void *out, hipStream_t st, int nste
     long long total = (long long)nsteps * h->M;
     long long blocks = (total + 255) / 256;
     long long grid = blocks < (long long)cus * 8 ? blocks : (long long)cus * 8;
-    if (h->R == h->M && !getenv("MI355_PFB_BRANCHES_PER_OUTPUT")) {
-        constexpr int T = 8, PC = 16;
+    const int over = h->R > 0 && h->M % h->R == 0 ? h->M / h->R : 0;  // 1: critically sampled; 2, 4: oversampled by that factor
+    if ((over == 1 || over == 2 || over == 4) && !getenv("MI355_PFB_BRANCHES_PER_OUTPUT")) {
+        constexpr int T = 8;
         const long long tt = ((long long)nsteps + T - 1) / T * h->M, tb = (tt + 255) / 256;
         const long long g2 = tb < (long long)cus * 16 ? tb : (long long)cus * 16;
-        hipLaunchKernelGGL((k_pfb_branches_t<T, PC>), dim3((unsigned)(g2 < 1 ? 1 : g2)), dim3(256), 0, st, (const c32 *)in, (c32 *)h->d_filt, h->d_taps, h->K,
-                           h->M, nsteps, tt);
+        const dim3 gd((unsigned)(g2 < 1 ? 1 : g2));
+        if (over == 1)
+            hipLaunchKernelGGL((k_pfb_branches_t<T, 16, 1>), gd, dim3(256), 0, st, (const c32 *)in, (c32 *)h->d_filt, h->d_taps, h->K, h->M, nsteps, tt);
+        else if (over == 2)
+            hipLaunchKernelGGL((k_pfb_branches_t<T, 8, 2>), gd, dim3(256), 0, st, (const c32 *)in, (c32 *)h->d_filt, h->d_taps, h->K, h->M, nsteps, tt);
+        else
+            hipLaunchKernelGGL((k_pfb_branches_t<T, 4, 4>), gd, dim3(256), 0, st, (const c32 *)in, (c32 *)h->d_filt, h->d_taps, h->K, h->M, nsteps, tt);
     } else
     hipLaunchKernelGGL(k_pfb_branches, dim3((unsigned)grid), dim3(256), 0, st, (const c32 *)in, (c32 *)h->d_filt, h->d_taps, h->K,
                        h->M, h->R, total);

@@ -62,6 +62,30 @@ def test_generic_path_oversampled_and_odd(gpu, oracle, M, R):
     assert relerr(y, oracle.pfb(taps, buf, M, R, chmap, xh, f64=True)) <= TOL
 
 
+# channel counts outside the specialised kernels: the branch filters register-tiled (critically sampled, 2- and 4-fold oversampled; any
+# other ratio one output per thread), the M-point DFT as a clFFT transform (power of two above 256, mixed radix, chirp-z for a prime count)
+# when 16 or more channels are mapped, M products per output below that; identity, scrambled and short channel maps
+@pytest.mark.parametrize("M,R,per_arm,nmap", [(10, 10, 17, 10), (20, 20, 3, 20), (48, 48, 70, 48), (100, 100, 17, 100), (100, 50, 33, 100),
+                                              (100, 25, 9, 37), (100, 30, 5, 100), (200, 200, 17, 16), (200, 200, 3, 15), (211, 211, 6, 211),
+                                              (512, 512, 70, 512), (1000, 1000, 4, 999), (1024, 512, 9, 1024), (64, 32, 80, 64), (256, 256, 65, 256)])
+def test_generic_path_large_and_unusual_channel_counts(gpu, oracle, monkeypatch, M, R, per_arm, nmap):
+    rng = np.random.default_rng(M * 7 + R + per_arm)
+    K = M * per_arm - (M // 3 if per_arm > 1 else 0)  # ragged last arm
+    taps = (rng.standard_normal(K) / np.sqrt(per_arm)).astype(np.float32)
+    steps = 83
+    buf = steps * R
+    while buf % M:  # (the reference asks for whole frames of M items per buffer, :59-62)
+        steps += 1
+        buf = steps * R
+    xh = crandn(rng, buf - R + K)
+    chmap = list(range(M)) if nmap == M else rng.permutation(M)[:nmap].tolist()
+    ref = oracle.pfb(taps, buf, M, R, chmap, xh, f64=True)
+    assert relerr(_run(gpu, taps, buf, M, R, chmap, xh), ref) <= TOL
+    monkeypatch.setenv("MI355_PFB_BRANCHES_PER_OUTPUT", "1")  # the per-output branch kernel (read per call) ...
+    monkeypatch.setenv("MI355_PFB_DIRECT_DFT", "1")            # ... and the direct DFT (read at create) on the same input
+    assert relerr(_run(gpu, taps, buf, M, R, chmap, xh), ref) <= TOL
+
+
 def test_baseline_config4_shape_and_streaming(gpu, oracle):
     """64 channels x 32 taps/arm, buf_items 65536 (BASELINE configs[3]); two consecutive calls
     with GNU Radio's history equal one double-length call."""

@@ -15,11 +15,11 @@ def ev(fn, it=5):
     t.record(); torch.cuda.synchronize()
     return s.elapsed_time(t) * 1e-3 / it
 rng = np.random.default_rng(1)
-for M, R, nmap in [(3,3,3),(5,5,5),(10,10,10),(12,12,12),(20,20,20),(48,48,48),(96,96,96),(100,100,100),(200,200,200),(512,512,512),(1024,1024,1024),(64,32,64),(64,48,64),(64,64,16),(256,64,256),(64,64,64)]:
+for M, R, nmap in [(3,3,3),(5,5,5),(10,10,10),(12,12,12),(20,20,20),(48,48,48),(96,96,96),(100,100,100),(200,200,200),(512,512,512),(1024,1024,1024),(64,32,64),(64,16,64),(100,50,100),(100,25,100),(60,20,60),(256,64,256),(64,64,64)]:
     for tpa in (8, 32, 48):
         try:
             tp = rng.standard_normal(M * tpa).astype(np.float32)
-            steps = (N // 2) // max(M, R)
+            steps = ((N // 2) // max(M, R)) // 4 * 4
             buf = steps * nmap
             blk = pkg.clPolyphaseChannelizer(1, 2, 0, 0, tp, buf, M, R, list(range(nmap)))
             dt = ev(lambda: blk.work_device([a], [c]))
