@@ -972,11 +972,12 @@ __global__ __launch_bounds__(CH * 64) void k_xe_f32_fused(const v4i *__restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void k_xe_reduce(const c32 *__restrict__ part, c32 *__restrict__ out, size_t n, int tsplit, int accumulate)
+__global__ __launch_bounds__(256) void k_xe_reduce(const c32 *__restrict__ part, c32 *__restrict__ out, size_t n, size_t stride, int tsplit, int accumulate)
 {
+    // n outputs (the caller's channels), partial matrices `stride` items apart (all channels incl. the padding ones, which come last)
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         c32 a = part[i];
-        for (int t = 1; t < tsplit; t++) { a.x += part[(size_t)t * n + i].x; a.y += part[(size_t)t * n + i].y; }
+        for (int t = 1; t < tsplit; t++) { a.x += part[(size_t)t * stride + i].x; a.y += part[(size_t)t * stride + i].y; }
         if (accumulate) { a.x += out[i].x; a.y += out[i].y; }
         out[i] = a;
     }
@@ -1081,6 +1082,18 @@ __global__ __launch_bounds__(256) void k_xe_pad_rows(const unsigned short *__res
     }
 }
 
+// the same for rows of complex floats (8-byte units)
+__global__ __launch_bounds__(256) void k_xe_pad_rows8(const unsigned long long *__restrict__ in, unsigned long long *__restrict__ out, size_t rows,
+                                                      int src_units, int dst_units)
+{
+    const size_t total = rows * (size_t)dst_units;
+    for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u < total; u += (size_t)gridDim.x * 256) {
+        const size_t row = u / dst_units;
+        const int c = (int)(u - row * dst_units);
+        out[u] = c < src_units ? __builtin_nontemporal_load(in + row * src_units + c) : 0ull;
+    }
+}
+
 int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipStream_t st, unsigned char *tiles, unsigned char *padbuf,
               int stations_per_group = 0)
 {
@@ -1091,6 +1104,12 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
         size_t blocks = (rows * dst_units + 255) / 256;
         const size_t cap = (size_t)(h->ctx->num_cus > 0 ? h->ctx->num_cus : 256) * 16;
         if (blocks > cap) blocks = cap;
+        if (h->data_type == MI355_DTYPE_COMPLEX) {
+            const int du = g.F * g.npol, su = g.Fout * g.npol;  // complex values per row
+            size_t b8 = (rows * du + 255) / 256;
+            if (b8 > cap) b8 = cap;
+            hipLaunchKernelGGL(k_xe_pad_rows8, dim3((unsigned)b8), dim3(256), 0, st, (const unsigned long long *)in, (unsigned long long *)padbuf, rows, su, du);
+        } else
         hipLaunchKernelGGL(k_xe_pad_rows, dim3((unsigned)blocks), dim3(256), 0, st, (const unsigned short *)in, (unsigned short *)padbuf, rows,
                            src_units, dst_units);
         MI355_HIP(hipGetLastError());
@@ -1101,8 +1120,17 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
                           xe_f32_row_tiles(g.NT) != 0 && !getenv("MI355_XE_CF32_VALU");
         // fused kernel: rows <= 64, whole groups of 8 channels; the partial matrices live in the tile workspace
         const int ts_env = getenv("MI355_XE_CF32_TSPLIT") ? atoi(getenv("MI355_XE_CF32_TSPLIT")) : 0;
-        const int tsplit = (ts_env > 0 && g.T % (16 * ts_env) == 0) ? ts_env : (g.T >= 64 ? 2 : 1);
         const size_t out_items = (size_t)g.F * (g.N * (g.N + 1) / 2) * g.npol * g.npol;
+        int tsplit = (ts_env > 0 && g.T % (16 * ts_env) == 0) ? ts_env : (g.T >= 64 ? 2 : 1);
+        if (ts_env <= 0 && g.T >= 64) {
+            // few channels: more time ranges, so that (channel groups) x (ranges) still covers the CUs -- 64 antennas x 16 channels x 16384
+            // frames ran as 4 workgroups (2.2 ms); the ranges keep at least two K blocks each and their partial matrices fit the workspace
+            const int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256, groups = (g.F + 7) / 8, kb_total = (g.T + kKB32 - 1) / kKB32;
+            int want = cus / groups;  // the most ranges that still run as one round of workgroups (125 groups x 3 ranges: a second round at 46 % -- slower than 2)
+            if (want > kb_total / 2) want = kb_total / 2;
+            while (want > 2 && (size_t)want * out_items * 8 > h->tile_bytes) want--;
+            if (want > tsplit) tsplit = want;
+        }
         if (mfma && g.NT <= 4 && g.F % 8 == 0 && h->tile_bytes >= (size_t)tsplit * out_items * 8 && !getenv("MI355_XE_CF32_TWO_KERNELS")) {
             const int ntt = g.NT == 3 ? 4 : g.NT;
             // 8 channels per workgroup (one workgroup per CU, 64-byte pieces of a row) or 4 (two workgroups per CU, 32-byte pieces).
@@ -1119,10 +1147,11 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
 #undef FUSED_CH
 #undef FUSED
             MI355_HIP(hipGetLastError());
-            size_t blocks = (out_items + 255) / 256;
+            const size_t real_items = (size_t)g.Fout * (g.N * (g.N + 1) / 2) * g.npol * g.npol;
+            size_t blocks = (real_items + 255) / 256;
             const size_t cap = (size_t)(h->ctx->num_cus > 0 ? h->ctx->num_cus : 256) * 16;
             if (blocks > cap) blocks = cap;
-            hipLaunchKernelGGL(k_xe_reduce, dim3((unsigned)blocks), dim3(256), 0, st, (const c32 *)tiles, (c32 *)out, out_items, tsplit, accumulate);
+            hipLaunchKernelGGL(k_xe_reduce, dim3((unsigned)blocks), dim3(256), 0, st, (const c32 *)tiles, (c32 *)out, real_items, out_items, tsplit, accumulate);
             MI355_HIP(hipGetLastError());
             return MI355_OK;
         }
@@ -1136,7 +1165,7 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
             MI355_HIP(hipGetLastError());
             const int npairs = gf.NT * (gf.NT + 1) / 2;
 #define CORR_F32(NTT, WV, PPW)                                                                                             \
-    hipLaunchKernelGGL((k_xe_corr_f32<NTT, WV, PPW>), dim3(g.F), dim3(WV * 64), 0, st, \
+    hipLaunchKernelGGL((k_xe_corr_f32<NTT, WV, PPW>), dim3(g.Fout), dim3(WV * 64), 0, st, \
                        (const unsigned char *)tiles, (c32 *)out, gf, npairs, accumulate)
             if (gf.NT == 1) CORR_F32(1, 1, 1);
             else if (gf.NT == 2) CORR_F32(2, 1, 3);
@@ -1285,7 +1314,14 @@ extern "C" int mi355_xengine_create(mi355_ctx *ctx, int data_type, int npol, int
     MI355_REQUIRE(num_channels >= 1 && integration >= 1, "num_channels and integration must be positive");
     MI355_REQUIRE(integration <= 65536, "integration above 65536 frames would overflow the int32 accumulators");
     // the corner turn consumes 4-byte units of the input rows: an odd count of 2-byte channels gets one zero channel on the device
-    const int pad = (data_type != MI355_DTYPE_COMPLEX && ((size_t)num_channels * (data_type == MI355_DTYPE_BYTE ? npol * 2 : 2)) % 4 != 0) ? 1 : 0;
+    int pad = (data_type != MI355_DTYPE_COMPLEX && ((size_t)num_channels * (data_type == MI355_DTYPE_BYTE ? npol * 2 : 2)) % 4 != 0) ? 1 : 0;
+    // complex float: the matrix-core kernels read whole 128-byte lines (16 values) of every (t, station) row; other channel counts get
+    // zero channels on the device up to the next whole line (1000 channels ran 4 x slower per sample than 1024 on the vector-ALU kernel,
+    // 100 channels 30 x) -- no output is produced for them
+    if (data_type == MI355_DTYPE_COMPLEX && !getenv("MI355_XE_CF32_NO_PAD")) {
+        const int vals = num_channels * npol, rest = vals % 16;
+        if (rest) pad = (16 - rest) / npol;  // (16 - rest is even when npol = 2: vals is)
+    }
     mi355_xengine *h = new (std::nothrow) mi355_xengine();
     if (!h) return MI355_ERR_NOMEM;
     h->ctx = ctx; h->data_type = data_type;
@@ -1332,7 +1368,7 @@ extern "C" int mi355_xengine_create(mi355_ctx *ctx, int data_type, int npol, int
         return MI355_ERR_HIP;
     }
     if (pad) {
-        h->pad_bytes = (size_t)g.T * g.N * g.F * 2;
+        h->pad_bytes = data_type == MI355_DTYPE_COMPLEX ? (size_t)g.T * g.N * g.F * npol * 8 : (size_t)g.T * g.N * g.F * 2;
         if (hipMalloc((void **)&h->d_pad, h->pad_bytes) != hipSuccess) { mi355_xengine_destroy(h); return MI355_ERR_NOMEM; }
     }
     mi355_log(ctx, MI355_LOG_INFO, "clXEngine: %d inputs x %d pol, %d channels, %d frames per integration, %s input: %zu input bytes, %zu output items, %zu workspace bytes",

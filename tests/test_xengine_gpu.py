@@ -222,7 +222,7 @@ def test_closed_form_cases(gpu):
     assert np.allclose(out, T, atol=1e-3)
 
 
-# F*npol % 16 == 0 takes the fp32 matrix-core path (row tiles 1, 2, 3->4, 4, 5->6, 8); the others the VALU kernel
+# the fp32 matrix-core path (row tiles 1, 2, 3->4, 4, 5->6, 8; rows padded on the device to whole 128-byte lines when F*npol % 16 != 0); more than 128 rows: the VALU kernel
 @pytest.mark.parametrize("N,F,T,npol", [(4, 8, 16, 1), (9, 5, 33, 2), (16, 32, 64, 1), (16, 16, 64, 1), (20, 16, 50, 1),
                                         (40, 32, 33, 1), (64, 16, 100, 1), (33, 8, 130, 2), (64, 8, 40, 2), (70, 16, 20, 2),
                                         # rows <= 64 and F % 8 == 0: the fused kernel (1, 2, 3->4 and 4 row tiles, both polarisation counts)
@@ -237,6 +237,33 @@ def test_complex_float_vs_oracle(gpu, oracle, N, F, T, npol):
     assert relerr(out, ref) <= TOL
     blk.xcorrelate(x, out, accumulate=True)
     assert relerr(out, ref + ref) <= TOL
+
+
+# channel counts whose rows are not whole 128-byte lines are padded on the device for the matrix-core kernels (no output for the padding
+# channels); few channels x long integrations run many time ranges; MI355_XE_CF32_NO_PAD keeps the vector-ALU kernel in the suite
+@pytest.mark.parametrize("N,F,T,npol", [(50, 100, 200, 1), (20, 37, 128, 1), (64, 10, 4096, 1), (12, 50, 300, 2), (30, 7, 1000, 2), (64, 2, 16384, 1),
+                                        (100, 20, 64, 1), (3, 1, 2, 1)])
+def test_complex_float_ragged_rows_and_many_time_ranges(gpu, oracle, monkeypatch, N, F, T, npol):
+    rng = np.random.default_rng(N * 3 + F + T)
+    x = crandn(rng, T * N * F * npol)
+    ref = oracle.xengine_cf32(N, F, npol, T, x)
+    for no_pad in (False, True):
+        if no_pad:
+            monkeypatch.setenv("MI355_XE_CF32_NO_PAD", "1")  # read when the block is made
+        blk = _xe(gpu, gpu.DTYPE_COMPLEX, npol, N, F, T)
+        guard = np.full(blk.get_output_buffer_size() + 64, 7 + 7j, np.complex64)  # nothing may be written behind the last real channel
+        out = guard[:blk.get_output_buffer_size()]
+        blk.xcorrelate(x, out)
+        assert relerr(out, ref) <= TOL and np.all(guard[out.size:] == 7 + 7j)
+        blk.xcorrelate(x, out, accumulate=True)
+        assert relerr(out, ref + ref) <= TOL
+        out2 = np.empty_like(ref)  # the double-buffered host pipeline pads in its own slot buffers
+        blk.submit(x)
+        blk.submit(x)
+        blk.wait(out2)
+        assert relerr(out2, ref) <= TOL
+        blk.wait(out2)
+        assert relerr(out2, ref) <= TOL
 
 
 @pytest.mark.parametrize("N,F,T", [(2, 2, 3), (5, 6, 70), (16, 8, 64), (6, 5, 40), (3, 1, 2)])  # odd channel counts: padded on the device
