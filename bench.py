@@ -529,6 +529,26 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank, out=None):
                   lambda dt: {"TFLOPs": round(flopc / dt / 1e12, 1), "mfma_frac_f32_157TF": round(flopc / dt / 157.3e12, 4)})
         out["clXEngine_64ant_1024ch_1024t_cf32"] = rc
         del xec, visc
+        # off the tuned geometries (found by sweeping the parameters, DESIGN_EXPERIMENTS A.3b / A.5b / A.6b): a channel count whose rows are not
+        # whole 128-byte lines, a channelizer with 100 channels, a time-domain filter decimating by 16
+        Fr = 1000
+        xf = a.view(-1)[:Tc * Nc * Fr * 2]
+        xec = pkg.clXEngine(*args, False, pkg.DTYPE_COMPLEX, 1, Nc, 1, 0, Fr, Tc, [])
+        visc = torch.zeros(xec.get_output_buffer_size(), 2, device="cuda")
+        out["clXEngine_64ant_1000ch_1024t_cf32"] = rate(lambda: xec.xcorrelate_device(xf, visc), Nc * Fr * Tc, 8)
+        del xec, visc
+    Mc = 100
+    tp100 = np.resize(taps2048, Mc * 32).astype(np.float32)
+    bufc = ((n // 2) // Mc) * Mc
+    pfbc = pkg.clPolyphaseChannelizer(*args, tp100, bufc, Mc, Mc, list(range(Mc)))
+    xi = a[:pfbc.ninput()]
+    yo = c[:pfbc.noutput()]
+    out["clPolyphaseChannelizer_100x32_stream"] = rate(lambda: pfbc.work_device([xi], [yo]), bufc, 16)
+    del pfbc
+    fd = pkg.clFilter(*args, 16, taps65, 1, 0, True)
+    nd = (n - 64) // 16
+    out["clFilter_fir_65taps_decim16"] = rate(lambda: fd.work_device(nd, [a], [c]), nd * 16, 8 + 0.5)
+    del fd
     del a, c
     torch.cuda.empty_cache()
     # BASELINE configs[4]: X-engine 64 antennas x 1024 channels x 1024 frames, IChar.  Both fractions.
