@@ -1617,9 +1617,26 @@ extern "C" int mi355_xengine_gather(const mi355_xengine *h, int nframes, int fra
                     const char *x = (const char *)j.inputs[i] + (size_t)b * g.Fout * j.esz;
                     const char *y = (const char *)j.inputs[i + g.N] + (size_t)b * g.Fout * j.esz;
                     char *row = fb + (size_t)i * g.Fout * 2 * j.esz;
-                    for (int c = 0; c < g.Fout; c++) {
-                        memcpy(row + (size_t)c * 2 * j.esz, x + (size_t)c * j.esz, j.esz);
-                        memcpy(row + (size_t)c * 2 * j.esz + j.esz, y + (size_t)c * j.esz, j.esz);
+                    // X and Y of a station arrive as two streams and are interleaved per channel (lib/clXEngine_impl.cc:1020-1045).  Fixed-size
+                    // copies the compiler turns into vector shuffles: the general memcpy(esz) loop moved 2 bytes per call
+                    if (j.esz == 2) {
+                        for (int c = 0; c < g.Fout; c++) {
+                            unsigned short a, b;
+                            memcpy(&a, x + (size_t)c * 2, 2);
+                            memcpy(&b, y + (size_t)c * 2, 2);
+                            const unsigned int v = (unsigned int)a | ((unsigned int)b << 16);
+                            memcpy(row + (size_t)c * 4, &v, 4);
+                        }
+                    } else if (j.esz == 8) {
+                        for (int c = 0; c < g.Fout; c++) {
+                            memcpy(row + (size_t)c * 16, x + (size_t)c * 8, 8);
+                            memcpy(row + (size_t)c * 16 + 8, y + (size_t)c * 8, 8);
+                        }
+                    } else {
+                        for (int c = 0; c < g.Fout; c++) {
+                            memcpy(row + (size_t)c * 2 * j.esz, x + (size_t)c * j.esz, j.esz);
+                            memcpy(row + (size_t)c * 2 * j.esz + j.esz, y + (size_t)c * j.esz, j.esz);
+                        }
                     }
                 }
             }
