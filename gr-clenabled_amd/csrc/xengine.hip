@@ -670,7 +670,7 @@ __global__ __launch_bounds__(NT * 32, 2) void k_xe_corr_sb(SbArgs a)
 constexpr int kKB32 = 16;
 typedef float v4f __attribute__((ext_vector_type(4)));
 // row tiles are padded (with zero rows) up to a count the staged correlator is instantiated for; 0 = use the VALU kernel
-static inline int xe_f32_row_tiles(int nt) { return nt <= 2 ? nt : nt <= 4 ? 4 : nt <= 6 ? 6 : nt <= 8 ? 8 : 0; }
+static inline int xe_f32_row_tiles(int nt) { return nt <= 2 ? nt : nt <= 4 ? 4 : nt <= 6 ? 6 : nt <= 8 ? 8 : nt <= 10 ? 10 : nt <= 12 ? 12 : nt <= 16 ? 16 : 0; }
 
 template <int NPOL>
 __global__ __launch_bounds__(256) void k_xe_turn_f32(const v4i *__restrict__ in, unsigned char *__restrict__ tiles, XeGeo g)
@@ -724,13 +724,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_xe_corr_f32(const unsigned char 
 {
     constexpr int NTHR = WAVES * 64, KBYTES = 2 * NTT * kTileBytes, PER_THREAD = KBYTES / (NTHR * 16);
     static_assert(KBYTES % (NTHR * 16) == 0 && PER_THREAD >= 1, "tile bytes per K block must split over the workgroup");
-    static_assert(NTT * (NTT + 1) / 2 == WAVES * PPW, "tile pairs must split exactly over the waves");
+    // (more than 8 row tiles -- 129 ... 256 rows: the triangle's pairs are split over gridDim.y workgroups of WAVES x PPW pairs; every one
+    // of them stages all NTT row tiles of a K block)
+    static_assert(NTT * (NTT + 1) / 2 <= WAVES * PPW || NTT > 8, "tile pairs must fit the waves");
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][KBYTES];
     const int f = blockIdx.x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     int bi[PPW], bj[PPW];
 #pragma unroll
-    for (int q = 0; q < PPW; q++) pair_to_tiles(q * WAVES + wave, bi[q], bj[q]);
+    for (int q = 0; q < PPW; q++) {
+        const int p = (int)blockIdx.y * WAVES * PPW + q * WAVES + wave;
+        pair_to_tiles(p < npairs ? p : 0, bi[q], bj[q]);  // (a pair past the triangle repeats pair 0 and stores nothing)
+    }
     v4f re[PPW], uu[PPW], ww[PPW];
 #pragma unroll
     for (int q = 0; q < PPW; q++) re[q] = uu[q] = ww[q] = (v4f){0.f, 0.f, 0.f, 0.f};
@@ -787,6 +792,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_xe_corr_f32(const unsigned char 
     const int nb = g.N * (g.N + 1) / 2, np2 = g.npol * g.npol;
 #pragma unroll
     for (int q = 0; q < PPW; q++) {
+        if ((int)blockIdx.y * WAVES * PPW + q * WAVES + wave >= npairs) continue;
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
             const int r1 = bi[q] * kRowTile + (lane >> 4) * 4 + reg, r2 = bj[q] * kRowTile + (lane & 15);
@@ -1164,14 +1170,18 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
             else hipLaunchKernelGGL((k_xe_turn_f32<2>), tgrid, dim3(256), 0, st, (const v4i *)in, tiles, gf);
             MI355_HIP(hipGetLastError());
             const int npairs = gf.NT * (gf.NT + 1) / 2;
+            const int chunks = gf.NT > 8 ? (npairs + 35) / 36 : 1;  // 129 ... 256 rows: 36 tile pairs per workgroup
 #define CORR_F32(NTT, WV, PPW)                                                                                             \
-    hipLaunchKernelGGL((k_xe_corr_f32<NTT, WV, PPW>), dim3(g.Fout), dim3(WV * 64), 0, st, \
+    hipLaunchKernelGGL((k_xe_corr_f32<NTT, WV, PPW>), dim3(g.Fout, chunks), dim3(WV * 64), 0, st, \
                        (const unsigned char *)tiles, (c32 *)out, gf, npairs, accumulate)
             if (gf.NT == 1) CORR_F32(1, 1, 1);
             else if (gf.NT == 2) CORR_F32(2, 1, 3);
             else if (gf.NT == 4) CORR_F32(4, 2, 5);
             else if (gf.NT == 6) CORR_F32(6, 3, 7);
-            else CORR_F32(8, 4, 9);
+            else if (gf.NT == 8) CORR_F32(8, 4, 9);
+            else if (gf.NT == 10) CORR_F32(10, 4, 9);
+            else if (gf.NT == 12) CORR_F32(12, 4, 9);
+            else CORR_F32(16, 4, 9);
 #undef CORR_F32
             MI355_HIP(hipGetLastError());
             return MI355_OK;

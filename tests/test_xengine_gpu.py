@@ -222,7 +222,7 @@ def test_closed_form_cases(gpu):
     assert np.allclose(out, T, atol=1e-3)
 
 
-# the fp32 matrix-core path (row tiles 1, 2, 3->4, 4, 5->6, 8; rows padded on the device to whole 128-byte lines when F*npol % 16 != 0); more than 128 rows: the VALU kernel
+# the fp32 matrix-core path (row tiles 1, 2, 3->4, 4, 5->6, 8; rows padded on the device to whole 128-byte lines when F*npol % 16 != 0); more than 256 rows: the VALU kernel
 @pytest.mark.parametrize("N,F,T,npol", [(4, 8, 16, 1), (9, 5, 33, 2), (16, 32, 64, 1), (16, 16, 64, 1), (20, 16, 50, 1),
                                         (40, 32, 33, 1), (64, 16, 100, 1), (33, 8, 130, 2), (64, 8, 40, 2), (70, 16, 20, 2),
                                         # rows <= 64 and F % 8 == 0: the fused kernel (1, 2, 3->4 and 4 row tiles, both polarisation counts)
@@ -242,7 +242,9 @@ def test_complex_float_vs_oracle(gpu, oracle, N, F, T, npol):
 # channel counts whose rows are not whole 128-byte lines are padded on the device for the matrix-core kernels (no output for the padding
 # channels); few channels x long integrations run many time ranges; MI355_XE_CF32_NO_PAD keeps the vector-ALU kernel in the suite
 @pytest.mark.parametrize("N,F,T,npol", [(50, 100, 200, 1), (20, 37, 128, 1), (64, 10, 4096, 1), (12, 50, 300, 2), (30, 7, 1000, 2), (64, 2, 16384, 1),
-                                        (100, 20, 64, 1), (3, 1, 2, 1)])
+                                        (100, 20, 64, 1), (3, 1, 2, 1),
+                                        # 129 ... 256 rows: the triangle's tile pairs split over several workgroups per channel (10, 12, 16 row tiles)
+                                        (130, 16, 48, 1), (180, 8, 40, 1), (100, 16, 33, 2), (256, 16, 32, 1), (200, 5, 64, 1)])
 def test_complex_float_ragged_rows_and_many_time_ranges(gpu, oracle, monkeypatch, N, F, T, npol):
     rng = np.random.default_rng(N * 3 + F + T)
     x = crandn(rng, T * N * F * npol)
