@@ -32,7 +32,7 @@ def note(name, ok):
 def churn_fft(seed):
     rng = np.random.default_rng(seed)
     while time.time() < T_END:
-        n = int(rng.choice([64, 1000, 4096, 8192, 32768, 65536, 131072]))
+        n = int(rng.choice([64, 1000, 1500, 2310, 4096, 4099, 8192, 20000, 32768, 65536, 131072]))  # (mixed radix incl. its measurement at create, chirp-z, two-pass forms)
         x = crandn(rng, 2 * n)
         y = np.empty_like(x)
         blk = pkg.clFFT(n, pkg.CLFFT_FORWARD, [], pkg.DTYPE_COMPLEX, *ARGS)
@@ -91,7 +91,7 @@ def churn_xengine(seed):
 def churn_pfb_math(seed):
     rng = np.random.default_rng(seed)
     while time.time() < T_END:
-        M = int(rng.choice([4, 32, 64, 128]))
+        M = int(rng.choice([4, 32, 64, 128, 20, 100, 512]))  # (the last three: branch filters + a clFFT transform per step)
         tpa = int(rng.choice([3, 8, 32]))
         buf = M * 128
         taps = rng.standard_normal(M * tpa).astype(np.float32)
