@@ -28,6 +28,10 @@ struct c32 { float x, y; };
 
 constexpr int kStageT = 16, kRing = 4, kChunk = 1024, kWaves = 8, kThreads = kWaves * 64;
 
+// an integration that is not a multiple of 32 frames: the time steps past its end are fetched from here (zero samples add nothing to any
+// sum: I = Q = 0 makes every product 0, ~Q = -1 meets I = 0, and the row sums' bias of 128 per byte is removed per step as for real data)
+__device__ __attribute__((aligned(64))) unsigned char xe_zero_row[64];
+
 struct FuArgs {
     const unsigned char *in;
     v4i *part;
@@ -156,7 +160,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
             const int idx = wave + kWaves * k, t16 = idx / NSH, sh = idx % NSH;
             const int s = sh * 32 + (lane >> 1);
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + slot * STAGE + idx * kChunk + (t16 >> 3) * 16);
-            if (s < a.N && !(a.dbg & 4)) dma16(src_lane[sh] + (size_t)(t0 + t16) * t_stride, dst);
+            const unsigned char *from = (t0 + t16 < a.T) ? src_lane[sh] + (size_t)(t0 + t16) * t_stride : xe_zero_row + (lane & 1) * 16;
+            if (s < a.N && !(a.dbg & 4)) dma16(from, dst);
         }
     };
 
@@ -588,7 +593,9 @@ XeFusedPlan mi355_xe_fused_plan(int N, int F, int Fout, int npol, int T, int num
     (void)Fout;
     const int A = N * npol;
     const size_t row_bytes = (size_t)F * npol * 2;
-    if (A > 64 || A < 1 || row_bytes % 128 != 0 || T % 32 != 0 || getenv("MI355_XE_NO_FUSED")) return p;
+    if (A > 64 || A < 1 || row_bytes % 128 != 0 || getenv("MI355_XE_NO_FUSED")) return p;
+    if (T % 32 != 0 && getenv("MI355_XE_FUSED_WHOLE_KBLOCKS")) return p;  // (tuning / test switch: ragged integrations through the two-kernel path)
+    T = (T + 31) / 32 * 32;  // the frames past the end of the integration read as zeros (xe_zero_row)
     p.npol = npol;
     const int nt = (A + 15) / 16;
     p.ntt = nt <= 1 ? 1 : nt <= 2 ? 2 : 4;
@@ -630,7 +637,8 @@ int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void 
     if (a.inkernel) a.epoch = ++*epoch;
     a.compact = (!a.inkernel && !getenv("MI355_XE_NO_COMPACT")) ? 1 : 0;
     // 24-bit planes: time ranges of at most 256 steps, at least two row tiles (a lone diagonal record has nothing to pair with)
-    if (a.compact && p.tsplit > 1 && T / p.tsplit <= 256 && p.ntt >= 2 && !getenv("MI355_XE_NO_PACK24")) a.compact = 2;
+    const int Tp = (T + 31) / 32 * 32;  // whole K blocks
+    if (a.compact && p.tsplit > 1 && Tp / p.tsplit <= 256 && p.ntt >= 2 && !getenv("MI355_XE_NO_PACK24")) a.compact = 2;
     a.out = (c32 *)out;
     a.N = N; a.F = F; a.Fout = Fout; a.T = T;
     a.ng = (stations_per_group > 0 && stations_per_group < N) ? stations_per_group : N;
@@ -646,7 +654,7 @@ int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void 
     }
     a.nlines = p.units / 4;
     a.tsplit = p.tsplit;
-    a.steps = T / (32 * p.tsplit);
+    a.steps = Tp / (32 * p.tsplit);
     a.pinned = (((long)a.nlines * p.tsplit * (nint > 0 ? nint : 1)) % 8 == 0) ? 1 : 0;
     a.accumulate = accumulate;
     a.kd = kd;

@@ -40,7 +40,9 @@ def test_golden_exact_integer_sums(gpu):
                                         # whole 128-byte input rows and <= 64 rows: the fused single-pass kernels (xengine_fused.hip), every
                                         # row-tile count, one and two polarisations, direct and time-split (partial sums) forms
                                         (64, 64, 64, 1), (20, 128, 96, 1), (5, 64, 32, 1), (33, 64, 256, 1), (48, 192, 128, 1), (64, 128, 512, 1),
-                                        (16, 32, 32, 2), (32, 64, 128, 2), (7, 96, 64, 2), (24, 32, 1024, 2)])
+                                        (16, 32, 32, 2), (32, 64, 128, 2), (7, 96, 64, 2), (24, 32, 1024, 2),
+                                        # ... and integrations that are not whole K blocks of 32 frames (the frames past the end read as zeros)
+                                        (64, 64, 100, 1), (20, 128, 1000, 1), (32, 64, 33, 2), (5, 64, 1, 1), (48, 64, 2047, 1), (16, 32, 31, 2)])
 def test_ichar_bit_exact_vs_oracle(gpu, oracle, N, F, T, npol):
     rng = np.random.default_rng(N * 1000 + T)
     x = rng.integers(-128, 128, size=T * N * F * npol * 2, dtype=np.int64).astype(np.int8)  # full range incl. -128
