@@ -1214,7 +1214,7 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
     }
     if (tiles) h->flags_stale[tiles == h->d_tiles ? 0 : 1] = true;  // the corner turn below writes over the whole workspace
     if (stations_per_group > 0 && stations_per_group < g.N) {
-        mi355_set_error("antenna-group-major input needs the fused IChar path (<= 64 rows, whole 128-byte rows)");
+        mi355_set_error("antenna-group-major input needs the fused IChar path (<= 64 rows, rows of whole 16-byte pieces)");
         return MI355_ERR_UNSUPPORTED;
     }
     const bool fast_turn = row_bytes % 128 == 0 && (reinterpret_cast<uintptr_t>(in) & 15u) == 0 && !getenv("MI355_XE_SLOW_TURN");
@@ -1420,7 +1420,7 @@ extern "C" int mi355_xengine_xcorrelate_n_dev(mi355_xengine *h, int nint, const 
     hipStream_t st = mi355_pick_stream(h->ctx, stream);
     const XeGeo &g = h->g;
     const bool grouped = stations_per_group > 0 && stations_per_group < g.N;
-    // one launch for all windows: the fused IChar path (<= 64 rows, whole 128-byte rows, 16-byte aligned input)
+    // one launch for all windows: the fused IChar path (<= 64 rows, rows of whole 16-byte pieces, 16-byte aligned input)
     if (h->data_type == MI355_DTYPE_BYTE && !h->pad && (reinterpret_cast<uintptr_t>(in_dev) & 15u) == 0) {
         const XeFusedPlan fp = mi355_xe_fused_plan(g.N, g.F, g.Fout, g.npol, g.T, h->ctx->num_cus, nint);
         if (fp.ok) {
@@ -1441,7 +1441,7 @@ extern "C" int mi355_xengine_xcorrelate_n_dev(mi355_xengine *h, int nint, const 
         }
     }
     if (grouped && nint > 1) {
-        mi355_set_error("group-major input of several windows needs the fused IChar path (<= 64 rows, whole 128-byte rows)");
+        mi355_set_error("group-major input of several windows needs the fused IChar path (<= 64 rows, rows of whole 16-byte pieces)");
         return MI355_ERR_UNSUPPORTED;
     }
     // every other geometry / sample format: one window after the other through the handle's workspace (stream ordered)

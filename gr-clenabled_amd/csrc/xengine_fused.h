@@ -7,7 +7,8 @@
 struct XeFusedPlan {
     bool ok = false;     // geometry supported by the fused kernels
     int npol = 1, ntt = 0;
-    int units = 0;       // 32-byte column slices of an input row
+    int units = 0;       // 32-byte column slices of an input row (rows rounded up to whole 128-byte lines)
+    int row_stride = 0;  // bytes of a row that exist = bytes between rows
     int tsplit = 1;      // time ranges (partial sums are combined by the reduce kernel when > 1)
     size_t part_bytes = 0;  // workspace needed: int32 partial sums + the reduction's counters (0 when tsplit == 1)
     size_t flag_offset = 0; // where the counters start

@@ -36,7 +36,8 @@ struct FuArgs {
     const unsigned char *in;
     v4i *part;
     c32 *out;
-    int N, F, Fout, T;
+    int N, F, Fout, T;  // F: channels of the workspace indexing (rows rounded up to whole 128-byte lines), Fout: the caller's
+    int row_stride;     // bytes between (t, station) rows of the input = the bytes of a row that exist (a multiple of 16)
     int ng;     // stations per antenna group: input is [group][t][station in group][...] (ng == N: the reference layout)
     int nlines, tsplit, steps;  // 128-byte lines per input row; time ranges; K blocks (32 time steps) per time range
     int pinned, accumulate;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
         a.out += (size_t)win * a.out_window;
         a.part += (size_t)win * a.part_window;
     }
-    const size_t row_bytes = (size_t)a.nlines * 128;
+    const size_t row_bytes = (size_t)a.row_stride;  // (a row may end inside its last 128-byte line: the pieces past its end read the zero row)
     const int t_base = q * a.steps * 32;
     const unsigned lds0 = (unsigned)(size_t)lds;
 
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
         const int s = sh * 32 + (lane >> 1);
         src_lane[sh] = a.in + (size_t)(s / a.ng) * a.in_group + (size_t)(s % a.ng) * row_bytes + (size_t)slice * 32 + (lane & 1) * 16;
     }
+    const bool in_row = slice * 32 + (lane & 1) * 16 < a.row_stride;  // this lane's 16 bytes of the slice exist
     auto issue_stage = [&](int sigma) {
         const int slot = sigma & (kRing - 1), t0 = t_base + sigma * kStageT;
 #pragma unroll
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
             const int idx = wave + kWaves * k, t16 = idx / NSH, sh = idx % NSH;
             const int s = sh * 32 + (lane >> 1);
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + slot * STAGE + idx * kChunk + (t16 >> 3) * 16);
-            const unsigned char *from = (t0 + t16 < a.T) ? src_lane[sh] + (size_t)(t0 + t16) * t_stride : xe_zero_row + (lane & 1) * 16;
+            const unsigned char *from = (t0 + t16 < a.T && in_row) ? src_lane[sh] + (size_t)(t0 + t16) * t_stride : xe_zero_row + (lane & 1) * 16;
             if (s < a.N && !(a.dbg & 4)) dma16(from, dst);
         }
     };
@@ -592,8 +594,14 @@ XeFusedPlan mi355_xe_fused_plan(int N, int F, int Fout, int npol, int T, int num
     XeFusedPlan p;
     (void)Fout;
     const int A = N * npol;
-    const size_t row_bytes = (size_t)F * npol * 2;
-    if (A > 64 || A < 1 || row_bytes % 128 != 0 || getenv("MI355_XE_NO_FUSED")) return p;
+    // rows of whole 16-byte pieces; a row that ends inside a 128-byte line is treated as the whole line (the missing pieces read as zeros, the
+    // channels they would hold have no output): 1000 channels run as 1024
+    const size_t row_real = (size_t)F * npol * 2;
+    if (A > 64 || A < 1 || row_real % 16 != 0 || getenv("MI355_XE_NO_FUSED")) return p;
+    if (row_real % 128 != 0 && getenv("MI355_XE_FUSED_WHOLE_LINES")) return p;  // (tuning / test switch: such rows through the two-kernel path)
+    const size_t row_bytes = (row_real + 127) / 128 * 128;
+    p.row_stride = (int)row_real;
+    F = (int)(row_bytes / (npol * 2));  // channels of the workspace indexing
     if (T % 32 != 0 && getenv("MI355_XE_FUSED_WHOLE_KBLOCKS")) return p;  // (tuning / test switch: ragged integrations through the two-kernel path)
     T = (T + 31) / 32 * 32;  // the frames past the end of the integration read as zeros (xe_zero_row)
     p.npol = npol;
@@ -640,10 +648,12 @@ int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void 
     const int Tp = (T + 31) / 32 * 32;  // whole K blocks
     if (a.compact && p.tsplit > 1 && Tp / p.tsplit <= 256 && p.ntt >= 2 && !getenv("MI355_XE_NO_PACK24")) a.compact = 2;
     a.out = (c32 *)out;
-    a.N = N; a.F = F; a.Fout = Fout; a.T = T;
+    (void)F;
+    a.N = N; a.F = p.units * 32 / (p.npol * 2); a.Fout = Fout; a.T = T;
     a.ng = (stations_per_group > 0 && stations_per_group < N) ? stations_per_group : N;
     {
-        const size_t row_bytes = (size_t)p.units * 32;
+        const size_t row_bytes = (size_t)p.row_stride;
+        a.row_stride = p.row_stride;
         a.nint_launch = nint > 0 ? nint : 1;
         a.wgs = p.units * p.tsplit;
         // reference layout: [window][t][station]; group-major: [group][window][t][station in group]

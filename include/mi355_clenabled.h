@@ -241,7 +241,7 @@ int mi355_xengine_xcorrelate(mi355_xengine *h, const void *in_host, void *out_ho
 int mi355_xengine_xcorrelate_dev(mi355_xengine *h, const void *in_dev, void *out_dev, int accumulate, void *stream);
 /* Multi-GPU form (no counterpart in the reference, which runs one X-engine on one device): the input is the
  * receive buffer of the all-to-all corner turn, [group][t][station in group][chan][pol], stations_per_group stations per
- * sending rank; it is read in place.  IChar geometries of the fused path only (<= 64 rows, rows of whole 128-byte lines),
+ * sending rank; it is read in place.  IChar geometries of the fused path only (<= 64 rows, rows of whole 16-byte pieces),
  * otherwise MI355_ERR_UNSUPPORTED. */
 int mi355_xengine_xcorrelate_grouped_dev(mi355_xengine *h, const void *in_dev, void *out_dev, int accumulate,
                                          int stations_per_group, void *stream);

@@ -42,7 +42,9 @@ def test_golden_exact_integer_sums(gpu):
                                         (64, 64, 64, 1), (20, 128, 96, 1), (5, 64, 32, 1), (33, 64, 256, 1), (48, 192, 128, 1), (64, 128, 512, 1),
                                         (16, 32, 32, 2), (32, 64, 128, 2), (7, 96, 64, 2), (24, 32, 1024, 2),
                                         # ... and integrations that are not whole K blocks of 32 frames (the frames past the end read as zeros)
-                                        (64, 64, 100, 1), (20, 128, 1000, 1), (32, 64, 33, 2), (5, 64, 1, 1), (48, 64, 2047, 1), (16, 32, 31, 2)])
+                                        (64, 64, 100, 1), (20, 128, 1000, 1), (32, 64, 33, 2), (5, 64, 1, 1), (48, 64, 2047, 1), (16, 32, 31, 2),
+                                        # ... and rows of whole 16-byte pieces that end inside a 128-byte line (the missing pieces read as zeros)
+                                        (64, 1000, 64, 1), (20, 72, 96, 1), (33, 40, 100, 1), (16, 20, 64, 2), (64, 8, 1000, 1), (40, 200, 77, 1), (9, 7, 50, 1)])
 def test_ichar_bit_exact_vs_oracle(gpu, oracle, N, F, T, npol):
     rng = np.random.default_rng(N * 1000 + T)
     x = rng.integers(-128, 128, size=T * N * F * npol * 2, dtype=np.int64).astype(np.int8)  # full range incl. -128
@@ -437,11 +439,28 @@ def test_group_major_input_read_in_place(gpu, oracle, N, F, T, npol, W):
 
 def test_group_major_input_refused_outside_the_fused_path(gpu):
     import torch
-    blk = _xe(gpu, gpu.DTYPE_BYTE, 1, 8, 16, 32)  # 32-byte rows: not the fused path
-    x = torch.zeros(32 * 8 * 16 * 2, dtype=torch.int8, device="cuda")
+    blk = _xe(gpu, gpu.DTYPE_BYTE, 1, 80, 16, 32)  # more than 64 rows: not the fused path
+    x = torch.zeros(32 * 80 * 16 * 2, dtype=torch.int8, device="cuda")
     out = torch.zeros(blk.get_output_buffer_size(), 2, device="cuda")
     with pytest.raises(gpu.Mi355Error):
         blk.xcorrelate_device(x, out, stations_per_group=4)
+    blk = _xe(gpu, gpu.DTYPE_BYTE, 1, 8, 5, 32)   # 10-byte rows: not whole 16-byte pieces
+    x = torch.zeros(32 * 8 * 5 * 2, dtype=torch.int8, device="cuda")
+    out = torch.zeros(blk.get_output_buffer_size(), 2, device="cuda")
+    with pytest.raises(gpu.Mi355Error):
+        blk.xcorrelate_device(x, out, stations_per_group=4)
+    # 32-byte rows (a quarter of a line) are inside the fused path since round 3: group-major input = the same matrix as the reference layout
+    N, F, T, ng = 8, 16, 33, 4
+    rng = np.random.default_rng(11)
+    xr = rng.integers(-128, 128, size=(T, N, F, 2), dtype=np.int64).astype(np.int8)
+    blk = _xe(gpu, gpu.DTYPE_BYTE, 1, N, F, T)
+    a = torch.zeros(blk.get_output_buffer_size(), 2, device="cuda")
+    b = torch.zeros_like(a)
+    blk.xcorrelate_device(torch.from_numpy(xr).cuda(), a)
+    xg = np.ascontiguousarray(xr.reshape(T, N // ng, ng, F, 2).transpose(1, 0, 2, 3, 4))  # [group][t][station in group][chan]
+    blk.xcorrelate_device(torch.from_numpy(xg).cuda(), b, stations_per_group=ng)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("N,F,T,npol,nint,W", [(64, 128, 1024, 1, 1, 1), (64, 128, 1024, 1, 3, 1), (64, 128, 1024, 1, 8, 1),   # the per-rank problem of config 5
@@ -482,8 +501,8 @@ def test_batched_integration_windows_bit_exact(gpu, oracle, N, F, T, npol, nint,
 
 def test_batched_group_major_refused_outside_the_fused_path(gpu):
     import torch
-    blk = _xe(gpu, gpu.DTYPE_BYTE, 1, 8, 16, 32)
-    x = torch.zeros(2 * 32 * 8 * 16 * 2, dtype=torch.int8, device="cuda")
+    blk = _xe(gpu, gpu.DTYPE_BYTE, 1, 80, 16, 32)  # (more than 64 rows)
+    x = torch.zeros(2 * 32 * 80 * 16 * 2, dtype=torch.int8, device="cuda")
     out = torch.zeros(2 * blk.get_output_buffer_size(), 2, device="cuda")
     with pytest.raises(gpu.Mi355Error):
         blk.xcorrelate_n_device(2, x, out, stations_per_group=4)
