@@ -822,7 +822,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_xe_corr_f32(const unsigned char 
 // HBM traffic = input once + 2-3 x the (small) output.
 // ------------------------------------------------------------------------------------
 template <int NTT, int NPOL, int CH>
-__global__ __launch_bounds__(CH * 64) void k_xe_f32_fused(const v4i *__restrict__ in, c32 *__restrict__ part, XeGeo g, int tsplit)
+__global__ __launch_bounds__(CH * 64) void k_xe_f32_fused(const v4i *__restrict__ in, c32 *__restrict__ part, XeGeo g, int tsplit,
+                                                           int row_pieces /* 16-byte pieces per (t, station) row that exist = the row stride */)
 {
     constexpr int NTHR = CH * 64, NP = NTT * (NTT + 1) / 2, CBYTES = 2 * NTT * kTileBytes;  // per channel and K block
     constexpr int SEGQ = CH * NPOL / 2;                 // 16-byte pieces per (t, station) segment
@@ -850,7 +851,9 @@ __global__ __launch_bounds__(CH * 64) void k_xe_f32_fused(const v4i *__restrict_
     }
     const int kb_total = (g.T + kKB32 - 1) / kKB32, kb_per = (kb_total + tsplit - 1) / tsplit;
     const int kb0 = ts * kb_per, kb1 = (kb0 + kb_per < kb_total) ? kb0 + kb_per : kb_total;
-    const size_t row_v4 = (size_t)g.F * NPOL / 2;      // 16-byte pieces per (t, station) row of the input
+    // (g.F counts whole 128-byte lines per row; a row that ends inside its last line has fewer pieces: the missing ones read as zeros and
+    // their channels have no output -- no padded copy of the input is needed)
+    const size_t row_v4 = (size_t)row_pieces;
     const size_t seg0 = (size_t)cgrp * SEGQ;            // first piece of this workgroup's channels inside a row
 
     v4f re[NP], uu[NP], ww[NP];
@@ -865,7 +868,7 @@ __global__ __launch_bounds__(CH * 64) void k_xe_f32_fused(const v4i *__restrict_
         for (int k = 0; k < PER; k++) {
             const int idx = tid + NTHR * k, q16 = idx % SEGQ, sidx = (idx / SEGQ) % NS, t = idx / (SEGQ * NS);
             const int tt = kb * kKB32 + t;
-            const bool ok = sidx < g.N && tt < t_end;
+            const bool ok = sidx < g.N && tt < t_end && seg0 + q16 < row_v4;
             v4i piece = (v4i){0, 0, 0, 0};
             if (ok) {
                 const v4i *src = in + ((size_t)tt * g.N + sidx) * row_v4 + seg0 + q16;
@@ -1104,7 +1107,30 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
               int stations_per_group = 0)
 {
     const XeGeo &g = h->g;
-    if (h->pad) {
+    // complex float: is this launch the fused kernel's?  (decided first: that kernel reads rows which end inside a 128-byte line as they
+    // are, every other complex-float kernel needs them padded to whole lines)
+    int tsplit = 1;
+    size_t out_items = 0;
+    bool cf32_fused = false;
+    if (h->data_type == MI355_DTYPE_COMPLEX) {
+        const int ts_env = getenv("MI355_XE_CF32_TSPLIT") ? atoi(getenv("MI355_XE_CF32_TSPLIT")) : 0;
+        out_items = (size_t)g.F * (g.N * (g.N + 1) / 2) * g.npol * g.npol;
+        tsplit = (ts_env > 0 && g.T % (16 * ts_env) == 0) ? ts_env : (g.T >= 64 ? 2 : 1);
+        if (ts_env <= 0 && g.T >= 64) {
+            // few channels: more time ranges, so that (channel groups) x (ranges) still covers the CUs -- 64 antennas x 16 channels x 16384
+            // frames ran as 4 workgroups (2.2 ms); the ranges keep at least two K blocks each and their partial matrices fit the workspace
+            const int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256, groups = (g.F + 7) / 8, kb_total = (g.T + kKB32 - 1) / kKB32;
+            int want = cus / groups;  // the most ranges that still run as one round of workgroups (125 groups x 3 ranges: a second round at 46 % -- slower than 2)
+            if (want > kb_total / 2) want = kb_total / 2;
+            while (want > 2 && (size_t)want * out_items * 8 > h->tile_bytes) want--;
+            if (want > tsplit) tsplit = want;
+        }
+        cf32_fused = ((size_t)g.F * g.npol * 8) % 128 == 0 && tiles && xe_f32_row_tiles(g.NT) != 0 && !getenv("MI355_XE_CF32_VALU") && g.NT <= 4 &&
+                     g.F % 8 == 0 && h->tile_bytes >= (size_t)tsplit * out_items * 8 && !getenv("MI355_XE_CF32_TWO_KERNELS");
+    }
+    const bool cf32_rows_as_given = h->data_type == MI355_DTYPE_COMPLEX && h->pad && cf32_fused && (g.Fout * g.npol) % 2 == 0 &&
+                                    (reinterpret_cast<uintptr_t>(in) & 15u) == 0 && !getenv("MI355_XE_CF32_PAD_COPY");
+    if (h->pad && !cf32_rows_as_given) {
         const size_t rows = (size_t)g.T * g.N;
         const int dst_units = g.F, src_units = g.Fout;  // 2-byte units per row (IChar one polarisation / packed: 2 bytes per channel)
         size_t blocks = (rows * dst_units + 255) / 256;
@@ -1125,19 +1151,7 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
         const bool mfma = ((size_t)g.F * g.npol * 8) % 128 == 0 && (reinterpret_cast<uintptr_t>(in) & 15u) == 0 && tiles &&
                           xe_f32_row_tiles(g.NT) != 0 && !getenv("MI355_XE_CF32_VALU");
         // fused kernel: rows <= 64, whole groups of 8 channels; the partial matrices live in the tile workspace
-        const int ts_env = getenv("MI355_XE_CF32_TSPLIT") ? atoi(getenv("MI355_XE_CF32_TSPLIT")) : 0;
-        const size_t out_items = (size_t)g.F * (g.N * (g.N + 1) / 2) * g.npol * g.npol;
-        int tsplit = (ts_env > 0 && g.T % (16 * ts_env) == 0) ? ts_env : (g.T >= 64 ? 2 : 1);
-        if (ts_env <= 0 && g.T >= 64) {
-            // few channels: more time ranges, so that (channel groups) x (ranges) still covers the CUs -- 64 antennas x 16 channels x 16384
-            // frames ran as 4 workgroups (2.2 ms); the ranges keep at least two K blocks each and their partial matrices fit the workspace
-            const int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256, groups = (g.F + 7) / 8, kb_total = (g.T + kKB32 - 1) / kKB32;
-            int want = cus / groups;  // the most ranges that still run as one round of workgroups (125 groups x 3 ranges: a second round at 46 % -- slower than 2)
-            if (want > kb_total / 2) want = kb_total / 2;
-            while (want > 2 && (size_t)want * out_items * 8 > h->tile_bytes) want--;
-            if (want > tsplit) tsplit = want;
-        }
-        if (mfma && g.NT <= 4 && g.F % 8 == 0 && h->tile_bytes >= (size_t)tsplit * out_items * 8 && !getenv("MI355_XE_CF32_TWO_KERNELS")) {
+        if (mfma && cf32_fused) {
             const int ntt = g.NT == 3 ? 4 : g.NT;
             // 8 channels per workgroup (one workgroup per CU, 64-byte pieces of a row) or 4 (two workgroups per CU, 32-byte pieces).
             // Interleaved A/B at 1024 channels x 1024 frames with the pinned K-block schedule: 64 antennas 226 us with 4 / 198 with 8,
@@ -1146,7 +1160,8 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
             const int chw = getenv("MI355_XE_CF32_CH") ? atoi(getenv("MI355_XE_CF32_CH")) : 8;
             const int ch = (chw == 8) ? 8 : 4;
             dim3 grid((g.F / ch) * tsplit);
-#define FUSED(NTT, NPOL, CHN) hipLaunchKernelGGL((k_xe_f32_fused<NTT, NPOL, CHN>), grid, dim3(CHN * 64), 0, st, (const v4i *)in, (c32 *)tiles, g, tsplit)
+            const int row_pieces = ((cf32_rows_as_given || !h->pad) ? g.Fout : g.F) * g.npol / 2;
+#define FUSED(NTT, NPOL, CHN) hipLaunchKernelGGL((k_xe_f32_fused<NTT, NPOL, CHN>), grid, dim3(CHN * 64), 0, st, (const v4i *)in, (c32 *)tiles, g, tsplit, row_pieces)
 #define FUSED_CH(NTT, NPOL) do { if (ch == 8) FUSED(NTT, NPOL, 8); else FUSED(NTT, NPOL, 4); } while (0)
             if (g.npol == 1) { if (ntt == 1) FUSED_CH(1, 1); else if (ntt == 2) FUSED_CH(2, 1); else FUSED_CH(4, 1); }
             else             { if (ntt == 1) FUSED_CH(1, 2); else if (ntt == 2) FUSED_CH(2, 2); else FUSED_CH(4, 2); }

@@ -253,8 +253,10 @@ def test_complex_float_ragged_rows_and_many_time_ranges(gpu, oracle, monkeypatch
     rng = np.random.default_rng(N * 3 + F + T)
     x = crandn(rng, T * N * F * npol)
     ref = oracle.xengine_cf32(N, F, npol, T, x)
-    for no_pad in (False, True):
-        if no_pad:
+    for mode in ("in place", "padded copy", "vector ALU"):
+        if mode == "padded copy":
+            monkeypatch.setenv("MI355_XE_CF32_PAD_COPY", "1")  # read per call: the fused kernel on a padded copy instead of the caller's rows
+        if mode == "vector ALU":
             monkeypatch.setenv("MI355_XE_CF32_NO_PAD", "1")  # read when the block is made
         blk = _xe(gpu, gpu.DTYPE_COMPLEX, npol, N, F, T)
         guard = np.full(blk.get_output_buffer_size() + 64, 7 + 7j, np.complex64)  # nothing may be written behind the last real channel
