@@ -505,15 +505,19 @@ namespace {
 // that leaves a thread the most values (16 / R butterflies of R points: 15 at R = 15, 10 at R = 10), provided 1024 threads hold a frame
 constexpr int kRadices[] = {16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
 struct Factorisation {
-    int np = 99, per_thread = 0;
+    int np = 99, per_thread = 0, sum = 1 << 30;  // (sum of the radices: on a tie the more even split -- 4000 = 10 x 10 x 8 x 5 rather than 16 x 10 x 5 x 5)
     int r[kMaxPass];
 };
 void search(int n, int m, int depth, int first, int per_thread, int floor_pt, int *cur, Factorisation *best)
 {
     if (m == 1) {
-        if (depth >= 2 && per_thread >= floor_pt && 1024LL * per_thread >= n && (depth < best->np || (depth == best->np && per_thread > best->per_thread))) {
+        int sum = 0;
+        for (int i = 0; i < depth; i++) sum += cur[i];
+        if (depth >= 2 && per_thread >= floor_pt && 1024LL * per_thread >= n &&
+            (depth < best->np || (depth == best->np && (per_thread > best->per_thread || (per_thread == best->per_thread && sum < best->sum))))) {
             best->np = depth;
             best->per_thread = per_thread;
+            best->sum = sum;
             for (int i = 0; i < depth; i++) best->r[i] = cur[i];
         }
         return;

@@ -52,7 +52,7 @@ def test_fft_plan_text_covers_every_length_class(pkg):
     assert plan(4099) == (0, "chirp-z, m = 16384 (fused)")  # a prime
     assert plan(20000) == (0, "mixed radix, two passes 125 x 160")  # longer than a workgroup holds: two passes
     assert plan(921600) == (0, "mixed radix, two passes 960 x 960") and plan(1000000)[1].startswith("chirp-z")  # beyond 960 x 960
-    assert plan(11 * 1024) == (0, "mixed radix 11 x 16 x 16 x 4") and plan(13 * 1024)[1].startswith("mixed radix 13")
+    assert plan(11 * 1024) == (0, "mixed radix 11 x 16 x 8 x 8") and plan(13 * 1024)[1].startswith("mixed radix 13")
     assert plan(17 * 1024)[1].startswith("chirp-z")          # a prime factor above 13 (clFFT itself refuses those)
     assert plan(11 * 1024 + 11)[1].startswith("chirp-z")     # 11 values per thread with a radix 11: 1024 threads hold 11264
     assert plan(1)[0] != 0 and plan((1 << 24) + 2)[0] != 0 and plan((1 << 23) + 1)[0] != 0
