@@ -202,16 +202,39 @@ __global__ __launch_bounds__(256, (PfbGeo<M, PMAX>::WPE)) void k_pfb(const c32 *
 // 16-points-per-thread layout and the 64-point backward DFT runs there (GeoW: all exchanges
 // stay inside the wave).
 // ------------------------------------------------------------------------------------
+// times (-i)^q.  On the bit patterns (swap, sign-bit flips): as floating-point negations the compiler folds them into the butterflies that
+// produce v, which changes where it contracts multiply-adds -- and the ring kernel must agree bit for bit with k_pfbq (one long call = several
+// short ones)
+__device__ __forceinline__ c32 quarter_turns(c32 v, int q)
+{
+    unsigned x = __builtin_bit_cast(unsigned, v.x), y = __builtin_bit_cast(unsigned, v.y);
+    if (q & 1) {  // times -i: (y, -x)
+        const unsigned t = x;
+        x = y;
+        y = t ^ 0x80000000u;
+    }
+    if (q & 2) {  // times -1
+        x ^= 0x80000000u;
+        y ^= 0x80000000u;
+    }
+    return mk(__builtin_bit_cast(float, x), __builtin_bit_cast(float, y));
+}
+
 // one thread per arm: M threads (M/64 waves) per workgroup, 16 steps per iteration
 template <int M> struct GeoArm {
     static constexpr int TH = M, PTS = M * 16, F = 16, WPE = 2;
 };
 
-template <int M, int PMAX, bool IDENT>
+template <int M, int PMAX, bool IDENT, int OS = 1>
 __global__ __launch_bounds__(M, 2) void k_pfbw(const c32 *__restrict__ in, c32 *__restrict__ out, const float *__restrict__ taps_pad,
                                                  const c32 *__restrict__ tw_inv, const int *__restrict__ ch_map, int nmap, int K,
-                                                 long long n_in, int nsteps, int groups_per_wave)
+                                                 long long n_in, int nsteps, int groups_per_wave, int par)
 {
+    // OS-fold oversampling (R = M / OS new samples per step; OS = 1: the critically sampled channelizer, par = 0): step n = OS m + par of the
+    // oversampled channelizer is step m of a critically sampled one whose input starts par R samples later (the launcher passes that
+    // pointer), its branch outputs rotated by par R slots (lib/clPolyphaseChannelizer_impl.cc:164) -- a factor exp(-2 pi i par c / os) on
+    // channel c, a multiple of a quarter turn for OS = 2 and 4.  This launch handles the steps of one par; it writes rows OS m + par.
+    // (OS is a template parameter so that the critically sampled instantiation stays the code k_pfbq agrees with bit for bit.)
     constexpr int U = 16, RS = PMAX + U;                        // ring slots = rows resident per lane
     constexpr int PERIOD = RS / (RS % 16 == 0 ? 16 : 8);  // = RS / gcd(RS, U): iterations until the ring mapping repeats
     static_assert((U * PERIOD) % RS == 0, "ring period");
@@ -287,9 +310,13 @@ __global__ __launch_bounds__(M, 2) void k_pfbw(const c32 *__restrict__ in, c32 *
             for (int q = 0; q < 16 / RL; q++) {
                 const int g = lane + M * q, fr = g / BL, j = g % BL;
                 if (i0 + fr < nsteps) {
-                    c32 *__restrict__ o = out + (size_t)(i0 + fr) * M + j;
+                    c32 *__restrict__ o = out + (OS == 1 ? (size_t)(i0 + fr) : (size_t)(i0 + fr) * OS + par) * M + j;
 #pragma unroll
-                    for (int t = 0; t < RL; t++) st_stream(o + orev<RL>(t) * BL, v[q * RL + t]);
+                    for (int t = 0; t < RL; t++) {
+                        const int c = j + orev<RL>(t) * BL;  // channel
+                        if constexpr (OS == 1) st_stream(o + orev<RL>(t) * BL, v[q * RL + t]);
+                        else st_stream(o + orev<RL>(t) * BL, quarter_turns(v[q * RL + t], par * c * (4 / OS)));
+                    }
                 }
             }
             __syncthreads();
@@ -304,8 +331,10 @@ __global__ __launch_bounds__(M, 2) void k_pfbw(const c32 *__restrict__ in, c32 *
             __syncthreads();
             const int steps = (nsteps - i0) < U ? (nsteps - i0) : U;
             for (int e = lane; e < steps * nmap; e += M) {
-                const int fr = e / nmap, qq = e - fr * nmap;
-                out[(size_t)i0 * nmap + e] = lds[fr * M + ch_map[qq]];
+                const int fr = e / nmap, qq = e - fr * nmap, c = ch_map[qq];
+                const c32 z = lds[fr * M + c];
+                if constexpr (OS == 1) out[(size_t)i0 * nmap + e] = z;
+                else out[((size_t)(i0 + fr) * OS + par) * nmap + qq] = quarter_turns(z, par * c * (4 / OS));
             }
             __syncthreads();
         }
@@ -628,6 +657,7 @@ struct mi355_pfb {
     mi355_ctx *ctx;
     int K, M, R, buf_items, nmap, nsteps;
     bool fast, ident;
+    bool fast_over = false;  // 64 / 128 / 256 channels, <= 32 taps per arm, 2- or 4-fold oversampled: the ring kernel once per residue of the step number
     int pmax;
     float *d_taps = nullptr;      // K floats (generic) or pmax*M zero padded (fast)
     void *d_tw = nullptr;         // M complex, exp(+2 pi i t / M)
@@ -672,11 +702,43 @@ int launch_wave(mi355_pfb *h, const void *in, void *out, hipStream_t st, int nst
     const long long n_in = (long long)buf_items - h->R + h->K;
     if (h->ident)
         hipLaunchKernelGGL((k_pfbw<M, PMAX, true>), dim3(grid), dim3(M), 0, st, (const c32 *)in, (c32 *)out, h->d_taps, (const c32 *)h->d_tw,
-                           h->d_map, h->nmap, h->K, n_in, nsteps, per);
+                           h->d_map, h->nmap, h->K, n_in, nsteps, per, 0);
     else
         hipLaunchKernelGGL((k_pfbw<M, PMAX, false>), dim3(grid), dim3(M), 0, st, (const c32 *)in, (c32 *)out, h->d_taps, (const c32 *)h->d_tw,
-                           h->d_map, h->nmap, h->K, n_in, nsteps, per);
+                           h->d_map, h->nmap, h->K, n_in, nsteps, per, 0);
     MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}
+
+// 2- / 4-fold oversampling on the ring kernel: one launch per residue of the step number (see k_pfbw)
+template <int M, int PMAX>
+int launch_wave_over(mi355_pfb *h, const void *in, void *out, hipStream_t st, int nsteps)
+{
+    const int S = h->M / h->R, cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
+    const long long n_in = (long long)nsteps * h->R - h->R + h->K;
+    const int wpc = getenv("MI355_PFB_WAVES_PER_CU") ? atoi(getenv("MI355_PFB_WAVES_PER_CU")) : 16;
+    for (int par = 0; par < S; par++) {
+        const int nsub = (nsteps - par + S - 1) / S;
+        if (nsub <= 0) continue;
+        const int ngroups = (nsub + 15) / 16;
+        long long wgs = (long long)cus * (wpc > 0 ? wpc : 16) / (M / 64) / S;
+        if (wgs < 1) wgs = 1;
+        if (wgs > ngroups) wgs = ngroups;
+        const int per = (int)((ngroups + wgs - 1) / wgs);
+        const int grid = (ngroups + per - 1) / per;
+        const c32 *src = (const c32 *)in + (size_t)par * h->R;
+        const long long n_p = n_in - (long long)par * h->R;
+#define PFBW_OVER(ID, OSF)                                                                                                                  \
+    hipLaunchKernelGGL((k_pfbw<M, PMAX, ID, OSF>), dim3(grid), dim3(M), 0, st, src, (c32 *)out, h->d_taps, (const c32 *)h->d_tw, h->d_map, \
+                       h->nmap, h->K, n_p, nsub, per, par)
+        if (S == 2) {
+            if (h->ident) PFBW_OVER(true, 2); else PFBW_OVER(false, 2);
+        } else {
+            if (h->ident) PFBW_OVER(true, 4); else PFBW_OVER(false, 4);
+        }
+#undef PFBW_OVER
+        MI355_HIP(hipGetLastError());
+    }
     return MI355_OK;
 }
 
@@ -758,6 +820,20 @@ int launch_pfb(mi355_pfb *h, const void *in, void *out, hipStream_t st, int nste
         }
         return MI355_ERR_STATE;
     }
+    if (h->fast_over) {
+#define OVER(MM)                                                                           \
+    case MM:                                                                               \
+        if (h->pmax == 8) return launch_wave_over<MM, 8>(h, in, out, st, nsteps);          \
+        if (h->pmax == 16) return launch_wave_over<MM, 16>(h, in, out, st, nsteps);        \
+        return launch_wave_over<MM, 32>(h, in, out, st, nsteps);
+        switch (h->M) {
+            OVER(64)
+            OVER(128)
+            OVER(256)
+        }
+#undef OVER
+        return MI355_ERR_STATE;
+    }
     int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
     long long total = (long long)nsteps * h->M;
     long long blocks = (total + 255) / 256;
@@ -834,6 +910,11 @@ extern "C" int mi355_pfb_create(mi355_ctx *ctx, const float *taps, int ntaps, in
     const int per_arm = (ntaps + M - 1) / M;
     h->fast = (M >= 2 && M <= 256 && (M & (M - 1)) == 0 && h->R == M && per_arm <= 64);
     h->pmax = per_arm <= 8 ? 8 : per_arm <= 16 ? 16 : per_arm <= 32 ? 32 : 64;
+    {
+        const long long n_in1 = (long long)buf_items - h->R + ntaps;
+        h->fast_over = !h->fast && (M == 64 || M == 128 || M == 256) && (h->R * 2 == M || h->R * 4 == M) && per_arm <= 32 &&
+                       n_in1 * 8 < (4ll << 30) - (64 << 10) && !getenv("MI355_PFB_NO_FAST_OVERSAMPLED");
+    }
     // the register-direct store writes short runs per lane for 8 <= M <= 16 (measured 10-27 % of HBM peak); those go through the
     // LDS gather of the mapped path, whose stores are lane-consecutive (46-49 %)
     h->ident = (nmap == M) && (M >= 32 || M <= 4);
@@ -841,7 +922,7 @@ extern "C" int mi355_pfb_create(mi355_ctx *ctx, const float *taps, int ntaps, in
     auto fail = [&](int rc) { mi355_pfb_destroy(h); return rc; };
     if (hipSetDevice(ctx->device) != hipSuccess) return fail(MI355_ERR_HIP);
     std::vector<float> t;
-    if (h->fast) {
+    if (h->fast || h->fast_over) {
         t.assign((size_t)h->pmax * M, 0.0f);
         for (int k = 0; k < ntaps; k++) t[k] = taps[k];
     } else {
@@ -855,8 +936,8 @@ extern "C" int mi355_pfb_create(mi355_ctx *ctx, const float *taps, int ntaps, in
     if (hipMalloc((void **)&h->d_taps, t.size() * sizeof(float)) != hipSuccess) return fail(MI355_ERR_NOMEM);
     if (hipMalloc(&h->d_tw, tw.size() * sizeof(float)) != hipSuccess) return fail(MI355_ERR_NOMEM);
     if (hipMalloc((void **)&h->d_map, (size_t)nmap * sizeof(int)) != hipSuccess) return fail(MI355_ERR_NOMEM);
-    if (!h->fast && hipMalloc(&h->d_filt, (size_t)h->nsteps * M * 8) != hipSuccess) return fail(MI355_ERR_NOMEM);
-    if (!h->fast && M >= 8 && nmap >= 16 && !getenv("MI355_PFB_DIRECT_DFT")) {
+    if (!h->fast && !h->fast_over && hipMalloc(&h->d_filt, (size_t)h->nsteps * M * 8) != hipSuccess) return fail(MI355_ERR_NOMEM);
+    if (!h->fast && !h->fast_over && M >= 8 && nmap >= 16 && !getenv("MI355_PFB_DIRECT_DFT")) {
         h->whole_map = nmap == M;
         for (int q = 0; q < nmap && h->whole_map; q++) h->whole_map = ch_map[q] == q;
         const int rc = mi355_fft_create(ctx, M, MI355_FFT_BACKWARD, nullptr, 0, MI355_DTYPE_COMPLEX, 1, 0, &h->dft);

@@ -86,6 +86,27 @@ def test_generic_path_large_and_unusual_channel_counts(gpu, oracle, monkeypatch,
     assert relerr(_run(gpu, taps, buf, M, R, chmap, xh), ref) <= TOL
 
 
+# 2- / 4-fold oversampled channelizers with 64 / 128 / 256 channels and <= 32 taps per arm run on the ring kernel, one launch per residue of
+# the step number (quarter-turn factors on the channels); identity and scrambled maps; step counts that leave the residues uneven; and the
+# generic path on the same input (MI355_PFB_NO_FAST_OVERSAMPLED)
+@pytest.mark.parametrize("M,R,per_arm,nmap,steps", [(64, 32, 8, 64, 203), (64, 32, 32, 64, 64), (64, 16, 13, 64, 205), (128, 64, 16, 128, 99),
+                                                    (128, 32, 32, 50, 134), (256, 128, 8, 256, 77), (256, 64, 20, 256, 42), (64, 32, 5, 7, 1001)])
+def test_oversampled_ring_kernel(gpu, oracle, monkeypatch, M, R, per_arm, nmap, steps):
+    rng = np.random.default_rng(M + R + per_arm + steps)
+    K = M * per_arm - (M // 5 if per_arm > 1 else 0)
+    taps = (rng.standard_normal(K) / np.sqrt(per_arm)).astype(np.float32)
+    buf = steps * R
+    while buf % M:
+        steps += 1
+        buf = steps * R
+    xh = crandn(rng, buf - R + K)
+    chmap = list(range(M)) if nmap == M else rng.permutation(M)[:nmap].tolist()
+    ref = oracle.pfb(taps, buf, M, R, chmap, xh, f64=True)
+    assert relerr(_run(gpu, taps, buf, M, R, chmap, xh), ref) <= TOL
+    monkeypatch.setenv("MI355_PFB_NO_FAST_OVERSAMPLED", "1")  # read at create
+    assert relerr(_run(gpu, taps, buf, M, R, chmap, xh), ref) <= TOL
+
+
 def test_baseline_config4_shape_and_streaming(gpu, oracle):
     """64 channels x 32 taps/arm, buf_items 65536 (BASELINE configs[3]); two consecutive calls
     with GNU Radio's history equal one double-length call."""
