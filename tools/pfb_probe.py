@@ -14,5 +14,5 @@ def ev(fn, it=20):
     for _ in range(it): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) * 1e-3 / it
-dt = ev(lambda: p.work_device([x], [y]))
+dt = ev(lambda: p.work_device([x], [y]), int(os.environ.get("PROBE_IT", "20")))
 print("pfb 64x32 N=2^%d: %.1f us %.1f GS/s %.3f of 8 TB/s" % (int(np.log2(N)), dt * 1e6, N / dt / 1e9, N * 16 / dt / 8e12))
