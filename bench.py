@@ -44,6 +44,11 @@ def dist_setup(ngpus):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != ngpus:
         raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: launch N>1 through torch.distributed.run" % (ngpus, world))
+    # MI355_BENCH_BACKEND=gloo MI355_BENCH_ONE_DEVICE=1: a dry run of the N>1 control flow with every rank on cuda:0 (a one-GPU box has no
+    # second device for RCCL); the numbers of such a run mean nothing, it only shows that every rank reaches every collective
+    backend = os.environ.get("MI355_BENCH_BACKEND", "nccl")
+    if os.environ.get("MI355_BENCH_ONE_DEVICE"):
+        local = 0
     torch.cuda.set_device(local)
     if "RANK" in os.environ:  # launched by torch.distributed.run (also with one rank, so that path is exercised)
         import torch.distributed as dist
@@ -51,8 +56,11 @@ def dist_setup(ngpus):
         os.environ.setdefault("MASTER_PORT", "29500")
         import datetime
         # a short collective timeout: a rank that dies in a secondary line must not hang the others for the 10-minute default
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local),
-                                timeout=datetime.timedelta(seconds=180))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local),
+                                    timeout=datetime.timedelta(seconds=180))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
         # The first collective builds the RCCL communicator (seconds).  Done here, the barrier that opens the timed region is a
         # plain barrier; left to that barrier, the device sits idle behind it and the K timed steps that follow run at the clocks
         # of a device that has just been idle (measured with one rank: 192 us per launch instead of 178).

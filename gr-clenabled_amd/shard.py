@@ -155,6 +155,16 @@ class XEngineCornerTurn:
             recv.record_stream(self._side)
             with torch.cuda.stream(self._side):
                 self.pack(local_frames, send)
+                if dist.get_backend(self.group) != "nccl":
+                    # device tensors under a backend without a device all-to-all (gloo: tests/test_multi_rank_gpu.py and
+                    # `MI355_BENCH_BACKEND=gloo`, several ranks sharing ONE GPU): the packed blocks go through the host.  A test
+                    # vehicle for everything around the collective (packing kernel, in-place group-major read, batched windows);
+                    # RCCL takes the branch below.
+                    self._side.synchronize()
+                    hs, hr = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+                    dist.all_to_all_single(hr, hs, group=self.group)
+                    recv.copy_(hr)
+                    return (None, recv, self._side)
                 work = dist.all_to_all_single(recv, send, group=self.group, async_op=True)
             return (work, recv, self._side)
         self.pack(local_frames, send)
