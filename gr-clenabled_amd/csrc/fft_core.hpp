@@ -175,6 +175,14 @@ template <int STEP, int N = 0> __device__ __forceinline__ int lds_at(int raw, in
     else return raw_swz ^ swzn<N>(c);
 }
 
+// The same slot as a BYTE offset from the LDS area's start, from the swizzled raw index already times 8: the XOR form then costs one
+// v_xor with a literal per access (slot index XOR, then times 8, was two instructions), the additive form folds into the DS offset field
+template <int STEP, int N = 0> __device__ __forceinline__ c32 &lds_slot(c32 *lds, int raw_swz8, int c)
+{
+    if constexpr (STEP % 256 == 0 && N != 256 && N != 64) return *(c32 *)((char *)lds + raw_swz8 + c * 8);
+    else return *(c32 *)((char *)lds + (raw_swz8 ^ (swzn<N>(c) * 8)));
+}
+
 // inverse of orev: slot that holds output index r
 template <int R> __host__ __device__ constexpr int irev(int r)
 {
@@ -247,9 +255,9 @@ __device__ __forceinline__ void transform_regs(c32 (&v)[16], const TwRegs<N> &tw
             __syncthreads();  // previous pass' LDS writes are visible
 #pragma unroll
             for (int q = 0; q < 16 / R; q++) {
-                const int g = tid + TH * q, raw = (g / B) * N + (g % B), rs = swzn<N>(raw);
+                const int g = tid + TH * q, raw = (g / B) * N + (g % B), rs8 = swzn<N>(raw) * 8;
 #pragma unroll
-                for (int r = 0; r < R; r++) v[q * R + r] = lds[lds_at<B, N>(raw, rs, r * B)];
+                for (int r = 0; r < R; r++) v[q * R + r] = lds_slot<B, N>(lds, rs8, r * B);
             }
 #pragma unroll
             for (int q = 0; q < 16 / R; q++) apply_twiddles<R, CJ>(&v[q * R], &tw.w[P - 1][q * tw_slots<R>()]);
@@ -262,9 +270,9 @@ __device__ __forceinline__ void transform_regs(c32 (&v)[16], const TwRegs<N> &tw
 #pragma unroll
             for (int q = 0; q < 16 / R; q++) {
                 const int g = tid + TH * q, fr = g / B, j = g % B;
-                const int raw = fr * N + (j / NS) * NS * R + (j % NS), rs = swzn<N>(raw);
+                const int raw = fr * N + (j / NS) * NS * R + (j % NS), rs8 = swzn<N>(raw) * 8;
 #pragma unroll
-                for (int s = 0; s < R; s++) lds[lds_at<NS, N>(raw, rs, orev<R>(s) * NS)] = v[q * R + s];
+                for (int s = 0; s < R; s++) lds_slot<NS, N>(lds, rs8, orev<R>(s) * NS) = v[q * R + s];
             }
         }
         transform_regs<N, SIGN, REV, G, P + 1, CJ>(v, tw, lds, tid);

@@ -242,9 +242,11 @@ __global__ __launch_bounds__(M, 2) void k_pfbw(const c32 *__restrict__ in, c32 *
     using PL = Plan<M, false>;
     __shared__ c32 lds[G::PTS];
     const int lane0 = threadIdx.x;
-    float hrev[PMAX];
+    // two taps per 64-bit register pair; the packed FMA picks its half and broadcasts it to both components (op_sel), so the taps take
+    // PMAX registers (the compiler's own form of the broadcast kept every tap twice and rebuilt pairs inside the loop)
+    f2v hp[PMAX / 2];
 #pragma unroll
-    for (int pp = 0; pp < PMAX; pp++) hrev[pp] = taps_pad[lane0 + (PMAX - 1 - pp) * M];
+    for (int pp = 0; pp < PMAX; pp += 2) hp[pp / 2] = f2v{taps_pad[lane0 + (PMAX - 1 - pp) * M], taps_pad[lane0 + (PMAX - 2 - pp) * M]};
     TwRegs<M> tw;
     load_twiddles<M, false, G>(tw, lane0, tw_inv);
 
@@ -273,20 +275,26 @@ __global__ __launch_bounds__(M, 2) void k_pfbw(const c32 *__restrict__ in, c32 *
         const long long row0 = (long long)(grp - g_begin) * U;  // ring row 0 of this iteration
         int lane = lane0;
         asm volatile("" : "+v"(lane));  // LDS addresses are recomputed per iteration instead of living in ~50 registers
-        const int lane_swz = swzn<M>(lane);
+        const int lane_swz8 = swzn<M>(lane) * 8;  // byte offsets: one v_xor per access (see fftc::lds_slot)
         // ---- phase 1: two steps at a time; their rows are retired and refilled right after ----
 #pragma unroll
         for (int u = 0; u < U; u += 2) {
-            f2v a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+            f2v a0, a1;  // fma like the reference (:163), taps in ascending order per output, starting from +0
+            asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(a0) : "v"(ring[(U * PH + u) % RS]), "v"(hp[0]));
+            asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(a1) : "v"(ring[(U * PH + u + 1) % RS]), "v"(hp[0]));
 #pragma unroll
-            for (int pp = 0; pp < PMAX; pp++) {
-                const f2v hh = {hrev[pp], hrev[pp]};  // one register per tap; the packed FMA broadcasts it (op_sel)
-                a0 = __builtin_elementwise_fma(ring[(U * PH + u + pp) % RS], hh, a0);      // fma like the reference (:163)
-                a1 = __builtin_elementwise_fma(ring[(U * PH + u + 1 + pp) % RS], hh, a1);
+            for (int pp = 1; pp < PMAX; pp++) {
+                if (pp & 1) {
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(a0) : "v"(ring[(U * PH + u + pp) % RS]), "v"(hp[pp / 2]));
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(a1) : "v"(ring[(U * PH + u + 1 + pp) % RS]), "v"(hp[pp / 2]));
+                } else {
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a0) : "v"(ring[(U * PH + u + pp) % RS]), "v"(hp[pp / 2]));
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a1) : "v"(ring[(U * PH + u + 1 + pp) % RS]), "v"(hp[pp / 2]));
+                }
             }
             __builtin_amdgcn_sched_barrier(0);  // the refill below must not be hoisted above the last use of its slot
-            lds[lane_swz ^ swzn<M>(u * M)] = mk(a0.x, a0.y);  // swizzles are XOR-linear: swz(u*M + lane) = swz(lane) ^ swz(u*M)
-            lds[lane_swz ^ swzn<M>((u + 1) * M)] = mk(a1.x, a1.y);
+            *(c32 *)((char *)lds + (lane_swz8 ^ (swzn<M>(u * M) * 8))) = mk(a0.x, a0.y);  // swizzles are XOR-linear: swz(u*M + lane) = swz(lane) ^ swz(u*M)
+            *(c32 *)((char *)lds + (lane_swz8 ^ (swzn<M>((u + 1) * M) * 8))) = mk(a1.x, a1.y);
             // unconditional: past the wave's range the rows are simply not used, past the stream they read as zero
             ring[(U * PH + u) % RS] = load_row(row0 + RS + u);
             ring[(U * PH + u + 1) % RS] = load_row(row0 + RS + u + 1);
@@ -297,9 +305,9 @@ __global__ __launch_bounds__(M, 2) void k_pfbw(const c32 *__restrict__ in, c32 *
         c32 v[16];
         constexpr int R0 = PL::radix(0), B0 = M / R0;
         {
-            const int raw_swz = swzn<M>((lane / B0) * M + (lane % B0));
+            const int raw_swz8 = swzn<M>((lane / B0) * M + (lane % B0)) * 8;
 #pragma unroll
-            for (int r = 0; r < R0; r++) v[r] = lds[raw_swz ^ swzn<M>(r * B0)];
+            for (int r = 0; r < R0; r++) v[r] = *(const c32 *)((const char *)lds + (raw_swz8 ^ (swzn<M>(r * B0) * 8)));
         }
         __syncthreads();
         transform_regs<M, 1, false, G>(v, tw, lds, lane);
