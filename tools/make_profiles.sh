@@ -15,5 +15,6 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE -d $O/${tag}_write -o r -- python $R/benc
 python $R/tools/prof_summary.py $O/${tag}_stats/r_results.db > $O/${tag}_stats.txt 2>&1
 python $R/tools/prof_summary.py $O/${tag}_fetch/r_results.db > $O/${tag}_fetch.txt 2>&1
 python $R/tools/prof_summary.py $O/${tag}_write/r_results.db > $O/${tag}_write.txt 2>&1
+rm -rf $O/${tag}_stats $O/${tag}_fetch $O/${tag}_write  # the raw databases exceed what gpurun copies back; the summaries are the evidence
 tail -1 $O/${tag}_bench.json | cut -c1-400
 grep -E "^k_|^void k_" $O/${tag}_stats.txt | head -20

@@ -17,6 +17,7 @@ for set in xe xl; do
   timeout 300 rocprofv3 --pmc WRITE_SIZE -d $O/${tag}_${set}_write -o r -- $CMD > $O/${tag}_${set}_write.log 2>&1
   timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/${tag}_${set}_mfma -o r -- $CMD > $O/${tag}_${set}_mfma.log 2>&1
   for k in stats fetch write mfma; do python $R/tools/prof_summary.py $O/${tag}_${set}_$k/r_results.db > $O/${tag}_${set}_$k.txt 2>&1; done
+  for k in stats fetch write mfma; do rm -rf $O/${tag}_${set}_$k; done
   grep -h "clXEngine\|per-rank\|single GPU" $O/${tag}_${set}_stats.log
   grep -E "^k_xe" $O/${tag}_${set}_stats.txt | cut -c1-70,88-140
 done
