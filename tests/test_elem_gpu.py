@@ -97,3 +97,38 @@ def test_device_path_unaligned_pointers_and_tails(gpu, oracle):
     q.work_device(n, [dc[:n + 1]], [out])
     torch.cuda.synchronize()
     assert relerr(out.cpu().numpy(), ref_q) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_arg_kernels_round_like_float64_atan2(gpu):
+    """clComplexToArg / clComplexToMagPhase / clQuadratureDemod evaluate atan2 in double like the reference
+    (lib/clComplexToArg_impl.cc:145-147, lib/clQuadratureDemod_impl.cc:125-143): every output must be the float64 result rounded to
+    float (one unit in the last place allowed for the rare value that sits on a rounding boundary), over 36 decades of dynamic range,
+    all octants, the axes, signed zeros and non-finite arguments."""
+    rng = np.random.default_rng(99)
+    n = 1 << 20
+    z = crandn(rng, n)
+    z[: n // 4] *= (10.0 ** rng.uniform(-18, 18, n // 4)).astype(np.float32)
+    sp = np.array([0, 1, -1, 1j, -1j, 1 + 1j, -1 + 1j, -1 - 1j, 1 - 1j, complex(0.0, -0.0), complex(-0.0, 0.0), complex(-1.0, -0.0),
+                   complex(-1.0, 0.0), complex(np.inf, 1), complex(-np.inf, 1), complex(1, np.inf), complex(np.inf, np.inf), complex(np.nan, 1),
+                   1e-30 + 1j, 1 + 1e-30j, 0.19891237 + 1j, 1 + 0.19891237j, 0.66817864 + 1j, 1 + 0.41421357j], dtype=np.complex64)
+    z[-len(sp):] = sp
+    ref = np.arctan2(z.imag.astype(np.float64), z.real.astype(np.float64))
+    out = np.empty(n, np.float32)
+    assert gpu.clComplexToArg(*GPU_ARGS).work(n, [z], [out]) == n
+    r32 = ref.astype(np.float32)
+    ok = (out == r32) | (np.isnan(out) & np.isnan(r32))
+    ulp = np.abs(out[~ok].astype(np.float64) - ref[~ok]) / np.spacing(np.abs(r32[~ok])).astype(np.float64)
+    assert np.count_nonzero(~ok) <= 2 and (ulp <= 0.5000001).all(), (np.count_nonzero(~ok), z[~ok][:4], out[~ok][:4], r32[~ok][:4])
+    assert np.array_equal(np.signbit(out[-len(sp):]), np.signbit(r32[-len(sp):]))  # -0 -> -0 / -pi, +0 behind a negative real part -> +pi
+    mag, ph = np.empty(n, np.float32), np.empty(n, np.float32)
+    assert gpu.clComplexToMagPhase(*GPU_ARGS).work(n, [z], [mag, ph]) == n
+    assert np.array_equal(ph, out, equal_nan=True)
+    # quadrature demodulator: gain * atan2 of a[i+1] conj(a[i]) in double
+    zq = crandn(rng, n + 1)
+    d64 = zq[1:].astype(np.complex128) * np.conj(zq[:-1].astype(np.complex128))
+    refq = (np.float64(np.float32(0.75)) * np.arctan2(d64.imag, d64.real))
+    oq = np.empty(n, np.float32)
+    assert gpu.clQuadratureDemod(0.75, *GPU_ARGS).work(n, [zq], [oq]) == n
+    bad = oq != refq.astype(np.float32)
+    assert np.count_nonzero(bad) <= n // 10000 and np.abs(oq - refq).max() <= 4e-7, np.count_nonzero(bad)

@@ -145,7 +145,10 @@ def rates_elem():
     cf = c.view(-1)
     for name, ctor, ins, outs, bps in (("clLog", lambda: pkg.clLog(*ARGS, 10.0, 0.0), [af], [cf], 8), ("clComplexToMag", lambda: pkg.clComplexToMag(*ARGS), [a], [cf], 12),
                                        ("clComplexToArg", lambda: pkg.clComplexToArg(*ARGS), [a], [cf], 12),
-                                       ("clQuadratureDemod", lambda: pkg.clQuadratureDemod(1.0, *ARGS), [a], [cf], 12)):
+                                       ("clQuadratureDemod", lambda: pkg.clQuadratureDemod(1.0, *ARGS), [a], [cf], 12),
+                                       ("clComplexToMagPhase", lambda: pkg.clComplexToMagPhase(*ARGS), [a], [cf[:N], cf[N:2 * N]], 16),
+                                       ("clMagPhaseToComplex", lambda: pkg.clMagPhaseToComplex(*ARGS), [af, a.view(-1)[N:2 * N]], [c], 16),
+                                       ("clSNR", lambda: pkg.clSNR(*ARGS, 10.0, 0.0), [af, af], [cf], 12)):
         blk = ctor()
         n = N - 1
         show(name, ev_time(lambda: blk.work_device(n, ins, outs)), n, bps)
