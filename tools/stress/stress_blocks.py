@@ -100,6 +100,14 @@ def churn_pfb_math(seed):
         blk = pkg.clPolyphaseChannelizer(*ARGS, taps, buf, M, M, list(range(M)))
         blk.general_work(buf, [x.size], [x], [y])
         note("pfb create/work/destroy", relerr(y, orc.pfb(taps, buf, M, M, list(range(M)), x, f64=True)) < 2e-5)
+        if M >= 64 and M <= 128:  # 2- / 4-fold oversampled on the ring kernel (one launch per residue of the step number)
+            R = M // int(rng.choice([2, 4]))
+            xo = crandn(rng, buf - R + taps.size)
+            blk2 = pkg.clPolyphaseChannelizer(*ARGS, taps, buf, M, R, list(range(M)))
+            yo = np.empty(blk2.noutput(), np.complex64)
+            blk2.general_work(yo.size, [xo.size], [xo], [yo])
+            note("pfb oversampled create/work/destroy", relerr(yo, orc.pfb(taps, buf, M, R, list(range(M)), xo, f64=True)) < 2e-5)
+            del blk2
         a = crandn(rng, 1 << int(rng.integers(10, 21)))
         c = np.empty_like(a)
         mc = pkg.clMathConst(pkg.DTYPE_COMPLEX, *ARGS, 1.5, pkg.MATHOP_MULTIPLY)
