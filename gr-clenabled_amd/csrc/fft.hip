@@ -273,46 +273,74 @@ __global__ __launch_bounds__(512, 2) void k_fft_32k(const void *__restrict__ in,
     const int in_xor = (SIGN > 0 && shift) ? 8 : 0;       // reverse: halves swapped on load == n ^ 2048 == r ^ 8
     const int m_xor = (SIGN < 0 && shift) ? (S / 2) : 0;  // forward: halves swapped on store
 
-    // rows 0..7 of the NEXT frame are fetched before the combine of the current one (64 registers that are free at that
-    // point: the peak is inside the transforms), so half of a frame's load latency runs under the combine and the stores
-    constexpr int PFW = REAL ? 1 : 2, PFR = REAL ? 8 : 5;  // complex: 4 rows 300 us, 5 rows 290 (13 spilled registers), 6 rows 306, 8 rows 333 per 2^26 samples
+    // Input: a thread reads WHOLE 64-byte groups (element n of all eight sub-frames) -- set g the rows 8g .. 8g+7 -- and hands the
+    // other set the half it transforms through LDS (128 KiB, the exchange image of the combine, free at this point).  When the two
+    // sets each read their own 32 bytes of every group (round 2), the two requests for one 64-byte sector came from different
+    // waves at almost the same time and a good part of them went to memory twice: FETCH_SIZE 1.67 x the input, now 1.11 x
+    // (the rate is unchanged, 298 -> 299 us per 2^26 samples: this kernel is bound by its phases -- one workgroup per CU -- not by HBM).
+    // The first rows of the NEXT frame are fetched before the combine of the current one (registers that are free at that
+    // point: the peak is inside the transforms), so part of a frame's load latency runs under the combine and the stores.
+    // (rows fetched ahead, complex input, per 2^26 samples: 1 -> 299 us, 2 -> 312, 3 -> 322: the registers they take are spilled)
+    constexpr int PFW = REAL ? 2 : 4, PFR = REAL ? 2 : 1;
     f4v pf[PFR][PFW];
-    auto fetch = [&](int frame, int r, int tid, f4v (&t)[PFW]) {
-        const unsigned n = (unsigned)(tid + ((r ^ in_xor) * BL));  // element n of every sub-frame
-        if constexpr (REAL) {
-            t[0] = *((const f4v *)in + (size_t)frame * (N / 4) + (size_t)n * 2 + set);
-        } else {
-            // plain loads: the other set takes the other 32 bytes of the same 64 (a nontemporal load would drop the line first)
-            t[0] = *((const f4v *)in + (size_t)frame * (N / 2) + (size_t)n * 4 + set * 2);
-            t[1] = *((const f4v *)in + (size_t)frame * (N / 2) + (size_t)n * 4 + set * 2 + 1);
-        }
+    auto fetch = [&](int frame, int j, int tid, f4v (&t)[PFW]) {
+        const unsigned n = (unsigned)(tid + (((8 * set + j) ^ in_xor) * BL));  // element n of every sub-frame
+        const f4v *p = (const f4v *)in + (size_t)frame * (REAL ? N / 4 : N / 2) + (size_t)n * PFW;
+#pragma unroll
+        for (int k = 0; k < PFW; k++) t[k] = p[k];
     };
     if ((int)blockIdx.x < nframes) {
 #pragma unroll
-        for (int r = 0; r < PFR; r++) fetch(blockIdx.x, r, tid0, pf[r]);
+        for (int j = 0; j < PFR; j++) fetch(blockIdx.x, j, tid0, pf[j]);
     }
     for (int frame = blockIdx.x; frame < nframes; frame += gridDim.x) {
         int tid = tid0;
         asm volatile("" : "+v"(tid));
         c32 v[H][16];
+        auto load_frame = [&](auto set_tag) {
+            constexpr int SET = decltype(set_tag)::value, OTHER = 1 - SET;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const unsigned n = (unsigned)(tid + ((r ^ in_xor) * BL));
-            const f4v w = *((const f4v *)window + (size_t)n * 2 + set);
-            f4v t[PFW];
-            if (r < PFR) {
+            for (int j = 0; j < 8; j++) {
+                const int r = 8 * SET + j;
+                const unsigned n = (unsigned)(tid + ((r ^ in_xor) * BL));
+                const f4v wa = *((const f4v *)window + (size_t)n * 2), wb = *((const f4v *)window + (size_t)n * 2 + 1);
+                const float w[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+                f4v t[PFW];
+                if (j < PFR) {
 #pragma unroll
-                for (int j = 0; j < PFW; j++) t[j] = pf[r][j];
-            } else {
-                fetch(frame, r, tid, t);
+                    for (int k = 0; k < PFW; k++) t[k] = pf[j][k];
+                } else {
+                    fetch(frame, j, tid, t);
+                }
+                c32 x[S];
+                if constexpr (REAL) {
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        x[4 * q] = mk(t[q].x * w[4 * q], 0.f); x[4 * q + 1] = mk(t[q].y * w[4 * q + 1], 0.f);
+                        x[4 * q + 2] = mk(t[q].z * w[4 * q + 2], 0.f); x[4 * q + 3] = mk(t[q].w * w[4 * q + 3], 0.f);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        x[2 * q] = mk(t[q].x * w[2 * q], t[q].y * w[2 * q]);
+                        x[2 * q + 1] = mk(t[q].z * w[2 * q + 1], t[q].w * w[2 * q + 1]);
+                    }
+                }
+#pragma unroll
+                for (int sp = 0; sp < H; sp++) {
+                    v[sp][r] = x[H * SET + sp];
+                    sm[((SET * H + sp) * 8 + j) * BL + tid] = x[H * OTHER + sp];  // xch[set of origin][sub-frame of the receiver][row][tid]
+                }
             }
-            if constexpr (REAL) {
-                v[0][r] = mk(t[0].x * w.x, 0.f); v[1][r] = mk(t[0].y * w.y, 0.f); v[2][r] = mk(t[0].z * w.z, 0.f); v[3][r] = mk(t[0].w * w.w, 0.f);
-            } else {
-                v[0][r] = mk(t[0].x * w.x, t[0].y * w.x); v[1][r] = mk(t[0].z * w.y, t[0].w * w.y);
-                v[2][r] = mk(t[PFW - 1].x * w.z, t[PFW - 1].y * w.z); v[3][r] = mk(t[PFW - 1].z * w.w, t[PFW - 1].w * w.w);
-            }
-        }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+#pragma unroll
+                for (int sp = 0; sp < H; sp++) v[sp][8 * OTHER + j] = sm[((OTHER * H + sp) * 8 + j) * BL + tid];
+            __syncthreads();  // the image is read before the transforms reuse the area
+        };
+        if (set == 0) load_frame(std::integral_constant<int, 0>{});
+        else load_frame(std::integral_constant<int, 1>{});
         TwRegs<NS> tw;  // re-read (L1/L2) per frame: their 24 registers are what the prefetch of the next frame lives in during the combine
         load_twiddles<NS, false, G>(tw, tid, twN + N);  // the 4096-point table follows the N-point one
         transform_regs2<NS, SIGN, false, G>(v[0], v[1], tw, lds, lds + NS, tid);
@@ -333,7 +361,7 @@ __global__ __launch_bounds__(512, 2) void k_fft_32k(const void *__restrict__ in,
             // (half of v[] is dead from here on: room for the first rows of the next frame)
             if (frame + (int)gridDim.x < nframes) {
 #pragma unroll
-                for (int r = 0; r < PFR; r++) fetch(frame + gridDim.x, r, tid, pf[r]);
+                for (int j = 0; j < PFR; j++) fetch(frame + gridDim.x, j, tid, pf[j]);
             }
             __syncthreads();
 #pragma unroll
