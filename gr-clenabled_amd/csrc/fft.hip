@@ -280,9 +280,13 @@ __global__ __launch_bounds__(512, 2) void k_fft_32k(const void *__restrict__ in,
     // (the rate is unchanged, 298 -> 299 us per 2^26 samples: this kernel is bound by its phases -- one workgroup per CU -- not by HBM).
     // The first rows of the NEXT frame are fetched before the combine of the current one (registers that are free at that
     // point: the peak is inside the transforms), so part of a frame's load latency runs under the combine and the stores.
-    // (rows fetched ahead, complex input, per 2^26 samples: 1 -> 299 us, 2 -> 312, 3 -> 322: the registers they take are spilled)
-    constexpr int PFW = REAL ? 2 : 4, PFR = REAL ? 2 : 1;
-    f4v pf[PFR][PFW];
+    // (rows of the next frame fetched ahead, complex input, per 2^26 samples: 0 -> 288 us, 1 -> 299, 2 -> 312, 3 -> 322: the registers they
+    // take are spilled -- 12 registers are spilled even with none -- so none are fetched ahead)
+#ifndef PFR32K
+#define PFR32K 0
+#endif
+    constexpr int PFW = REAL ? 2 : 4, PFR = REAL ? 2 * PFR32K : PFR32K;
+    f4v pf[PFR > 0 ? PFR : 1][PFW];
     auto fetch = [&](int frame, int j, int tid, f4v (&t)[PFW]) {
         const unsigned n = (unsigned)(tid + (((8 * set + j) ^ in_xor) * BL));  // element n of every sub-frame
         const f4v *p = (const f4v *)in + (size_t)frame * (REAL ? N / 4 : N / 2) + (size_t)n * PFW;
