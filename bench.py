@@ -581,6 +581,19 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank, out=None):
     r.pop("hbm_frac", None)
     out["clXEngine_64ant_1024ch_1024t_ichar"] = r
     t_full = r["us_per_launch"]
+    if world > 1:
+        # SURVEY 8e (B), the comparison form of the sharding: every rank ingests ALL antennas of its F/W channels (the corner turn done by
+        # the network in front of the GPUs, as packet-switched FX correlators do) -- no data-path collective at all; a rank's slab is too
+        # small to fill the device one window at a time, so eight windows go into one launch (mi355_xengine_xcorrelate_n_dev)
+        nint = 8
+        xb = torch.randint(-127, 128, (nint, T, N, Fw, 1, 2), dtype=torch.int8, device="cuda", generator=g)
+        vb = torch.zeros(nint * xe.get_output_buffer_size(), 2, device="cuda")
+        rb = rate(lambda: xe.xcorrelate_n_device(nint, xb, vb), nint * N * Fw * T, 2)
+        tw = max_over_ranks(rb["us_per_launch"], world) / nint
+        out["clXEngine_channel_sharded"] = {"us_per_window_all_ranks": round(tw, 2), "windows_per_launch": nint, "channels_per_rank": Fw,
+                                            "total_input_MSamples_per_s": round(N * F * T / tw, 1), "n_gpus": world,
+                                            "collective": "none (every rank ingests all antennas of its F/W channels)"}
+        del xb, vb
     del xe, x8, vis
     # The per-rank problem of the 8-GPU antenna-group sharding: after the corner turn a rank correlates 64 antennas x 128
     # channels.  One window per launch cannot fill the device; the batched entry point (mi355_xengine_xcorrelate_n_dev, what one
