@@ -80,3 +80,24 @@ def test_ranks_sharing_one_gpu(gpu, oracle, tmp_path, N, F, T, npol, windows, wo
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     for k in range(world):
         assert "rank %d ok" % k in r.stdout
+
+
+def test_bench_two_rank_dry_run(gpu, tmp_path):
+    """bench.py's N>1 control flow with two ranks on the one GPU (gloo, MI355_BENCH_ONE_DEVICE): every rank reaches every collective
+    (barriers, max-over-ranks, the per-GPU gathers, the X-engine exchange), rank 0 prints ONE JSON line, no secondary leg reports an
+    error.  The numbers of such a run mean nothing (two ranks share a device); under the driver the same code runs over RCCL."""
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-sustained"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", MI355_BENCH_BACKEND="gloo", MI355_BENCH_ONE_DEVICE="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["value"] > 0 and d["roofline"]["bound"] == "hbm"
+    b = d["blocks"]
+    assert "error" not in b, b.get("error")
+    assert "error" not in b["clXEngine_sharded"] and b["clXEngine_sharded"]["n_gpus"] == 2 and b["clXEngine_sharded"]["channels_per_rank"] == 512
+    assert b["clXEngine_channel_sharded"]["channels_per_rank"] == 512 and b["clXEngine_channel_sharded"]["us_per_window_all_ranks"] > 0
+    assert len(b["clPolyphaseChannelizer_64x32_stream"]["per_gpu_MSamples_per_s"]) == 2
