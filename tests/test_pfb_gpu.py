@@ -161,6 +161,30 @@ def test_batched_call_equals_single_calls(gpu, oracle, M, tpa, ident, monkeypatc
     assert torch.equal(yr, yb)
 
 
+@pytest.mark.parametrize("M,R,tpa,ident", [(64, 32, 32, True), (128, 32, 16, False), (256, 128, 8, True)])
+def test_batched_oversampled_equals_single_calls(gpu, oracle, M, R, tpa, ident):
+    """The same for 2- / 4-fold oversampled channelizers on the ring kernel (one launch per residue of the step number and buffer): k
+    buffers in one call == k single calls bit for bit, and every buffer matches the oracle on its span of the stream."""
+    import torch
+    rng = np.random.default_rng(M + R + tpa)
+    taps = rng.standard_normal(M * tpa).astype(np.float32)
+    chmap = list(range(M)) if ident else [int(c) for c in rng.permutation(M)[:M // 2]]
+    buf, k = M * 24, 4
+    blk = gpu.clPolyphaseChannelizer(*GPU_ARGS, taps, buf, M, R, chmap)
+    x = torch.randn((k * buf + taps.size - R), 2, device="cuda")
+    ys = torch.empty(k * blk.noutput(), 2, device="cuda")
+    yb = torch.empty_like(ys)
+    for b in range(k):
+        blk.work_device([x[b * buf:]], [ys[b * blk.noutput():]])
+    assert blk.work_device([x], [yb], nbuf=k) == k * blk.noutput()
+    torch.cuda.synchronize()
+    assert torch.equal(ys, yb)
+    xh = x.cpu().numpy().view(np.complex64).reshape(-1)
+    for b in (0, k - 1):
+        ref = oracle.pfb(taps, buf, M, R, chmap, xh[b * buf:b * buf + blk.ninput()], f64=True)
+        assert relerr(yb[b * blk.noutput():(b + 1) * blk.noutput()].cpu().numpy().view(np.complex64).reshape(-1), ref) <= TOL
+
+
 def test_device_path_full_size_linearity(gpu, oracle):
     import torch
     taps = np.concatenate([oracle.firdes_low_pass(1.0, 64.0, 0.5, 0.0753), [0.0]]).astype(np.float32)
