@@ -983,7 +983,10 @@ extern "C" int mi355_pfb_work_dev_n(mi355_pfb *h, int nbuf, const void *in, void
     MI355_REQUIRE((long long)h->nsteps * nbuf <= 0x7fffffffLL, "too many buffers in one call");
     MI355_HIP(hipSetDevice(h->ctx->device));
     hipStream_t st = mi355_pick_stream(h->ctx, stream);
-    if (!h->fast) {  // the generic two-kernel path keeps a one-buffer scratch: one buffer at a time
+    // (2- / 4-fold oversampled on the ring kernel: buf_items is a whole number of M-item frames, so a buffer holds a whole number of
+    // step residues and nbuf buffers are one longer stream)
+    const bool over_one_stream = h->fast_over && ((long long)h->buf_items * nbuf + h->K) * 8 < (4ll << 30) - (64 << 10);  // (32-bit row offsets)
+    if (!h->fast && !over_one_stream) {  // the generic two-kernel path keeps a one-buffer scratch: one buffer at a time
         for (int b = 0; b < nbuf; b++) {
             const int rc = launch_pfb(h, (const char *)in + (size_t)b * h->buf_items * 8, (char *)out + (size_t)b * h->nmap * h->nsteps * 8, st,
                                       h->nsteps, h->buf_items);
