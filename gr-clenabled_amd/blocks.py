@@ -42,9 +42,13 @@ def _hp(a):
     return C.c_void_p(a.ctypes.data)
 
 
-def _dp(t):
+def _dp(t, nbytes=None, name="device buffer"):
+    """Device pointer of a contiguous CUDA tensor; nbytes: what the call reads or writes there (the C ABI takes plain pointers, so a
+    tensor that is too short would be a memory fault on the device, not an error)."""
     if not t.is_cuda or not t.is_contiguous():
         raise TypeError("device path needs contiguous CUDA tensors")
+    if nbytes is not None and t.numel() * t.element_size() < nbytes:
+        raise ValueError("%s holds %d bytes, the call needs %d" % (name, t.numel() * t.element_size(), nbytes))
     return C.c_void_p(t.data_ptr())
 
 
@@ -117,8 +121,9 @@ class clMathOp(_Block):
     testOpenCL = work  # lib/clMathOp_impl.cc:354-359
 
     def work_device(self, noutput_items, input_items, output_items):
-        check(self._L.mi355_mathop_work_dev(self._h, noutput_items, _dp(input_items[0]), _dp(input_items[1]),
-                                            _dp(output_items[0]), _torch_stream(self.device)), "mi355_mathop_work_dev")
+        nb = int(noutput_items) * np.dtype(_NP_OF[self.dtype]).itemsize
+        check(self._L.mi355_mathop_work_dev(self._h, noutput_items, _dp(input_items[0], nb, "input 0"), _dp(input_items[1], nb, "input 1"),
+                                            _dp(output_items[0], nb, "output"), _torch_stream(self.device)), "mi355_mathop_work_dev")
         return noutput_items
 
 
@@ -153,7 +158,8 @@ class clMathConst(_Block):
     testOpenCL = work
 
     def work_device(self, noutput_items, input_items, output_items):
-        check(self._L.mi355_mathconst_work_dev(self._h, noutput_items, _dp(input_items[0]), _dp(output_items[0]),
+        nb = int(noutput_items) * np.dtype(_NP_OF[self.dtype]).itemsize
+        check(self._L.mi355_mathconst_work_dev(self._h, noutput_items, _dp(input_items[0], nb, "input"), _dp(output_items[0], nb, "output"),
                                                _torch_stream(self.device)), "mi355_mathconst_work_dev")
         return noutput_items
 
@@ -198,8 +204,10 @@ class clFFT(_Block):
 
     def work_device(self, noutput_items, input_items, output_items):
         st = _torch_stream(self.device)
+        n = int(noutput_items) * self.fft_size
         for x, y in zip(input_items[:self.num_streams], output_items[:self.num_streams]):
-            check(self._L.mi355_fft_work_dev(self._h, noutput_items, _dp(x), _dp(y), st), "mi355_fft_work_dev")
+            check(self._L.mi355_fft_work_dev(self._h, noutput_items, _dp(x, n * np.dtype(_NP_OF[self.dtype]).itemsize, "input"),
+                                             _dp(y, n * 8, "output"), st), "mi355_fft_work_dev")
         return noutput_items
 
 
@@ -251,7 +259,9 @@ class _FilterBase(_Block):
         return self.work(noutput_items, input_items, output_items)
 
     def work_device(self, noutput_items, input_items, output_items):
-        check(self._L.mi355_filter_work_dev(self._h, noutput_items, _dp(input_items[0]), _dp(output_items[0]),
+        need = int(noutput_items) * self.decimation + self.ntaps() - 1  # history-prefixed input, like work()
+        check(self._L.mi355_filter_work_dev(self._h, noutput_items, _dp(input_items[0], need * 8, "input"),
+                                            _dp(output_items[0], int(noutput_items) * 8, "output"),
                                             _torch_stream(self.device)), "mi355_filter_work_dev")
         return noutput_items
 
@@ -293,6 +303,7 @@ class clPolyphaseChannelizer(_Block):
         t = np.ascontiguousarray(taps, dtype=np.float32)
         m = np.ascontiguousarray(ch_map, dtype=np.int32)
         self._ntaps = int(t.size)
+        self.buf_items = int(buf_items)
         check(self._L.mi355_pfb_create(self._ctx, _hp(t), int(t.size), int(buf_items), int(num_channels),
                                        int(ninputs_per_iter), _hp(m), int(m.size), C.byref(self._h)), "mi355_pfb_create")
 
@@ -316,12 +327,16 @@ class clPolyphaseChannelizer(_Block):
     def work_device(self, input_items, output_items, nbuf=1):
         """Device-resident call; nbuf > 1: that many consecutive buffers of the stream in one launch (general_work() with
         noutput_items = nbuf * noutput()); input nbuf * buf_items - ninputs_per_iter + ntaps items, output nbuf * noutput()."""
+        nbuf = int(nbuf)
+        nin = (self.ninput() + (nbuf - 1) * self.buf_items) * 8  # k buffers of the stream share the history in front
+        nout = nbuf * self.noutput() * 8
         if nbuf == 1:
-            check(self._L.mi355_pfb_work_dev(self._h, _dp(input_items[0]), _dp(output_items[0]), _torch_stream(self.device)),
-                  "mi355_pfb_work_dev")
+            check(self._L.mi355_pfb_work_dev(self._h, _dp(input_items[0], nin, "input"), _dp(output_items[0], nout, "output"),
+                                             _torch_stream(self.device)), "mi355_pfb_work_dev")
             return self.noutput()
         x, y = input_items[0], output_items[0]
-        check(self._L.mi355_pfb_work_dev_n(self._h, int(nbuf), _dp(x), _dp(y), _torch_stream(self.device)), "mi355_pfb_work_dev_n")
+        check(self._L.mi355_pfb_work_dev_n(self._h, nbuf, _dp(x, nin, "input"), _dp(y, nout, "output"), _torch_stream(self.device)),
+              "mi355_pfb_work_dev_n")
         return nbuf * self.noutput()
 
 
@@ -401,12 +416,13 @@ class clXEngine(_Block):
     def xcorrelate_device(self, input_matrix, cross_correlation, accumulate=False, stations_per_group=None):
         """Device-resident xcorrelate.  stations_per_group: the input is the receive buffer of the multi-GPU corner turn,
         [group][t][station in group][chan][pol] (gr-clenabled_amd/shard.py), read in place."""
+        nin, nout = self.input_bytes(), self.get_output_buffer_size() * 8
         if stations_per_group:
-            check(self._L.mi355_xengine_xcorrelate_grouped_dev(self._h, _dp(input_matrix), _dp(cross_correlation), 1 if accumulate else 0,
+            check(self._L.mi355_xengine_xcorrelate_grouped_dev(self._h, _dp(input_matrix, nin, "input"), _dp(cross_correlation, nout, "output"), 1 if accumulate else 0,
                                                                int(stations_per_group), _torch_stream(self.device)),
                   "mi355_xengine_xcorrelate_grouped_dev")
             return self.get_output_buffer_size()
-        check(self._L.mi355_xengine_xcorrelate_dev(self._h, _dp(input_matrix), _dp(cross_correlation),
+        check(self._L.mi355_xengine_xcorrelate_dev(self._h, _dp(input_matrix, nin, "input"), _dp(cross_correlation, nout, "output"),
                                                    1 if accumulate else 0, _torch_stream(self.device)),
               "mi355_xengine_xcorrelate_dev")
         return self.get_output_buffer_size()
@@ -415,7 +431,8 @@ class clXEngine(_Block):
         """nint integration windows in one launch (the per-integration loop of lib/clXEngine_impl.cc:1234-1299, batched).  input_matrices:
         nint windows back to back, or with stations_per_group the receive buffer of ONE all-to-all over nint windows,
         [group][window][t][station in group][chan][pol]; cross_correlations: nint matrices back to back."""
-        check(self._L.mi355_xengine_xcorrelate_n_dev(self._h, int(nint), _dp(input_matrices), _dp(cross_correlations), 1 if accumulate else 0,
+        check(self._L.mi355_xengine_xcorrelate_n_dev(self._h, int(nint), _dp(input_matrices, int(nint) * self.input_bytes(), "input"),
+                                                     _dp(cross_correlations, int(nint) * self.get_output_buffer_size() * 8, "output"), 1 if accumulate else 0,
                                                      int(stations_per_group or 0), _torch_stream(self.device)),
               "mi355_xengine_xcorrelate_n_dev")
         return nint * self.get_output_buffer_size()
@@ -461,8 +478,11 @@ class _Elem(_Block):
 
     def work_device(self, noutput_items, input_items, output_items):
         i, o = input_items, output_items
-        check(self._L.mi355_elem_work_dev(self._h, noutput_items, _dp(i[0]), _dp(i[1]) if len(self._in) > 1 else None, _dp(o[0]),
-                                          _dp(o[1]) if len(self._out) > 1 else None, _torch_stream(self.device)), "mi355_elem_work_dev")
+        nin = [(int(noutput_items) + self.history() - 1) * np.dtype(t).itemsize for t in self._in]
+        nout = [int(noutput_items) * np.dtype(t).itemsize for t in self._out]
+        check(self._L.mi355_elem_work_dev(self._h, noutput_items, _dp(i[0], nin[0], "input 0"), _dp(i[1], nin[1], "input 1") if len(self._in) > 1 else None,
+                                          _dp(o[0], nout[0], "output 0"), _dp(o[1], nout[1], "output 1") if len(self._out) > 1 else None,
+                                          _torch_stream(self.device)), "mi355_elem_work_dev")
         return noutput_items
 
 

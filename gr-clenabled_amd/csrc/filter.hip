@@ -767,8 +767,7 @@ __global__ __launch_bounds__(kDlThreads) void k_fir_dec_lds(const c32 *__restric
         for (int o = tid; o < no; o += kDlThreads) {
             const int base = o * decim;
             c32 acc = mk(0.f, 0.f);
-            for (int k = 0; k < K; k++) {
-                const c32 v = dl_x[dl_slot(base + k)];
+            auto step = [&](const c32 v, int k) {
                 if constexpr (CTAPS) {
                     const float hr = taps_rev[2 * k], hi = taps_rev[2 * k + 1];
                     acc.x += hr * v.x - hi * v.y;
@@ -778,7 +777,18 @@ __global__ __launch_bounds__(kDlThreads) void k_fir_dec_lds(const c32 *__restric
                     acc.x += h * v.x;
                     acc.y += h * v.y;
                 }
+            };
+            // eight samples requested from LDS before the first is used (one at a time, a tap cost an LDS round trip: the tap count is
+            // a run-time value and the compiler does not pipeline the loop itself); the sums keep their order
+            int k = 0;
+            for (; k + 8 <= K; k += 8) {
+                c32 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = dl_x[dl_slot(base + k + j)];
+#pragma unroll
+                for (int j = 0; j < 8; j++) step(v[j], k + j);
             }
+            for (; k < K; k++) step(dl_x[dl_slot(base + k)], k);
             out[o0 + o] = acc;
         }
     }
@@ -1137,9 +1147,10 @@ int launch_filter(mi355_filter *h, size_t nout, const void *in, void *out, hipSt
     static const int dl_min = getenv("MI355_FIR_DEC_LDS_MIN") ? atoi(getenv("MI355_FIR_DEC_LDS_MIN")) : 9;  // smallest decimation of the LDS-staged kernel
     const int dmax = dl_min - 1 < 8 ? dl_min - 1 : 8;  // largest decimation of the kernels that compute every undecimated output
     // decimations above 8: either every undecimated output on the matrix cores (rate ~ 17500 / (K + 15) GS/s of input whatever D: 33 taps
-    // 280, 65 taps 205, 200 taps 97, 400 taps 58) or the LDS-staged kernel below (time per output ~ 0.65 K + 2.55 D ns: 65 taps 148 / 193 /
-    // 223 GS/s at D = 10 / 16 / 50, 200 taps 80 / 122 / 171) -- whichever this model puts ahead
-    double r_all = 17500.0 / (h->ntaps + 15), r_lds = h->decim / (0.00065 * h->ntaps + 0.00255 * h->decim);
+    // 280, 65 taps 218, 200 taps 100, 400 taps 58) or the LDS-staged kernel below (time per output ~ 0.17 K + 3.7 D ps since its tap loop
+    // requests eight samples at a time: 65 taps 192 / 226 / 245 GS/s at D = 10 / 16 / 32, 200 taps 131 / 178 / 216, 400 taps 86 / 134 /
+    // 180; tools/fir_dec_probe.py) -- whichever this model puts ahead
+    double r_all = 17500.0 / (h->ntaps + 15), r_lds = h->decim / (0.00017 * h->ntaps + 0.0037 * h->decim);
     if (r_all > 300.0) r_all = 300.0;
     if (r_lds > 250.0) r_lds = 250.0;
     const bool all_outputs_above_8 = h->decim > dmax && h->decim >= dl_min && r_all >= r_lds;

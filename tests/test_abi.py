@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 
+import numpy as np
 import pytest
 
 from conftest import ROOT
@@ -158,3 +159,40 @@ def test_dropin_python_module_name():
     env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "gr-clenabled_amd", "python"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_device_paths_refuse_short_tensors(gpu):
+    """The C ABI takes plain device pointers; the Python mirror knows the tensors and refuses the ones that are too short for the
+    call (a short buffer is otherwise a memory fault on the device), for every block of the hot path."""
+    import torch
+    from conftest import GPU_ARGS
+    z = lambda n, dt=torch.float32: torch.zeros(n, dtype=dt, device="cuda")
+    fft = gpu.clFFT(1024, gpu.CLFFT_FORWARD, [], gpu.DTYPE_COMPLEX, *GPU_ARGS)
+    with pytest.raises(ValueError):
+        fft.work_device(4, [z(4 * 1024 * 2)], [z(4 * 1024 * 2 - 2)])
+    mul = gpu.clMathOp(gpu.DTYPE_COMPLEX, *GPU_ARGS, gpu.MATHOP_MULTIPLY)
+    with pytest.raises(ValueError):
+        mul.work_device(100, [z(200), z(198)], [z(200)])
+    fil = gpu.clFilter(*GPU_ARGS, 4, np.ones(9, np.float32), 1, 0, True)
+    with pytest.raises(ValueError):
+        fil.work_device(100, [z(2 * (400 + 8) - 2)], [z(200)])  # the history-prefixed input is one item short
+    with pytest.raises(ValueError):
+        fil.work_device(100, [z(2 * (400 + 8))], [z(198)])
+    assert fil.work_device(100, [z(2 * (400 + 8))], [z(200)]) == 100
+    pfb = gpu.clPolyphaseChannelizer(*GPU_ARGS, np.ones(64, np.float32), 256, 8, 8, list(range(8)))
+    with pytest.raises(ValueError):
+        pfb.work_device([z(2 * (3 * 256 + 56))], [z(2 * 3 * 256 - 2)], nbuf=3)
+    with pytest.raises(ValueError):
+        pfb.work_device([z(2 * (3 * 256 + 56) - 2)], [z(2 * 3 * 256)], nbuf=3)
+    assert pfb.work_device([z(2 * (3 * 256 + 56))], [z(2 * 3 * 256)], nbuf=3) == 3 * 256
+    xe = gpu.clXEngine(*GPU_ARGS, False, gpu.DTYPE_BYTE, 1, 4, 1, 0, 8, 32, [])
+    vis = z(2 * xe.get_output_buffer_size())
+    with pytest.raises(ValueError):
+        xe.xcorrelate_device(z(xe.input_bytes() - 1, torch.int8), vis)
+    with pytest.raises(ValueError):
+        xe.xcorrelate_n_device(2, z(2 * xe.input_bytes(), torch.int8), vis)
+    arg = gpu.clQuadratureDemod(1.0, *GPU_ARGS)
+    with pytest.raises(ValueError):
+        arg.work_device(10, [z(2 * 10)], [z(10)])  # history 2: eleven input items
+    torch.cuda.synchronize()
