@@ -25,6 +25,8 @@
 #include <cstdlib>
 #include <vector>
 
+#include <cstring>
+
 #include "common.h"
 #include "fft_core.hpp"
 
@@ -801,8 +803,7 @@ __global__ __launch_bounds__(256) void k_fir_td_dec(const c32 *__restrict__ in, 
     for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < n_out; m += (long long)gridDim.x * 256) {
         const c32 *x = in + m * decim;
         c32 acc = mk(0.f, 0.f);
-        for (int k = 0; k < K; k++) {
-            const c32 s = x[k];
+        auto step = [&](const c32 s, int k) {
             if constexpr (CTAPS) {
                 const float hr = taps_rev[2 * k], hi = taps_rev[2 * k + 1];
                 acc.x += hr * s.x - hi * s.y;
@@ -812,7 +813,16 @@ __global__ __launch_bounds__(256) void k_fir_td_dec(const c32 *__restrict__ in, 
                 acc.x += h * s.x;
                 acc.y += h * s.y;
             }
+        };
+        int k = 0;
+        for (; k + 8 <= K; k += 8) {  // (eight samples requested before the first is used, see k_fir_dec_lds)
+            c32 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = x[k + j];
+#pragma unroll
+            for (int j = 0; j < 8; j++) step(v[j], k + j);
         }
+        for (; k < K; k++) step(x[k], k);
         out[m] = acc;
     }
 }
@@ -1153,7 +1163,24 @@ int launch_filter(mi355_filter *h, size_t nout, const void *in, void *out, hipSt
     double r_all = 17500.0 / (h->ntaps + 15), r_lds = h->decim / (0.00017 * h->ntaps + 0.0037 * h->decim);
     if (r_all > 300.0) r_all = 300.0;
     if (r_lds > 250.0) r_lds = 250.0;
-    const bool all_outputs_above_8 = h->decim > dmax && h->decim >= dl_min && r_all >= r_lds;
+    // (a decimation above eight filter lengths skips most of the input: neither of the two, the per-output kernel reads only what it needs --
+    // 33 taps at D = 600: 277 GS/s of input with every undecimated output on the matrix cores, several thousand per output)
+    // ... or the per-output kernel (k_fir_td_dec), which reads only the K samples an output needs: since its tap loop requests eight samples
+    // at a time it runs at ~ D / (K c(D)) GS/s of input, c = 0.5 + 0.03 D ps up to 1.9 (neighbouring outputs share lines while D is small):
+    // 33 taps 370 / 490 / 1360 at D = 10 / 32 / 100, 65 taps 260 / 334 / 628, 200 taps 128 / 147 / 299, 400 taps 70 / 78 / 172, and
+    // thousands once D passes a few filter lengths (before: 16 - 56 at D = 10 - 50, which is why it was only used above eight lengths)
+    const double c_po = 0.0005 + 0.00003 * h->decim < 0.0019 ? 0.0005 + 0.00003 * h->decim : 0.0019;
+    double r_po = h->decim / (h->ntaps * c_po);
+    // test switches, read per call: MI355_FIR_DEC_KERNEL = per_output | lds | all forces one of the three where it applies
+    const bool lds_off = getenv("MI355_FIR_DEC_LDS_OFF") != nullptr;
+    if (const char *force = getenv("MI355_FIR_DEC_KERNEL")) {
+        if (!strcmp(force, "per_output")) r_po = 1e30;
+        else if (!strcmp(force, "lds")) r_po = r_all = 0.0;
+        else if (!strcmp(force, "all")) r_po = r_lds = 0.0;
+    }
+    const bool mf_ok = mf_on && h->mf_kk && h->ntaps >= 16, lds_ok = h->ntaps <= kDlSpan / 2 && !lds_off;
+    const bool per_output = h->decim > dmax && r_po >= (mf_ok ? r_all : 0.0) && r_po >= (lds_ok ? r_lds : 0.0) && !(h->ntaps < 16 && h->decim <= 64);
+    const bool all_outputs_above_8 = h->decim > dmax && h->decim >= dl_min && r_all >= r_lds && !per_output;
     if (mf_on && h->mf_kk && ((h->decim == 1 && h->ntaps >= 16) || (h->decim >= 2 && h->decim <= dmax && h->ntaps >= 96) || (all_outputs_above_8 && h->ntaps >= 16))) {  // fewer taps: the vector kernel's short loop wins (9 taps: 350 vs 330 GS/s)
         const int span = kMfTile + 4 * h->mf_kk;
         const int nq = (span + kMfThreads - 1) / kMfThreads;
@@ -1199,7 +1226,7 @@ int launch_filter(mi355_filter *h, size_t nout, const void *in, void *out, hipSt
         if (h->complex_taps) LAUNCH_TD(true);
         else LAUNCH_TD(false);
 #undef LAUNCH_TD
-    } else if (h->ntaps <= kDlSpan / 2 && h->decim <= 8 * h->ntaps && !getenv("MI355_FIR_DEC_LDS_OFF")) {
+    } else if (lds_ok && !per_output) {
         // (a decimation far above the filter length skips most of the input: the per-output kernel reads only what it needs)
         int tile_out = (kDlSpan - h->ntaps) / h->decim + 1;
         if (tile_out > 2048) tile_out = 2048;

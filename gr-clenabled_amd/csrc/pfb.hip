@@ -567,8 +567,20 @@ __global__ __launch_bounds__(256) void k_pfb_branches(const c32 *__restrict__ in
         const long long i = e / M;
         const int j = (int)(e - i * M);
         float sr = 0.f, si = 0.f;
-        for (int k = j; k < K; k += M) {
-            const c32 x = in[i * R - k + K - 1];
+        // (eight taps' loads requested before the first is used: the trip count is a run-time value and the compiler does not pipeline the
+        // loop itself; the sums keep their order)
+        int k = j;
+        const c32 *__restrict__ xp = in + (i * R + K - 1);
+        for (; k + 7 * M < K; k += 8 * M) {
+            c32 x[8];
+            float h[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { x[u] = xp[-(k + u * M)]; h[u] = taps[k + u * M]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { sr = fmaf(x[u].x, h[u], sr); si = fmaf(x[u].y, h[u], si); }
+        }
+        for (; k < K; k += M) {
+            const c32 x = xp[-k];
             sr = fmaf(x.x, taps[k], sr);
             si = fmaf(x.y, taps[k], si);
         }
@@ -637,8 +649,23 @@ __global__ __launch_bounds__(256) void k_pfb_dft_map(const c32 *__restrict__ fil
         const int c = ch_map[(int)(e - i * nmap)];
         const c32 *v = filt + i * M;
         float sr = 0.f, si = 0.f;
-        int t = 0;
-        for (int m = 0; m < M; m++) {
+        int t = 0, m = 0;
+        for (; m + 8 <= M; m += 8) {  // (loads of eight terms ahead of their use, as above)
+            c32 w[8], x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                w[u] = twM[t];
+                x[u] = v[m + u];
+                t += c;
+                if (t >= M) t -= M;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                sr += x[u].x * w[u].x - x[u].y * w[u].y;
+                si += x[u].x * w[u].y + x[u].y * w[u].x;
+            }
+        }
+        for (; m < M; m++) {
             const c32 w = twM[t], x = v[m];
             sr += x.x * w.x - x.y * w.y;
             si += x.x * w.y + x.y * w.x;

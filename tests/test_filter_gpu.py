@@ -231,10 +231,11 @@ def test_decimations_both_modes(gpu, oracle, decim, use_time):
     assert relerr(y, full[::decim][:nout]) <= TOL
 
 
-@pytest.mark.parametrize("ntaps,decim,ctaps", [(33, 12, True), (1000, 12, False), (1500, 25, True), (4000, 10, False), (5000, 9, False)])
+@pytest.mark.parametrize("ntaps,decim,ctaps", [(33, 12, True), (65, 40, False), (200, 100, False), (1000, 12, False), (1500, 25, True), (4000, 10, False), (5000, 9, False)])
 def test_large_decimations_time_domain_shapes(gpu, oracle, monkeypatch, ntaps, decim, ctaps):
     """The LDS-staged decimating kernel: complex taps, filters that fill most of a tile's span (4000 of 8192 samples), one that does not
-    fit (5000 taps: the per-output kernel), a ragged last tile -- and the per-output kernel on the same inputs (MI355_FIR_DEC_LDS_OFF)."""
+    fit (5000 taps: the per-output kernel), a ragged last tile -- and each of the three kernels for decimations above 8 (LDS-staged, per
+    output, every undecimated output on the matrix cores) forced on the same inputs (MI355_FIR_DEC_KERNEL)."""
     rng = np.random.default_rng(ntaps + decim)
     nout = 2777
     xh = crandn(rng, nout * decim + ntaps - 1)
@@ -244,13 +245,13 @@ def test_large_decimations_time_domain_shapes(gpu, oracle, monkeypatch, ntaps, d
     else:
         taps = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
         ref = oracle.fir_ccf(taps, xh, nout * decim)[::decim][:nout]
-    for off in (False, True):
-        if off:
-            monkeypatch.setenv("MI355_FIR_DEC_LDS_OFF", "1")  # read per call
+    for force in (None, "lds", "per_output", "all"):  # the block's own choice, then each of the three kernels where it applies (read per call)
+        if force:
+            monkeypatch.setenv("MI355_FIR_DEC_KERNEL", force)
         blk = gpu.clComplexFilter(*GPU_ARGS, decim, taps, 1, 0, use_time=True) if ctaps else gpu.clFilter(*GPU_ARGS, decim, taps, 1, 0, True)
         y = np.empty(nout, np.complex64)
         assert blk.work(nout, [xh], [y]) == nout
-        assert relerr(y, ref) <= TOL, (ntaps, decim, ctaps, off)
+        assert relerr(y, ref) <= TOL, (ntaps, decim, ctaps, force)
 
 
 def test_zero_outputs_and_bad_args(gpu):
