@@ -1160,8 +1160,11 @@ int launch_filter(mi355_filter *h, size_t nout, const void *in, void *out, hipSt
     // 280, 65 taps 218, 200 taps 100, 400 taps 58) or the LDS-staged kernel below (time per output ~ 0.17 K + 3.7 D ps since its tap loop
     // requests eight samples at a time: 65 taps 192 / 226 / 245 GS/s at D = 10 / 16 / 32, 200 taps 131 / 178 / 216, 400 taps 86 / 134 /
     // 180; tools/fir_dec_probe.py) -- whichever this model puts ahead
-    double r_all = 17500.0 / (h->ntaps + 15), r_lds = h->decim / (0.00017 * h->ntaps + 0.0037 * h->decim);
-    if (r_all > 300.0) r_all = 300.0;
+    // (complex taps: four real products per tap on the matrix cores instead of two -- 65 / 200 / 400 taps 148 / 64 / 35 GS/s -- and a
+    // little more per tap in the LDS-staged kernel)
+    double r_all = (h->complex_taps ? 12000.0 : 17500.0) / (h->ntaps + 15);
+    double r_lds = h->decim / ((h->complex_taps ? 0.00022 : 0.00017) * h->ntaps + 0.0037 * h->decim);
+    if (r_all > (h->complex_taps ? 210.0 : 300.0)) r_all = h->complex_taps ? 210.0 : 300.0;
     if (r_lds > 250.0) r_lds = 250.0;
     // (a decimation above eight filter lengths skips most of the input: neither of the two, the per-output kernel reads only what it needs --
     // 33 taps at D = 600: 277 GS/s of input with every undecimated output on the matrix cores, several thousand per output)
