@@ -1182,9 +1182,15 @@ int launch_filter(mi355_filter *h, size_t nout, const void *in, void *out, hipSt
         else if (!strcmp(force, "all")) r_po = r_lds = 0.0;
     }
     const bool mf_ok = mf_on && h->mf_kk && h->ntaps >= 16, lds_ok = h->ntaps <= kDlSpan / 2 && !lds_off;
-    const bool per_output = h->decim > dmax && r_po >= (mf_ok ? r_all : 0.0) && r_po >= (lds_ok ? r_lds : 0.0) && !(h->ntaps < 16 && h->decim <= 64);
+    // decimations 6 ... 8 belong to the kernels that compute every undecimated output (the matrix-core one from 96 taps, the register-tiled
+    // one, ~ 14600 / K GS/s, below) unless one of the other two is predicted clearly ahead: at D = 8, 200 / 400 taps 107 / 60 -> 133 / 89 GS/s
+    // of input LDS-staged, 33 taps 297 -> 334 per output
+    const double r_inc = h->ntaps >= 96 && mf_ok ? r_all : (14600.0 / h->ntaps < 420.0 ? 14600.0 / h->ntaps : 420.0);
+    const bool early = h->decim >= 6 && h->decim <= dmax && h->ntaps >= 16 && (r_po > 1.05 * r_inc || (lds_ok && r_lds > 1.05 * r_inc));
+    const bool above = h->decim > dmax || early;
+    const bool per_output = above && r_po >= (mf_ok ? r_all : 0.0) && r_po >= (lds_ok ? r_lds : 0.0) && !(h->ntaps < 16 && h->decim <= 64);
     const bool all_outputs_above_8 = h->decim > dmax && h->decim >= dl_min && r_all >= r_lds && !per_output;
-    if (mf_on && h->mf_kk && ((h->decim == 1 && h->ntaps >= 16) || (h->decim >= 2 && h->decim <= dmax && h->ntaps >= 96) || (all_outputs_above_8 && h->ntaps >= 16))) {  // fewer taps: the vector kernel's short loop wins (9 taps: 350 vs 330 GS/s)
+    if (mf_on && h->mf_kk && ((h->decim == 1 && h->ntaps >= 16) || (h->decim >= 2 && h->decim <= dmax && h->ntaps >= 96 && !early) || (all_outputs_above_8 && h->ntaps >= 16))) {  // fewer taps: the vector kernel's short loop wins (9 taps: 350 vs 330 GS/s)
         const int span = kMfTile + 4 * h->mf_kk;
         const int nq = (span + kMfThreads - 1) / kMfThreads;
         const size_t smem = ((size_t)2 * (mf_pad(nq * kMfThreads + 16) + 1) + (size_t)(h->complex_taps ? 2 : 1) * (4 * h->mf_kk + 24)) * sizeof(float);
@@ -1208,7 +1214,7 @@ int launch_filter(mi355_filter *h, size_t nout, const void *in, void *out, hipSt
     }
     const int kpad0 = (h->ntaps + kTdU - 1) / kTdU * kTdU;
     // the register-tiled kernel computes every undecimated output: worth it up to a decimation of 8
-    if (h->decim == 1 || ((h->decim <= dmax || (h->ntaps < 16 && h->decim <= 64 && h->decim >= dl_min)) && (size_t)td_rows(kpad0) * kTdU * sizeof(c32) <= 160 * 1024)) {  // (fewer than 16 taps: this kernel runs at 400 GS/s of input whatever the decimation)
+    if (h->decim == 1 || (((h->decim <= dmax && !early) || (h->ntaps < 16 && h->decim <= 64 && h->decim >= dl_min)) && (size_t)td_rows(kpad0) * kTdU * sizeof(c32) <= 160 * 1024)) {  // (fewer than 16 taps: this kernel runs at 400 GS/s of input whatever the decimation)
         const int kpad = kpad0;
         const size_t smem = (size_t)td_rows(kpad) * kTdU * sizeof(c32);
         if (smem > 160 * 1024) { mi355_set_error("time-domain mode supports up to ~18000 taps"); return MI355_ERR_UNSUPPORTED; }

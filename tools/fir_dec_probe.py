@@ -5,13 +5,14 @@ import numpy as np, torch
 import __graft_entry__ as e
 pkg = e.load_package()
 N = 1 << 26
-a = torch.randn(N, 2, device="cuda"); c = torch.empty(N // 8, 2, device="cuda")
+DECS = [int(v) for v in os.environ.get("PROBE_DECS", "10,16,32,50,100").split(",")]
+a = torch.randn(N, 2, device="cuda"); c = torch.empty(N // min(DECS) + 1, 2, device="cuda")
 rng = np.random.default_rng(1)
 CT = bool(os.environ.get("PROBE_CTAPS"))  # complex taps (clComplexFilter)
 for nt in (33, 65, 200, 400):
     t = (rng.standard_normal(nt) / np.sqrt(nt)).astype(np.float32)
     row = []
-    for dec in [int(v) for v in os.environ.get("PROBE_DECS", "10,16,32,50,100").split(",")]:
+    for dec in DECS:
         blk = pkg.clFilter(1, 2, 0, 0, dec, t, 1, 0, True) if not CT else pkg.clComplexFilter(1, 2, 0, 0, dec, (t + 1j * t[::-1]).astype(np.complex64), 1, 0, use_time=True)
         nout = (N - nt) // dec
         fn = lambda: blk.work_device(nout, [a], [c])
