@@ -1671,7 +1671,12 @@ extern "C" int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, con
                 if (hipMalloc(&pl.d_tw, t.size() * sizeof(float)) != hipSuccess) return (int)MI355_ERR_NOMEM;
                 return mi355_upload(ctx, pl.d_tw, t.data(), t.size() * sizeof(float)) != hipSuccess ? (int)MI355_ERR_HIP : (int)MI355_OK;
             };
-            const int known = mi355_fft_mr_cached_variant(fft_size);
+            // The factorisation decides the rounding of the result (workgroup size and frames per iteration do not), so it has to be
+            // a stable choice: the second one replaces the rule's only when it measures at least 10 % faster (a margin the run-to-run
+            // noise of these timings, 2-4 %, does not cross), and MI355_FFT_MR_VARIANT=0 / 1 pins it; MI355_FFT_MR_AUTOTUNE=0 skips
+            // every measurement (the rule's factorisation, workgroup size and frames).
+            int known = mi355_fft_mr_cached_variant(fft_size);
+            if (const char *e = getenv("MI355_FFT_MR_VARIANT")) known = atoi(e) != 0 ? 1 : 0;
             MrPlan alt;
             std::vector<float> atw;
             const bool have_alt = mi355_fft_mr_plan(fft_size, h->sign, 1, &alt, &atw) && (alt.npass != h->mr.npass || alt.per_thread != h->mr.per_thread);
@@ -1686,7 +1691,7 @@ extern "C" int mi355_fft_create(mi355_ctx *ctx, int fft_size, int direction, con
                 if ((rc = put(alt, atw))) { if (alt.d_tw) (void)hipFree(alt.d_tw); return fail(rc); }
                 rc = mi355_fft_mr_tune(&alt, ctx, h->sign, h->d_window, &ms1);
                 if (rc) { (void)hipFree(alt.d_tw); return fail(rc); }
-                if (ms1 > 0.f && ms1 < ms0 * 0.98f) {
+                if (ms1 > 0.f && ms1 < ms0 * 0.90f) {
                     (void)hipFree(h->mr.d_tw);
                     h->mr = alt;
                 } else {

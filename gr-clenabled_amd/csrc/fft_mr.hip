@@ -707,8 +707,10 @@ int mi355_fft_mr_tune(MrPlan *plan, mi355_ctx *ctx, int sign, const float *windo
     const size_t total = (size_t)1 << 23;
     const int nframes = (int)(total / n);
     void *din = nullptr, *dout = nullptr;
-    if (hipMalloc(&din, (size_t)nframes * n * 8) != hipSuccess) return MI355_OK;  // no room to measure: the rule stands
-    if (hipMalloc(&dout, (size_t)nframes * n * 8) != hipSuccess) { (void)hipFree(din); return MI355_OK; }
+    // no room to measure: the rule stands (and the failed allocation must not stay behind as HIP's last error, where the next
+    // launch's hipGetLastError() would report it)
+    if (hipMalloc(&din, (size_t)nframes * n * 8) != hipSuccess) { (void)hipGetLastError(); return MI355_OK; }
+    if (hipMalloc(&dout, (size_t)nframes * n * 8) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(din); return MI355_OK; }
     std::lock_guard<std::mutex> g(ctx->upload_lock);
     hipStream_t st = ctx->upload;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -718,6 +720,7 @@ int mi355_fft_mr_tune(MrPlan *plan, mi355_ctx *ctx, int sign, const float *windo
         if (e1) (void)hipEventDestroy(e1);
         (void)hipFree(din);
         (void)hipFree(dout);
+        if (r == MI355_OK) (void)hipGetLastError();  // (a bail-out above leaves nothing sticky behind)
         return r;
     };
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return done(MI355_OK);

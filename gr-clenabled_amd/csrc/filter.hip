@@ -1337,7 +1337,9 @@ extern "C" int mi355_filter_work(mi355_filter *h, size_t noutput_items, const vo
     MI355_HIP(hipSetDevice(h->ctx->device));
     // chunks of outputs; each chunk re-sends its ntaps-1 samples of history
     const size_t hist = (size_t)h->ntaps - 1;
-    size_t chunk_out = mi355_chunk_bytes(noutput_items * 8) / 8;
+    // sized from the larger side of a chunk, its INPUT (decim x the outputs): a slot's staging stays within the 1 ... 8 MiB pieces the
+    // pipeline overlaps in, whatever the decimation
+    size_t chunk_out = mi355_chunk_bytes(noutput_items * (size_t)h->decim * 8) / (8 * (size_t)h->decim);
     if (chunk_out < 1) chunk_out = 1;
     size_t first = noutput_items < chunk_out ? noutput_items : chunk_out;
     size_t inb = (first * h->decim + hist) * 8;

@@ -299,22 +299,46 @@ int HostPipe::ensure(int nin, const size_t *in_bytes, size_t out_bytes, int nslo
     size_t want_in[MAXIN] = {cap_in[0], cap_in[1]}, want_out = cap_out > out_bytes ? cap_out : out_bytes;
     for (int i = 0; i < nin; i++) if (in_bytes[i] > want_in[i]) want_in[i] = in_bytes[i];
     const int upto = nslots > slots_ready ? nslots : slots_ready;
-    for (int s = 0; s < upto; s++) {
-        for (int i = 0; i < MAXIN; i++) {
-            if (want_in[i] == 0 || (want_in[i] == cap_in[i] && s < slots_ready)) continue;
-            if (h_in[s][i]) MI355_HIP(hipHostFree(h_in[s][i]));
-            if (d_in[s][i]) MI355_HIP(hipFree(d_in[s][i]));
-            h_in[s][i] = d_in[s][i] = nullptr;
-            MI355_HIP(hipHostMalloc(&h_in[s][i], want_in[i], hipHostMallocDefault));
-            MI355_HIP(hipMalloc(&d_in[s][i], want_in[i]));
+    const int rc = [&]() -> int {
+        for (int s = 0; s < upto; s++) {
+            for (int i = 0; i < MAXIN; i++) {
+                if (want_in[i] == 0 || (want_in[i] == cap_in[i] && s < slots_ready)) continue;
+                if (h_in[s][i]) MI355_HIP(hipHostFree(h_in[s][i]));
+                h_in[s][i] = nullptr;
+                if (d_in[s][i]) MI355_HIP(hipFree(d_in[s][i]));
+                d_in[s][i] = nullptr;
+                MI355_HIP(hipHostMalloc(&h_in[s][i], want_in[i], hipHostMallocDefault));
+                MI355_HIP(hipMalloc(&d_in[s][i], want_in[i]));
+            }
+            if (want_out && !(want_out == cap_out && s < slots_ready)) {
+                if (h_out[s]) MI355_HIP(hipHostFree(h_out[s]));
+                h_out[s] = nullptr;
+                if (d_out[s]) MI355_HIP(hipFree(d_out[s]));
+                d_out[s] = nullptr;
+                MI355_HIP(hipHostMalloc(&h_out[s], want_out, hipHostMallocDefault));
+                MI355_HIP(hipMalloc(&d_out[s], want_out));
+            }
         }
-        if (want_out && !(want_out == cap_out && s < slots_ready)) {
-            if (h_out[s]) MI355_HIP(hipHostFree(h_out[s]));
-            if (d_out[s]) MI355_HIP(hipFree(d_out[s]));
+        return MI355_OK;
+    }();
+    if (rc != MI355_OK) {
+        // a slot may be half replaced: drop all staging (the old capacities would vouch for buffers that no longer exist) and leave no
+        // sticky HIP error behind; the next call allocates from scratch
+        (void)hipGetLastError();
+        for (int s = 0; s < kSlots; s++) {
+            for (int i = 0; i < MAXIN; i++) {
+                if (h_in[s][i]) (void)hipHostFree(h_in[s][i]);
+                if (d_in[s][i]) (void)hipFree(d_in[s][i]);
+                h_in[s][i] = d_in[s][i] = nullptr;
+            }
+            if (h_out[s]) (void)hipHostFree(h_out[s]);
+            if (d_out[s]) (void)hipFree(d_out[s]);
             h_out[s] = d_out[s] = nullptr;
-            MI355_HIP(hipHostMalloc(&h_out[s], want_out, hipHostMallocDefault));
-            MI355_HIP(hipMalloc(&d_out[s], want_out));
         }
+        cap_in[0] = cap_in[1] = cap_out = 0;
+        slots_ready = 0;
+        (void)hipGetLastError();
+        return rc;
     }
     for (int i = 0; i < MAXIN; i++) cap_in[i] = want_in[i];
     cap_out = want_out;

@@ -23,6 +23,7 @@
 // Complex-float input keeps fp32 arithmetic (register-tiled VALU kernel, 8x8 station blocks).
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -1004,7 +1005,7 @@ __global__ __launch_bounds__(256) void k_xe_cf32(const c32 *__restrict__ in, c32
     const int f = blockIdx.x * 256 + threadIdx.x;
     int bi, bj;
     pair_to_tiles(blockIdx.y, bi, bj);
-    if (f >= g.F) return;
+    if (f >= g.Fout) return;  // g.F (>= g.Fout: rows padded to whole lines) is only the input's row stride; `out` holds Fout channels
     (void)nblk;
     c32 acc[kCfBlk][kCfBlk];
 #pragma unroll
@@ -1072,6 +1073,7 @@ struct mi355_xengine {
     // batched form (mi355_xengine_xcorrelate_n_dev): partial sums of nint windows, grown on demand
     unsigned char *d_batch = nullptr;
     size_t batch_bytes = 0;
+    std::mutex dev_lock;    // device-pointer entry points: workspace growth, the reduction's counters and the launch itself, one caller at a time
     int pad = 0;            // one zero channel appended on the device (odd channel count of 2-byte samples)
     size_t pad_bytes = 0;
     unsigned char *d_pad = nullptr;
@@ -1202,7 +1204,7 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
             return MI355_OK;
         }
         const int nblk = (g.A + kCfBlk - 1) / kCfBlk;
-        dim3 grid((g.F + 255) / 256, nblk * (nblk + 1) / 2);
+        dim3 grid((g.Fout + 255) / 256, nblk * (nblk + 1) / 2);
         hipLaunchKernelGGL(k_xe_cf32, grid, dim3(256), 0, st, (const c32 *)in, (c32 *)out, g, nblk, accumulate);
         MI355_HIP(hipGetLastError());
         return MI355_OK;
@@ -1418,6 +1420,7 @@ extern "C" int mi355_xengine_xcorrelate_grouped_dev(mi355_xengine *h, const void
                   "device buffers must be 16-byte (input) / 8-byte (output) aligned");
     MI355_REQUIRE(h->data_type == MI355_DTYPE_BYTE && !h->pad, "group-major input: IChar with an even channel count only");
     MI355_HIP(hipSetDevice(h->ctx->device));
+    std::lock_guard<std::mutex> dl(h->dev_lock);
     return launch_xe(h, in_dev, out_dev, accumulate, mi355_pick_stream(h->ctx, stream), h->d_tiles, h->d_pad, stations_per_group);
 }
 
@@ -1433,6 +1436,7 @@ extern "C" int mi355_xengine_xcorrelate_n_dev(mi355_xengine *h, int nint, const 
                   "device buffers must be 4-byte (int8 / packed input) or 8-byte (complex input, output) aligned");
     MI355_HIP(hipSetDevice(h->ctx->device));
     hipStream_t st = mi355_pick_stream(h->ctx, stream);
+    std::lock_guard<std::mutex> dl(h->dev_lock);
     const XeGeo &g = h->g;
     const bool grouped = stations_per_group > 0 && stations_per_group < g.N;
     // one launch for all windows: the fused IChar path (<= 64 rows, rows of whole 16-byte pieces, 16-byte aligned input)
@@ -1441,7 +1445,8 @@ extern "C" int mi355_xengine_xcorrelate_n_dev(mi355_xengine *h, int nint, const 
         if (fp.ok) {
             if (fp.part_bytes > h->batch_bytes) {  // (first call at this batch size: the only allocation of the device path)
                 std::lock_guard<std::mutex> lk(h->ctx->lock);
-                MI355_HIP(hipStreamSynchronize(st));
+                // a launch at a smaller batch size may still be running on ANOTHER stream: wait for the device, not for this stream
+                MI355_HIP(hipDeviceSynchronize());
                 if (h->d_batch) MI355_HIP(hipFree(h->d_batch));
                 h->d_batch = nullptr;
                 h->batch_bytes = 0;
@@ -1476,6 +1481,7 @@ extern "C" int mi355_xengine_xcorrelate_dev(mi355_xengine *h, const void *in_dev
                       (reinterpret_cast<uintptr_t>(out_dev) & 7u) == 0,
                   "device buffers must be 4-byte (int8 / packed input) or 8-byte (complex input, output) aligned");
     MI355_HIP(hipSetDevice(h->ctx->device));
+    std::lock_guard<std::mutex> dl(h->dev_lock);
     return launch_xe(h, in_dev, out_dev, accumulate, mi355_pick_stream(h->ctx, stream), h->d_tiles, h->d_pad);
 }
 

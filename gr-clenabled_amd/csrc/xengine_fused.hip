@@ -21,6 +21,10 @@
 // so a channel needs 2 accumulators per tile pair (80 registers for 64 rows) + 4 row-sum registers.
 #include "xengine_fused.h"
 
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+
 namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -46,6 +50,7 @@ struct FuArgs {
     int inkernel;      // 1: time ranges are combined by the kernel's own tail, 0: by k_xe_i8_reduce
     int compact;       // partial matrices of the diagonal tile pairs as ONE record (re on and below the diagonal, im above it)
     int dbg;  // tuning aid (MI355_XE_DBG): 1 = no compute, 2 = no stores, 4 = no DMA
+    unsigned long long *ts;  // tuning aid (MI355_XE_TS): per-workgroup phase stamps (100 MHz wall clock), NULL in normal use
     double kd;
     // batched form: nint integration windows per launch, wgs workgroups each
     int wgs;                       // workgroups per window = units * tsplit
@@ -56,6 +61,10 @@ struct FuArgs {
 };
 
 __device__ __forceinline__ unsigned perm(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+__device__ __forceinline__ void stamp(const FuArgs &a, int k)
+{
+    if (a.ts && threadIdx.x == 0) a.ts[(size_t)blockIdx.x * 8 + k] = wall_clock64();
+}
 
 // 4 dwords (bytes b0..b3 of four consecutive time steps) -> out[j] = byte j of each input dword
 __device__ __forceinline__ void transpose4x4(unsigned i0, unsigned i1, unsigned i2, unsigned i3, unsigned (&out)[4])
@@ -105,7 +114,7 @@ __device__ __forceinline__ int pk_get(unsigned lo, unsigned hi, int k)
     return ((int)((h8 << 24) | (l16 << 8)) >> 8) + 1;
 }
 
-template <int NPOL, int NTT, bool SPLIT>
+template <int NPOL, int NTT, bool SPLIT, bool PP>
 __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
 {
     constexpr int NSH = (NTT * 16 / NPOL > 32) ? 2 : 1;     // 32-station halves of a time step
@@ -116,6 +125,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    stamp(a, 0);
+    if (a.ts && tid == 0) a.ts[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID, 4 bits
     // ---- which slice / time range: the 4 workgroups of a 128-byte line on one XCD, same time range
     // (the batched form adds the integration window to the combination: consecutive workgroups go to the eight XCDs round robin, so the
     // four workgroups of a 128-byte line must be 8 apart to meet in one L2)
@@ -124,7 +135,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
         const int b = blockIdx.x;
         int combo, sector;
         if (a.pinned) {
-            const int xcd = b & 7, within = b >> 3;
+            const int xcd = (b + (a.dbg >> 8)) & 7, within = b >> 3;  // (dbg bits 8..10: which lines an XCD gets, a tuning aid)
             sector = within & 3;
             combo = xcd + 8 * (within >> 2);
         } else {
@@ -135,9 +146,21 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
         const int rest = combo / a.nlines;
         q = rest % a.tsplit;
         win = rest / a.tsplit;
+        if (a.pinned && a.nlines == 16 && a.tsplit == 4 && a.nint_launch == 1 && ((a.dbg >> 12) & 3)) {  // tuning aid: other line -> XCD maps
+            const int xcd = b & 7, within = b >> 3, mode = (a.dbg >> 12) & 3;
+            int line;
+            if (mode == 1) { line = ((within >> 2) & 1) ? 8 + ((xcd + 4) & 7) : xcd; q = within >> 3; }
+            else if (mode == 2) { q = xcd >> 1; line = (xcd & 1) * 8 + (within >> 2); }
+            else { q = xcd & 3; line = (xcd >> 2) * 8 + (within >> 2); }
+            slice = line * 4 + (within & 3);
+        }
         a.in += (size_t)win * a.in_window;
         a.out += (size_t)win * a.out_window;
         a.part += (size_t)win * a.part_window;
+    }
+    if ((a.dbg >> 16) & 3) {  // tuning aid: only (1) / all but (2) the lines 3 and 11 of a row
+        const bool l3 = ((slice >> 2) & 7) == 3;
+        if ((((a.dbg >> 16) & 3) == 1) != l3) return;
     }
     const size_t row_bytes = (size_t)a.row_stride;  // (a row may end inside its last 128-byte line: the pieces past its end read the zero row)
     const int t_base = q * a.steps * 32;
@@ -192,7 +215,43 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
         issue_stage(2);
         issue_stage(3);
     }
-    for (int j = 0; j < a.steps; j++) {
+    // the raw bytes of block j (stages 2j, 2j + 1) -> MFMA operands in registers
+    auto read_block = [&](int j, long (&I)[CPW][NTT], long (&Q)[CPW][NTT]) {
+        {
+            const unsigned char *base = lds + ((2 * j) & (kRing - 1)) * STAGE + lane_base;
+#pragma unroll
+            for (int rt = 0; rt < NTT; rt++) {
+                const int tile_imm = (NPOL == 1) ? (rt >> 1) * kChunk + (rt & 1) * 512 : rt * 256;
+                unsigned raw[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) raw[i] = *(const unsigned *)(base + i * NSH * kChunk + tile_imm);
+                unsigned o0[4], o1[4];
+                transpose4x4(raw[0], raw[1], raw[2], raw[3], o0);
+                transpose4x4(raw[4], raw[5], raw[6], raw[7], o1);
+                if constexpr (NPOL == 1) {
+                    // unit bytes: I(2w) Q(2w) I(2w+1) Q(2w+1); row = station
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        I[c][rt] = pack64(o0[2 * c], o1[2 * c]);
+                        Q[c][rt] = pack64(o0[2 * c + 1], o1[2 * c + 1]);
+                    }
+                } else {
+                    // unit bytes: XI XQ YI YQ of channel w; rows 2s (X), 2s+1 (Y): even / odd lanes of a station pair
+                    I[0][rt] = odd_pol ? pack64(o0[2], o1[2]) : pack64(o0[0], o1[0]);
+                    Q[0][rt] = odd_pol ? pack64(o0[3], o1[3]) : pack64(o0[1], o1[1]);
+                }
+#pragma unroll
+                for (int c = 0; c < CPW; c++) {
+                    const unsigned lo = (unsigned)(unsigned long)I[c][rt], hi = (unsigned)((unsigned long)I[c][rt] >> 32);
+                    rs[c][rt] = __builtin_amdgcn_sad_u8(lo ^ 0x80808080u, 0u, rs[c][rt]);
+                    rs[c][rt] = __builtin_amdgcn_sad_u8(hi ^ 0x80808080u, 0u, rs[c][rt]);
+                }
+            }
+        }
+    };
+    // lockstep form: wait for the block's two stages, pull the raw bytes into registers (the slots are free again after the second barrier),
+    // request the stages two blocks ahead
+    auto load_block = [&](int j, long (&I)[CPW][NTT], long (&Q)[CPW][NTT]) {
         if (j + 1 < a.steps) {
             if constexpr (PER_STEP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -200,47 +259,16 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();  // stages 2j, 2j+1 have landed for every wave
-        if (a.dbg & 1) {
-            __syncthreads();
-            if (j + 2 < a.steps) { issue_stage(2 * j + 4); issue_stage(2 * j + 5); }
-            continue;
-        }
-        const unsigned char *base = lds + ((2 * j) & (kRing - 1)) * STAGE + lane_base;
-        long I[CPW][NTT], Q[CPW][NTT];
-#pragma unroll
-        for (int rt = 0; rt < NTT; rt++) {
-            const int tile_imm = (NPOL == 1) ? (rt >> 1) * kChunk + (rt & 1) * 512 : rt * 256;
-            unsigned raw[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) raw[i] = *(const unsigned *)(base + i * NSH * kChunk + tile_imm);
-            unsigned o0[4], o1[4];
-            transpose4x4(raw[0], raw[1], raw[2], raw[3], o0);
-            transpose4x4(raw[4], raw[5], raw[6], raw[7], o1);
-            if constexpr (NPOL == 1) {
-                // unit bytes: I(2w) Q(2w) I(2w+1) Q(2w+1); row = station
-#pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    I[c][rt] = pack64(o0[2 * c], o1[2 * c]);
-                    Q[c][rt] = pack64(o0[2 * c + 1], o1[2 * c + 1]);
-                }
-            } else {
-                // unit bytes: XI XQ YI YQ of channel w; rows 2s (X), 2s+1 (Y): even / odd lanes of a station pair
-                I[0][rt] = odd_pol ? pack64(o0[2], o1[2]) : pack64(o0[0], o1[0]);
-                Q[0][rt] = odd_pol ? pack64(o0[3], o1[3]) : pack64(o0[1], o1[1]);
-            }
-#pragma unroll
-            for (int c = 0; c < CPW; c++) {
-                const unsigned lo = (unsigned)(unsigned long)I[c][rt], hi = (unsigned)((unsigned long)I[c][rt] >> 32);
-                rs[c][rt] = __builtin_amdgcn_sad_u8(lo ^ 0x80808080u, 0u, rs[c][rt]);
-                rs[c][rt] = __builtin_amdgcn_sad_u8(hi ^ 0x80808080u, 0u, rs[c][rt]);
-            }
-        }
+        if (j == 0) stamp(a, 1);
+        if (!(a.dbg & 1)) read_block(j, I, Q);
         __syncthreads();  // every wave holds its operands in registers: the two slots are free
         if (j + 2 < a.steps) {
             issue_stage(2 * j + 4);
             issue_stage(2 * j + 5);
         }
-        // two sweeps over the pairs so that consecutive MFMAs never touch the same accumulator
+    };
+    // two sweeps over the pairs so that consecutive MFMAs never touch the same accumulator
+    auto mfma32 = [&](const long (&I)[CPW][NTT], const long (&Q)[CPW][NTT]) {
 #pragma unroll
         for (int c = 0; c < CPW; c++) {
 #pragma unroll
@@ -260,8 +288,77 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
                     im[c][p] = __builtin_amdgcn_mfma_i32_16x16x32_i8(I[c][bi], ~Q[c][bj], im[c][p], 0, 0, 0);
                 }
         }
+    };
+    if constexpr (PP) {
+        // Ping-pong: the two waves of a SIMD (w and w + 4) run half a step apart.  Waves 0-3 read block j and then multiply it; waves 4-7
+        // first multiply block j - 1 (operands kept across the barrier) and then read block j: one wave's matrix products run beside the
+        // other's LDS reads and byte transposes instead of both doing the same thing at the same time.  ONE barrier per step: behind it
+        // block j has landed and nobody reads block j - 1 any more, whose slots take block j + 1.
+        // Both groups run the same body -- read block j, multiply block j -- and differ only in where the step's barrier sits: before the
+        // read (group 0) or between read and multiply (group 1, which therefore multiplies block j while group 0 already reads j + 1).
+        // (waves w and w + 4 share a SIMD: a workgroup's waves are placed round robin over the four SIMDs -- checked with HW_REG_HW_ID.)
+        // The second group gets static priority: the first group's products (older waves win the arbitration) would otherwise hold back
+        // the last few products of the second group's phase for a whole phase, and everybody waits for them at the barrier.
+        const int grp = wave >> 2;
+        if (grp == 1 && !(a.dbg & 32)) __builtin_amdgcn_s_setprio(1);
+        auto top = [&](int j) {  // block j has landed for every wave, nobody reads block j - 1 any more: its slots take block j + 1
+            if (j == 0 && a.steps > 1) {
+                if constexpr (PER_STEP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            if (j == 0) stamp(a, 1);
+            if (j >= 1 && j + 1 < a.steps) {
+                issue_stage(2 * j + 2);
+                issue_stage(2 * j + 3);
+            }
+        };
+        unsigned long long c_top = 0, c_read = 0, c_mul = 0;  // (tuning aid: shader cycles per phase, waves 0 and 4)
+        for (int j = 0; j < a.steps; j++) {
+            long I[CPW][NTT], Q[CPW][NTT];
+            const unsigned long long t0 = a.ts ? __builtin_readcyclecounter() : 0;
+            if (grp == 0 || j == 0) top(j);
+            const unsigned long long t1 = a.ts ? __builtin_readcyclecounter() : 0;
+            if (!(a.dbg & (1 | 128))) read_block(j, I, Q);
+            else if (a.dbg & 128) {
+#pragma unroll
+                for (int c = 0; c < CPW; c++)
+#pragma unroll
+                    for (int rt = 0; rt < NTT; rt++) { I[c][rt] = rs[c][rt]; Q[c][rt] = j; }
+            }
+            if (a.ts) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long t2 = a.ts ? __builtin_readcyclecounter() : 0;
+            if (grp == 1 && j + 1 < a.steps) top(j + 1);
+            const unsigned long long t3 = a.ts ? __builtin_readcyclecounter() : 0;
+            if (!(a.dbg & (1 | 64))) mfma32(I, Q);
+            else if (a.dbg & 64) {
+#pragma unroll
+                for (int c = 0; c < CPW; c++)
+#pragma unroll
+                    for (int rt = 0; rt < NTT; rt++) rs[c][rt] += (unsigned)I[c][rt] ^ (unsigned)Q[c][rt];
+            }
+            if (a.ts) {
+                const unsigned long long t4 = __builtin_readcyclecounter();
+                c_top += (t1 - t0) + (t3 - t2);
+                c_read += t2 - t1;
+                c_mul += t4 - t3;
+            }
+        }
+        if (a.ts && (tid == 0 || tid == 256)) {
+            unsigned long long *d = a.ts + (size_t)blockIdx.x * 8 + 5 + (tid >> 8);
+            *d = (c_top & 0xfffff) | ((c_read & 0xfffff) << 20) | ((c_mul & 0xfffff) << 40);
+        }
+    } else {
+        for (int j = 0; j < a.steps; j++) {
+            long I[CPW][NTT], Q[CPW][NTT];
+            load_block(j, I, Q);
+            if (!(a.dbg & 1)) mfma32(I, Q);
+        }
     }
 
+    stamp(a, 2);
     // ---- epilogue.  Row sums: lane (r, g) summed its 8 bytes of every step; total over the four g; remove the bias.
     const int nb = a.N * (a.N + 1) / 2, np2 = NPOL * NPOL, A = a.N * NPOL;
 #pragma unroll
@@ -345,6 +442,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
                 }
             }
         }
+    }
+    if (a.ts) {
+        stamp(a, 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        stamp(a, 4);
     }
     if constexpr (SPLIT) {
         if (!a.inkernel) return;
@@ -557,13 +660,13 @@ __global__ __launch_bounds__(256) void k_xe_i8_reduce(const v4i *__restrict__ pa
     }
 }
 
-template <int NPOL, int NTT, bool SPLIT> int launch_fused_s(const XeFusedPlan &p, const FuArgs &a, hipStream_t st)
+template <int NPOL, int NTT, bool SPLIT, bool PP> int launch_fused_s(const XeFusedPlan &p, const FuArgs &a, hipStream_t st)
 {
     constexpr int NSH = (NTT * 16 / NPOL > 32) ? 2 : 1;
     constexpr int lds_bytes = kRing * (kStageT * NSH * kChunk + 16);
-    MI355_HIP(hipFuncSetAttribute((const void *)k_xe_i8_fused<NPOL, NTT, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    MI355_HIP(hipFuncSetAttribute((const void *)k_xe_i8_fused<NPOL, NTT, SPLIT, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     const int nint = a.nint_launch;
-    hipLaunchKernelGGL((k_xe_i8_fused<NPOL, NTT, SPLIT>), dim3((unsigned)(p.units * p.tsplit * nint)), dim3(kThreads), lds_bytes, st, a);
+    hipLaunchKernelGGL((k_xe_i8_fused<NPOL, NTT, SPLIT, PP>), dim3((unsigned)(p.units * p.tsplit * nint)), dim3(kThreads), lds_bytes, st, a);
     MI355_HIP(hipGetLastError());
     if (SPLIT && !a.inkernel) {
         const int NP = NTT * (NTT + 1) / 2;
@@ -584,7 +687,73 @@ template <int NPOL, int NTT, bool SPLIT> int launch_fused_s(const XeFusedPlan &p
 }
 template <int NPOL, int NTT> int launch_fused(const XeFusedPlan &p, const FuArgs &a, hipStream_t st)
 {
-    return p.tsplit > 1 ? launch_fused_s<NPOL, NTT, true>(p, a, st) : launch_fused_s<NPOL, NTT, false>(p, a, st);
+    // ping-pong schedule (the two waves of a SIMD half a step apart) whenever a time range has at least four blocks
+    const bool pp = a.steps >= 4 && !getenv("MI355_XE_NO_PINGPONG");
+    if (p.tsplit > 1) return pp ? launch_fused_s<NPOL, NTT, true, true>(p, a, st) : launch_fused_s<NPOL, NTT, true, false>(p, a, st);
+    return pp ? launch_fused_s<NPOL, NTT, false, true>(p, a, st) : launch_fused_s<NPOL, NTT, false, false>(p, a, st);
+}
+
+template <int NPOL> int launch_by_tiles(const XeFusedPlan &p, const FuArgs &a, hipStream_t st)
+{
+    if (p.ntt == 1) return launch_fused<NPOL, 1>(p, a, st);
+    if (p.ntt == 2) return launch_fused<NPOL, 2>(p, a, st);
+    return launch_fused<NPOL, 4>(p, a, st);
+}
+
+// tuning aid (MI355_XE_TS=1): one synchronous launch with per-workgroup phase stamps, summary on stderr
+int launch_with_stamps(const XeFusedPlan &p, FuArgs a, hipStream_t st)
+{
+    const int wgs = p.units * p.tsplit * a.nint_launch;
+    static unsigned long long *d_ts = nullptr;
+    static int cap = 0;
+    if (cap < wgs) {
+        if (d_ts) (void)hipFree(d_ts);
+        MI355_HIP(hipMalloc(&d_ts, (size_t)wgs * 64));
+        cap = wgs;
+    }
+    MI355_HIP(hipMemsetAsync(d_ts, 0, (size_t)wgs * 64, st));
+    a.ts = d_ts;
+    const int rc = p.npol == 1 ? launch_by_tiles<1>(p, a, st) : launch_by_tiles<2>(p, a, st);
+    if (rc != MI355_OK) return rc;
+    MI355_HIP(hipStreamSynchronize(st));
+    std::vector<unsigned long long> h((size_t)wgs * 8);
+    MI355_HIP(hipMemcpy(h.data(), d_ts, (size_t)wgs * 64, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull;
+    for (int b = 0; b < wgs; b++) t0 = std::min(t0, h[(size_t)b * 8]);
+    static const char *names[5] = {"start", "first data", "loop end", "stores issued", "stores done"};
+    fprintf(stderr, "[xe stamps] %d workgroups, us after the first start (min / median / max):\n", wgs);
+    for (int k = 0; k < 5; k++) {
+        std::vector<double> v;
+        for (int b = 0; b < wgs; b++) if (h[(size_t)b * 8 + k]) v.push_back((double)(h[(size_t)b * 8 + k] - t0) * 0.01);
+        if (v.empty()) continue;
+        std::sort(v.begin(), v.end());
+        fprintf(stderr, "  %-14s %7.2f %7.2f %7.2f\n", names[k], v.front(), v[v.size() / 2], v.back());
+    }
+    if (const char *path = getenv("MI355_XE_TS_FILE")) {  // one line per workgroup: block, XCD, then the five stamps in us
+        if (FILE *f = fopen(path, "w")) {
+            for (int b = 0; b < wgs; b++) {
+                fprintf(f, "%d %d", b, (int)h[(size_t)b * 8 + 7]);
+                for (int k = 0; k < 5; k++) fprintf(f, " %.2f", h[(size_t)b * 8 + k] ? (double)(h[(size_t)b * 8 + k] - t0) * 0.01 : -1.0);
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
+    }
+    for (int w = 0; w < 2; w++) {
+        double st[3] = {0, 0, 0};
+        int n = 0;
+        for (int b = 0; b < wgs; b++) {
+            const unsigned long long v = h[(size_t)b * 8 + 5 + w];
+            if (!v) continue;
+            st[0] += (double)(v & 0xfffff); st[1] += (double)((v >> 20) & 0xfffff); st[2] += (double)((v >> 40) & 0xfffff);
+            n++;
+        }
+        if (n) fprintf(stderr, "  wave %d: shader cycles in barrier+wait / read / multiply, mean over workgroups: %.0f / %.0f / %.0f\n", 4 * w, st[0] / n, st[1] / n, st[2] / n);
+    }
+    int bad = 0;
+    for (int b = 0; b < wgs; b++) bad += ((int)h[(size_t)b * 8 + 7] != (b & 7));
+    fprintf(stderr, "  workgroups not on XCD blockIdx %% 8: %d\n", bad);
+    return MI355_OK;
 }
 
 }  // namespace
@@ -670,6 +839,8 @@ int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void 
     a.kd = kd;
     const int dbg = getenv("MI355_XE_DBG") ? atoi(getenv("MI355_XE_DBG")) : 0;
     a.dbg = dbg;
+    a.ts = nullptr;
+    if (getenv("MI355_XE_TS")) return launch_with_stamps(p, a, st);
     if (p.npol == 1) {
         if (p.ntt == 1) return launch_fused<1, 1>(p, a, st);
         if (p.ntt == 2) return launch_fused<1, 2>(p, a, st);

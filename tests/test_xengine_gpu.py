@@ -274,6 +274,35 @@ def test_complex_float_ragged_rows_and_many_time_ranges(gpu, oracle, monkeypatch
         assert relerr(out2, ref) <= TOL
 
 
+# the vector-ALU kernel on channels padded to whole lines (more than 256 rows, or MI355_XE_CF32_VALU): the padding channels have no output.
+# The guard is on the DEVICE, right behind the matrix (round 3's advisor finding: the kernel wrote Fout .. F - 1 past the end).
+@pytest.mark.parametrize("N,F,T,npol,valu", [(260, 10, 24, 1, False), (130, 5, 16, 2, False), (300, 100, 4, 1, False), (20, 37, 64, 1, True), (12, 50, 40, 2, True)])
+def test_complex_float_padded_channels_vector_alu_stays_in_bounds(gpu, oracle, monkeypatch, N, F, T, npol, valu):
+    import torch
+    if valu:
+        monkeypatch.setenv("MI355_XE_CF32_VALU", "1")
+    rng = np.random.default_rng(N + F + T)
+    x = crandn(rng, T * N * F * npol)
+    ref = oracle.xengine_cf32(N, F, npol, T, x)
+    blk = _xe(gpu, gpu.DTYPE_COMPLEX, npol, N, F, T)
+    n = blk.get_output_buffer_size()
+    guard = 1 << 16
+    buf = torch.full((n + guard, 2), 7.0, device="cuda")
+    xd = torch.from_numpy(x.view(np.float32)).cuda()
+    blk.xcorrelate_device(xd, buf[:n])
+    torch.cuda.synchronize()
+    got = buf.cpu().numpy()
+    assert relerr(got[:n].view(np.complex64).ravel(), ref) <= TOL
+    assert np.all(got[n:] == 7.0)
+    blk.xcorrelate_device(xd, buf[:n], accumulate=True)
+    torch.cuda.synchronize()
+    got = buf.cpu().numpy()
+    assert relerr(got[:n].view(np.complex64).ravel(), ref + ref) <= TOL and np.all(got[n:] == 7.0)
+    out = np.zeros(n + 64, np.complex64)  # and through the host path
+    blk.xcorrelate(x, out[:n])
+    assert relerr(out[:n], ref) <= TOL and np.all(out[n:] == 0)
+
+
 @pytest.mark.parametrize("N,F,T", [(2, 2, 3), (5, 6, 70), (16, 8, 64), (6, 5, 40), (3, 1, 2)])  # odd channel counts: padded on the device
 def test_packed4_vs_oracle(gpu, oracle, N, F, T):
     rng = np.random.default_rng(N * 7 + T)
