@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -47,7 +48,7 @@ struct FuArgs {
     int pinned, accumulate;
     int *flags;        // pub[units] then claim[units * tsplit]: arrival counters / piece claims of the in-kernel reduction (epoch valued)
     unsigned epoch;    // launch number on this workspace (>= 1)
-    int inkernel;      // 1: time ranges are combined by the kernel's own tail, 0: by k_xe_i8_reduce
+    int rs;            // 1: the four time ranges of a slice are combined by the kernel's own tail (reduce-scatter), 0: by k_xe_i8_reduce
     int compact;       // partial matrices of the diagonal tile pairs as ONE record (re on and below the diagonal, im above it)
     int dbg;  // tuning aid (MI355_XE_DBG): 1 = no compute, 2 = no stores, 4 = no DMA
     unsigned long long *ts;  // tuning aid (MI355_XE_TS): per-workgroup phase stamps (100 MHz wall clock), NULL in normal use
@@ -63,7 +64,7 @@ struct FuArgs {
 __device__ __forceinline__ unsigned perm(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 __device__ __forceinline__ void stamp(const FuArgs &a, int k)
 {
-    if (a.ts && threadIdx.x == 0) a.ts[(size_t)blockIdx.x * 8 + k] = wall_clock64();
+    if (a.ts && threadIdx.x == 0) a.ts[(size_t)blockIdx.x * 16 + k] = wall_clock64();
 }
 
 // 4 dwords (bytes b0..b3 of four consecutive time steps) -> out[j] = byte j of each input dword
@@ -89,10 +90,15 @@ __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst)
                  : "memory");
 }
 
-// partial-sum traffic between the workgroups of one unit: write-through stores and L1/L2-bypassing loads on both sides (one of
-// the valid hand-off forms of MI355X_MICROARCH.md: no fences, the flag follows the stores' completion)
-__device__ __forceinline__ void st_sys(v4i *p, v4i v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void ld_sys(v4i &d, const v4i *p) { asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(d) : "v"(p) : "memory"); }
+// partial-sum traffic between the workgroups of one slice, the hand-off recipe of cdna_hip_programming.md (Guideline 16, R1): write-through
+// (sc1) 16-byte stores, every storing wave drains them, one lane raises the count; the consumer polls that one word relaxed and, after the
+// match, reads the pieces with sc1 loads (which may stand in for the agent-scope acquire when the producer stored sc1)
+__device__ __forceinline__ void st_sys(v4i *p, v4i v)
+{
+    // (the s_nop: a store of more than 8 bytes reads its data registers a cycle or two after it issues, and the compiler's hazard pass does
+    // not look inside an asm statement -- without it the next vector instruction may overwrite the data of the last lanes)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(p), "v"(v) : "memory");
+}
 
 // ---- 24-bit partial sums (compact == 2): a time range of <= 256 steps keeps |re - 1| and |im - 1| below 2^23 (re <= 2^23 only for
 // -128 * -128 throughout, im <= 255 * 128 * 256), so a value travels as its low 16 bits in one plane and bits 16..23 in another:
@@ -114,7 +120,7 @@ __device__ __forceinline__ int pk_get(unsigned lo, unsigned hi, int k)
     return ((int)((h8 << 24) | (l16 << 8)) >> 8) + 1;
 }
 
-template <int NPOL, int NTT, bool SPLIT, bool PP>
+template <int NPOL, int NTT, bool SPLIT, bool PP, bool RS>
 __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
 {
     constexpr int NSH = (NTT * 16 / NPOL > 32) ? 2 : 1;     // 32-station halves of a time step
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     stamp(a, 0);
-    if (a.ts && tid == 0) a.ts[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID, 4 bits
+    if (a.ts && tid == 0) a.ts[(size_t)blockIdx.x * 16 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID, 4 bits
     // ---- which slice / time range: the 4 workgroups of a 128-byte line on one XCD, same time range
     // (the batched form adds the integration window to the combination: consecutive workgroups go to the eight XCDs round robin, so the
     // four workgroups of a 128-byte line must be 8 apart to meet in one L2)
@@ -246,6 +252,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
                     rs[c][rt] = __builtin_amdgcn_sad_u8(lo ^ 0x80808080u, 0u, rs[c][rt]);
                     rs[c][rt] = __builtin_amdgcn_sad_u8(hi ^ 0x80808080u, 0u, rs[c][rt]);
                 }
+                // (two row tiles' raw dwords in flight at most: all four at once cost sixteen more registers than the kernel has)
+                if (rt & 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
@@ -347,7 +355,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
             }
         }
         if (a.ts && (tid == 0 || tid == 256)) {
-            unsigned long long *d = a.ts + (size_t)blockIdx.x * 8 + 5 + (tid >> 8);
+            unsigned long long *d = a.ts + (size_t)blockIdx.x * 16 + 8 + (tid >> 8);
             *d = (c_top & 0xfffff) | ((c_read & 0xfffff) << 20) | ((c_mul & 0xfffff) << 40);
         }
     } else {
@@ -359,7 +367,311 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
     }
 
     stamp(a, 2);
+    // ---- Reduce-scatter of the four time ranges of a slice INSIDE the launch (64-row geometry, four ranges of at most 256 steps).
+    // A lane holds 64 values per channel: 8 per off-diagonal tile pair (re, im) and 4 per diagonal one (re on and below the diagonal, im
+    // above it), i.e. 16 quads; quads 4u .. 4u+3 belong to unit (time range) u of the slice: u = 0, 1, 2 two off-diagonal pairs each,
+    // u = 3 the four diagonal ones.  Every unit keeps its own quads in registers, sends the other twelve as 24-bit planes (three 16-byte
+    // pieces per lane and unit: write-through stores, the only store form that is cheap per byte at system scope) to the owners' inboxes,
+    // raises the slice's arrival count, and once all four have arrived adds the three pieces it received to its registers, scales and
+    // scatters its quarter of the matrix.  37.5 MB written and read back per BASELINE integration instead of 50 + 50 + a second kernel.
+    // Placement independent: system-scope stores and loads on both sides, the count raised after the stores have drained.  Bounded wait:
+    // a unit that gives up stores its own quads too, sets its bit in the slice's word and exits; the LAST unit to arrive sees the bits
+    // with its own arrival and finishes those quarters from the inboxes -- complete for any dispatch order, nobody waits for a workgroup
+    // that has not started.
+    if constexpr (RS) {
+        static_assert(SPLIT && NTT == 4, "the reduce-scatter tail is the 64-row, split form's");
+        {
+            const int QC = q;
+            // (lane-derived values re-defined here: otherwise every index expression of this tail is hoisted to the kernel's entry and
+            // lives -- in registers the main loop does not have -- across the whole integration)
+            int r = lane & 15, g = lane >> 4, ll = lane;
+            asm volatile("" : "+v"(r), "+v"(g), "+v"(ll));
+            const int nbl = a.N * (a.N + 1) / 2, np2l = NPOL * NPOL, Al = a.N * NPOL;
+            unsigned char *inbox = (unsigned char *)a.part + (size_t)slice * (4 * 4 * kWaves * CPW * 3072);
+            auto slot = [&](int dst, int src, int c) { return inbox + ((size_t)((dst * 4 + src) * kWaves + wave) * CPW + c) * 3072 + ll * 16; };
+            int own[CPW][16];
+#pragma unroll
+            for (int c = 0; c < CPW; c++) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) own[c][i] = 0;
+                int rsum[NTT];
+#pragma unroll
+                for (int rt = 0; rt < NTT; rt++) {
+                    int v = (int)rs[c][rt] - 128 * 8 * a.steps;
+                    v += __shfl_xor(v, 16);
+                    v += __shfl_xor(v, 32);
+                    rsum[rt] = v;
+                }
+                auto pair_vals = [&](int bi, int bj, v4i &vre, v4i &vim) {
+                    const int p = bi * (bi + 1) / 2 + bj;
+                    vre = re[c][p];
+                    vim = im[c][p];
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) vim[reg] += __shfl(rsum[bi], 4 * g + reg);
+                };
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    int v[16];
+                    if (u < 3) {
+#pragma unroll
+                        for (int it = 0; it < 2; it++) {
+                            const int k = 2 * u + it, bi = k < 1 ? 1 : k < 3 ? 2 : 3, bj = k - bi * (bi - 1) / 2;
+                            v4i vre, vim;
+                            pair_vals(bi, bj, vre, vim);
+#pragma unroll
+                            for (int reg = 0; reg < 4; reg++) { v[8 * it + reg] = vre[reg]; v[8 * it + 4 + reg] = vim[reg]; }
+                        }
+                    } else {
+#pragma unroll
+                        for (int d = 0; d < 4; d++) {
+                            v4i vre, vim;
+                            pair_vals(d, d, vre, vim);
+#pragma unroll
+                            for (int reg = 0; reg < 4; reg++) v[4 * d + reg] = (4 * g + reg >= r) ? vre[reg] : vim[reg];
+                        }
+                    }
+                    const bool mine_u = u == QC;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) own[c][i] = mine_u ? v[i] : own[c][i];  // (selects, not a branch: the quads stay in registers)
+                    if (!mine_u && !(a.dbg & 2)) {
+                        unsigned char *d = slot(u, QC, c);
+#pragma unroll
+                        for (int i = 0; i < 16; i++) v[i] -= 1;
+                        st_sys((v4i *)d, (v4i){(int)pk_lo(v[0], v[1]), (int)pk_lo(v[2], v[3]), (int)pk_lo(v[4], v[5]), (int)pk_lo(v[6], v[7])});
+                        st_sys((v4i *)(d + 1024), (v4i){(int)pk_lo(v[8], v[9]), (int)pk_lo(v[10], v[11]), (int)pk_lo(v[12], v[13]), (int)pk_lo(v[14], v[15])});
+                        st_sys((v4i *)(d + 2048), (v4i){(int)pk_hi((v4i){v[0], v[1], v[2], v[3]}), (int)pk_hi((v4i){v[4], v[5], v[6], v[7]}),
+                                                        (int)pk_hi((v4i){v[8], v[9], v[10], v[11]}), (int)pk_hi((v4i){v[12], v[13], v[14], v[15]})});
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // one unit's quads at a time (the accumulators die as they are sent)
+                }
+            }
+            stamp(a, 3);
+            __shared__ int s_mode, s_mask;
+            unsigned long long *state = (unsigned long long *)a.flags + slice;  // arrival count in the high word, {launch tag, give-up bits} in the low
+            const unsigned full = a.epoch * 4u, tag = a.epoch & 0x0fffffffu;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have completed
+            __syncthreads();
+            stamp(a, 4);
+            if (tid == 0) {
+                const unsigned long long old = __hip_atomic_fetch_add(state, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int mode = 0, mask = 0;
+                if ((unsigned)(old >> 32) + 1u == full) {  // the last to arrive: the give-up bits are final (they can only be set while the count is short)
+                    mode = 2;
+                    if (((unsigned)old >> 4) == tag) mask = (int)((unsigned)old & 15u);
+                    if ((unsigned)old) __hip_atomic_fetch_and(state, 0xffffffff00000000ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    const int spins = (a.dbg & 512) ? 1 : 2048;  // (dbg 512: give up at once -- exercises the fallback in the tests)
+                    for (int i = 0; i < spins && !mode; i++) {
+                        const unsigned long long cur = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((unsigned)(cur >> 32) == full) mode = 1;
+                        else __builtin_amdgcn_s_sleep(8);
+                    }
+                    if (!mode) mode = 3;
+                }
+                s_mode = mode;
+                s_mask = mask;
+            }
+            __syncthreads();
+            stamp(a, 5);
+            if (s_mode == 3) {  // waited long enough: hand this unit's own quads over as well, then say so -- unless everybody has arrived meanwhile
+#pragma unroll
+                for (int c = 0; c < CPW; c++) {
+                    unsigned char *d = slot(QC, QC, c);
+                    int v[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) v[i] = own[c][i] - 1;
+                    st_sys((v4i *)d, (v4i){(int)pk_lo(v[0], v[1]), (int)pk_lo(v[2], v[3]), (int)pk_lo(v[4], v[5]), (int)pk_lo(v[6], v[7])});
+                    st_sys((v4i *)(d + 1024), (v4i){(int)pk_lo(v[8], v[9]), (int)pk_lo(v[10], v[11]), (int)pk_lo(v[12], v[13]), (int)pk_lo(v[14], v[15])});
+                    st_sys((v4i *)(d + 2048), (v4i){(int)pk_hi((v4i){v[0], v[1], v[2], v[3]}), (int)pk_hi((v4i){v[4], v[5], v[6], v[7]}),
+                                                    (int)pk_hi((v4i){v[8], v[9], v[10], v[11]}), (int)pk_hi((v4i){v[12], v[13], v[14], v[15]})});
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    int mode = -1;
+                    while (mode < 0) {
+                        unsigned long long cur = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((unsigned)(cur >> 32) == full) { mode = 1; break; }
+                        const unsigned bits = (((unsigned)cur >> 4) == tag ? ((unsigned)cur & 15u) : 0u) | (1u << QC);
+                        const unsigned long long want = (cur & 0xffffffff00000000ull) | (unsigned long long)((tag << 4) | bits);
+                        if (__hip_atomic_compare_exchange_strong(state, &cur, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) mode = 0;
+                    }
+                    s_mode = mode;
+                }
+                __syncthreads();
+                if (s_mode == 0) return;
+            }
+            // scale and scatter the sixteen quads' worth of unit u, channel c (values in the order they were sent)
+            auto emit = [&](int u, int c, const int (&v)[16]) {
+                const int f = slice * (16 / NPOL) + ((NPOL == 1) ? 2 * wave + c : wave);
+                if (f >= a.Fout) return;
+                if (u < 3 && NPOL == 1 && Al == 64 && !a.accumulate) {
+                    // whole tiles, one polarisation: neighbouring lanes hold neighbouring baselines of a row, so a lane pair swaps one value
+                    // each and every lane stores 16 bytes (two baselines) of ONE row -- half the store instructions of the 8-byte form, and
+                    // the tail of this kernel is bound by store issue, not by bytes
+#pragma unroll
+                    for (int it = 0; it < 2; it++) {
+                        const int k = 2 * u + it, bi = k < 1 ? 1 : k < 3 ? 2 : 3, bj = k - bi * (bi - 1) / 2;
+#pragma unroll
+                        for (int rp = 0; rp < 4; rp += 2) {
+                            c32 w[2];
+#pragma unroll
+                            for (int e = 0; e < 2; e++) {
+                                w[e].x = (float)((double)v[8 * it + rp + e] * a.kd * a.kd);  // the oracle's expression: (double)S * kd * kd, rounded once
+                                w[e].y = (float)((double)v[8 * it + 4 + rp + e] * a.kd * a.kd);
+                            }
+                            const bool odd = (r & 1) != 0;
+                            const float sx = odd ? w[0].x : w[1].x, sy = odd ? w[0].y : w[1].y;  // what the neighbour stores of this lane's values
+                            const float gx = __shfl_xor(sx, 1), gy = __shfl_xor(sy, 1);
+                            const int s1 = bi * 16 + 4 * g + rp + (odd ? 1 : 0), s2 = bj * 16 + (r & ~1);
+                            const size_t o = (size_t)f * nbl + (s1 * (s1 + 1) / 2 + s2);
+                            typedef float v4f __attribute__((ext_vector_type(4)));
+                            const v4f q4 = odd ? (v4f){gx, gy, w[1].x, w[1].y} : (v4f){w[0].x, w[0].y, gx, gy};
+                            __builtin_memcpy((void *)(a.out + o), &q4, 16);
+                        }
+                    }
+                } else if (u < 3) {
+#pragma unroll
+                    for (int it = 0; it < 2; it++) {
+                        const int k = 2 * u + it, bi = k < 1 ? 1 : k < 3 ? 2 : 3, bj = k - bi * (bi - 1) / 2;
+#pragma unroll
+                        for (int reg = 0; reg < 4; reg++) {
+                            const int r1 = bi * 16 + 4 * g + reg, r2 = bj * 16 + r;
+                            if (r1 >= Al || r2 >= Al) continue;
+                            const int s1 = r1 / NPOL, p1 = r1 % NPOL, s2 = r2 / NPOL, p2 = r2 % NPOL;
+                            if (s1 < s2) continue;
+                            const size_t o = ((size_t)f * nbl + (s1 * (s1 + 1) / 2 + s2)) * np2l + p1 * NPOL + p2;
+                            c32 w;
+                            w.x = (float)((double)v[8 * it + reg] * a.kd * a.kd);  // the oracle's expression: (double)S * kd * kd, rounded once
+                            w.y = (float)((double)v[8 * it + 4 + reg] * a.kd * a.kd);
+                            if (a.accumulate) { w.x += a.out[o].x; w.y += a.out[o].y; }
+                            a.out[o] = w;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        // v[4d + k] = C[i][j] at i = 4 g + k, j = r: re[i][j] for i >= j, im[i][j] for i < j.  C[j][i] sits in lane 16 (j / 4) + i,
+                        // register j % 4
+                        // the transposed tile through this wave's corner of the (now idle) ring: element (i, j) is written to row i, read
+                        // back by the lane that holds (j, i) as the four consecutive words of ITS row -- four 4-byte writes and one 16-byte
+                        // read per tile instead of sixteen lane permutes
+                        int *tile = (int *)(lds + wave * (16 * 20 * 4));
+#pragma unroll
+                        for (int k = 0; k < 4; k++) tile[(4 * g + k) * 20 + r] = v[4 * d + k];
+                        const v4i trow = *(const v4i *)(tile + r * 20 + 4 * g);  // C[r][4 g + reg], reg = 0 .. 3 (same wave wrote it: no barrier)
+#pragma unroll
+                        for (int reg = 0; reg < 4; reg++) {
+                            const int i = 4 * g + reg;
+                            const int tr = trow[reg];
+                            int sre = v[4 * d + reg], sim;
+                            if (i > r) sim = -tr;                 // im[i][j] = -im[j][i]
+                            else if (i == r) sim = 0;
+                            else { sim = sre; sre = tr; }         // above the diagonal (same-station polarisation products): re[i][j] = re[j][i]
+                            const int r1 = d * 16 + i, r2 = d * 16 + r;
+                            if (r1 >= Al || r2 >= Al) continue;
+                            const int s1 = r1 / NPOL, p1 = r1 % NPOL, s2 = r2 / NPOL, p2 = r2 % NPOL;
+                            if (s1 < s2) continue;
+                            const size_t o = ((size_t)f * nbl + (s1 * (s1 + 1) / 2 + s2)) * np2l + p1 * NPOL + p2;
+                            c32 w;
+                            w.x = (float)((double)sre * a.kd * a.kd);
+                            w.y = (float)((double)sim * a.kd * a.kd);
+                            if (a.accumulate) { w.x += a.out[o].x; w.y += a.out[o].y; }
+                            a.out[o] = w;
+                        }
+                    }
+                }
+            };
+            auto unpack_add = [&](int (&v)[16], const v4i &c0, const v4i &c1, const v4i &c2) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int j = i >> 2, k = i & 3;
+                    v[i] += pk_get((unsigned)((j >> 1) ? c1 : c0)[(j & 1) * 2 + (k >> 1)], (unsigned)c2[j], k);
+                }
+            };
+            // this unit's quarter: the three other ranges' pieces for both channels in ONE batch of loads.  (The loads AND their wait are one
+            // asm statement: the compiler may move or spill an asm's outputs right behind the statement, which for a bare load instruction
+            // means before the data has arrived.  sc1 loads: served from the memory side like the sc1 stores that wrote the data, no acquire.)
+            {
+                v4i x[CPW][3][3];
+                const unsigned char *d[CPW][3];
+#pragma unroll
+                for (int c = 0; c < CPW; c++)
+#pragma unroll
+                    for (int k = 0; k < 3; k++) d[c][k] = slot(QC, (QC + 1 + k) & 3, c);
+                if constexpr (CPW == 2) {
+                    asm volatile(
+                        "global_load_dwordx4 %0, %18, off sc1\n\tglobal_load_dwordx4 %1, %18, off offset:1024 sc1\n\tglobal_load_dwordx4 %2, %18, off offset:2048 sc1\n\t"
+                        "global_load_dwordx4 %3, %19, off sc1\n\tglobal_load_dwordx4 %4, %19, off offset:1024 sc1\n\tglobal_load_dwordx4 %5, %19, off offset:2048 sc1\n\t"
+                        "global_load_dwordx4 %6, %20, off sc1\n\tglobal_load_dwordx4 %7, %20, off offset:1024 sc1\n\tglobal_load_dwordx4 %8, %20, off offset:2048 sc1\n\t"
+                        "global_load_dwordx4 %9, %21, off sc1\n\tglobal_load_dwordx4 %10, %21, off offset:1024 sc1\n\tglobal_load_dwordx4 %11, %21, off offset:2048 sc1\n\t"
+                        "global_load_dwordx4 %12, %22, off sc1\n\tglobal_load_dwordx4 %13, %22, off offset:1024 sc1\n\tglobal_load_dwordx4 %14, %22, off offset:2048 sc1\n\t"
+                        "global_load_dwordx4 %15, %23, off sc1\n\tglobal_load_dwordx4 %16, %23, off offset:1024 sc1\n\tglobal_load_dwordx4 %17, %23, off offset:2048 sc1\n\t"
+                        "s_waitcnt vmcnt(0)"
+                        : "=&v"(x[0][0][0]), "=&v"(x[0][0][1]), "=&v"(x[0][0][2]), "=&v"(x[0][1][0]), "=&v"(x[0][1][1]), "=&v"(x[0][1][2]), "=&v"(x[0][2][0]),
+                          "=&v"(x[0][2][1]), "=&v"(x[0][2][2]), "=&v"(x[CPW - 1][0][0]), "=&v"(x[CPW - 1][0][1]), "=&v"(x[CPW - 1][0][2]), "=&v"(x[CPW - 1][1][0]),
+                          "=&v"(x[CPW - 1][1][1]), "=&v"(x[CPW - 1][1][2]), "=&v"(x[CPW - 1][2][0]), "=&v"(x[CPW - 1][2][1]), "=&v"(x[CPW - 1][2][2])
+                        : "v"(d[0][0]), "v"(d[0][1]), "v"(d[0][2]), "v"(d[CPW - 1][0]), "v"(d[CPW - 1][1]), "v"(d[CPW - 1][2])
+                        : "memory");
+                } else {
+                    asm volatile(
+                        "global_load_dwordx4 %0, %9, off sc1\n\tglobal_load_dwordx4 %1, %9, off offset:1024 sc1\n\tglobal_load_dwordx4 %2, %9, off offset:2048 sc1\n\t"
+                        "global_load_dwordx4 %3, %10, off sc1\n\tglobal_load_dwordx4 %4, %10, off offset:1024 sc1\n\tglobal_load_dwordx4 %5, %10, off offset:2048 sc1\n\t"
+                        "global_load_dwordx4 %6, %11, off sc1\n\tglobal_load_dwordx4 %7, %11, off offset:1024 sc1\n\tglobal_load_dwordx4 %8, %11, off offset:2048 sc1\n\t"
+                        "s_waitcnt vmcnt(0)"
+                        : "=&v"(x[0][0][0]), "=&v"(x[0][0][1]), "=&v"(x[0][0][2]), "=&v"(x[0][1][0]), "=&v"(x[0][1][1]), "=&v"(x[0][1][2]), "=&v"(x[0][2][0]),
+                          "=&v"(x[0][2][1]), "=&v"(x[0][2][2])
+                        : "v"(d[0][0]), "v"(d[0][1]), "v"(d[0][2])
+                        : "memory");
+                }
+                if (a.dbg & 1024) stamp(a, 1);  // (tuning aid: "first data" then holds the time the pieces have arrived)
+#pragma unroll
+                for (int c = 0; c < CPW; c++) {
+                    int v[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) v[i] = own[c][i];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) unpack_add(v, x[c][k][0], x[c][k][1], x[c][k][2]);
+                    emit(QC, c, v);
+                }
+            }
+            // (last arriver only, and only after a bounded wait ran out somewhere) the quarters of the units that gave up: all four pieces
+            // come from the inboxes, the unit's own one included
+            const int todo = s_mode == 2 ? (s_mask & ~(1 << QC)) : 0;
+            for (int u = 0; u < 4; u++) {
+                if (!((todo >> u) & 1)) continue;
+#pragma unroll
+                for (int c = 0; c < CPW; c++) {
+                    v4i x[4][3];
+                    const unsigned char *d0 = slot(u, 0, c), *d1 = slot(u, 1, c), *d2 = slot(u, 2, c), *d3 = slot(u, 3, c);
+                    asm volatile(
+                        "global_load_dwordx4 %0, %12, off sc1\n\tglobal_load_dwordx4 %1, %12, off offset:1024 sc1\n\tglobal_load_dwordx4 %2, %12, off offset:2048 sc1\n\t"
+                        "global_load_dwordx4 %3, %13, off sc1\n\tglobal_load_dwordx4 %4, %13, off offset:1024 sc1\n\tglobal_load_dwordx4 %5, %13, off offset:2048 sc1\n\t"
+                        "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %14, off offset:1024 sc1\n\tglobal_load_dwordx4 %8, %14, off offset:2048 sc1\n\t"
+                        "global_load_dwordx4 %9, %15, off sc1\n\tglobal_load_dwordx4 %10, %15, off offset:1024 sc1\n\tglobal_load_dwordx4 %11, %15, off offset:2048 sc1\n\t"
+                        "s_waitcnt vmcnt(0)"
+                        : "=&v"(x[0][0]), "=&v"(x[0][1]), "=&v"(x[0][2]), "=&v"(x[1][0]), "=&v"(x[1][1]), "=&v"(x[1][2]), "=&v"(x[2][0]), "=&v"(x[2][1]),
+                          "=&v"(x[2][2]), "=&v"(x[3][0]), "=&v"(x[3][1]), "=&v"(x[3][2])
+                        : "v"(d0), "v"(d1), "v"(d2), "v"(d3)
+                        : "memory");
+                    int v[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) v[i] = 0;
+#pragma unroll
+                    for (int src = 0; src < 4; src++) unpack_add(v, x[src][0], x[src][1], x[src][2]);
+                    emit(u, c, v);
+                }
+            }
+            if (a.ts) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                stamp(a, 6);
+            }
+            return;
+        }
+    }
     // ---- epilogue.  Row sums: lane (r, g) summed its 8 bytes of every step; total over the four g; remove the bias.
+    if constexpr (!RS) {
     const int nb = a.N * (a.N + 1) / 2, np2 = NPOL * NPOL, A = a.N * NPOL;
 #pragma unroll
     for (int c = 0; c < CPW; c++) {
@@ -419,8 +731,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
                         }
                     } else {
                         v4i *dst = a.part + ((((size_t)q * a.F + f) * NP + p) * 2) * 64 + lane;
-                        if (a.inkernel) { st_sys(dst, vre); st_sys(dst + 64, vim); }
-                        else { __builtin_nontemporal_store(vre, dst); __builtin_nontemporal_store(vim, dst + 64); }
+                        __builtin_nontemporal_store(vre, dst);
+                        __builtin_nontemporal_store(vim, dst + 64);
                     }
                 } else {
                     if (f >= a.Fout) continue;
@@ -449,99 +761,6 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
         __syncthreads();
         stamp(a, 4);
     }
-    if constexpr (SPLIT) {
-        if (!a.inkernel) return;
-        // ---- the time ranges of this slice are combined HERE (no second kernel).  Every workgroup has published its partial
-        // matrix; it raises the unit's arrival counter and waits -- for a bounded time -- until all tsplit ranges have arrived.
-        // The unit's (channel, tile pair) items are cut into tsplit pieces; a workgroup claims pieces (its own first) with a
-        // compare-and-swap and finishes them: sum of the ranges in int64, one rounding, scatter into the output order.  A
-        // workgroup that gives up waiting leaves its piece unclaimed; the last range to arrive sees the full count at once
-        // and sweeps whatever is unclaimed, so the result is complete for any dispatch order (nobody waits on a workgroup that
-        // has not started).  Counters and claims hold launch numbers (epoch): nothing is reset between launches.
-        __shared__ int s_flag;
-        const int units = a.nlines * 4;
-        int *pub = a.flags + slice, *claim = a.flags + units + slice * a.tsplit;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have completed
-        __syncthreads();
-        if (tid == 0) {
-            __hip_atomic_fetch_add(pub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int target = (int)(a.epoch * (unsigned)a.tsplit);
-            int ok = 0;
-            for (int spin = 0; spin < 4096 && !ok; spin++) {
-                ok = (__hip_atomic_load(pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0;
-                if (!ok) __builtin_amdgcn_s_sleep(16);
-            }
-            s_flag = ok;
-        }
-        __syncthreads();
-        if (!s_flag) return;
-        const int cpwg = 16 / NPOL, total = cpwg * NP, per = (total + a.tsplit - 1) / a.tsplit;
-        for (int kk = 0; kk < a.tsplit; kk++) {
-            const int k = (q + kk) % a.tsplit;
-            __syncthreads();
-            if (tid == 0) s_flag = atomicCAS((unsigned *)claim + k, a.epoch - 1u, a.epoch) == a.epoch - 1u;
-            __syncthreads();
-            if (!s_flag) continue;
-            const int it_end = (k + 1) * per < total ? (k + 1) * per : total;
-            // four items per wave and round, four time ranges per group: 32 16-byte loads in flight per lane (the loads come from
-            // the memory side -- the partial sums were stored write-through -- so a wave's time is (rounds) x (one latency))
-            for (int it0 = k * per + wave; it0 < it_end; it0 += 4 * kWaves) {
-                long sre[4][4], sim[4][4];
-#pragma unroll
-                for (int b = 0; b < 4; b++)
-#pragma unroll
-                    for (int e = 0; e < 4; e++) sre[b][e] = sim[b][e] = 0;
-                for (int q0 = 0; q0 < a.tsplit; q0 += 4) {
-                    v4i x[4][8];
-#pragma unroll
-                    for (int b = 0; b < 4; b++) {
-                        const int it = (it0 + b * kWaves < it_end) ? it0 + b * kWaves : it0;  // (a missing item re-reads the first, unused)
-                        const int cu = it / NP, p = it - cu * NP, f = slice * cpwg + cu;
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            const int qq = (q0 + u < a.tsplit) ? q0 + u : q0;
-                            const v4i *src = a.part + ((((size_t)qq * a.F + f) * NP + p) * 2) * 64 + lane;
-                            ld_sys(x[b][2 * u], src);
-                            ld_sys(x[b][2 * u + 1], src + 64);
-                        }
-                    }
-#pragma unroll
-                    for (int b = 0; b < 4; b++)
-                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[b][0]), "+v"(x[b][1]), "+v"(x[b][2]), "+v"(x[b][3]), "+v"(x[b][4]), "+v"(x[b][5]), "+v"(x[b][6]), "+v"(x[b][7])::"memory");
-#pragma unroll
-                    for (int b = 0; b < 4; b++)
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            if (q0 + u >= a.tsplit) continue;
-#pragma unroll
-                            for (int e = 0; e < 4; e++) { sre[b][e] += x[b][2 * u][e]; sim[b][e] += x[b][2 * u + 1][e]; }
-                        }
-                }
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const int it = it0 + b * kWaves;
-                    if (it >= it_end) continue;
-                    const int cu = it / NP, p = it - cu * NP, f = slice * cpwg + cu;
-                    if (f >= a.Fout) continue;
-                    int bi = 0;
-                    while ((bi + 1) * (bi + 2) / 2 <= p) bi++;
-                    const int bj = p - bi * (bi + 1) / 2;
-#pragma unroll
-                    for (int reg = 0; reg < 4; reg++) {
-                        const int r1 = bi * 16 + 4 * g + reg, r2 = bj * 16 + r;
-                        if (r1 >= A || r2 >= A) continue;
-                        const int s1 = r1 / NPOL, p1 = r1 % NPOL, s2 = r2 / NPOL, p2 = r2 % NPOL;
-                        if (s1 < s2) continue;
-                        const size_t o = ((size_t)f * nb + (s1 * (s1 + 1) / 2 + s2)) * np2 + p1 * NPOL + p2;
-                        c32 v;
-                        v.x = (float)((double)sre[b][reg] * a.kd * a.kd);  // the oracle's expression: (double)S * kd * kd, rounded once
-                        v.y = (float)((double)sim[b][reg] * a.kd * a.kd);
-                        if (a.accumulate) { v.x += a.out[o].x; v.y += a.out[o].y; }
-                        a.out[o] = v;
-                    }
-                }
-            }
-        }
     }
 }
 
@@ -660,15 +879,15 @@ __global__ __launch_bounds__(256) void k_xe_i8_reduce(const v4i *__restrict__ pa
     }
 }
 
-template <int NPOL, int NTT, bool SPLIT, bool PP> int launch_fused_s(const XeFusedPlan &p, const FuArgs &a, hipStream_t st)
+template <int NPOL, int NTT, bool SPLIT, bool PP, bool RS> int launch_fused_s(const XeFusedPlan &p, const FuArgs &a, hipStream_t st)
 {
     constexpr int NSH = (NTT * 16 / NPOL > 32) ? 2 : 1;
     constexpr int lds_bytes = kRing * (kStageT * NSH * kChunk + 16);
-    MI355_HIP(hipFuncSetAttribute((const void *)k_xe_i8_fused<NPOL, NTT, SPLIT, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    MI355_HIP(hipFuncSetAttribute((const void *)k_xe_i8_fused<NPOL, NTT, SPLIT, PP, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     const int nint = a.nint_launch;
-    hipLaunchKernelGGL((k_xe_i8_fused<NPOL, NTT, SPLIT, PP>), dim3((unsigned)(p.units * p.tsplit * nint)), dim3(kThreads), lds_bytes, st, a);
+    hipLaunchKernelGGL((k_xe_i8_fused<NPOL, NTT, SPLIT, PP, RS>), dim3((unsigned)(p.units * p.tsplit * nint)), dim3(kThreads), lds_bytes, st, a);
     MI355_HIP(hipGetLastError());
-    if (SPLIT && !a.inkernel) {
+    if (SPLIT && !RS) {
         const int NP = NTT * (NTT + 1) / 2;
         const size_t items = (size_t)a.Fout * NP;
         int ipw = 1;  // items per wave: as many as it takes for all waves to be resident together (32 per CU)
@@ -689,8 +908,11 @@ template <int NPOL, int NTT> int launch_fused(const XeFusedPlan &p, const FuArgs
 {
     // ping-pong schedule (the two waves of a SIMD half a step apart) whenever a time range has at least four blocks
     const bool pp = a.steps >= 4 && !getenv("MI355_XE_NO_PINGPONG");
-    if (p.tsplit > 1) return pp ? launch_fused_s<NPOL, NTT, true, true>(p, a, st) : launch_fused_s<NPOL, NTT, true, false>(p, a, st);
-    return pp ? launch_fused_s<NPOL, NTT, false, true>(p, a, st) : launch_fused_s<NPOL, NTT, false, false>(p, a, st);
+    if constexpr (NTT == 4) {
+        if (a.rs) return pp ? launch_fused_s<NPOL, NTT, true, true, true>(p, a, st) : launch_fused_s<NPOL, NTT, true, false, true>(p, a, st);
+    }
+    if (p.tsplit > 1) return pp ? launch_fused_s<NPOL, NTT, true, true, false>(p, a, st) : launch_fused_s<NPOL, NTT, true, false, false>(p, a, st);
+    return pp ? launch_fused_s<NPOL, NTT, false, true, false>(p, a, st) : launch_fused_s<NPOL, NTT, false, false, false>(p, a, st);
 }
 
 template <int NPOL> int launch_by_tiles(const XeFusedPlan &p, const FuArgs &a, hipStream_t st)
@@ -708,23 +930,23 @@ int launch_with_stamps(const XeFusedPlan &p, FuArgs a, hipStream_t st)
     static int cap = 0;
     if (cap < wgs) {
         if (d_ts) (void)hipFree(d_ts);
-        MI355_HIP(hipMalloc(&d_ts, (size_t)wgs * 64));
+        MI355_HIP(hipMalloc(&d_ts, (size_t)wgs * 128));
         cap = wgs;
     }
-    MI355_HIP(hipMemsetAsync(d_ts, 0, (size_t)wgs * 64, st));
+    MI355_HIP(hipMemsetAsync(d_ts, 0, (size_t)wgs * 128, st));
     a.ts = d_ts;
     const int rc = p.npol == 1 ? launch_by_tiles<1>(p, a, st) : launch_by_tiles<2>(p, a, st);
     if (rc != MI355_OK) return rc;
     MI355_HIP(hipStreamSynchronize(st));
-    std::vector<unsigned long long> h((size_t)wgs * 8);
-    MI355_HIP(hipMemcpy(h.data(), d_ts, (size_t)wgs * 64, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> h((size_t)wgs * 16);
+    MI355_HIP(hipMemcpy(h.data(), d_ts, (size_t)wgs * 128, hipMemcpyDeviceToHost));
     unsigned long long t0 = ~0ull;
-    for (int b = 0; b < wgs; b++) t0 = std::min(t0, h[(size_t)b * 8]);
-    static const char *names[5] = {"start", "first data", "loop end", "stores issued", "stores done"};
+    for (int b = 0; b < wgs; b++) t0 = std::min(t0, h[(size_t)b * 16]);
+    static const char *names[7] = {"start", "first data", "loop end", "stores issued", "stores done", "all ranges in", "end"};
     fprintf(stderr, "[xe stamps] %d workgroups, us after the first start (min / median / max):\n", wgs);
-    for (int k = 0; k < 5; k++) {
+    for (int k = 0; k < 7; k++) {
         std::vector<double> v;
-        for (int b = 0; b < wgs; b++) if (h[(size_t)b * 8 + k]) v.push_back((double)(h[(size_t)b * 8 + k] - t0) * 0.01);
+        for (int b = 0; b < wgs; b++) if (h[(size_t)b * 16 + k]) v.push_back((double)(h[(size_t)b * 16 + k] - t0) * 0.01);
         if (v.empty()) continue;
         std::sort(v.begin(), v.end());
         fprintf(stderr, "  %-14s %7.2f %7.2f %7.2f\n", names[k], v.front(), v[v.size() / 2], v.back());
@@ -732,8 +954,8 @@ int launch_with_stamps(const XeFusedPlan &p, FuArgs a, hipStream_t st)
     if (const char *path = getenv("MI355_XE_TS_FILE")) {  // one line per workgroup: block, XCD, then the five stamps in us
         if (FILE *f = fopen(path, "w")) {
             for (int b = 0; b < wgs; b++) {
-                fprintf(f, "%d %d", b, (int)h[(size_t)b * 8 + 7]);
-                for (int k = 0; k < 5; k++) fprintf(f, " %.2f", h[(size_t)b * 8 + k] ? (double)(h[(size_t)b * 8 + k] - t0) * 0.01 : -1.0);
+                fprintf(f, "%d %d", b, (int)h[(size_t)b * 16 + 7]);
+                for (int k = 0; k < 7; k++) fprintf(f, " %.2f", h[(size_t)b * 16 + k] ? (double)(h[(size_t)b * 16 + k] - t0) * 0.01 : -1.0);
                 fprintf(f, "\n");
             }
             fclose(f);
@@ -743,7 +965,7 @@ int launch_with_stamps(const XeFusedPlan &p, FuArgs a, hipStream_t st)
         double st[3] = {0, 0, 0};
         int n = 0;
         for (int b = 0; b < wgs; b++) {
-            const unsigned long long v = h[(size_t)b * 8 + 5 + w];
+            const unsigned long long v = h[(size_t)b * 16 + 8 + w];
             if (!v) continue;
             st[0] += (double)(v & 0xfffff); st[1] += (double)((v >> 20) & 0xfffff); st[2] += (double)((v >> 40) & 0xfffff);
             n++;
@@ -751,7 +973,7 @@ int launch_with_stamps(const XeFusedPlan &p, FuArgs a, hipStream_t st)
         if (n) fprintf(stderr, "  wave %d: shader cycles in barrier+wait / read / multiply, mean over workgroups: %.0f / %.0f / %.0f\n", 4 * w, st[0] / n, st[1] / n, st[2] / n);
     }
     int bad = 0;
-    for (int b = 0; b < wgs; b++) bad += ((int)h[(size_t)b * 8 + 7] != (b & 7));
+    for (int b = 0; b < wgs; b++) bad += ((int)h[(size_t)b * 16 + 7] != (b & 7));
     fprintf(stderr, "  workgroups not on XCD blockIdx %% 8: %d\n", bad);
     return MI355_OK;
 }
@@ -779,6 +1001,7 @@ XeFusedPlan mi355_xe_fused_plan(int N, int F, int Fout, int npol, int T, int num
     p.units = (int)(row_bytes / 32);
     // time split: fill the device (one workgroup per CU), whole K blocks per range
     const int cus = num_cus > 0 ? num_cus : 256;
+    p.cus = cus;
     int s = 1;
     if (const char *e = getenv("MI355_XE_TSPLIT")) s = atoi(e) > 0 ? atoi(e) : 1;
     else
@@ -803,18 +1026,16 @@ int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void 
     a.part = (v4i *)part;
     a.flags = p.tsplit > 1 ? (int *)((char *)part + p.flag_offset) : nullptr;
     a.epoch = 1;
-    // Measured at BASELINE config 5: 69-70 us with the reduction inside the launch, 67 us with k_xe_i8_reduce -- the 84 MB of partial
-    // sums do not fit the XCD's L2 (10.5 MB per XCD against 4 MiB), so either way they are written to and read back from the
-    // memory side at HBM-like rates (~28 us of the total); the second kernel streams them with every CU, the in-launch tail is
-    // kept as an option (MI355_XE_INKERNEL_REDUCE=1) and for the tests.
-    // (read per launch: a tuning / test switch.  The workspace's epoch advances only with launches that use the counters, so switching
-    // between the two forms of the reduction mid-process leaves them consistent)
-    const bool inkernel_env = getenv("MI355_XE_INKERNEL_REDUCE") && atoi(getenv("MI355_XE_INKERNEL_REDUCE")) != 0;
-    a.inkernel = (nint <= 1 && epoch && inkernel_env && p.tsplit > 1) ? 1 : 0;
-    if (a.inkernel) a.epoch = ++*epoch;
-    a.compact = (!a.inkernel && !getenv("MI355_XE_NO_COMPACT")) ? 1 : 0;
-    // 24-bit planes: time ranges of at most 256 steps, at least two row tiles (a lone diagonal record has nothing to pair with)
+    // The four time ranges of a 64-row slice are combined inside the launch (reduce-scatter tail of k_xe_i8_fused) when every workgroup of
+    // the launch is resident at once (one per CU) and a range fits the 24-bit planes; MI355_XE_INKERNEL_REDUCE=0 keeps the second kernel.
+    // (Read per launch: a tuning / test switch.  The workspace's epoch advances only with launches that use the arrival words, so
+    // switching between the two forms mid-process leaves them consistent.)
     const int Tp = (T + 31) / 32 * 32;  // whole K blocks
+    const char *rs_env = getenv("MI355_XE_INKERNEL_REDUCE");
+    a.rs = (nint <= 1 && epoch && p.tsplit == 4 && p.ntt == 4 && Tp / 4 <= 256 && p.units * 4 <= p.cus && !(rs_env && atoi(rs_env) == 0)) ? 1 : 0;
+    if (a.rs) a.epoch = ++*epoch;
+    a.compact = !getenv("MI355_XE_NO_COMPACT") ? 1 : 0;
+    // 24-bit planes: time ranges of at most 256 steps, at least two row tiles (a lone diagonal record has nothing to pair with)
     if (a.compact && p.tsplit > 1 && Tp / p.tsplit <= 256 && p.ntt >= 2 && !getenv("MI355_XE_NO_PACK24")) a.compact = 2;
     a.out = (c32 *)out;
     (void)F;

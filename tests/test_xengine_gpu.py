@@ -156,12 +156,20 @@ def test_fused_24_bit_partial_sums_at_their_limits(gpu, oracle, monkeypatch, N, 
         assert np.array_equal(out32, ref)
 
 
-@pytest.mark.parametrize("N,F,T,npol,tsplit", [(64, 64, 256, 1, "4"), (33, 128, 512, 1, "8"), (32, 64, 128, 2, "2"), (20, 64, 1024, 1, "16")])
-def test_fused_in_launch_reduction(gpu, oracle, monkeypatch, N, F, T, npol, tsplit):
-    """The time ranges combined by the fused kernel's own tail (arrival counters, claimed pieces, epoch-valued flags) instead of the
-    second kernel: bit-exact, also over repeated launches on the same workspace and with accumulation."""
+@pytest.mark.parametrize("N,F,T,npol,tsplit,giveup", [(64, 64, 256, 1, "4", False), (64, 128, 512, 1, "4", False), (50, 64, 1024, 1, "4", False),
+                                                      (32, 64, 512, 2, "4", False), (25, 128, 256, 2, "4", False),  # the reduce-scatter tail (64 rows x 4 ranges)
+                                                      (64, 128, 512, 1, "4", True), (32, 64, 256, 2, "4", True),   # ... with every bounded wait running out at once
+                                                      (33, 128, 512, 1, "8", False), (32, 64, 128, 2, "2", False), (20, 64, 1024, 1, "16", False)])
+def test_fused_in_launch_reduction(gpu, oracle, monkeypatch, N, F, T, npol, tsplit, giveup):
+    """The four time ranges of a 64-row slice combined by the fused kernel's own tail (reduce-scatter: write-through 24-bit pieces, an
+    arrival word per slice, bounded waits with the last arriver finishing what others gave up) instead of the second kernel: bit-exact,
+    also over repeated launches on the same workspace and with accumulation.  Geometries the tail does not cover (other range counts,
+    fewer row tiles) take the second kernel and must agree as well.  giveup: MI355_XE_DBG=512 makes every workgroup but the last of a
+    slice give up at once, so the fallback path produces the whole matrix."""
     monkeypatch.setenv("MI355_XE_INKERNEL_REDUCE", "1")
     monkeypatch.setenv("MI355_XE_TSPLIT", tsplit)
+    if giveup:
+        monkeypatch.setenv("MI355_XE_DBG", "512")
     rng = np.random.default_rng(N + T)
     blk = _xe(gpu, gpu.DTYPE_BYTE, npol, N, F, T)
     out = np.empty(blk.get_output_buffer_size(), np.complex64)
@@ -186,10 +194,7 @@ def test_in_launch_reduction_survives_mode_switches(gpu, oracle, monkeypatch):
     per = blk.get_output_buffer_size()
 
     def run(inkernel, misaligned=False):
-        if inkernel:
-            monkeypatch.setenv("MI355_XE_INKERNEL_REDUCE", "1")
-        else:
-            monkeypatch.delenv("MI355_XE_INKERNEL_REDUCE", raising=False)
+        monkeypatch.setenv("MI355_XE_INKERNEL_REDUCE", "1" if inkernel else "0")
         x = rng.integers(-128, 128, size=T * N * F * 2, dtype=np.int64).astype(np.int8)
         buf = torch.zeros(x.size + 16, dtype=torch.int8, device="cuda")
         off = 4 if misaligned else 0  # 4-byte aligned only: not the fused path
