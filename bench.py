@@ -255,6 +255,21 @@ def config1_testcpu(o):
             "result_is_0.75+1.0j": ok, "kind": "port (oracle mathop through ctypes; the call overhead is included)"}
 
 
+def cpu_harness(seconds=1.0):
+    """The oracle's CPU legs timed from C (oracle/cpu_bench: one warm-up call, then calls for `seconds` around a steady clock, one core --
+    the loop of lib/test_clenabled.cc:1562-1691 without an interpreter in it).  Measurement infrastructure like the oracle itself; None
+    when the binary is missing (build() makes it)."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "cpu_bench")
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe, "%.2f" % seconds], capture_output=True, text=True, timeout=120)
+        return json.loads(r.stdout) if r.returncode == 0 else None
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def cpu_extras(o, o_taps):
     """Oracle (port of the reference's CPU paths) on ONE host core, ~1-2 s each, for the secondary blocks."""
     rng = np.random.default_rng(7)
@@ -805,7 +820,18 @@ def main():
                 extras["hostpath_error"] = "%s: %s" % (type(exc).__name__, exc)
     if rank == 0 and world == 1 and not a.no_cpu:
         line["cpu_baseline"] = cpu_baseline_fft(entry.load_oracle(), window)
-        extras["config1_clMathOp_testCPU_8192"] = config1_testcpu(entry.load_oracle())
+        # BASELINE configs[0] and the secondary blocks' one-core legs are timed from C (oracle/cpu_bench); the same calls made from Python
+        # through ctypes stay beside them (an 8192-item call is dominated by the interpreter there; SURVEY 8d asks for the CLI's loop)
+        c1 = config1_testcpu(entry.load_oracle())
+        harness = cpu_harness(1.0)
+        if harness:
+            h1 = dict(harness["config1_clMathOp_testCPU_8192"])
+            h1["kind"] = "port (oracle mathop, the CLI's loop in C: 1 warm-up + 200 timed calls, one core)"
+            h1["through_ctypes_us_per_call"] = c1["us_per_call"]
+            h1["through_ctypes_MSamples_per_s"] = c1["MSamples_per_s"]
+            extras["config1_clMathOp_testCPU_8192"] = h1
+        else:
+            extras["config1_clMathOp_testCPU_8192"] = c1
         if not a.no_extra:
             for k, v in cpu_extras(entry.load_oracle(), taps_pair).items():
                 if k in extras and isinstance(extras[k], dict):
@@ -814,6 +840,16 @@ def main():
                         extras[k]["cpu_1core_sample"] = v["sample"]
                     else:
                         extras[k]["cpu_1core_MSamples_per_s"] = v
+            if harness:  # the C-timed figures replace the ctypes ones, which keep a key of their own
+                names = {"clComplexFilter_fft_65ctaps": "clComplexFilter_fir_65ctaps"}
+                for k in list(extras):
+                    hk = names.get(k, k)
+                    if isinstance(extras[k], dict) and "cpu_1core_MSamples_per_s" in extras[k] and hk in harness:
+                        hv = harness[hk]
+                        extras[k]["cpu_1core_through_ctypes_MSamples_per_s"] = extras[k]["cpu_1core_MSamples_per_s"]
+                        extras[k]["cpu_1core_MSamples_per_s"] = hv["MSamples_per_s"] if isinstance(hv, dict) else hv
+                extras["cpu_harness"] = {"kind": harness["kind"], "seconds_per_leg": harness["seconds_per_leg"],
+                                         "clFFT_4096_blackman_shift_MSamples_per_s": harness["clFFT_4096_blackman_shift"]}
     dog.cancel()
     emit()
     import torch.distributed as dist

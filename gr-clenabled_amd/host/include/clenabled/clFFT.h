@@ -16,9 +16,11 @@ namespace clenabled {
 class CLENABLED_API clFFT : virtual public gr::sync_block {
 public:
     typedef std::shared_ptr<clFFT> sptr;
-    // positional order of lib/clFFT_impl.cc:34-36 (what GRC passes; the reference header's parameter NAMES differ, App. B-1)
+    // positional order of lib/clFFT_impl.cc:34-36 (what GRC passes; the reference header's parameter NAMES differ, App. B-1).  The
+    // defaults are the reference header's (include/clenabled/clFFT.h:54-55: the 8th positional argument defaults to 4): a seven-argument
+    // caller compiles against both headers, and its seventh argument lands where the reference's implementation reads it.
     static sptr make(int fftSize, int clFFTDir, const std::vector<float> &window, int idataType, int openCLPlatformType,
-                     int devSelector, int platformId, int devId, int setDebug = 0, int num_streams = 1, bool shift = false);
+                     int devSelector, int platformId, int devId = 4, int setDebug = 0, int num_streams = 1, bool shift = false);
     // counts SAMPLES like the reference's test hook (lib/clFFT_impl.cc:520-524)
     virtual int testOpenCL(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &output_items) = 0;
 };

@@ -36,7 +36,9 @@ PUBLIC_HEADERS = {
     "clMathConst.h": "gr::clenabled::clMathConst::sptr (*f)(int, int, int, int, int, float, int, int) = &gr::clenabled::clMathConst::make; "
                      "float (gr::clenabled::clMathConst::*k)() const = &gr::clenabled::clMathConst::k;",
     "clFFT.h": "gr::clenabled::clFFT::sptr (*f)(int, int, const std::vector<float> &, int, int, int, int, int, int, int, bool) = "
-               "&gr::clenabled::clFFT::make; static_assert(CLFFT_FORWARD == -1 && CLFFT_BACKWARD == 1, \"\");",
+               "&gr::clenabled::clFFT::make; static_assert(CLFFT_FORWARD == -1 && CLFFT_BACKWARD == 1, \"\"); "
+               # the reference header's seven-argument call (include/clenabled/clFFT.h:54-55 defaults the 8th positional argument to 4)
+               "gr::clenabled::clFFT::sptr seven_args(const std::vector<float> &w) { return gr::clenabled::clFFT::make(2048, -1, w, 1, 2, 0, 0); }",
     "clFilter.h": "gr::clenabled::clFilter::sptr (*f)(int, int, int, int, int, const std::vector<float> &, int, int, bool) = "
                   "&gr::clenabled::clFilter::make; static_assert(!gr::clenabled::DEFAULT_USE_TIME_DOMAIN_SETTING, \"\");",
     "clComplexFilter.h": "gr::clenabled::clComplexFilter::sptr (*f)(int, int, int, int, int, const std::vector<gr_complex> &, int, int) = "
