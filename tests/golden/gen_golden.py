@@ -77,6 +77,96 @@ def widen_golden():
     np.savez_compressed(os.path.join(HERE, "widen_golden.npz"), **g)
 
 
+def independent_golden():
+    """Fixtures for the two blocks the reference holds nothing for (clPolyphaseChannelizer, clXEngine), produced by implementations that
+    are NOT this repository's: scipy.signal.upfirdn (mix down, low-pass FIR, decimate -- the textbook channelizer, one channel at a
+    time), numpy.einsum on integers / complex128 with numpy.tril_indices for the baseline order, and scipy.signal.correlate's zero lag
+    for single baselines.  The oracle and the GPU path are then checked against data no author of either wrote the arithmetic for."""
+    import scipy.signal as sig
+    rng = np.random.default_rng(20260929)
+    g = {}
+
+    def pfb_scipy(taps, M, R, buf_items, chmap, xh):
+        """u_i[c] = sum_k h[k] x[n_i - k] exp(j 2 pi c (k + i (M - R)) / M), n_i = i R + K - 1, as
+        exp(j 2 pi c n_i / M) * (h * (x exp(-j 2 pi c n / M)))[n_i] * exp(j 2 pi c i (M - R) / M): mix, FIR, decimate by R."""
+        K = taps.size
+        nsteps = buf_items // R
+        n = np.arange(xh.size)
+        pad = (-(K - 1)) % R          # zeros in front so that the wanted samples fall on the decimation grid
+        j0 = (K - 1 + pad) // R
+        out = np.zeros((nsteps, len(chmap)), np.complex128)
+        i = np.arange(nsteps)
+        ni = i * R + K - 1
+        for q, c in enumerate(chmap):
+            xm = xh.astype(np.complex128) * np.exp(-2j * np.pi * c * n / M)
+            y = sig.upfirdn(taps.astype(np.float64), np.concatenate([np.zeros(pad, np.complex128), xm]), up=1, down=R)
+            out[:, q] = y[j0:j0 + nsteps] * np.exp(2j * np.pi * c * ni / M) * np.exp(2j * np.pi * c * i * (M - R) / M)
+        return out.reshape(-1).astype(np.complex64)
+
+    def pfb_closed(taps, M, R, buf_items, chmap, xh):  # (the definition, only to make sure the scipy form above is the same quantity)
+        K = taps.size
+        kk = np.arange(K)
+        out = np.zeros((buf_items // R, len(chmap)), np.complex128)
+        for i in range(buf_items // R):
+            seg = xh[i * R + K - 1 - kk].astype(np.complex128) * taps.astype(np.float64)
+            for q, c in enumerate(chmap):
+                out[i, q] = np.sum(seg * np.exp(2j * np.pi * c * (kk + i * (M - R)) / M))
+        return out.reshape(-1).astype(np.complex64)
+
+    cases = {
+        "pa": (firdes_low_pass64(1.0, 300e3, 48e3, 5e3).astype(np.float32), 3, 2, 60, [0, 1, 2]),                    # the reference flowgraph's case
+        "pb": (np.concatenate([firdes_low_pass64(1.0, 64.0, 0.5, 0.0753), [0.0]]).astype(np.float32), 64, 64, 64 * 8, list(range(64))),  # BASELINE config 4
+        "pc": (rng.standard_normal(8 * 6).astype(np.float32), 8, 4, 96, [5, 0, 7, 2, 2, 1]),                           # 2-fold oversampled, permuted partial map
+        "pd": (rng.standard_normal(16 * 4 + 5).astype(np.float32), 16, 4, 64, list(range(16))),                         # 4-fold oversampled, ragged tap count
+    }
+    for key, (taps, M, R, buf, cm) in cases.items():
+        xh = crandn(rng, buf - R + taps.size)
+        y = pfb_scipy(taps, M, R, buf, cm, xh)
+        ref = pfb_closed(taps, M, R, buf, cm, xh)
+        assert np.abs(y - ref).max() <= 2e-6 * np.abs(ref).max(), key
+        g[key + "_taps"], g[key + "_x"], g[key + "_cfg"], g[key + "_chmap"], g[key + "_y"] = taps, xh, np.array([M, R, buf], np.int32), np.array(cm, np.int32), y
+
+    def xeng_einsum(x, N, F, npol, T):
+        """x: int8 [T][N][F][npol][2] -> exact integer sums [F][B][npol^2] (re, im) by numpy.einsum on int64; baselines by numpy.tril_indices."""
+        rows = x.reshape(T, N, F, npol, 2).transpose(0, 1, 3, 2, 4).reshape(T, N * npol, F, 2).astype(np.int64)  # [t][row = s * npol + p][f]
+        I, Q = rows[..., 0], rows[..., 1]
+        re = np.einsum("trf,tuf->fru", I, I) + np.einsum("trf,tuf->fru", Q, Q)      # z_r conj(z_u): re = I I + Q Q
+        im = np.einsum("trf,tuf->fru", Q, I) - np.einsum("trf,tuf->fru", I, Q)      #                im = Q I - I Q
+        s1, s2 = np.tril_indices(N)                                                    # k = s1 (s1 + 1) / 2 + s2, s1 >= s2
+        out_re = np.zeros((F, s1.size, npol * npol), np.int64)
+        out_im = np.zeros_like(out_re)
+        for p1 in range(npol):
+            for p2 in range(npol):
+                out_re[:, :, p1 * npol + p2] = re[:, s1 * npol + p1, s2 * npol + p2]
+                out_im[:, :, p1 * npol + p2] = im[:, s1 * npol + p1, s2 * npol + p2]
+        return out_re, out_im
+
+    for key, (N, F, T, npol) in {"xa": (6, 5, 40, 1), "xb": (5, 4, 24, 2), "xc": (9, 3, 33, 1)}.items():
+        x = rng.integers(-128, 128, size=(T, N, F, npol, 2), dtype=np.int64).astype(np.int8)
+        sre, sim = xeng_einsum(x, N, F, npol, T)
+        g[key + "_x"], g[key + "_cfg"] = x.reshape(-1), np.array([N, F, T, npol], np.int32)
+        g[key + "_sum_re"], g[key + "_sum_im"] = sre.reshape(-1), sim.reshape(-1)
+        # the same through complex128 on the scaled samples (the reference kernel's arithmetic order: scale first, lib/clXEngine_impl.cc:859-867)
+        z = (x[..., 0].astype(np.float64) + 1j * x[..., 1].astype(np.float64)) / 127.0
+        rows = z.transpose(0, 1, 3, 2).reshape(T, N * npol, F)
+        v = np.einsum("trf,tuf->fru", rows, rows.conj())
+        s1, s2 = np.tril_indices(N)
+        vv = np.zeros((F, s1.size, npol * npol), np.complex128)
+        for p1 in range(npol):
+            for p2 in range(npol):
+                vv[:, :, p1 * npol + p2] = v[:, s1 * npol + p1, s2 * npol + p2]
+        g[key + "_y"] = vv.reshape(-1).astype(np.complex64)
+        assert np.abs(vv.reshape(-1) - (sre.reshape(-1) + 1j * sim.reshape(-1)) / 127.0 ** 2).max() < 1e-9
+    # single baselines as the zero lag of scipy.signal.correlate (which conjugates its second argument)
+    N, F, T, npol = (int(v) for v in g["xa_cfg"])
+    x = g["xa_x"].reshape(T, N, F, 2).astype(np.float64)
+    z = (x[..., 0] + 1j * x[..., 1]) / 127.0
+    picks = [(3, 1, 2), (5, 5, 0), (4, 0, 4)]
+    g["xa_picks"] = np.array(picks, np.int32)
+    g["xa_pick_vals"] = np.array([sig.correlate(z[:, s1, f], z[:, s2, f], mode="valid")[0] for s1, s2, f in picks]).astype(np.complex64)
+    np.savez_compressed(os.path.join(HERE, "independent_golden.npz"), **g)
+
+
 def cli_golden():
     """Inputs the reference's own timing CLIs build (closed forms), with float64 expectations:
     * lib/test-clfilter.cc:98-100 + :76-80: taps i/1000 over a constant (1.0, 0.5) stream -> every output is
@@ -260,6 +350,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "xengine_golden.npz"), **xe)
     widen_golden()
     cli_golden()
+    independent_golden()
 
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith((".npz", ".json")))
     print("golden fixtures written, %.1f KiB" % (tot / 1024))

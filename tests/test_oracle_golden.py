@@ -212,6 +212,37 @@ def test_pfb_vs_closed_form(oracle):
         pass
 
 
+def test_pfb_vs_independent_scipy(oracle):
+    """The channelizer restatement against an implementation that is not this repository's: scipy.signal.upfirdn, one channel at a time
+    (mix down, FIR, decimate; tests/golden/gen_golden.py::independent_golden) -- the reference flowgraph's 3-channel case, BASELINE
+    config 4's shape, a 2-fold and a 4-fold oversampled map."""
+    g = golden("independent_golden.npz")
+    for c in ("pa", "pb", "pc", "pd"):
+        M, R, buf = (int(v) for v in g[c + "_cfg"])
+        for f64, tol in ((True, 1e-6), (False, 1e-5)):
+            y = oracle.pfb(g[c + "_taps"], buf, M, R, g[c + "_chmap"], g[c + "_x"], f64=f64)
+            assert y.size == g[c + "_y"].size and relerr(y, g[c + "_y"]) < tol, (c, f64)
+
+
+def test_xengine_vs_independent_numpy(oracle):
+    """The X-engine restatement against numpy.einsum (integer sums, exact) + numpy.tril_indices (baseline order) and against
+    scipy.signal.correlate's zero lag for single baselines: the exact mode bit for bit, the float mode within 1e-5."""
+    g = golden("independent_golden.npz")
+    kd = 0.007874015748031496063
+    for c in ("xa", "xb", "xc"):
+        N, F, T, npol = (int(v) for v in g[c + "_cfg"])
+        x = g[c + "_x"]
+        ref = ((g[c + "_sum_re"].astype(np.float64) * kd * kd).astype(np.float32)
+               + 1j * (g[c + "_sum_im"].astype(np.float64) * kd * kd).astype(np.float32)).astype(np.complex64)  # (double)S * kd * kd, one rounding
+        assert np.array_equal(oracle.xengine_ichar(N, F, npol, T, x, exact=True), ref), c
+        assert relerr(oracle.xengine_ichar(N, F, npol, T, x, exact=False), g[c + "_y"]) < 1e-5, c
+        assert relerr(ref, g[c + "_y"]) < 1e-6
+    N, F, T, npol = (int(v) for v in g["xa_cfg"])
+    v = oracle.xengine_ichar(N, F, npol, T, g["xa_x"], exact=True).reshape(F, N * (N + 1) // 2)
+    for (s1, s2, f), want in zip(g["xa_picks"], g["xa_pick_vals"]):
+        assert abs(v[f, s1 * (s1 + 1) // 2 + s2] - want) <= 1e-6 * max(1.0, abs(want))
+
+
 def test_xengine_exact_and_closed_forms(oracle):
     g = golden("xengine_golden.npz")
     N, F, T = (int(v) for v in g["cfg"])

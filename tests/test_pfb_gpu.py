@@ -1,6 +1,7 @@
 """GPU parity: clPolyphaseChannelizer through the C ABI vs the oracle and the float64
 closed form.  The reference holds no vectors for this block (parity
-unpinned): the anchors are the closed-form golden fixtures."""
+unpinned by the reference): the anchors are an independent implementation
+(scipy.signal.upfirdn, independent_golden.npz) and the closed-form golden fixtures."""
 import numpy as np
 import pytest
 
@@ -21,6 +22,17 @@ def _run(gpu, taps, buf, M, R, chmap, xh):
 def test_golden_closed_form_cases(gpu):
     g = golden("pfb_golden.npz")
     for c in "abc":  # a: reference flowgraph M=3,R=2,145 taps; b: config-4 shape M=64; c: oversampled M=8,R=4 permuted map
+        M, R, buf = (int(v) for v in g[c + "_cfg"])
+        y = _run(gpu, g[c + "_taps"], buf, M, R, g[c + "_chmap"], g[c + "_x"])
+        assert relerr(y, g[c + "_y"]) <= TOL, c
+
+
+def test_independent_scipy_cases(gpu):
+    """The HIP path against data no author of it (or of the oracle) wrote the arithmetic for: scipy.signal.upfirdn, one channel at a
+    time -- mix down, FIR, decimate (tests/golden/gen_golden.py::independent_golden).  pa: the reference flowgraph's 3 channels at
+    R = 2; pb: BASELINE config 4's shape (64 channels x 32 taps per arm); pc / pd: 2-fold and 4-fold oversampled maps."""
+    g = golden("independent_golden.npz")
+    for c in ("pa", "pb", "pc", "pd"):
         M, R, buf = (int(v) for v in g[c + "_cfg"])
         y = _run(gpu, g[c + "_taps"], buf, M, R, g[c + "_chmap"], g[c + "_x"])
         assert relerr(y, g[c + "_y"]) <= TOL, c

@@ -35,6 +35,34 @@ def test_golden_exact_integer_sums(gpu):
     assert relerr(out, g["p4_y"]) <= TOL  # includes the code-8 -> 0 LUT quirk (lib/clXEngine_impl.cc:833)
 
 
+def test_independent_numpy_scipy_cases(gpu):
+    """The HIP path against numpy.einsum's exact integer sums in numpy.tril_indices order (bit for bit), the same contraction in
+    complex128 on the scaled samples, and scipy.signal.correlate's zero lag for single baselines
+    (tests/golden/gen_golden.py::independent_golden): data no author of the kernels or of the oracle wrote the arithmetic for."""
+    g = golden("independent_golden.npz")
+    kd = 0.007874015748031496063
+    for c in ("xa", "xb", "xc"):
+        N, F, T, npol = (int(v) for v in g[c + "_cfg"])
+        blk = _xe(gpu, gpu.DTYPE_BYTE, npol, N, F, T)
+        out = np.empty(blk.get_output_buffer_size(), np.complex64)
+        blk.xcorrelate(g[c + "_x"], out)
+        ref = ((g[c + "_sum_re"].astype(np.float64) * kd * kd).astype(np.float32)
+               + 1j * (g[c + "_sum_im"].astype(np.float64) * kd * kd).astype(np.float32)).astype(np.complex64)
+        assert np.array_equal(out, ref), c
+        assert relerr(out, g[c + "_y"]) <= 1e-6, c
+        xf = (g[c + "_x"].astype(np.float32) / np.float32(127.0)).view(np.complex64)  # the complex-float path on the same samples
+        blk = _xe(gpu, gpu.DTYPE_COMPLEX, npol, N, F, T)
+        blk.xcorrelate(xf, out)
+        assert relerr(out, g[c + "_y"]) <= TOL, c
+    N, F, T, npol = (int(v) for v in g["xa_cfg"])
+    blk = _xe(gpu, gpu.DTYPE_BYTE, npol, N, F, T)
+    out = np.empty(blk.get_output_buffer_size(), np.complex64)
+    blk.xcorrelate(g["xa_x"], out)
+    v = out.reshape(F, N * (N + 1) // 2)
+    for (s1, s2, f), want in zip(g["xa_picks"], g["xa_pick_vals"]):
+        assert abs(v[f, s1 * (s1 + 1) // 2 + s2] - want) <= 1e-6 * max(1.0, abs(want))
+
+
 @pytest.mark.parametrize("N,F,T,npol", [(2, 2, 1, 1), (3, 6, 5, 1), (16, 8, 64, 1), (17, 4, 65, 1), (33, 10, 130, 2), (5, 1, 9, 1), (12, 7, 70, 1),
                                         (64, 16, 256, 1), (64, 4, 128, 2), (40, 6, 200, 2), (100, 2, 70, 1),
                                         # whole 128-byte input rows and <= 64 rows: the fused single-pass kernels (xengine_fused.hip), every
