@@ -614,10 +614,21 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank, out=None):
         vb = torch.zeros(nint * xe.get_output_buffer_size(), 2, device="cuda")
         rb = rate(lambda: xe.xcorrelate_n_device(nint, xb, vb), nint * N * Fw * T, 2)
         tw = max_over_ranks(rb["us_per_launch"], world) / nint
+        del xb, vb
+        # the N = 1 number IN THIS LINE: the whole 64 x 1024 x 1024 integration on one device (every rank measures it on its own GPU at the
+        # same time; the slowest is quoted), so that the sharded rows below carry their own scaling efficiency = t(1 GPU) / (N x t(N GPUs))
+        xf = pkg.clXEngine(*args, False, pkg.DTYPE_BYTE, 1, N, 1, 0, F, T, [])
+        x1 = torch.randint(-127, 128, (T, N, F, 1, 2), dtype=torch.int8, device="cuda", generator=g)
+        v1 = torch.zeros(xf.get_output_buffer_size(), 2, device="cuda")
+        r1 = rate(lambda: xf.xcorrelate_device(x1, v1), N * F * T, 2)
+        t1 = max_over_ranks(r1["us_per_launch"], world)
+        del xf, x1, v1
+        out["clXEngine_n1_reference"] = {"us_per_integration_one_gpu": round(t1, 2), "what": "the full 64 ant x 1024 ch x 1024 frame integration on ONE device, "
+                                         "measured by every rank of this run on its own GPU (slowest rank)"}
         out["clXEngine_channel_sharded"] = {"us_per_window_all_ranks": round(tw, 2), "windows_per_launch": nint, "channels_per_rank": Fw,
                                             "total_input_MSamples_per_s": round(N * F * T / tw, 1), "n_gpus": world,
+                                            "scaling_efficiency_vs_n1": round(t1 / (world * tw), 3), "n1_us_per_integration": round(t1, 2),
                                             "collective": "none (every rank ingests all antennas of its F/W channels)"}
-        del xb, vb
     del xe, x8, vis
     # The per-rank problem of the 8-GPU antenna-group sharding: after the corner turn a rank correlates 64 antennas x 128
     # channels.  One window per launch cannot fill the device; the batched entry point (mi355_xengine_xcorrelate_n_dev, what one
@@ -811,6 +822,10 @@ def main():
         # the only data-path collective of the hot path, INSIDE the JSON line (world 1: the same pipeline, no peers)
         try:
             extras["clXEngine_sharded"] = sharded_xengine(pkg, local, max(20, a.steps // 2), world, rank)
+            n1 = extras.get("clXEngine_n1_reference", {}).get("us_per_integration_one_gpu") or extras.get("clXEngine_64ant_1024ch_1024t_ichar", {}).get("us_per_launch")
+            if n1:  # strong scaling of ONE integration: efficiency = t(1 GPU) / (N x t(N GPUs)); world 1: the pipeline against the bare call
+                extras["clXEngine_sharded"]["n1_us_per_integration"] = n1
+                extras["clXEngine_sharded"]["scaling_efficiency_vs_n1"] = round(n1 / (world * extras["clXEngine_sharded"]["us_per_integration"]), 3)
         except Exception as exc:  # noqa: BLE001
             extras["clXEngine_sharded"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         if rank == 0 and world == 1:

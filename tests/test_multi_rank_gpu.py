@@ -101,3 +101,9 @@ def test_bench_two_rank_dry_run(gpu, tmp_path):
     assert "error" not in b["clXEngine_sharded"] and b["clXEngine_sharded"]["n_gpus"] == 2 and b["clXEngine_sharded"]["channels_per_rank"] == 512
     assert b["clXEngine_channel_sharded"]["channels_per_rank"] == 512 and b["clXEngine_channel_sharded"]["us_per_window_all_ranks"] > 0
     assert len(b["clPolyphaseChannelizer_64x32_stream"]["per_gpu_MSamples_per_s"]) == 2
+    # the keys the driver's N = 1, 2, 4, 8 runs are read by: whole-job value, per-GPU rates, and for config 5 both sharded forms with their
+    # own scaling efficiency against an N = 1 time measured in the same line
+    assert d["per_gpu_MSamples_per_s"] > 0 and d["config"]["parallelism"] == "replica-per-gpu x2"
+    n1 = b["clXEngine_n1_reference"]["us_per_integration_one_gpu"]
+    for key, t in (("clXEngine_sharded", "us_per_integration"), ("clXEngine_channel_sharded", "us_per_window_all_ranks")):
+        assert b[key]["n1_us_per_integration"] == n1 and abs(b[key]["scaling_efficiency_vs_n1"] - n1 / (2 * b[key][t])) < 2e-3, key
