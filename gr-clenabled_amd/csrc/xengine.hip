@@ -1073,6 +1073,8 @@ struct mi355_xengine {
     // batched form (mi355_xengine_xcorrelate_n_dev): partial sums of nint windows, grown on demand
     unsigned char *d_batch = nullptr;
     size_t batch_bytes = 0;
+    unsigned batch_epoch = 0;  // launches of the in-launch reduction on d_batch with the current window count
+    int batch_nint = 0;        // ... whose arrival words sit behind that count's partial sums (another count: another place, zeroed first)
     std::mutex dev_lock;    // device-pointer entry points: workspace growth, the reduction's counters and the launch itself, one caller at a time
     int pad = 0;            // one zero channel appended on the device (odd channel count of 2-byte samples)
     size_t pad_bytes = 0;
@@ -1455,9 +1457,15 @@ extern "C" int mi355_xengine_xcorrelate_n_dev(mi355_xengine *h, int nint, const 
                     return MI355_ERR_NOMEM;
                 }
                 h->batch_bytes = fp.part_bytes;
+                h->batch_nint = 0;
+            }
+            if (h->batch_nint != nint && fp.part_bytes > fp.flag_offset) {  // the arrival words of this window count start from zero
+                MI355_HIP(hipMemsetAsync(h->d_batch + fp.flag_offset, 0, fp.part_bytes - fp.flag_offset, st));
+                h->batch_epoch = 0;
+                h->batch_nint = nint;
             }
             return mi355_xe_fused_launch(fp, in_dev, out_dev, h->d_batch, g.N, g.F, g.Fout, g.T, 0.007874015748031496063, accumulate, st,
-                                         stations_per_group, nullptr, nint);
+                                         stations_per_group, &h->batch_epoch, nint);
         }
     }
     if (grouped && nint > 1) {

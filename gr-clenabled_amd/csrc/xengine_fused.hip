@@ -402,12 +402,17 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
                     v += __shfl_xor(v, 32);
                     rsum[rt] = v;
                 }
+                int corr[NTT][4];  // row sums of the rows this lane holds in the C layout: row = 4 * (lane / 16) + reg
+#pragma unroll
+                for (int rt = 0; rt < NTT; rt++)
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) corr[rt][reg] = __shfl(rsum[rt], 4 * g + reg);
                 auto pair_vals = [&](int bi, int bj, v4i &vre, v4i &vim) {
                     const int p = bi * (bi + 1) / 2 + bj;
                     vre = re[c][p];
                     vim = im[c][p];
 #pragma unroll
-                    for (int reg = 0; reg < 4; reg++) vim[reg] += __shfl(rsum[bi], 4 * g + reg);
+                    for (int reg = 0; reg < 4; reg++) vim[reg] += corr[bi][reg];
                 };
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
@@ -437,17 +442,20 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
                         unsigned char *d = slot(u, QC, c);
 #pragma unroll
                         for (int i = 0; i < 16; i++) v[i] -= 1;
-                        st_sys((v4i *)d, (v4i){(int)pk_lo(v[0], v[1]), (int)pk_lo(v[2], v[3]), (int)pk_lo(v[4], v[5]), (int)pk_lo(v[6], v[7])});
-                        st_sys((v4i *)(d + 1024), (v4i){(int)pk_lo(v[8], v[9]), (int)pk_lo(v[10], v[11]), (int)pk_lo(v[12], v[13]), (int)pk_lo(v[14], v[15])});
-                        st_sys((v4i *)(d + 2048), (v4i){(int)pk_hi((v4i){v[0], v[1], v[2], v[3]}), (int)pk_hi((v4i){v[4], v[5], v[6], v[7]}),
-                                                        (int)pk_hi((v4i){v[8], v[9], v[10], v[11]}), (int)pk_hi((v4i){v[12], v[13], v[14], v[15]})});
+                        const v4i c0 = (v4i){(int)pk_lo(v[0], v[1]), (int)pk_lo(v[2], v[3]), (int)pk_lo(v[4], v[5]), (int)pk_lo(v[6], v[7])};
+                        const v4i c1 = (v4i){(int)pk_lo(v[8], v[9]), (int)pk_lo(v[10], v[11]), (int)pk_lo(v[12], v[13]), (int)pk_lo(v[14], v[15])};
+                        const v4i c2 = (v4i){(int)pk_hi((v4i){v[0], v[1], v[2], v[3]}), (int)pk_hi((v4i){v[4], v[5], v[6], v[7]}),
+                                             (int)pk_hi((v4i){v[8], v[9], v[10], v[11]}), (int)pk_hi((v4i){v[12], v[13], v[14], v[15]})};
+                        st_sys((v4i *)d, c0);
+                        st_sys((v4i *)(d + 1024), c1);
+                        st_sys((v4i *)(d + 2048), c2);
                     }
                     __builtin_amdgcn_sched_barrier(0);  // one unit's quads at a time (the accumulators die as they are sent)
                 }
             }
             stamp(a, 3);
             __shared__ int s_mode, s_mask;
-            unsigned long long *state = (unsigned long long *)a.flags + slice;  // arrival count in the high word, {launch tag, give-up bits} in the low
+            unsigned long long *state = (unsigned long long *)a.flags + (size_t)win * (a.nlines * 4) + slice;  // arrival count in the high word, {launch tag, give-up bits} in the low
             const unsigned full = a.epoch * 4u, tag = a.epoch & 0x0fffffffu;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have completed
             __syncthreads();
@@ -1013,7 +1021,8 @@ XeFusedPlan mi355_xe_fused_plan(int N, int F, int Fout, int npol, int T, int num
     const int NP = p.ntt * (p.ntt + 1) / 2;
     p.part_per_window = s > 1 ? (size_t)s * F * NP * 2 * 1024 : 0;
     p.flag_offset = p.part_per_window * (nint > 0 ? nint : 1);
-    p.part_bytes = s > 1 ? p.flag_offset + (((size_t)p.units * (s + 1) * 4 + 255) & ~(size_t)255) : 0;
+    // (behind the partial sums: one 8-byte arrival word per slice and window for the in-launch reduction)
+    p.part_bytes = s > 1 ? p.flag_offset + (((size_t)p.units * (nint > 0 ? nint : 1) * 8 + (size_t)p.units * (s + 1) * 4 + 255) & ~(size_t)255) : 0;
     p.ok = true;
     return p;
 }
@@ -1032,7 +1041,7 @@ int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void 
     // switching between the two forms mid-process leaves them consistent.)
     const int Tp = (T + 31) / 32 * 32;  // whole K blocks
     const char *rs_env = getenv("MI355_XE_INKERNEL_REDUCE");
-    a.rs = (nint <= 1 && epoch && p.tsplit == 4 && p.ntt == 4 && Tp / 4 <= 256 && p.units * 4 <= p.cus && !(rs_env && atoi(rs_env) == 0)) ? 1 : 0;
+    a.rs = (epoch && p.tsplit == 4 && p.ntt == 4 && Tp / 4 <= 256 && (long)p.units * 4 * (nint > 0 ? nint : 1) <= p.cus && !(rs_env && atoi(rs_env) == 0)) ? 1 : 0;
     if (a.rs) a.epoch = ++*epoch;
     a.compact = !getenv("MI355_XE_NO_COMPACT") ? 1 : 0;
     // 24-bit planes: time ranges of at most 256 steps, at least two row tiles (a lone diagonal record has nothing to pair with)

@@ -7,8 +7,10 @@ export PROBE_NINT=1
 echo "== stamps"; MI355_XE_TS=1 PROBE_IT=3 python $R/tools/xe_batch_probe.py 2>&1 | tail -12
 echo "== plain"; PROBE_IT=200 python $R/tools/xe_batch_probe.py
 for d in 1 2 3 4 6 7; do echo "== MI355_XE_DBG=$d"; MI355_XE_DBG=$d PROBE_IT=200 python $R/tools/xe_batch_probe.py; done
-echo "== inkernel reduce"; MI355_XE_INKERNEL_REDUCE=1 PROBE_IT=200 python $R/tools/xe_batch_probe.py
+echo "== second kernel instead of the in-launch reduction"; MI355_XE_INKERNEL_REDUCE=0 PROBE_IT=200 python $R/tools/xe_batch_probe.py
+echo "== lockstep schedule instead of ping-pong"; MI355_XE_NO_PINGPONG=1 PROBE_IT=200 python $R/tools/xe_batch_probe.py
 echo "== slice_read"; timeout 120 $R/tools/ubench/slice_read 2>&1 | grep -E "^---|W=32|dma"
+echo "== slice_tl (finish time per 128-byte line index of the rows)"; timeout 120 $R/tools/ubench/slice_tl 2>&1 | grep -E "^W=32 stride 2048 |base \+ 128|stride 2304|prefetch 1"
 } > $O/r04_xe_phases.txt 2>&1
 rocprofv3 -L > $O/counters_avail.txt 2>&1
 export PROBE_IT=20
