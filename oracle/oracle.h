@@ -18,10 +18,16 @@
  *   - math ops, FFT, window, firdes, fft_filter sizes: pinned by the
  *     reference's own known-answer tests and by the outputs of the reference
  *     files recorded in SURVEY.md section 8(c) (tests/golden/kat.json);
- *   - polyphase channelizer and X-engine: PARITY UNPINNED by the reference
- *     (it holds no test vectors, no CPU implementation and no compilable
- *     source for them); they are cross-checked against independent float64
- *     closed forms only.
+ *   - polyphase channelizer and X-engine: the reference holds nothing for
+ *     them (no test vectors, no CPU implementation, no compilable source), so
+ *     they cannot be pinned by reference-held data; they are pinned by
+ *     implementations that are not this repository's -- scipy.signal.upfirdn
+ *     per channel, numpy.einsum + numpy.tril_indices, scipy.signal.correlate
+ *     (tests/golden/independent_golden.npz) -- and cross-checked against
+ *     float64 closed forms.
+ *
+ * cpu_bench.c (same directory) times these restatements from C for bench.py's
+ * cpu_baseline leg; it is measurement infrastructure under the same rule.
  */
 #ifndef CLENABLED_ORACLE_H
 #define CLENABLED_ORACLE_H

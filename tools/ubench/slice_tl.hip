@@ -187,10 +187,15 @@ int main()
     setvbuf(stdout, nullptr, _IONBF, 0);
     const int rows = 1024 * 64;
     char *buf; unsigned long long *ts;
-    CK(hipMalloc(&buf, (size_t)rows * 4096 + (1 << 20))); CK(hipMalloc(&ts, 1 << 16));
-    CK(hipMemset(buf, 1, (size_t)rows * 4096 + (1 << 20)));
+    const size_t big = (size_t)9 << 30;  // room for the far-offset cases below
+    CK(hipMalloc(&buf, big)); CK(hipMalloc(&ts, 1 << 16));
+    CK(hipMemset(buf, 1, big));
     printf("buffer at %p\n", (void *)buf);
     run<32, 8>(buf, ts, rows, 2048, 0, "W=32 stride 2048");
+    run<32, 8>(buf + ((size_t)128 << 20), ts, rows, 2048, 0, "W=32 stride 2048, base + 128 MiB");
+    run<32, 8>(buf + ((size_t)1 << 30), ts, rows, 2048, 0, "W=32 stride 2048, base + 1 GiB");
+    run<32, 8>(buf + ((size_t)3 << 30) + ((size_t)192 << 20), ts, rows, 2048, 0, "W=32 stride 2048, base + 3.19 GiB");
+    run<32, 8>(buf + ((size_t)8 << 30), ts, rows, 2048, 0, "W=32 stride 2048, base + 8 GiB");
     run_m2<8, 0>(buf, ts, rows, 2048, "W=32 map M2 (all lines per XCD)");
     run_m2<8, 1>(buf, ts, rows, 2048, "W=32 map M2 + slow-line prefetch 1 ahead");
     run_m2<8, 2>(buf, ts, rows, 2048, "W=32 map M2 + slow-line prefetch 2 ahead");
