@@ -468,12 +468,16 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
                     if (((unsigned)old >> 4) == tag) mask = (int)((unsigned)old & 15u);
                     if ((unsigned)old) __hip_atomic_fetch_and(state, 0xffffffff00000000ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
-                    const int spins = (a.dbg & 512) ? 1 : 2048;  // (dbg 512: give up at once -- exercises the fallback in the tests)
-                    for (int i = 0; i < spins && !mode; i++) {
+                    // Bounded by TIME (100 MHz wall clock): the units of a slice finish within a microsecond or two of each other when all are
+                    // resident; a partner that is not (the device shared with another stream's kernels, e.g. the exchange of the sharded
+                    // pipeline) gets a CU only when somebody leaves, so waiting longer than a few tail lengths only delays everybody.
+                    // (dbg 512: give up at once -- exercises the fallback in the tests)
+                    const unsigned long long t_wait = wall_clock64(), limit = (a.dbg & 512) ? 0 : 4000;  // 40 us
+                    do {
                         const unsigned long long cur = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if ((unsigned)(cur >> 32) == full) mode = 1;
                         else __builtin_amdgcn_s_sleep(8);
-                    }
+                    } while (!mode && wall_clock64() - t_wait < limit);
                     if (!mode) mode = 3;
                 }
                 s_mode = mode;

@@ -127,3 +127,21 @@ def test_world2_gloo_single_pol(pkg, oracle, tmp_path):
 
 def test_world2_gloo_dual_pol(pkg, oracle, tmp_path):
     _run_world2(tmp_path, 2)
+
+
+def test_bench_line_scaling_keys():
+    """The bookkeeping behind the N > 1 line's `scaling_efficiency_vs_n1` (bench.annotate_sharded_scaling): efficiency = t(1 GPU) / (N x t(N GPUs))
+    against a one-GPU time carried by the same line.  (The two-rank run of bench.py itself needs a device: tests/test_multi_rank_gpu.py.)"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    blocks = {"clXEngine_n1_reference": {"us_per_integration_one_gpu": 54.0}, "clXEngine_sharded": {"us_per_integration": 13.5, "n_gpus": 8}}
+    bench.annotate_sharded_scaling(blocks, 8)
+    assert blocks["clXEngine_sharded"]["n1_us_per_integration"] == 54.0 and blocks["clXEngine_sharded"]["scaling_efficiency_vs_n1"] == 0.5
+    one = {"clXEngine_64ant_1024ch_1024t_ichar": {"us_per_launch": 54.0}, "clXEngine_sharded": {"us_per_integration": 60.0}}
+    bench.annotate_sharded_scaling(one, 1)
+    assert one["clXEngine_sharded"]["scaling_efficiency_vs_n1"] == 0.9
+    assert bench.annotate_sharded_scaling({"clXEngine_sharded": {"error": "x"}}, 2) == {"clXEngine_sharded": {"error": "x"}}
