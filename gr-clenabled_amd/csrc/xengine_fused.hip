@@ -469,10 +469,12 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
                     if ((unsigned)old) __hip_atomic_fetch_and(state, 0xffffffff00000000ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
                     // Bounded by TIME (100 MHz wall clock): the units of a slice finish within a microsecond or two of each other when all are
-                    // resident; a partner that is not (the device shared with another stream's kernels, e.g. the exchange of the sharded
-                    // pipeline) gets a CU only when somebody leaves, so waiting longer than a few tail lengths only delays everybody.
+                    // resident.  A partner that is not -- the device shared with another stream's kernels, e.g. the exchange of the sharded
+                    // pipeline: a workgroup of this kernel needs a whole CU's registers -- starts when the first workgroups leave and arrives
+                    // one loop + send later (~80 us after launch at config 5's range length); waiting for it costs the same as the
+                    // second kernel would, giving up before it comes makes it finish the whole slice alone.  Beyond that nobody waits.
                     // (dbg 512: give up at once -- exercises the fallback in the tests)
-                    const unsigned long long t_wait = wall_clock64(), limit = (a.dbg & 512) ? 0 : 4000;  // 40 us
+                    const unsigned long long t_wait = wall_clock64(), limit = (a.dbg & 512) ? 0 : 10000;  // 100 us
                     do {
                         const unsigned long long cur = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if ((unsigned)(cur >> 32) == full) mode = 1;
