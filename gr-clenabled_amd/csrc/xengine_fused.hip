@@ -50,7 +50,10 @@ struct FuArgs {
     unsigned epoch;    // launch number on this workspace (>= 1)
     int rs;            // 1: the four time ranges of a slice are combined by the kernel's own tail (reduce-scatter), 0: by k_xe_i8_reduce
     int compact;       // partial matrices of the diagonal tile pairs as ONE record (re on and below the diagonal, im above it)
-    int dbg;  // tuning aid (MI355_XE_DBG): 1 = no compute, 2 = no stores, 4 = no DMA
+    // tuning aid (MI355_XE_DBG), bits: 1 no compute, 2 no partial-sum stores, 4 no DMA, 32 no priority for the second wave group, 64 no products, 128 no LDS
+    // reads, 512 every bounded wait of the in-launch reduction runs out at once (the tests' way into its fallback), 1024 stamp the arrival of the pieces,
+    // 4096 * m (m = 1..3) other line -> XCD maps, 65536 / 131072 only / all but lines 3 and 11 of a row, 1048576 * k lines rotated over the XCDs
+    int dbg;
     unsigned long long *ts;  // tuning aid (MI355_XE_TS): per-workgroup phase stamps (100 MHz wall clock), NULL in normal use
     double kd;
     // batched form: nint integration windows per launch, wgs workgroups each
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
         const int b = blockIdx.x;
         int combo, sector;
         if (a.pinned) {
-            const int xcd = (b + (a.dbg >> 8)) & 7, within = b >> 3;  // (dbg bits 8..10: which lines an XCD gets, a tuning aid)
+            const int xcd = (b + ((a.dbg >> 20) & 7)) & 7, within = b >> 3;  // (dbg bits 20..22: which lines an XCD gets, a tuning aid)
             sector = within & 3;
             combo = xcd + 8 * (within >> 2);
         } else {
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
     // pieces per lane and unit: write-through stores, the only store form that is cheap per byte at system scope) to the owners' inboxes,
     // raises the slice's arrival count, and once all four have arrived adds the three pieces it received to its registers, scales and
     // scatters its quarter of the matrix.  37.5 MB written and read back per BASELINE integration instead of 50 + 50 + a second kernel.
-    // Placement independent: system-scope stores and loads on both sides, the count raised after the stores have drained.  Bounded wait:
+    // Placement independent: write-through (sc1) stores, sc1 loads, the count raised after the stores have drained.  Bounded wait:
     // a unit that gives up stores its own quads too, sets its bit in the slice's word and exits; the LAST unit to arrive sees the bits
     // with its own arrival and finishes those quarters from the inboxes -- complete for any dispatch order, nobody waits for a workgroup
     // that has not started.
