@@ -577,6 +577,37 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
 #pragma unroll
                         for (int k = 0; k < 4; k++) tile[(4 * g + k) * 20 + r] = v[4 * d + k];
                         const v4i trow = *(const v4i *)(tile + r * 20 + 4 * g);  // C[r][4 g + reg], reg = 0 .. 3 (same wave wrote it: no barrier)
+                        if (NPOL == 1 && Al == 64 && !a.accumulate && !(a.dbg & 2048)) {
+                            // whole tiles, one polarisation: as in the off-diagonal quarters a lane pair swaps a value and every lane stores two
+                            // neighbouring baselines of ONE row (16 bytes) -- or one (8 bytes) where the row's triangle ends inside the pair
+#pragma unroll
+                            for (int rp = 0; rp < 4; rp += 2) {
+                                c32 w[2];
+#pragma unroll
+                                for (int e = 0; e < 2; e++) {
+                                    const int i = 4 * g + rp + e;
+                                    const int tr = trow[rp + e], sre = v[4 * d + rp + e];
+                                    const int sim = i > r ? -tr : 0;  // (below the diagonal im[i][j] = -im[j][i]; on it 0; above it: not stored)
+                                    w[e].x = (float)((double)sre * a.kd * a.kd);
+                                    w[e].y = (float)((double)sim * a.kd * a.kd);
+                                }
+                                const bool odd = (r & 1) != 0;
+                                const float sx = odd ? w[0].x : w[1].x, sy = odd ? w[0].y : w[1].y;
+                                const float gx = __shfl_xor(sx, 1), gy = __shfl_xor(sy, 1);
+                                const int i = 4 * g + rp + (odd ? 1 : 0), j0 = r & ~1;  // this lane stores columns j0, j0 + 1 of row i
+                                const int s1 = d * 16 + i;
+                                c32 *dst = a.out + (size_t)f * nbl + (s1 * (s1 + 1) / 2 + d * 16 + j0);
+                                const c32 first = odd ? c32{gx, gy} : w[0], second = odd ? w[1] : c32{gx, gy};
+                                if (j0 + 1 <= i) {
+                                    typedef float v4f __attribute__((ext_vector_type(4)));
+                                    const v4f q4 = (v4f){first.x, first.y, second.x, second.y};
+                                    __builtin_memcpy((void *)dst, &q4, 16);
+                                } else if (j0 <= i) {
+                                    *dst = first;
+                                }
+                            }
+                            continue;
+                        }
 #pragma unroll
                         for (int reg = 0; reg < 4; reg++) {
                             const int i = 4 * g + reg;
