@@ -159,12 +159,14 @@ template <int INFL, int PF> int run_m2(const char *in, unsigned long long *ts, i
     return 0;
 }
 
-template <int W, int INFL> int run(const char *in, unsigned long long *ts, int rows, size_t stride, int order, const char *what)
+static size_t g_rotate = 0;  // bytes between the images of consecutive repetitions (0: the same image, i.e. served by the 256 MiB Infinity Cache)
+template <int W, int INFL> int run(const char *in0, unsigned long long *ts, int rows, size_t stride, int order, const char *what)
 {
     const int grid = (2048 / W) * 4;
     std::vector<unsigned long long> h(grid + 1);
     double fin[16] = {0};
     for (int rep = 0; rep < 3; rep++) {
+        const char *in = in0 + (size_t)rep * g_rotate;
         hipLaunchKernelGGL(k_t0, dim3(1), dim3(1), 0, 0, ts + grid);
         hipLaunchKernelGGL((k_slice<W, INFL>), dim3(grid), dim3(512), 0, 0, in, ts, rows, stride, order);
         CK(hipDeviceSynchronize());
@@ -192,6 +194,12 @@ int main()
     CK(hipMemset(buf, 1, big));
     printf("buffer at %p\n", (void *)buf);
     run<32, 8>(buf, ts, rows, 2048, 0, "W=32 stride 2048");
+    g_rotate = (size_t)512 << 20;
+    run<32, 8>(buf, ts, rows, 2048, 0, "W=32 stride 2048, a fresh image every run (HBM)");
+    run<32, 16>(buf + ((size_t)2 << 30), ts, rows, 2048, 0, "W=32 infl 16, fresh image (HBM)");
+    run<32, 4>(buf + ((size_t)4 << 30), ts, rows, 2048, 0, "W=32 infl 4, fresh image (HBM)");
+    run<128, 8>(buf + ((size_t)6 << 30), ts, rows, 2048, 0, "W=128 (64 workgroups), fresh image (HBM)");
+    g_rotate = 0;
     run<32, 8>(buf + ((size_t)128 << 20), ts, rows, 2048, 0, "W=32 stride 2048, base + 128 MiB");
     run<32, 8>(buf + ((size_t)1 << 30), ts, rows, 2048, 0, "W=32 stride 2048, base + 1 GiB");
     run<32, 8>(buf + ((size_t)3 << 30) + ((size_t)192 << 20), ts, rows, 2048, 0, "W=32 stride 2048, base + 3.19 GiB");
