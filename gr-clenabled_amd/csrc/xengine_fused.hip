@@ -54,6 +54,7 @@ struct FuArgs {
     // reads, 512 every bounded wait of the in-launch reduction runs out at once (the tests' way into its fallback), 1024 stamp the arrival of the pieces,
     // 4096 * m (m = 1..3) other line -> XCD maps, 65536 / 131072 only / all but lines 3 and 11 of a row, 1048576 * k lines rotated over the XCDs
     int dbg;
+    int slow_first;    // >= 0: ((input address >> 7) & 7); the units of the rows' slow lines get the lowest workgroup numbers (several windows, no time ranges)
     unsigned long long *ts;  // tuning aid (MI355_XE_TS): per-workgroup phase stamps (100 MHz wall clock), NULL in normal use
     double kd;
     // batched form: nint integration windows per launch, wgs workgroups each
@@ -155,6 +156,21 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
         const int rest = combo / a.nlines;
         q = rest % a.tsplit;
         win = rest / a.tsplit;
+        if (a.slow_first >= 0) {
+            // Several windows per launch, every unit a whole integration, more units than CUs: the dispatcher hands out workgroups in
+            // blockIdx order, and a unit of a slow line (address bits 7..9 == 3: 6.9 us per K block from HBM against 4.2) that starts in the
+            // last round ends the launch 90 us after everything else.  Longest first: the slow lines of ALL windows, then the rest.
+            const int n8 = a.nlines >> 3, nslow = n8 * a.nint_launch, l3 = (3 - a.slow_first) & 7;
+            int line;
+            if (combo < nslow) { line = l3 + 8 * (combo % n8); win = combo / n8; }
+            else {
+                const int c2 = combo - nslow, per = a.nlines - n8, k = c2 % per;  // k-th line of the window that is not slow
+                win = c2 / per;
+                line = k + (k + 7 - l3) / 7;  // skips l3, l3 + 8, ...: 7 lines between two slow ones
+                if (k < l3) line = k;
+            }
+            slice = line * 4 + sector;
+        }
         if (a.pinned && a.nlines == 16 && a.tsplit == 4 && a.nint_launch == 1 && ((a.dbg >> 12) & 3)) {  // tuning aid: other line -> XCD maps
             const int xcd = b & 7, within = b >> 3, mode = (a.dbg >> 12) & 3;
             int line;
@@ -1110,6 +1126,10 @@ int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void 
     const int dbg = getenv("MI355_XE_DBG") ? atoi(getenv("MI355_XE_DBG")) : 0;
     a.dbg = dbg;
     a.ts = nullptr;
+    a.slow_first = -1;
+    if (p.tsplit == 1 && a.nint_launch > 1 && a.nlines % 8 == 0 && p.row_stride % 1024 == 0 && ((size_t)in & 127) == 0 &&
+        (long)p.units * a.nint_launch > p.cus && !getenv("MI355_XE_NO_SLOW_FIRST"))
+        a.slow_first = (int)(((size_t)in >> 7) & 7);
     if (getenv("MI355_XE_TS")) return launch_with_stamps(p, a, st);
     if (p.npol == 1) {
         if (p.ntt == 1) return launch_fused<1, 1>(p, a, st);
