@@ -652,6 +652,22 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank, out=None):
                                             "total_input_MSamples_per_s": round(N * F * T / tw, 1), "n_gpus": world,
                                             "scaling_efficiency_vs_n1": round(t1 / (world * tw), 3), "n1_us_per_integration": round(t1, 2),
                                             "collective": "none (every rank ingests all antennas of its F/W channels)"}
+    if world == 1:
+        # A stream of integrations handed over eight or sixteen at a time (mi355_xengine_xcorrelate_n_dev): every unit is a whole integration of
+        # its 32-byte slice (no time ranges, no partial sums), 512 / 1024 units on 256 CUs, the slow lines' units first.  Inputs in rotation.
+        row = {}
+        for nint in (8, 16):
+            vb = torch.zeros(nint * xe.get_output_buffer_size(), 2, device="cuda")
+            fn_rot, bufs = rotate(lambda: torch.randint(-127, 128, (nint, T, N, Fw, 1, 2), dtype=torch.int8, device="cuda", generator=g),
+                                  nint * T * N * Fw * 2, lambda x: xe.xcorrelate_n_device(nint, x, vb))
+            rb = rate(fn_rot, nint * N * Fw * T, 2)
+            tw = rb["us_per_launch"] / nint
+            row["windows_per_launch_%d" % nint] = {"us_per_window": round(tw, 2), "MSamples_per_s": rb["MSamples_per_s"],
+                                                  "hbm_frac_algorithmic": round(alg_bytes / (tw * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                                  "distinct_inputs_in_rotation": len(bufs)}
+            del bufs, fn_rot, vb
+            torch.cuda.empty_cache()
+        out["clXEngine_64ant_1024ch_1024t_ichar_batched"] = row
     del xe, x8, vis
     # The per-rank problem of the 8-GPU antenna-group sharding: after the corner turn a rank correlates 64 antennas x 128
     # channels.  One window per launch cannot fill the device; the batched entry point (mi355_xengine_xcorrelate_n_dev, what one
