@@ -31,7 +31,8 @@ else:
     tot = (2 * f1 + w1 + 2 * f2 + w2) * 1024 / 1e6
     traffic = "# config 5: 2 x %.2f + %.2f (fused) + 2 x %.2f + %.2f (reduce) KiB = %.1f MB = %.2f x the 151.3 MB algorithmic bytes (round 1: 2.78 x)" % (f1, w1, f2, w2, tot, tot / 151.3)
 out = ["# X-engine IChar path alone, BASELINE config 5 (64 ant x 1024 ch x 1024 frames) and its dual-polarisation sibling (32 ant), device resident,",
-       "# back-to-back launches: tools/make_profiles_xe.sh %s  (two command sets, each with its own passes; 20 launches right after idle, so the times" % tag,
+       "# back-to-back launches over >= 640 MB of distinct inputs in rotation (every launch reads its input from HBM; rounds 1-3 and the first r04 files re-read",
+       "# ONE buffer, which the 256 MiB Infinity Cache serves: 54 us instead of 86 at config 5): tools/make_profiles_xe.sh %s  (two command sets, each with its own passes; 20 launches right after idle, so the times" % tag,
        "# here are a few per cent above the bench's).  SQ_VALU_MFMA_BUSY_CYCLES = 16 cycles per v_mfma_i32_16x16x64_i8 / _16x16x32_i8, summed over the 1024 SIMDs.",
        "# pass 1: rocprofv3 --kernel-trace --stats ; passes 2-4: --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE (separate runs)",
        "# FETCH_SIZE / WRITE_SIZE are KiB per dispatch; gfx950: HBM read bytes = 2 x FETCH_SIZE x 1024 (MI355X_MICROARCH.md, HBM section)",
