@@ -1,7 +1,9 @@
 """GPU parity: clXEngine through the C ABI vs the oracle.  The reference holds no vectors
-for this block (parity unpinned); anchors are exact integer sums (golden fixtures),
+for this block; since round 4 the oracle and this path are pinned by fixtures computed with numpy.einsum / scipy.signal.correlate
+(tests/golden/independent_golden.npz); further anchors are exact integer sums (golden fixtures),
 closed-form cases and the oracle's restatement of the kernel text.
 Integer paths (IChar, packed 4-bit sums) are required BIT EXACT against the oracle's exact mode."""
+import os
 import numpy as np
 import pytest
 
@@ -561,6 +563,40 @@ def test_batched_integration_windows_bit_exact(gpu, oracle, N, F, T, npol, nint,
     blk.xcorrelate_device(torch.from_numpy(wins[nint - 1]).cuda(), one)
     torch.cuda.synchronize()
     assert np.array_equal(one.cpu().numpy().view(np.complex64).reshape(-1), ref[(nint - 1) * per:])
+
+
+@pytest.mark.parametrize("N,F,T,npol,nint,W,shift", [(64, 512, 32, 1, 10, 1, 0), (20, 1024, 40, 1, 5, 1, 3), (32, 512, 32, 2, 5, 1, 5),
+                                                    (64, 512, 32, 1, 9, 8, 2), (16, 2048, 16, 1, 3, 1, 7)])
+def test_batched_more_units_than_cus_slow_lines_first(gpu, oracle, N, F, T, npol, nint, W, shift):
+    """More whole-integration units than CUs in one launch: the units of the rows' slow 128-byte lines (address bits 7..9 == 3) get the lowest
+    workgroup numbers (FuArgs::slow_first).  The permutation depends on the input's address class, so the input is placed at every shift of
+    128 bytes tried here; every window bit-exact against the oracle, reference and group-major layout."""
+    import torch
+    rng = np.random.default_rng(N * 7 + nint + shift)
+    wins = rng.integers(-128, 128, size=(nint, T, N, F, npol, 2), dtype=np.int64).astype(np.int8)
+    blk = _xe(gpu, gpu.DTYPE_BYTE, npol, N, F, T)
+    per = blk.get_output_buffer_size()
+    ref = np.concatenate([oracle.xengine_ichar(N, F, npol, T, wins[i].reshape(-1), exact=True) for i in range(nint)])
+    if W > 1:
+        Ng = N // W
+        host = np.ascontiguousarray(wins.reshape(nint, T, W, Ng, F, npol, 2).transpose(2, 0, 1, 3, 4, 5, 6)).reshape(-1)
+    else:
+        Ng = 0
+        host = wins.reshape(-1)
+    raw = torch.zeros(host.size + 1024, dtype=torch.int8, device="cuda")
+    x = raw[128 * shift:128 * shift + host.size]
+    x.copy_(torch.from_numpy(host))
+    out = torch.zeros(nint * per, 2, device="cuda")
+    for env in (None, "1"):  # second pass: the plain order, same results
+        if env: os.environ["MI355_XE_NO_SLOW_FIRST"] = env
+        try:
+            out.zero_()
+            if W > 1: blk.xcorrelate_n_device(nint, x, out, stations_per_group=Ng)
+            else: blk.xcorrelate_n_device(nint, x, out)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("MI355_XE_NO_SLOW_FIRST", None)
+        assert np.array_equal(out.cpu().numpy().view(np.complex64).reshape(-1), ref)
 
 
 def test_batched_group_major_refused_outside_the_fused_path(gpu):
