@@ -630,27 +630,44 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank, out=None):
         # SURVEY 8e (B), the comparison form of the sharding: every rank ingests ALL antennas of its F/W channels (the corner turn done by
         # the network in front of the GPUs, as packet-switched FX correlators do) -- no data-path collective at all; a rank's slab is too
         # small to fill the device one window at a time, so eight windows go into one launch (mi355_xengine_xcorrelate_n_dev)
-        nint = 8
-        vb = torch.zeros(nint * xe.get_output_buffer_size(), 2, device="cuda")
-        fn_rot, bufs = rotate(lambda: torch.randint(-127, 128, (nint, T, N, Fw, 1, 2), dtype=torch.int8, device="cuda", generator=g),
-                              nint * T * N * Fw * 2, lambda x: xe.xcorrelate_n_device(nint, x, vb))
-        rb = rate(fn_rot, nint * N * Fw * T, 2)
-        tw = max_over_ranks(rb["us_per_launch"], world) / nint
-        del bufs, fn_rot, vb
-        # the N = 1 number IN THIS LINE: the whole 64 x 1024 x 1024 integration on one device (every rank measures it on its own GPU at the
-        # same time; the slowest is quoted), so that the sharded rows below carry their own scaling efficiency = t(1 GPU) / (N x t(N GPUs))
+        # -- 8 windows per launch, and as many as give every CU a whole integration of a 32-byte slice (no time ranges, no partial sums)
+        units = max(1, Fw * 2 // 32)
+        nfill = max(8, (-(-256 // units) + 7) // 8 * 8)
+        per_nint = {}
+        for nint in sorted({8, nfill}):
+            vb = torch.zeros(nint * xe.get_output_buffer_size(), 2, device="cuda")
+            fn_rot, bufs = rotate(lambda: torch.randint(-127, 128, (nint, T, N, Fw, 1, 2), dtype=torch.int8, device="cuda", generator=g),
+                                  nint * T * N * Fw * 2, lambda x: xe.xcorrelate_n_device(nint, x, vb))
+            rb = rate(fn_rot, nint * N * Fw * T, 2)
+            per_nint[nint] = max_over_ranks(rb["us_per_launch"], world) / nint
+            del bufs, fn_rot, vb
+            torch.cuda.empty_cache()
+        nint = min(per_nint, key=per_nint.get)
+        tw = per_nint[nint]
+        # the N = 1 numbers IN THIS LINE: the whole 64 x 1024 x 1024 integration on one device (every rank measures it on its own GPU at the
+        # same time; the slowest is quoted), one window per call and eight per call, so that the sharded rows below carry their own scaling
+        # efficiency = t(1 GPU) / (N x t(N GPUs)) -- against the single call (what one integration costs) and like for like against the batch
         xf = pkg.clXEngine(*args, False, pkg.DTYPE_BYTE, 1, N, 1, 0, F, T, [])
-        v1 = torch.zeros(xf.get_output_buffer_size(), 2, device="cuda")
+        v1 = torch.zeros(8 * xf.get_output_buffer_size(), 2, device="cuda")
         fn_rot, bufs = rotate(lambda: torch.randint(-127, 128, (T, N, F, 1, 2), dtype=torch.int8, device="cuda", generator=g), T * N * F * 2,
                               lambda x: xf.xcorrelate_device(x, v1))
         r1 = rate(fn_rot, N * F * T, 2)
         t1 = max_over_ranks(r1["us_per_launch"], world)
+        del bufs, fn_rot
+        fn_rot, bufs = rotate(lambda: torch.randint(-127, 128, (8, T, N, F, 1, 2), dtype=torch.int8, device="cuda", generator=g), 8 * T * N * F * 2,
+                              lambda x: xf.xcorrelate_n_device(8, x, v1))
+        r1b = rate(fn_rot, 8 * N * F * T, 2)
+        t1b = max_over_ranks(r1b["us_per_launch"], world) / 8
         del xf, bufs, fn_rot, v1
-        out["clXEngine_n1_reference"] = {"us_per_integration_one_gpu": round(t1, 2), "what": "the full 64 ant x 1024 ch x 1024 frame integration on ONE device, "
+        torch.cuda.empty_cache()
+        out["clXEngine_n1_reference"] = {"us_per_integration_one_gpu": round(t1, 2), "us_per_window_one_gpu_8_windows_per_launch": round(t1b, 2),
+                                         "what": "the full 64 ant x 1024 ch x 1024 frame integration on ONE device, "
                                          "measured by every rank of this run on its own GPU (slowest rank), inputs in rotation (read from HBM)"}
         out["clXEngine_channel_sharded"] = {"us_per_window_all_ranks": round(tw, 2), "windows_per_launch": nint, "channels_per_rank": Fw,
+                                            "us_per_window_by_windows_per_launch": {str(k): round(v, 2) for k, v in per_nint.items()},
                                             "total_input_MSamples_per_s": round(N * F * T / tw, 1), "n_gpus": world,
                                             "scaling_efficiency_vs_n1": round(t1 / (world * tw), 3), "n1_us_per_integration": round(t1, 2),
+                                            "scaling_efficiency_vs_n1_batched": round(t1b / (world * tw), 3), "n1_us_per_window_batched": round(t1b, 2),
                                             "collective": "none (every rank ingests all antennas of its F/W channels)"}
     if world == 1:
         # A stream of integrations handed over eight or sixteen at a time (mi355_xengine_xcorrelate_n_dev): every unit is a whole integration of
@@ -770,6 +787,12 @@ def annotate_sharded_scaling(extras, world):
     if n1 and isinstance(row, dict) and row.get("us_per_integration"):
         row["n1_us_per_integration"] = n1
         row["scaling_efficiency_vs_n1"] = round(n1 / (world * row["us_per_integration"]), 3)
+        # like for like: the exchange carries eight windows per launch, so does this one-GPU time
+        n1b = extras.get("clXEngine_n1_reference", {}).get("us_per_window_one_gpu_8_windows_per_launch") or \
+            extras.get("clXEngine_64ant_1024ch_1024t_ichar_batched", {}).get("windows_per_launch_8", {}).get("us_per_window")
+        if n1b:
+            row["n1_us_per_window_batched"] = n1b
+            row["scaling_efficiency_vs_n1_batched"] = round(n1b / (world * row["us_per_integration"]), 3)
     return extras
 
 

@@ -141,7 +141,12 @@ def test_bench_line_scaling_keys():
     blocks = {"clXEngine_n1_reference": {"us_per_integration_one_gpu": 54.0}, "clXEngine_sharded": {"us_per_integration": 13.5, "n_gpus": 8}}
     bench.annotate_sharded_scaling(blocks, 8)
     assert blocks["clXEngine_sharded"]["n1_us_per_integration"] == 54.0 and blocks["clXEngine_sharded"]["scaling_efficiency_vs_n1"] == 0.5
-    one = {"clXEngine_64ant_1024ch_1024t_ichar": {"us_per_launch": 54.0}, "clXEngine_sharded": {"us_per_integration": 60.0}}
+    assert "scaling_efficiency_vs_n1_batched" not in blocks["clXEngine_sharded"]  # no batched one-GPU time in the line, no like-for-like figure
+    blocks["clXEngine_n1_reference"]["us_per_window_one_gpu_8_windows_per_launch"] = 27.0
+    bench.annotate_sharded_scaling(blocks, 8)
+    assert blocks["clXEngine_sharded"]["scaling_efficiency_vs_n1_batched"] == 0.25 and blocks["clXEngine_sharded"]["n1_us_per_window_batched"] == 27.0
+    one = {"clXEngine_64ant_1024ch_1024t_ichar": {"us_per_launch": 54.0}, "clXEngine_sharded": {"us_per_integration": 60.0},
+           "clXEngine_64ant_1024ch_1024t_ichar_batched": {"windows_per_launch_8": {"us_per_window": 48.0}}}
     bench.annotate_sharded_scaling(one, 1)
-    assert one["clXEngine_sharded"]["scaling_efficiency_vs_n1"] == 0.9
+    assert one["clXEngine_sharded"]["scaling_efficiency_vs_n1"] == 0.9 and one["clXEngine_sharded"]["scaling_efficiency_vs_n1_batched"] == 0.8
     assert bench.annotate_sharded_scaling({"clXEngine_sharded": {"error": "x"}}, 2) == {"clXEngine_sharded": {"error": "x"}}

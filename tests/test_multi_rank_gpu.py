@@ -107,3 +107,7 @@ def test_bench_two_rank_dry_run(gpu, tmp_path):
     n1 = b["clXEngine_n1_reference"]["us_per_integration_one_gpu"]
     for key, t in (("clXEngine_sharded", "us_per_integration"), ("clXEngine_channel_sharded", "us_per_window_all_ranks")):
         assert b[key]["n1_us_per_integration"] == n1 and abs(b[key]["scaling_efficiency_vs_n1"] - n1 / (2 * b[key][t])) < 2e-3, key
+    n1b = b["clXEngine_n1_reference"]["us_per_window_one_gpu_8_windows_per_launch"]  # like for like: eight windows per launch on one GPU
+    for key, t in (("clXEngine_sharded", "us_per_integration"), ("clXEngine_channel_sharded", "us_per_window_all_ranks")):
+        assert b[key]["n1_us_per_window_batched"] == n1b and abs(b[key]["scaling_efficiency_vs_n1_batched"] - n1b / (2 * b[key][t])) < 2e-3, key
+    assert b["clXEngine_channel_sharded"]["windows_per_launch"] in (8, 16, 32)
