@@ -164,6 +164,29 @@ def independent_golden():
     picks = [(3, 1, 2), (5, 5, 0), (4, 0, 4)]
     g["xa_picks"] = np.array(picks, np.int32)
     g["xa_pick_vals"] = np.array([sig.correlate(z[:, s1, f], z[:, s2, f], mode="valid")[0] for s1, s2, f in picks]).astype(np.complex64)
+    # ---- clFFT and the filters: library implementations as well (scipy.fft = pocketfft, scipy.signal.windows, scipy.signal.firwin /
+    # upfirdn / lfilter), so that no block's general-input parity rests on arithmetic written for this repository
+    import scipy.fft as sfft
+    import scipy.signal.windows as swin
+    for key, n, frames in (("ta", 4096, 3), ("tb", 1000, 2), ("tc", 4099, 1), ("td", 64, 5)):     # BASELINE config 2's length; 2^3 5^3; a prime (chirp-z); small
+        x = crandn(rng, n * frames)
+        w = swin.blackman(n, sym=True).astype(np.float32)
+        X = sfft.fft(x.astype(np.complex128).reshape(frames, n) * w.astype(np.float64), axis=1)
+        g[key + "_x"], g[key + "_win"] = x, w
+        g[key + "_fwd_win_shift"] = sfft.fftshift(X, axes=1).reshape(-1).astype(np.complex64)
+        g[key + "_fwd"] = sfft.fft(x.astype(np.complex128).reshape(frames, n), axis=1).reshape(-1).astype(np.complex64)
+        g[key + "_inv"] = (sfft.ifft(x.astype(np.complex128).reshape(frames, n), axis=1) * n).reshape(-1).astype(np.complex64)  # unscaled inverse, as clFFT
+    taps = sig.firwin(65, 0.2, window="hamming").astype(np.float32)                                   # 65 taps: BASELINE config 3's length
+    ctaps = (taps * np.exp(2j * np.pi * 0.11 * np.arange(65))).astype(np.complex64)
+    long_taps = sig.firwin(3001, 0.05, window=("kaiser", 7.0)).astype(np.float32)                     # past 2048: the partitioned fast convolution
+    x = crandn(rng, 6000)
+    g["fa_x"], g["fa_taps"], g["fa_ctaps"], g["fa_long_taps"] = x, taps, ctaps, long_taps
+    for d in (1, 2, 3, 10):
+        g["fa_y_d%d" % d] = sig.upfirdn(taps.astype(np.float64), x.astype(np.complex128), up=1, down=d)[:x.size // d].astype(np.complex64)
+        g["fa_yc_d%d" % d] = sig.upfirdn(ctaps.astype(np.complex128), x.astype(np.complex128), up=1, down=d)[:x.size // d].astype(np.complex64)
+    g["fa_y_lfilter"] = sig.lfilter(taps.astype(np.float64), [1.0], x.astype(np.complex128)).astype(np.complex64)       # the same numbers by another routine
+    assert np.abs(g["fa_y_lfilter"] - g["fa_y_d1"]).max() <= 1e-6 * np.abs(g["fa_y_d1"]).max()
+    g["fa_y_long"] = sig.fftconvolve(x.astype(np.complex128), long_taps.astype(np.float64))[:x.size].astype(np.complex64)
     np.savez_compressed(os.path.join(HERE, "independent_golden.npz"), **g)
 
 

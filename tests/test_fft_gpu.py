@@ -440,3 +440,20 @@ def test_reference_cli_tone_through_window_and_shift(gpu):
     blk.work(3, [x], [y])
     for v in range(3):
         assert relerr(y[v * 4096:(v + 1) * 4096], g["tone4096_fwd_win_shift"]) <= TOL
+
+
+@pytest.mark.parametrize("case,n", [("ta", 4096), ("tb", 1000), ("tc", 4099), ("td", 64)])
+def test_independent_scipy_cases(gpu, case, n):
+    """Against scipy.fft (pocketfft) + scipy.signal.windows.blackman -- an implementation that is not this repository's
+    (tests/golden/gen_golden.py::independent_golden): BASELINE config 2's length, a 2^3 5^3 length (mixed-radix kernel), a prime (chirp-z)
+    and a small one; windowed + shifted forward, plain forward, unscaled inverse."""
+    g = golden("independent_golden.npz")
+    x, w = g[case + "_x"], g[case + "_win"]
+    nvec = x.size // n
+    y = np.empty_like(x)
+    assert _fft(gpu, n, gpu.CLFFT_FORWARD, window=w, shift=True).work(nvec, [x], [y]) == nvec
+    assert relerr(y, g[case + "_fwd_win_shift"]) <= TOL
+    _fft(gpu, n, gpu.CLFFT_FORWARD).work(nvec, [x], [y])
+    assert relerr(y, g[case + "_fwd"]) <= TOL
+    _fft(gpu, n, gpu.CLFFT_BACKWARD).work(nvec, [x], [y])
+    assert relerr(y, g[case + "_inv"]) <= TOL

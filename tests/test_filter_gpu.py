@@ -283,3 +283,23 @@ def test_reference_cli_ramp_taps_closed_form(gpu, use_time):
         assert blk.work(n, [x], [y]) == n
         want = complex(*case["expect"])
         assert np.abs(y - want).max() <= TOL * abs(want), (nt, use_time)
+
+
+@pytest.mark.parametrize("use_time", [False, True])
+def test_independent_scipy_cases(gpu, use_time):
+    """Against scipy.signal (firwin taps through upfirdn at decimations 1, 2, 3, 10, real and complex taps; lfilter; fftconvolve for 3001 taps)
+    -- implementations that are not this repository's (tests/golden/gen_golden.py::independent_golden), both kernels of both blocks."""
+    g = golden("independent_golden.npz")
+    x, taps, ctaps, lt = g["fa_x"], g["fa_taps"], g["fa_ctaps"], g["fa_long_taps"]
+    for d in (1, 2, 3, 10):
+        n = x.size // d
+        y = np.empty(n, np.complex64)
+        assert gpu.clFilter(*GPU_ARGS, d, taps, 1, 0, use_time).work(n, [_hist(x, 65)], [y]) == n
+        assert relerr(y, g["fa_y_d%d" % d]) <= TOL, d
+        gpu.clComplexFilter(*GPU_ARGS, d, ctaps, 1, 0, use_time=use_time).work(n, [_hist(x, 65)], [y])
+        assert relerr(y, g["fa_yc_d%d" % d]) <= TOL, d
+    y = np.empty(x.size, np.complex64)
+    gpu.clFilter(*GPU_ARGS, 1, taps, 1, 0, use_time).work(x.size, [_hist(x, 65)], [y])
+    assert relerr(y, g["fa_y_lfilter"]) <= TOL
+    gpu.clFilter(*GPU_ARGS, 1, lt, 1, 0, use_time).work(x.size, [_hist(x, 3001)], [y])
+    assert relerr(y, g["fa_y_long"]) <= TOL

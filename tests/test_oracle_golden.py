@@ -312,3 +312,27 @@ def test_widened_rows_vs_golden(oracle):
         y = o.fft_block(nn, True, g["fftw%d" % nn], True, o.DTYPE_COMPLEX, g["fftx%d" % nn], f64=True)
         assert relerr(y, g["fft_fwd_win_shift%d" % nn]) < 1e-6
     assert relerr(o.fft(g["fftx8192"]), g["fft_fwd8192"]) < 2e-6
+
+
+def test_fft_and_filters_vs_independent_scipy(oracle):
+    """clFFT and the filter restatements against library implementations that are not this repository's: scipy.fft (pocketfft) with
+    scipy.signal.windows.blackman for the windowed + shifted forward transform, the plain forward and the unscaled inverse (power-of-two
+    lengths: the oracle's FFT handles nothing else); scipy.signal.firwin taps through scipy.signal.upfirdn (decimations 1, 2, 3, 10, real and
+    complex taps), scipy.signal.lfilter, and scipy.signal.fftconvolve for 3001 taps (tests/golden/gen_golden.py::independent_golden)."""
+    g = golden("independent_golden.npz")
+    for c, n in (("ta", 4096), ("td", 64)):
+        x, w = g[c + "_x"], g[c + "_win"]
+        for f64, tol in ((True, 2e-7), (False, 2e-6)):
+            assert relerr(oracle.fft_block(n, True, w, True, oracle.DTYPE_COMPLEX, x, f64=f64), g[c + "_fwd_win_shift"]) < tol, (c, f64)
+            assert relerr(oracle.fft_block(n, True, None, False, oracle.DTYPE_COMPLEX, x, f64=f64), g[c + "_fwd"]) < tol, (c, f64)
+            assert relerr(oracle.fft_block(n, False, None, False, oracle.DTYPE_COMPLEX, x, f64=f64), g[c + "_inv"]) < tol, (c, f64)
+    x, taps, ctaps, lt = g["fa_x"], g["fa_taps"], g["fa_ctaps"], g["fa_long_taps"]
+    hist = lambda k: np.concatenate([np.zeros(k - 1, np.complex64), x])
+    for d in (1, 2, 3, 10):
+        n = x.size // d
+        assert relerr(oracle.fir_ccf(taps, hist(65), n, d), g["fa_y_d%d" % d]) < 1e-6, d
+        assert relerr(oracle.fir_ccc(ctaps, hist(65), n, d), g["fa_yc_d%d" % d]) < 1e-6, d
+        f = oracle.FFTFilter(d, taps)            # the stateful overlap-add restatement of fft_filter_ccf
+        assert relerr(f.filter(n, x)[:n], g["fa_y_d%d" % d][:n]) < 2e-6, d
+    assert relerr(oracle.fir_ccf(taps, hist(65), x.size, 1), g["fa_y_lfilter"]) < 1e-6
+    assert relerr(oracle.fir_ccf(lt, hist(3001), x.size, 1), g["fa_y_long"]) < 1e-5  # (float accumulation over 3001 products, as the reference's dot product)
