@@ -187,6 +187,21 @@ def independent_golden():
     g["fa_y_lfilter"] = sig.lfilter(taps.astype(np.float64), [1.0], x.astype(np.complex128)).astype(np.complex64)       # the same numbers by another routine
     assert np.abs(g["fa_y_lfilter"] - g["fa_y_d1"]).max() <= 1e-6 * np.abs(g["fa_y_d1"]).max()
     g["fa_y_long"] = sig.fftconvolve(x.astype(np.complex128), long_taps.astype(np.float64))[:x.size].astype(np.complex64)
+    # ---- clxcorrelate_fft_vcf, time-series inputs: circular cross-correlation as scipy.signal.correlate's direct-form linear correlation folded
+    # onto N lags (lag k and lag k - N land on the same output), magnitude, half swap
+    n, nfr = 256, 2
+    xin = [crandn(rng, n * nfr) for _ in range(3)]
+    for s_ in (1, 2):
+        rows = []
+        for fr in range(nfr):
+            a, b = (v[fr * n:(fr + 1) * n].astype(np.complex128) for v in (xin[0], xin[s_]))
+            full = sig.correlate(a, b, mode="full", method="direct")          # full[k + n - 1] = sum_m a[m + k] conj(b[m]), k = -(n-1) .. n-1
+            circ = full[n - 1:].copy()
+            circ[1:] += full[:n - 1]
+            rows.append(sfft.fftshift(np.abs(circ * n)))                      # the block's transform pair is unscaled: n x the correlation
+        g["xc_out%d" % s_] = np.concatenate(rows).astype(np.float32)
+    for i, v in enumerate(xin):
+        g["xc_in%d" % i] = v
     np.savez_compressed(os.path.join(HERE, "independent_golden.npz"), **g)
 
 

@@ -336,3 +336,12 @@ def test_fft_and_filters_vs_independent_scipy(oracle):
         assert relerr(f.filter(n, x)[:n], g["fa_y_d%d" % d][:n]) < 2e-6, d
     assert relerr(oracle.fir_ccf(taps, hist(65), x.size, 1), g["fa_y_lfilter"]) < 1e-6
     assert relerr(oracle.fir_ccf(lt, hist(3001), x.size, 1), g["fa_y_long"]) < 1e-5  # (float accumulation over 3001 products, as the reference's dot product)
+
+
+def test_xcorr_vs_independent_scipy(oracle):
+    """clxcorrelate_fft_vcf (time-series inputs) against scipy.signal.correlate's direct-form linear correlation folded onto N circular lags."""
+    g = golden("independent_golden.npz")
+    ins = [g["xc_in%d" % i] for i in range(3)]
+    for f64, tol in ((True, 1e-6), (False, 1e-5)):
+        for got, s_ in zip(oracle.xcorr_fft(256, 2, ins, use_f64=f64), (1, 2)):
+            assert relerr(got, g["xc_out%d" % s_]) < tol, (f64, s_)

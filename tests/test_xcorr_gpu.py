@@ -4,7 +4,7 @@ lib/clxcorrelate_fft_vcf_impl.cc:886-935,1058-1143 and the circular cross-correl
 import numpy as np
 import pytest
 
-from conftest import GPU_ARGS, crandn, relerr
+from conftest import GPU_ARGS, crandn, golden, relerr
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -109,3 +109,14 @@ def test_errors(gpu):
     blk = _blk(gpu, 64, 2, 1)
     with pytest.raises(ValueError):
         blk.work(1, [np.zeros(64, np.complex64)], [np.zeros(64, np.float32)])
+
+
+def test_independent_scipy_case(gpu):
+    """Against scipy.signal.correlate (direct form, folded onto N circular lags) -- not this repository's arithmetic
+    (tests/golden/gen_golden.py::independent_golden)."""
+    g = golden("independent_golden.npz")
+    ins = [g["xc_in%d" % i] for i in range(3)]
+    outs = [np.empty(ins[0].size, np.float32) for _ in range(2)]
+    assert _blk(gpu, 256, 3, 2).work(ins[0].size // 256, ins, outs) == ins[0].size // 256
+    for o, s_ in zip(outs, (1, 2)):
+        assert relerr(o, g["xc_out%d" % s_]) <= TOL
