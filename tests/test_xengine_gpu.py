@@ -606,3 +606,29 @@ def test_batched_group_major_refused_outside_the_fused_path(gpu):
     out = torch.zeros(2 * blk.get_output_buffer_size(), 2, device="cuda")
     with pytest.raises(gpu.Mi355Error):
         blk.xcorrelate_n_device(2, x, out, stations_per_group=4)
+
+
+def test_in_launch_reduction_two_streams_share_the_device(gpu, oracle):
+    """Two fused launches of 256 workgroups each on two streams at once: only one workgroup fits a CU, so the units of a slice are no longer
+    all resident together and the in-launch reduction's bounded waits and hand-overs do real work (the case a sharded pipeline's exchange
+    or any other block's kernels create).  Every result of every launch bit-exact."""
+    import torch
+    N, F, T = 64, 1024, 256
+    rng = np.random.default_rng(77)
+    xs = [rng.integers(-128, 128, size=(T, N, F, 1, 2), dtype=np.int64).astype(np.int8) for _ in range(2)]
+    refs = [oracle.xengine_ichar(N, F, 1, T, x.reshape(-1), exact=True) for x in xs]
+    blks = [_xe(gpu, gpu.DTYPE_BYTE, 1, N, F, T) for _ in range(2)]
+    dx = [torch.from_numpy(x).cuda() for x in xs]
+    per = blks[0].get_output_buffer_size()
+    rounds = 12
+    outs = [[torch.zeros(per, 2, device="cuda") for _ in range(rounds)] for _ in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for r in range(rounds):
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                blks[k].xcorrelate_device(dx[k], outs[k][r])
+    torch.cuda.synchronize()
+    for k in range(2):
+        for r in range(rounds):
+            assert np.array_equal(outs[k][r].cpu().numpy().view(np.complex64).reshape(-1), refs[k]), (k, r)
