@@ -54,6 +54,8 @@ struct FuArgs {
     // reads, 512 every bounded wait of the in-launch reduction runs out at once (the tests' way into its fallback), 1024 stamp the arrival of the pieces,
     // 4096 * m (m = 1..3) other line -> XCD maps, 65536 / 131072 only / all but lines 3 and 11 of a row, 1048576 * k lines rotated over the XCDs
     int dbg;
+    unsigned pf_mask;  // the rows' slow 128-byte lines (bit l = line l of a row), which the workgroups of the other lines touch pf_dist K blocks ahead
+    int pf_dist;       // (see prefetch_slow; 0: off)
     int slow_first;    // >= 0: ((input address >> 7) & 7); the units of the rows' slow lines get the lowest workgroup numbers (several windows, no time ranges)
     unsigned long long *ts;  // tuning aid (MI355_XE_TS): per-workgroup phase stamps (100 MHz wall clock), NULL in normal use
     double kd;
@@ -234,6 +236,33 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
     // operands) first, so the slots are free again after a second barrier and the DMA of step j+2 is issued BEFORE the matrix
     // products of step j: two steps (128 KB per CU) are in flight while the wave multiplies.
     constexpr int PER_STEP = 4 * NSH;  // DMA instructions per wave and step (every wave issues all of them: N > 32 when NSH == 2)
+    // ---- The slow lines.  HBM serves the 128-byte lines whose address has bits 7..9 == 3 (two of a 2 KiB row's sixteen) with ~1.75 x the
+    // latency of the others, and a CU's request stream is latency bound: from HBM the 32 workgroups of those lines end their loop at 69 us
+    // when the other 224 are done at 37 (profiles/r04_xengine_counters.txt section 0).  Once a line sits in the Infinity Cache the gap is small
+    // (35 against 29 us on a cache-resident input).  So the workgroups of the OTHER lines -- which run ahead -- touch the slow lines' rows of
+    // their own time range two K blocks early: one 16-byte request per line, the 52 workgroups of the other lines share a block's 6144 lines
+    // (lines 3 and 11, and line 15 whose latency is 1.15 x), 32 lanes of each wave of the first group, ~6 % more requests for them; the data land in a 1 KiB scratch behind the ring and are never read.  (First in the wave's queue of a
+    // step, so the step's own loads are not held up by the slow class's latency; only the ping-pong schedule, whose waits are vmcnt(0).)
+    // (the lane's source address for K block 0 is worked out once; a step adds the block's offset: one address add and one request)
+    const unsigned char *pf_src = nullptr;
+    if (PP && a.pf_dist > 0 && wave < 4) {
+        const int pf_line = slice >> 2, pf_n = __builtin_popcount(a.pf_mask);
+        const int pf_wgs = (a.nlines - pf_n) * 4, pf_rank = __builtin_popcount(~a.pf_mask & ((1u << pf_line) - 1u)) * 4 + (slice & 3);  // this workgroup among those of the other lines
+        const int items = 32 * a.N * pf_n, per = (items + pf_wgs - 1) / pf_wgs;  // (row of a K block, slow line): at most 128 per workgroup, 32 per wave of the first group
+        const int k = wave * 32 + lane, i = pf_rank * per + k;
+        if (!((a.pf_mask >> pf_line) & 1) && lane < 32 && k < per && i < items) {
+            const int which = i % pf_n, row = i / pf_n, t = row / a.N, st = row - t * a.N;
+            int ln = 0, seen = -1;  // the which-th slow line
+            for (int l = 0; l < 32; l++) {
+                seen += (a.pf_mask >> l) & 1;
+                if (seen == which && ((a.pf_mask >> l) & 1)) { ln = l; break; }
+            }
+            pf_src = a.in + (size_t)(st / a.ng) * a.in_group + ((size_t)(t_base + t) * a.ng + st % a.ng) * row_bytes + (size_t)ln * 128;
+        }
+    }
+    auto prefetch_slow = [&](int blk) {
+        if (pf_src) dma16(pf_src + (size_t)blk * 32 * t_stride, __builtin_amdgcn_readfirstlane(lds0 + kRing * STAGE));
+    };
     issue_stage(0);
     issue_stage(1);
     if (a.steps > 1) {
@@ -337,6 +366,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
             }
             __syncthreads();
             if (j == 0) stamp(a, 1);
+            if (PP && a.pf_dist > 0) {  // (the slow lines' own requests for blocks 0 and 1 go out at launch: nothing to gain there)
+                if (j == 0) for (int b2 = 2; b2 < a.pf_dist && b2 < a.steps; b2++) prefetch_slow(b2);
+                if (j + a.pf_dist < a.steps) prefetch_slow(j + a.pf_dist);
+            }
             if (j >= 1 && j + 1 < a.steps) {
                 issue_stage(2 * j + 2);
                 issue_stage(2 * j + 3);
@@ -946,7 +979,7 @@ __global__ __launch_bounds__(256) void k_xe_i8_reduce(const v4i *__restrict__ pa
 template <int NPOL, int NTT, bool SPLIT, bool PP, bool RS> int launch_fused_s(const XeFusedPlan &p, const FuArgs &a, hipStream_t st)
 {
     constexpr int NSH = (NTT * 16 / NPOL > 32) ? 2 : 1;
-    constexpr int lds_bytes = kRing * (kStageT * NSH * kChunk + 16);
+    constexpr int lds_bytes = kRing * (kStageT * NSH * kChunk + 16) + 1024;  // (+ the scratch the slow lines' early touches land in)
     MI355_HIP(hipFuncSetAttribute((const void *)k_xe_i8_fused<NPOL, NTT, SPLIT, PP, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     const int nint = a.nint_launch;
     hipLaunchKernelGGL((k_xe_i8_fused<NPOL, NTT, SPLIT, PP, RS>), dim3((unsigned)(p.units * p.tsplit * nint)), dim3(kThreads), lds_bytes, st, a);
@@ -1126,9 +1159,23 @@ int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void 
     const int dbg = getenv("MI355_XE_DBG") ? atoi(getenv("MI355_XE_DBG")) : 0;
     a.dbg = dbg;
     a.ts = nullptr;
+    // Early touches of the slow lines (prefetch_slow): rows of 8, 16 or 32 whole lines, whole K blocks, the ping-pong schedule.  Which lines:
+    // address bits 7..9 == 3 (1.75 x the latency from HBM), and bits 7..10 == 15 (1.15 x) where a line keeps bit 10 from row to row.
+    // MI355_XE_PF: distance in K blocks (default 2), + 16: without the 1.15 x line; MI355_XE_NO_PREFETCH: off.
+    a.pf_mask = 0;
+    a.pf_dist = 0;
+    if ((a.nlines == 8 || a.nlines == 16 || a.nlines == 32) && p.row_stride == a.nlines * 128 && ((size_t)in & 127) == 0 && T % 32 == 0 && a.steps >= 4 &&
+        !getenv("MI355_XE_NO_PREFETCH")) {
+        const int key = (int)(((size_t)in >> 7) & 15), tune = getenv("MI355_XE_PF") ? atoi(getenv("MI355_XE_PF")) : 2;
+        for (int l = 0; l < a.nlines; l++) {
+            const int c = (l + key) & 15;
+            if ((c & 7) == 3 || (c == 15 && a.nlines >= 16 && !(tune & 16))) a.pf_mask |= 1u << l;
+        }
+        a.pf_dist = (tune & 15) >= 2 ? (tune & 15) : 2;
+    }
     a.slow_first = -1;
     if (p.tsplit == 1 && a.nint_launch > 1 && a.nlines % 8 == 0 && p.row_stride % 1024 == 0 && ((size_t)in & 127) == 0 &&
-        (long)p.units * a.nint_launch > p.cus && !getenv("MI355_XE_NO_SLOW_FIRST"))
+        (long)p.units * a.nint_launch > p.cus && (a.pf_dist == 0 || getenv("MI355_XE_SLOW_FIRST")) && !getenv("MI355_XE_NO_SLOW_FIRST"))
         a.slow_first = (int)(((size_t)in >> 7) & 7);
     if (getenv("MI355_XE_TS")) return launch_with_stamps(p, a, st);
     if (p.npol == 1) {
