@@ -588,7 +588,8 @@ def test_batched_more_units_than_cus_slow_lines_first(gpu, oracle, N, F, T, npol
     x.copy_(torch.from_numpy(host))
     out = torch.zeros(nint * per, 2, device="cuda")
     for env in (None, "1"):  # second pass: the plain order, same results
-        if env: os.environ["MI355_XE_NO_SLOW_FIRST"] = env
+        # (the order is the default only when the early touches of the slow lines are off: MI355_XE_SLOW_FIRST forces it beside them)
+        os.environ["MI355_XE_NO_SLOW_FIRST" if env else "MI355_XE_SLOW_FIRST"] = "1"
         try:
             out.zero_()
             if W > 1: blk.xcorrelate_n_device(nint, x, out, stations_per_group=Ng)
@@ -596,6 +597,7 @@ def test_batched_more_units_than_cus_slow_lines_first(gpu, oracle, N, F, T, npol
             torch.cuda.synchronize()
         finally:
             os.environ.pop("MI355_XE_NO_SLOW_FIRST", None)
+            os.environ.pop("MI355_XE_SLOW_FIRST", None)
         assert np.array_equal(out.cpu().numpy().view(np.complex64).reshape(-1), ref)
 
 
@@ -632,3 +634,34 @@ def test_in_launch_reduction_two_streams_share_the_device(gpu, oracle):
     for k in range(2):
         for r in range(rounds):
             assert np.array_equal(outs[k][r].cpu().numpy().view(np.complex64).reshape(-1), refs[k]), (k, r)
+
+
+@pytest.mark.parametrize("N,F,T,npol,nint,W,shift", [(64, 1024, 512, 1, 1, 1, 0), (50, 1024, 512, 1, 1, 1, 5), (64, 512, 256, 1, 1, 1, 9), (32, 1024, 256, 2, 1, 1, 3),
+                                                    (64, 2048, 128, 1, 1, 1, 14), (64, 1024, 128, 1, 3, 1, 2), (64, 1024, 128, 1, 2, 8, 11), (20, 512, 160, 1, 6, 1, 7)])
+def test_early_touches_of_the_slow_lines(gpu, oracle, N, F, T, npol, nint, W, shift):
+    """The fused kernel's early touches of the rows' slow 128-byte lines (prefetch_slow: rows of 8 / 16 / 32 whole lines, whole K blocks, at
+    least four K blocks per time range): which lines and which lanes depends on the input's address bits 7..10, so the input is placed at
+    several 128-byte shifts; one and several windows, reference and group-major layout, antennas that do not fill the row tiles.  Bit exact
+    against the oracle with the touches on and off."""
+    import torch
+    rng = np.random.default_rng(N + F + T + shift)
+    wins = rng.integers(-128, 128, size=(nint, T, N, F, npol, 2), dtype=np.int64).astype(np.int8)
+    blk = _xe(gpu, gpu.DTYPE_BYTE, npol, N, F, T)
+    per = blk.get_output_buffer_size()
+    ref = np.concatenate([oracle.xengine_ichar(N, F, npol, T, wins[i].reshape(-1), exact=True) for i in range(nint)])
+    Ng = N // W if W > 1 else 0
+    host = np.ascontiguousarray(wins.reshape(nint, T, W, Ng, F, npol, 2).transpose(2, 0, 1, 3, 4, 5, 6)).reshape(-1) if W > 1 else wins.reshape(-1)
+    raw = torch.zeros(host.size + 4096, dtype=torch.int8, device="cuda")
+    x = raw[128 * shift:128 * shift + host.size]
+    x.copy_(torch.from_numpy(host))
+    out = torch.zeros(nint * per, 2, device="cuda")
+    for off in (None, "1"):
+        if off: os.environ["MI355_XE_NO_PREFETCH"] = off
+        try:
+            out.zero_()
+            if nint > 1 or W > 1: blk.xcorrelate_n_device(nint, x, out, stations_per_group=Ng)
+            else: blk.xcorrelate_device(x, out)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("MI355_XE_NO_PREFETCH", None)
+        assert np.array_equal(out.cpu().numpy().view(np.complex64).reshape(-1), ref), off
