@@ -24,7 +24,7 @@ K1 = "k_xe_i8_fused<1, 4, true, true, true>"
 f1, w1 = val_or(O + tag + "_xe_fetch.txt", K1, "FETCH_SIZE"), val_or(O + tag + "_xe_write.txt", K1, "WRITE_SIZE")
 if f1 is not None:
     tot = (2 * f1 + w1) * 1024 / 1e6
-    traffic = "# config 5: 2 x %.2f + %.2f KiB (ONE kernel: corner turn, correlation and the reduce-scatter of the four time ranges) = %.1f MB = %.2f x the 151.3 MB algorithmic bytes (round 3: 1.70 x, round 1: 2.78 x)" % (f1, w1, tot, tot / 151.3)
+    traffic = "# config 5: 2 x %.2f + %.2f KiB (ONE kernel: corner turn, correlation and the reduce-scatter of the four time ranges) = %.1f MB = %.2f x the 151.3 MB algorithmic bytes at the L2's memory side (the early touches of the slow lines count twice here, HBM reads them once: 1.50 x without them; round 3: 1.70 x, round 1: 2.78 x)" % (f1, w1, tot, tot / 151.3)
 else:
     f1, w1 = val(O + tag + "_xe_fetch.txt", "k_xe_i8_fused<1, 4, true>", "FETCH_SIZE"), val(O + tag + "_xe_write.txt", "k_xe_i8_fused<1, 4, true>", "WRITE_SIZE")
     f2, w2 = val(O + tag + "_xe_fetch.txt", "k_xe_i8_reduce<1, 4>", "FETCH_SIZE"), val(O + tag + "_xe_write.txt", "k_xe_i8_reduce<1, 4>", "WRITE_SIZE")
@@ -32,7 +32,7 @@ else:
     traffic = "# config 5: 2 x %.2f + %.2f (fused) + 2 x %.2f + %.2f (reduce) KiB = %.1f MB = %.2f x the 151.3 MB algorithmic bytes (round 1: 2.78 x)" % (f1, w1, f2, w2, tot, tot / 151.3)
 out = ["# X-engine IChar path alone, BASELINE config 5 (64 ant x 1024 ch x 1024 frames) and its dual-polarisation sibling (32 ant), device resident,",
        "# back-to-back launches over >= 640 MB of distinct inputs in rotation (every launch reads its input from HBM; rounds 1-3 and the first r04 files re-read",
-       "# ONE buffer, which the 256 MiB Infinity Cache serves: 54 us instead of 86 at config 5): tools/make_profiles_xe.sh %s  (two command sets, each with its own passes; 20 launches right after idle, so the times" % tag,
+       "# ONE buffer, which the 256 MiB Infinity Cache serves: 55 us at config 5 against 86 from HBM then, 64 from HBM since the early touches of the slow lines): tools/make_profiles_xe.sh %s  (two command sets, each with its own passes; 20 launches right after idle, so the times" % tag,
        "# here are a few per cent above the bench's).  SQ_VALU_MFMA_BUSY_CYCLES = 16 cycles per v_mfma_i32_16x16x64_i8 / _16x16x32_i8, summed over the 1024 SIMDs.",
        "# pass 1: rocprofv3 --kernel-trace --stats ; passes 2-4: --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE (separate runs)",
        "# FETCH_SIZE / WRITE_SIZE are KiB per dispatch; gfx950: HBM read bytes = 2 x FETCH_SIZE x 1024 (MI355X_MICROARCH.md, HBM section)",
