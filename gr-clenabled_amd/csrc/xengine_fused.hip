@@ -245,7 +245,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
     // step, so the step's own loads are not held up by the slow class's latency; only the ping-pong schedule, whose waits are vmcnt(0).)
     // (the lane's source address for K block 0 is worked out once; a step adds the block's offset: one address add and one request)
     const unsigned char *pf_src = nullptr;
-    if (PP && a.pf_dist > 0 && wave < 4) {
+    if (a.pf_dist > 0 && wave < 4) {
         const int pf_line = slice >> 2, pf_n = __builtin_popcount(a.pf_mask);
         const int pf_wgs = (a.nlines - pf_n) * 4, pf_rank = __builtin_popcount(~a.pf_mask & ((1u << pf_line) - 1u)) * 4 + (slice & 3);  // this workgroup among those of the other lines
         const int items = 32 * a.N * pf_n, per = (items + pf_wgs - 1) / pf_wgs;  // (row of a K block, slow line): at most 128 per workgroup, 32 per wave of the first group
@@ -318,6 +318,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
         if (j == 0) stamp(a, 1);
         if (!(a.dbg & 1)) read_block(j, I, Q);
         __syncthreads();  // every wave holds its operands in registers: the two slots are free
+        if (a.pf_dist > 0) {  // (older than the stages issued next: the next step's vmcnt wait covers it, nothing is miscounted)
+            if (j == 0) for (int b2 = 2; b2 <= a.pf_dist && b2 < a.steps; b2++) prefetch_slow(b2);
+            if (j + 1 + a.pf_dist < a.steps) prefetch_slow(j + 1 + a.pf_dist);
+        }
         if (j + 2 < a.steps) {
             issue_stage(2 * j + 4);
             issue_stage(2 * j + 5);
