@@ -109,6 +109,7 @@ def lib():
         "mi355_xengine_xcorrelate_n_dev": (i, [vp, i, vp, vp, i, i, vp]),
         "mi355_pack3d_dev": (i, [vp, vp, vp, sz, sz, sz, sz, sz, sz, sz, vp]),
         "mi355_xengine_gather": (i, [vp, i, i, pp, vp]),
+        "mi355_xengine_selftest_scale": (i, [vp, C.POINTER(C.c_longlong)]),
         "mi355_xengine_submit": (i, [vp, vp, vp]),
         "mi355_xengine_wait": (i, [vp, vp]),
         "mi355_xengine_pending": (i, [vp]),

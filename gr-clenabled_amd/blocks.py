@@ -443,6 +443,12 @@ class clXEngine(_Block):
                                        int(src_block_stride), int(dst_pitch), int(dst_block_stride), _torch_stream(self.device)),
               "mi355_pack3d_dev")
 
+    def selftest_scale(self):
+        """Sums S in [-2^24, 2^24] whose single-precision IChar scale differs from (float)((double)S / 127 / 127): must be 0."""
+        n = C.c_longlong(-1)
+        check(self._L.mi355_xengine_selftest_scale(self._ctx, C.byref(n)), "mi355_xengine_selftest_scale")
+        return int(n.value)
+
     def gather(self, nframes, frame0, input_items, frame_buffer):
         """Host frame gather of work_processor (lib/clXEngine_impl.cc:987-1061)."""
         ins = [np.ascontiguousarray(x) for x in input_items]

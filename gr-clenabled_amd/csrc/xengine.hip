@@ -1076,6 +1076,12 @@ struct mi355_xengine {
     unsigned batch_epoch = 0;  // launches of the in-launch reduction on d_batch with the current window count
     int batch_nint = 0;        // ... whose arrival words sit behind that count's partial sums (another count: another place, zeroed first)
     std::mutex dev_lock;    // device-pointer entry points: workspace growth, the reduction's counters and the launch itself, one caller at a time
+    // Launches that share a workspace (0: d_tiles = the device-pointer path and slot 0, 1: slot 1's tiles, 2: d_batch) must not overlap: the
+    // partial sums, the inboxes and the arrival words of the in-launch reduction belong to one launch at a time.  On one stream they are ordered
+    // anyway; when a call arrives on ANOTHER stream than the workspace's last one, an event recorded on the old stream is waited for on the new one.
+    hipStream_t ws_stream[3] = {nullptr, nullptr, nullptr};
+    bool ws_used[3] = {false, false, false};
+    hipEvent_t ws_event = nullptr;
     int pad = 0;            // one zero channel appended on the device (odd channel count of 2-byte samples)
     size_t pad_bytes = 0;
     unsigned char *d_pad = nullptr;
@@ -1107,10 +1113,27 @@ __global__ __launch_bounds__(256) void k_xe_pad_rows8(const unsigned long long *
     }
 }
 
+// stream-order this call on workspace ws behind the workspace's previous launch (see mi355_xengine::ws_stream); called under dev_lock
+int xe_order_workspace(mi355_xengine *h, int ws, hipStream_t st)
+{
+    if (h->ws_used[ws] && h->ws_stream[ws] != st) {
+        if (!h->ws_event) MI355_HIP(hipEventCreateWithFlags(&h->ws_event, hipEventDisableTiming));
+        MI355_HIP(hipEventRecord(h->ws_event, h->ws_stream[ws]));
+        MI355_HIP(hipStreamWaitEvent(st, h->ws_event, 0));
+    }
+    h->ws_stream[ws] = st;
+    h->ws_used[ws] = true;
+    return MI355_OK;
+}
+
 int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipStream_t st, unsigned char *tiles, unsigned char *padbuf,
               int stations_per_group = 0)
 {
     const XeGeo &g = h->g;
+    if (tiles) {
+        const int rc = xe_order_workspace(h, tiles == h->d_tiles ? 0 : 1, st);
+        if (rc != MI355_OK) return rc;
+    }
     // complex float: is this launch the fused kernel's?  (decided first: that kernel reads rows which end inside a 128-byte line as they
     // are, every other complex-float kernel needs them padded to whole lines)
     int tsplit = 1;
@@ -1227,8 +1250,10 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
                 h->fused_epoch[ws] = 0;
                 h->flags_stale[ws] = false;
             }
-            return mi355_xe_fused_launch(fp, in, out, tiles, g.N, g.F, g.Fout, g.T, 0.007874015748031496063, accumulate, st, stations_per_group,
-                                         &h->fused_epoch[ws]);
+            const int rc = mi355_xe_fused_launch(fp, in, out, tiles, g.N, g.F, g.Fout, g.T, 0.007874015748031496063, accumulate, st, stations_per_group,
+                                                 &h->fused_epoch[ws]);
+            if (rc != MI355_OK) h->flags_stale[ws] = true;  // whatever failed: the arrival words are zeroed and the count restarts before the next launch
+            return rc;
         }
     }
     if (tiles) h->flags_stale[tiles == h->d_tiles ? 0 : 1] = true;  // the corner turn below writes over the whole workspace
@@ -1326,6 +1351,7 @@ extern "C" int mi355_xengine_destroy(mi355_xengine *h)
     }
     if (h->d_pad) (void)hipFree(h->d_pad);
     if (h->d_batch) (void)hipFree(h->d_batch);
+    if (h->ws_event) (void)hipEventDestroy(h->ws_event);
     delete h;
     return MI355_OK;
 }
@@ -1459,13 +1485,19 @@ extern "C" int mi355_xengine_xcorrelate_n_dev(mi355_xengine *h, int nint, const 
                 h->batch_bytes = fp.part_bytes;
                 h->batch_nint = 0;
             }
+            {
+                const int rc = xe_order_workspace(h, 2, st);  // (before the fill below: it must not run under a launch still in flight on another stream)
+                if (rc != MI355_OK) return rc;
+            }
             if (h->batch_nint != nint && fp.part_bytes > fp.flag_offset) {  // the arrival words of this window count start from zero
                 MI355_HIP(hipMemsetAsync(h->d_batch + fp.flag_offset, 0, fp.part_bytes - fp.flag_offset, st));
                 h->batch_epoch = 0;
                 h->batch_nint = nint;
             }
-            return mi355_xe_fused_launch(fp, in_dev, out_dev, h->d_batch, g.N, g.F, g.Fout, g.T, 0.007874015748031496063, accumulate, st,
-                                         stations_per_group, &h->batch_epoch, nint);
+            const int rc = mi355_xe_fused_launch(fp, in_dev, out_dev, h->d_batch, g.N, g.F, g.Fout, g.T, 0.007874015748031496063, accumulate, st,
+                                                 stations_per_group, &h->batch_epoch, nint);
+            if (rc != MI355_OK) h->batch_nint = 0;  // whatever failed: the arrival words are zeroed and the count restarts before the next launch
+            return rc;
         }
     }
     if (grouped && nint > 1) {
@@ -1562,6 +1594,7 @@ static int xe_submit_slot(mi355_xengine *h, const void *in_host /* nullptr: the 
 extern "C" int mi355_xengine_submit(mi355_xengine *h, const void *in_host, const void *acc_host)
 {
     MI355_REQUIRE(h && in_host, "NULL argument");
+    std::lock_guard<std::mutex> dl(h->dev_lock);  // (slot 0 shares its workspace with the device-pointer path; lock order: dev_lock, then the context's)
     std::lock_guard<std::mutex> g(h->ctx->lock);
     MI355_HIP(hipSetDevice(h->ctx->device));
     if (h->pending == 2) {
@@ -1594,6 +1627,7 @@ extern "C" int mi355_xengine_acquire(mi355_xengine *h, void **frame_buffer)
 extern "C" int mi355_xengine_submit_acquired(mi355_xengine *h, const void *acc_host)
 {
     MI355_REQUIRE(h != nullptr, "NULL argument");
+    std::lock_guard<std::mutex> dl(h->dev_lock);
     std::lock_guard<std::mutex> g(h->ctx->lock);
     MI355_HIP(hipSetDevice(h->ctx->device));
     MI355_REQUIRE(h->acquired, "no frame buffer acquired");

@@ -26,8 +26,12 @@ XeFusedPlan mi355_xe_fused_plan(int N, int F, int Fout, int npol, int T, int num
 // all-to-all corner turn delivers (gr-clenabled_amd/shard.py) -- read in place, no re-layout pass.
 // nint > 1: `in` holds nint windows, [window][t][station].. (reference layout) or [group][window][t][station in group].. (group-major: what
 // ONE all-to-all of nint windows delivers); `out` holds nint matrices back to back; the plan must have been made for the same nint.
-// epoch: the workspace's launch counter for the in-launch reduction (default where it applies; MI355_XE_INKERNEL_REDUCE=0 disables it); it advances only
-// with launches that use the counters, so a process that mixes both forms of the reduction on one workspace stays consistent.
-// NULL (or nint > 1): the reduce kernel is used.
+// epoch: the workspace's launch counter for the in-launch reduction (the default where it applies -- 64 rows, four time ranges of at most 256 frames,
+// every workgroup of the launch resident, one or several windows; MI355_XE_INKERNEL_REDUCE=0 disables it).  The arrival words behind the partial sums
+// (plan.flag_offset) are two banks of one 8-byte word per (window, slice): launch e counts in bank e % 2 and clears the other bank, so nothing an
+// unfinished launch leaves behind is seen by a later one.  The counter advances only when a kernel that uses the words has been enqueued; a call that
+// returns an error leaves it as it was (the caller should still treat the words as unknown: zero them and restart the counter from 0).
+// Launches that share a workspace must be stream-ordered (the caller's job: mi355_xengine orders them with an event when the stream changes).
+// NULL: the reduce kernel is used.
 int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void *part, int N, int F, int Fout, int T, double kd,
                           int accumulate, hipStream_t st, int stations_per_group = 0, unsigned *epoch = nullptr, int nint = 1);

@@ -46,8 +46,12 @@ struct FuArgs {
     int ng;     // stations per antenna group: input is [group][t][station in group][...] (ng == N: the reference layout)
     int nlines, tsplit, steps;  // 128-byte lines per input row; time ranges; K blocks (32 time steps) per time range
     int pinned, accumulate;
-    int *flags;        // pub[units] then claim[units * tsplit]: arrival counters / piece claims of the in-kernel reduction (epoch valued)
+    int *flags;        // the in-launch reduction's arrival words: two banks of flag_bank 8-byte words, one word per (window, slice):
+                       // {arrival count (high 32 bits) | launch tag << 4 | give-up bits (low 32 bits)}; launch e uses bank e % 2 and clears the other
     unsigned epoch;    // launch number on this workspace (>= 1)
+    unsigned flag_bank;  // words per bank = windows of the launch x slices
+    unsigned wait_ticks; // bound of a unit's wait for its slice's other units, 100 MHz ticks
+    int k127;            // kd == 1 / 127 exactly: the single-precision form of the scale applies (xe_scale127_small)
     int rs;            // 1: the four time ranges of a slice are combined by the kernel's own tail (reduce-scatter), 0: by k_xe_i8_reduce
     int compact;       // partial matrices of the diagonal tile pairs as ONE record (re on and below the diagonal, im above it)
     // tuning aid (MI355_XE_DBG), bits: 1 no compute, 2 no partial-sum stores, 4 no DMA, 32 no priority for the second wave group, 64 no products, 128 no LDS
@@ -56,6 +60,7 @@ struct FuArgs {
     int dbg;
     unsigned pf_mask;  // the rows' slow 128-byte lines (bit l = line l of a row), which the workgroups of the other lines touch pf_dist K blocks ahead
     int pf_dist;       // (see prefetch_slow; 0: off)
+    unsigned long long pf_lines;  // the slow lines' numbers, one byte each in rising order (at most eight)
     int slow_first;    // >= 0: ((input address >> 7) & 7); the units of the rows' slow lines get the lowest workgroup numbers (several windows, no time ranges)
     unsigned long long *ts;  // tuning aid (MI355_XE_TS): per-workgroup phase stamps (100 MHz wall clock), NULL in normal use
     double kd;
@@ -65,6 +70,11 @@ struct FuArgs {
     size_t in_window, in_group;    // bytes between windows / between antenna groups of the input
     size_t out_window;             // output elements per window
     size_t part_window;            // v4i elements of partial sums per window
+    // persistent form: a workgroup runs `items` units one after the other, unit k of workgroup b is the unit the one-unit-per-workgroup form
+    // gives workgroup b + k * gridDim.x (same XCD, same 32-byte sector); the first K blocks of unit k + 1 are requested before unit k's matrix is stored
+    // (only where unit k + 1 of a workgroup is the SAME slice and time range of a later window: the request addresses move by unit_in_step bytes)
+    int items;
+    size_t unit_in_step;
 };
 
 __device__ __forceinline__ unsigned perm(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
@@ -85,6 +95,26 @@ __device__ __forceinline__ void transpose4x4(unsigned i0, unsigned i1, unsigned 
 }
 
 __device__ __forceinline__ long pack64(unsigned lo, unsigned hi) { return (long)(((unsigned long)hi << 32) | (unsigned long)lo); }
+
+// ---- The IChar scale in single precision, bit for bit the oracle's (float)((double)S * kd * kd) at kd = 1 / 127 (lib/clXEngine_impl.cc:859-867).
+// That expression is the correctly rounded float of the rational S / 16129: a double evaluation is off by < 2^-50, and S / 16129 is never
+// nearer than 2^-39 (relative) to a float rounding boundary -- a boundary below 2^17 has an odd numerator over 2^(24-e), and
+// S * 2^(24-e) - 16129 * odd is a non-zero integer.  So ANY evaluation good to 2^-40 rounds to the same float.  For |S| < 2^24 (S exact in a
+// float): q = fl(S * c), r = S - 16129 q exactly (one fma: |r| < 2 and a multiple of ulp(q) with a 14-bit factor), result = fl(q + r * c) --
+// off by ulp(q) * 2^-25 before the final rounding.  Four full-rate instructions instead of four half-rate double ones; the matrix stores of a unit
+// are bound by this arithmetic, not by the store path (measured: the same values stored to linear addresses take the same time).
+// Checked against the double expression for every |S| <= 2^24 (tests/test_xengine_gpu.py::test_ichar_scale_single_precision_is_exact).
+__device__ __forceinline__ float xe_scale127_small(int S)
+{
+    const float c = 6.2000123e-05f;  // fl(1 / 16129)
+    const float sf = (float)S;
+    const float q = sf * c;
+    const float r = __builtin_fmaf(-q, 16129.0f, sf);
+    return __builtin_fmaf(r, c, q);
+}
+// all values of every lane inside (-2^24, 2^24)?  (wave-uniform)
+__device__ __forceinline__ bool xe_all_small(unsigned m) { return __builtin_amdgcn_ballot_w64((m >> 25) != 0u) == 0ull; }
+__device__ __forceinline__ unsigned xe_mag_bits(int v) { return (unsigned)(v + 0x1000000); }  // bits 25.. set unless -2^24 <= v < 2^24
 
 // one LDS-DMA piece: every lane fetches 16 bytes from its own global address; they land at lds_dst + lane * 16
 __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst)
@@ -142,9 +172,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
     // ---- which slice / time range: the 4 workgroups of a 128-byte line on one XCD, same time range
     // (the batched form adds the integration window to the combination: consecutive workgroups go to the eight XCDs round robin, so the
     // four workgroups of a 128-byte line must be 8 apart to meet in one L2)
-    int slice, q, win;
-    {
-        const int b = blockIdx.x;
+    // b: the unit's number = the workgroup number of the one-unit-per-workgroup form
+    auto map_unit = [&](int b, int &slice, int &q, int &win) {
         int combo, sector;
         if (a.pinned) {
             const int xcd = (b + ((a.dbg >> 20) & 7)) & 7, within = b >> 3;  // (dbg bits 20..22: which lines an XCD gets, a tuning aid)
@@ -181,16 +210,26 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
             else { q = xcd & 3; line = (xcd >> 2) * 8 + (within >> 2); }
             slice = line * 4 + (within & 3);
         }
-        a.in += (size_t)win * a.in_window;
-        a.out += (size_t)win * a.out_window;
-        a.part += (size_t)win * a.part_window;
+    };
+    if constexpr (RS) {
+        // The arrival words come in two banks, launch e counts in bank e % 2 from zero to four and every launch first clears the OTHER bank's word
+        // of its slice: whatever an earlier launch left there (a launch that did not run to its end, a debug switch that made workgroups leave
+        // before they arrived) is gone before launch e + 1 -- stream-ordered behind this one -- looks at it.  No state survives two launches.
+        if (tid == 0) {
+            int slice, q, win;
+            map_unit(blockIdx.x, slice, q, win);
+            if (q == 0)
+                __hip_atomic_store((unsigned long long *)a.flags + (size_t)((a.epoch + 1u) & 1u) * a.flag_bank + (size_t)win * (a.nlines * 4) + slice, 0ull,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     if ((a.dbg >> 16) & 3) {  // tuning aid: only (1) / all but (2) the lines 3 and 11 of a row
+        int slice, q, win;
+        map_unit(blockIdx.x, slice, q, win);
         const bool l3 = ((slice >> 2) & 7) == 3;
         if ((((a.dbg >> 16) & 3) == 1) != l3) return;
     }
     const size_t row_bytes = (size_t)a.row_stride;  // (a row may end inside its last 128-byte line: the pieces past its end read the zero row)
-    const int t_base = q * a.steps * 32;
     const unsigned lds0 = (unsigned)(size_t)lds;
 
     // ---- DMA of one 16-step stage: chunk = (time step, station half) = 32 stations x 32 B, 2 * NSH chunks per wave
@@ -198,15 +237,48 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
     // contiguous block (what the all-to-all corner turn of shard.py delivers; in_group = windows * T * ng rows); ng == N is the
     // reference's layout
     const size_t t_stride = (size_t)a.ng * row_bytes;
+    // the unit whose K blocks are being REQUESTED (in the persistent form one unit ahead of the unit being multiplied at a unit's end)
     const unsigned char *src_lane[NSH];
+    const unsigned char *pf_src = nullptr;
+    bool in_row = false;
+    int t_base = 0;
+    // ---- The slow lines.  HBM serves the 128-byte lines whose address has bits 7..9 == 3 (two of a 2 KiB row's sixteen) with ~1.75 x the
+    // latency of the others, and a CU's request stream is latency bound: from HBM the 32 workgroups of those lines end their loop at 69 us
+    // when the other 224 are done at 37 (profiles/r04_xengine_counters.txt section 0).  Once a line sits in the Infinity Cache the gap is small
+    // (35 against 29 us on a cache-resident input).  So the workgroups of the OTHER lines -- which run ahead -- touch the slow lines' rows of
+    // their own time range two K blocks early: one 16-byte request per line, the 52 workgroups of the other lines share a block's 6144 lines
+    // (lines 3 and 11, and line 15 whose latency is 1.15 x), 32 lanes of each wave of the first group, ~6 % more requests for them; the data land in a 1 KiB scratch behind the ring and are never read.  (First in the wave's queue of a
+    // step, so the step's own loads are not held up by the slow class's latency; only the ping-pong schedule, whose waits are vmcnt(0).)
+    // (the lane's source address for K block 0 is worked out once per unit; a step adds the block's offset: one address add and one request)
+    auto setup_requests = [&](int b) {
+        int slice, q, win;
+        map_unit(b, slice, q, win);
+        const unsigned char *in_w = a.in + (size_t)win * a.in_window;
+        t_base = q * a.steps * 32;
 #pragma unroll
-    for (int sh = 0; sh < NSH; sh++) {
-        const int s = sh * 32 + (lane >> 1);
-        src_lane[sh] = a.in + (size_t)(s / a.ng) * a.in_group + (size_t)(s % a.ng) * row_bytes + (size_t)slice * 32 + (lane & 1) * 16;
-    }
-    const bool in_row = slice * 32 + (lane & 1) * 16 < a.row_stride;  // this lane's 16 bytes of the slice exist
-    auto issue_stage = [&](int sigma) {
-        const int slot = sigma & (kRing - 1), t0 = t_base + sigma * kStageT;
+        for (int sh = 0; sh < NSH; sh++) {
+            const int s = sh * 32 + (lane >> 1);
+            src_lane[sh] = in_w + (size_t)(s / a.ng) * a.in_group + (size_t)(s % a.ng) * row_bytes + (size_t)slice * 32 + (lane & 1) * 16;
+        }
+        in_row = slice * 32 + (lane & 1) * 16 < a.row_stride;  // this lane's 16 bytes of the slice exist
+        pf_src = nullptr;
+        if (a.pf_dist > 0 && wave < 4) {
+            const int pf_line = slice >> 2, pf_n = __builtin_popcount(a.pf_mask);
+            const int pf_wgs = (a.nlines - pf_n) * 4, pf_rank = __builtin_popcount(~a.pf_mask & ((1u << pf_line) - 1u)) * 4 + (slice & 3);  // this workgroup among those of the other lines
+            const int items = 32 * a.N * pf_n, per = (items + pf_wgs - 1) / pf_wgs;  // (row of a K block, slow line): at most 128 per workgroup, 32 per wave of the first group
+            const int k = wave * 32 + lane, i = pf_rank * per + k;
+            if (!((a.pf_mask >> pf_line) & 1) && lane < 32 && k < per && i < items) {
+                const int which = i % pf_n, row = i / pf_n, t = row / a.N, st = row - t * a.N;
+                const int ln = (int)((a.pf_lines >> (8 * which)) & 0xffu);  // the which-th slow line
+                pf_src = in_w + (size_t)(st / a.ng) * a.in_group + ((size_t)(t_base + t) * a.ng + st % a.ng) * row_bytes + (size_t)ln * 128;
+            }
+        }
+    };
+    setup_requests(blockIdx.x);
+    // stage sigma (16 time steps) of the unit being requested, into ring slot ring_stage % 4 (ring_stage counts the stages of ALL units of
+    // this workgroup: the ring does not care which unit a stage belongs to)
+    auto issue_stage = [&](int sigma, int ring_stage) {
+        const int slot = ring_stage & (kRing - 1), t0 = t_base + sigma * kStageT;
 #pragma unroll
         for (int k = 0; k < 2 * NSH; k++) {
             const int idx = wave + kWaves * k, t16 = idx / NSH, sh = idx % NSH;
@@ -219,12 +291,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
 
     v4i re[CPW][NP], im[CPW][NP];
     unsigned rs[CPW][NTT];  // biased row sums of I (v_sad_u8 of the bytes xor 0x80)
+    if constexpr (!PP) {
 #pragma unroll
-    for (int c = 0; c < CPW; c++) {
+        for (int c = 0; c < CPW; c++) {
 #pragma unroll
-        for (int p = 0; p < NP; p++) re[c][p] = im[c][p] = (v4i){0, 0, 0, 0};
+            for (int p = 0; p < NP; p++) re[c][p] = im[c][p] = (v4i){0, 0, 0, 0};
 #pragma unroll
-        for (int rt = 0; rt < NTT; rt++) rs[c][rt] = 0u;
+            for (int rt = 0; rt < NTT; rt++) rs[c][rt] = 0u;
+        }
     }
 
     const int r = lane & 15, g = lane >> 4;
@@ -236,38 +310,14 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
     // operands) first, so the slots are free again after a second barrier and the DMA of step j+2 is issued BEFORE the matrix
     // products of step j: two steps (128 KB per CU) are in flight while the wave multiplies.
     constexpr int PER_STEP = 4 * NSH;  // DMA instructions per wave and step (every wave issues all of them: N > 32 when NSH == 2)
-    // ---- The slow lines.  HBM serves the 128-byte lines whose address has bits 7..9 == 3 (two of a 2 KiB row's sixteen) with ~1.75 x the
-    // latency of the others, and a CU's request stream is latency bound: from HBM the 32 workgroups of those lines end their loop at 69 us
-    // when the other 224 are done at 37 (profiles/r04_xengine_counters.txt section 0).  Once a line sits in the Infinity Cache the gap is small
-    // (35 against 29 us on a cache-resident input).  So the workgroups of the OTHER lines -- which run ahead -- touch the slow lines' rows of
-    // their own time range two K blocks early: one 16-byte request per line, the 52 workgroups of the other lines share a block's 6144 lines
-    // (lines 3 and 11, and line 15 whose latency is 1.15 x), 32 lanes of each wave of the first group, ~6 % more requests for them; the data land in a 1 KiB scratch behind the ring and are never read.  (First in the wave's queue of a
-    // step, so the step's own loads are not held up by the slow class's latency; only the ping-pong schedule, whose waits are vmcnt(0).)
-    // (the lane's source address for K block 0 is worked out once; a step adds the block's offset: one address add and one request)
-    const unsigned char *pf_src = nullptr;
-    if (a.pf_dist > 0 && wave < 4) {
-        const int pf_line = slice >> 2, pf_n = __builtin_popcount(a.pf_mask);
-        const int pf_wgs = (a.nlines - pf_n) * 4, pf_rank = __builtin_popcount(~a.pf_mask & ((1u << pf_line) - 1u)) * 4 + (slice & 3);  // this workgroup among those of the other lines
-        const int items = 32 * a.N * pf_n, per = (items + pf_wgs - 1) / pf_wgs;  // (row of a K block, slow line): at most 128 per workgroup, 32 per wave of the first group
-        const int k = wave * 32 + lane, i = pf_rank * per + k;
-        if (!((a.pf_mask >> pf_line) & 1) && lane < 32 && k < per && i < items) {
-            const int which = i % pf_n, row = i / pf_n, t = row / a.N, st = row - t * a.N;
-            int ln = 0, seen = -1;  // the which-th slow line
-            for (int l = 0; l < 32; l++) {
-                seen += (a.pf_mask >> l) & 1;
-                if (seen == which && ((a.pf_mask >> l) & 1)) { ln = l; break; }
-            }
-            pf_src = a.in + (size_t)(st / a.ng) * a.in_group + ((size_t)(t_base + t) * a.ng + st % a.ng) * row_bytes + (size_t)ln * 128;
-        }
-    }
     auto prefetch_slow = [&](int blk) {
         if (pf_src) dma16(pf_src + (size_t)blk * 32 * t_stride, __builtin_amdgcn_readfirstlane(lds0 + kRing * STAGE));
     };
-    issue_stage(0);
-    issue_stage(1);
+    issue_stage(0, 0);
+    issue_stage(1, 1);
     if (a.steps > 1) {
-        issue_stage(2);
-        issue_stage(3);
+        issue_stage(2, 2);
+        issue_stage(3, 3);
     }
     // the raw bytes of block j (stages 2j, 2j + 1) -> MFMA operands in registers
     auto read_block = [&](int j, long (&I)[CPW][NTT], long (&Q)[CPW][NTT]) {
@@ -323,8 +373,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
             if (j + 1 + a.pf_dist < a.steps) prefetch_slow(j + 1 + a.pf_dist);
         }
         if (j + 2 < a.steps) {
-            issue_stage(2 * j + 4);
-            issue_stage(2 * j + 5);
+            issue_stage(2 * j + 4, 2 * j + 4);
+            issue_stage(2 * j + 5, 2 * j + 5);
         }
     };
     // two sweeps over the pairs so that consecutive MFMAs never touch the same accumulator
@@ -349,80 +399,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
                 }
         }
     };
-    if constexpr (PP) {
-        // Ping-pong: the two waves of a SIMD (w and w + 4) run half a step apart.  Waves 0-3 read block j and then multiply it; waves 4-7
-        // first multiply block j - 1 (operands kept across the barrier) and then read block j: one wave's matrix products run beside the
-        // other's LDS reads and byte transposes instead of both doing the same thing at the same time.  ONE barrier per step: behind it
-        // block j has landed and nobody reads block j - 1 any more, whose slots take block j + 1.
-        // Both groups run the same body -- read block j, multiply block j -- and differ only in where the step's barrier sits: before the
-        // read (group 0) or between read and multiply (group 1, which therefore multiplies block j while group 0 already reads j + 1).
-        // (waves w and w + 4 share a SIMD: a workgroup's waves are placed round robin over the four SIMDs -- checked with HW_REG_HW_ID.)
-        // The second group gets static priority: the first group's products (older waves win the arbitration) would otherwise hold back
-        // the last few products of the second group's phase for a whole phase, and everybody waits for them at the barrier.
-        const int grp = wave >> 2;
-        if (grp == 1 && !(a.dbg & 32)) __builtin_amdgcn_s_setprio(1);
-        auto top = [&](int j) {  // block j has landed for every wave, nobody reads block j - 1 any more: its slots take block j + 1
-            if (j == 0 && a.steps > 1) {
-                if constexpr (PER_STEP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __syncthreads();
-            if (j == 0) stamp(a, 1);
-            if (PP && a.pf_dist > 0) {  // (the slow lines' own requests for blocks 0 and 1 go out at launch: nothing to gain there)
-                if (j == 0) for (int b2 = 2; b2 < a.pf_dist && b2 < a.steps; b2++) prefetch_slow(b2);
-                if (j + a.pf_dist < a.steps) prefetch_slow(j + a.pf_dist);
-            }
-            if (j >= 1 && j + 1 < a.steps) {
-                issue_stage(2 * j + 2);
-                issue_stage(2 * j + 3);
-            }
-        };
-        unsigned long long c_top = 0, c_read = 0, c_mul = 0;  // (tuning aid: shader cycles per phase, waves 0 and 4)
-        for (int j = 0; j < a.steps; j++) {
-            long I[CPW][NTT], Q[CPW][NTT];
-            const unsigned long long t0 = a.ts ? __builtin_readcyclecounter() : 0;
-            if (grp == 0 || j == 0) top(j);
-            const unsigned long long t1 = a.ts ? __builtin_readcyclecounter() : 0;
-            if (!(a.dbg & (1 | 128))) read_block(j, I, Q);
-            else if (a.dbg & 128) {
-#pragma unroll
-                for (int c = 0; c < CPW; c++)
-#pragma unroll
-                    for (int rt = 0; rt < NTT; rt++) { I[c][rt] = rs[c][rt]; Q[c][rt] = j; }
-            }
-            if (a.ts) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const unsigned long long t2 = a.ts ? __builtin_readcyclecounter() : 0;
-            if (grp == 1 && j + 1 < a.steps) top(j + 1);
-            const unsigned long long t3 = a.ts ? __builtin_readcyclecounter() : 0;
-            if (!(a.dbg & (1 | 64))) mfma32(I, Q);
-            else if (a.dbg & 64) {
-#pragma unroll
-                for (int c = 0; c < CPW; c++)
-#pragma unroll
-                    for (int rt = 0; rt < NTT; rt++) rs[c][rt] += (unsigned)I[c][rt] ^ (unsigned)Q[c][rt];
-            }
-            if (a.ts) {
-                const unsigned long long t4 = __builtin_readcyclecounter();
-                c_top += (t1 - t0) + (t3 - t2);
-                c_read += t2 - t1;
-                c_mul += t4 - t3;
-            }
-        }
-        if (a.ts && (tid == 0 || tid == 256)) {
-            unsigned long long *d = a.ts + (size_t)blockIdx.x * 16 + 8 + (tid >> 8);
-            *d = (c_top & 0xfffff) | ((c_read & 0xfffff) << 20) | ((c_mul & 0xfffff) << 40);
-        }
-    } else {
-        for (int j = 0; j < a.steps; j++) {
-            long I[CPW][NTT], Q[CPW][NTT];
-            load_block(j, I, Q);
-            if (!(a.dbg & 1)) mfma32(I, Q);
-        }
-    }
-
+    __shared__ int s_mode, s_mask;
+    // ---- what a unit does with its finished accumulators (b: the unit's number, see map_unit)
+    auto finish_unit = [&](int b, int unit_idx, bool last_unit) {
+    int slice, q, win;
+    map_unit(b, slice, q, win);
+    c32 *const out_w = a.out + (size_t)win * a.out_window;
+    v4i *const part_w = a.part + (size_t)win * a.part_window;
     stamp(a, 2);
+    if (a.ts && tid == 0 && unit_idx >= 1 && unit_idx < 4) a.ts[(size_t)blockIdx.x * 16 + 8 + 2 * unit_idx] = wall_clock64();  // (later units: loop end)
     // ---- Reduce-scatter of the four time ranges of a slice INSIDE the launch (64-row geometry, four ranges of at most 256 steps).
     // A lane holds 64 values per channel: 8 per off-diagonal tile pair (re, im) and 4 per diagonal one (re on and below the diagonal, im
     // above it), i.e. 16 quads; quads 4u .. 4u+3 belong to unit (time range) u of the slice: u = 0, 1, 2 two off-diagonal pairs each,
@@ -443,7 +428,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
             int r = lane & 15, g = lane >> 4, ll = lane;
             asm volatile("" : "+v"(r), "+v"(g), "+v"(ll));
             const int nbl = a.N * (a.N + 1) / 2, np2l = NPOL * NPOL, Al = a.N * NPOL;
-            unsigned char *inbox = (unsigned char *)a.part + (size_t)slice * (4 * 4 * kWaves * CPW * 3072);
+            unsigned char *inbox = (unsigned char *)part_w + (size_t)slice * (4 * 4 * kWaves * CPW * 3072);
             auto slot = [&](int dst, int src, int c) { return inbox + ((size_t)((dst * 4 + src) * kWaves + wave) * CPW + c) * 3072 + ll * 16; };
             int own[CPW][16];
 #pragma unroll
@@ -510,9 +495,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
                 }
             }
             stamp(a, 3);
-            __shared__ int s_mode, s_mask;
-            unsigned long long *state = (unsigned long long *)a.flags + (size_t)win * (a.nlines * 4) + slice;  // arrival count in the high word, {launch tag, give-up bits} in the low
-            const unsigned full = a.epoch * 4u, tag = a.epoch & 0x0fffffffu;
+            // arrival count in the high word, {launch tag, give-up bits} in the low; this launch's bank of words (see the kernel's entry)
+            unsigned long long *state = (unsigned long long *)a.flags + (size_t)(a.epoch & 1u) * a.flag_bank + (size_t)win * (a.nlines * 4) + slice;
+            const unsigned full = 4u, tag = a.epoch & 0x0fffffffu;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have completed
             __syncthreads();
             stamp(a, 4);
@@ -527,10 +512,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
                     // Bounded by TIME (100 MHz wall clock): the units of a slice finish within a microsecond or two of each other when all are
                     // resident.  A partner that is not -- the device shared with another stream's kernels, e.g. the exchange of the sharded
                     // pipeline: a workgroup of this kernel needs a whole CU's registers -- starts when the first workgroups leave and arrives
-                    // one loop + send later (~80 us after launch at config 5's range length); waiting for it costs the same as the
-                    // second kernel would, giving up before it comes makes it finish the whole slice alone.  Beyond that nobody waits.
+                    // one loop + send later; waiting that long costs the same as the second kernel would, giving up before it comes makes
+                    // it finish the whole slice alone.  So the bound is about one loop of THIS geometry (FuArgs::wait_ticks: 10 us + 6 us per
+                    // K block of a range, between 20 and 100 us); beyond that nobody holds a CU.
                     // (dbg 512: give up at once -- exercises the fallback in the tests)
-                    const unsigned long long t_wait = wall_clock64(), limit = (a.dbg & 512) ? 0 : 10000;  // 100 us
+                    const unsigned long long t_wait = wall_clock64(), limit = (a.dbg & 512) ? 0 : (unsigned long long)a.wait_ticks;
                     do {
                         const unsigned long long cur = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if ((unsigned)(cur >> 32) == full) mode = 1;
@@ -575,6 +561,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
             auto emit = [&](int u, int c, const int (&v)[16]) {
                 const int f = slice * (16 / NPOL) + ((NPOL == 1) ? 2 * wave + c : wave);
                 if (f >= a.Fout) return;
+                unsigned mag = 0;
+#pragma unroll
+                for (int i = 0; i < 16; i++) mag |= xe_mag_bits(v[i]);
+                const bool small = a.k127 && xe_all_small(mag);  // (wave-uniform: the single-precision form of the scale, see xe_scale127_small)
                 if (u < 3 && NPOL == 1 && Al == 64 && !a.accumulate) {
                     // whole tiles, one polarisation: neighbouring lanes hold neighbouring baselines of a row, so a lane pair swaps one value
                     // each and every lane stores 16 bytes (two baselines) of ONE row -- half the store instructions of the 8-byte form, and
@@ -587,8 +577,13 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
                             c32 w[2];
 #pragma unroll
                             for (int e = 0; e < 2; e++) {
-                                w[e].x = (float)((double)v[8 * it + rp + e] * a.kd * a.kd);  // the oracle's expression: (double)S * kd * kd, rounded once
-                                w[e].y = (float)((double)v[8 * it + 4 + rp + e] * a.kd * a.kd);
+                                if (small) {
+                                    w[e].x = xe_scale127_small(v[8 * it + rp + e]);
+                                    w[e].y = xe_scale127_small(v[8 * it + 4 + rp + e]);
+                                } else {
+                                    w[e].x = (float)((double)v[8 * it + rp + e] * a.kd * a.kd);  // the oracle's expression: (double)S * kd * kd, rounded once
+                                    w[e].y = (float)((double)v[8 * it + 4 + rp + e] * a.kd * a.kd);
+                                }
                             }
                             const bool odd = (r & 1) != 0;
                             const float sx = odd ? w[0].x : w[1].x, sy = odd ? w[0].y : w[1].y;  // what the neighbour stores of this lane's values
@@ -597,7 +592,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
                             const size_t o = (size_t)f * nbl + (s1 * (s1 + 1) / 2 + s2);
                             typedef float v4f __attribute__((ext_vector_type(4)));
                             const v4f q4 = odd ? (v4f){gx, gy, w[1].x, w[1].y} : (v4f){w[0].x, w[0].y, gx, gy};
-                            __builtin_memcpy((void *)(a.out + o), &q4, 16);
+                            __builtin_memcpy((void *)(out_w + o), &q4, 16);
                         }
                     }
                 } else if (u < 3) {
@@ -614,8 +609,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
                             c32 w;
                             w.x = (float)((double)v[8 * it + reg] * a.kd * a.kd);  // the oracle's expression: (double)S * kd * kd, rounded once
                             w.y = (float)((double)v[8 * it + 4 + reg] * a.kd * a.kd);
-                            if (a.accumulate) { w.x += a.out[o].x; w.y += a.out[o].y; }
-                            a.out[o] = w;
+                            if (a.accumulate) { w.x += out_w[o].x; w.y += out_w[o].y; }
+                            out_w[o] = w;
                         }
                     }
                 } else {
@@ -641,15 +636,20 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
                                     const int i = 4 * g + rp + e;
                                     const int tr = trow[rp + e], sre = v[4 * d + rp + e];
                                     const int sim = i > r ? -tr : 0;  // (below the diagonal im[i][j] = -im[j][i]; on it 0; above it: not stored)
-                                    w[e].x = (float)((double)sre * a.kd * a.kd);
-                                    w[e].y = (float)((double)sim * a.kd * a.kd);
+                                    if (small) {
+                                        w[e].x = xe_scale127_small(sre);
+                                        w[e].y = xe_scale127_small(sim);
+                                    } else {
+                                        w[e].x = (float)((double)sre * a.kd * a.kd);
+                                        w[e].y = (float)((double)sim * a.kd * a.kd);
+                                    }
                                 }
                                 const bool odd = (r & 1) != 0;
                                 const float sx = odd ? w[0].x : w[1].x, sy = odd ? w[0].y : w[1].y;
                                 const float gx = __shfl_xor(sx, 1), gy = __shfl_xor(sy, 1);
                                 const int i = 4 * g + rp + (odd ? 1 : 0), j0 = r & ~1;  // this lane stores columns j0, j0 + 1 of row i
                                 const int s1 = d * 16 + i;
-                                c32 *dst = a.out + (size_t)f * nbl + (s1 * (s1 + 1) / 2 + d * 16 + j0);
+                                c32 *dst = out_w + (size_t)f * nbl + (s1 * (s1 + 1) / 2 + d * 16 + j0);
                                 const c32 first = odd ? c32{gx, gy} : w[0], second = odd ? w[1] : c32{gx, gy};
                                 if (j0 + 1 <= i) {
                                     typedef float v4f __attribute__((ext_vector_type(4)));
@@ -677,8 +677,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
                             c32 w;
                             w.x = (float)((double)sre * a.kd * a.kd);
                             w.y = (float)((double)sim * a.kd * a.kd);
-                            if (a.accumulate) { w.x += a.out[o].x; w.y += a.out[o].y; }
-                            a.out[o] = w;
+                            if (a.accumulate) { w.x += out_w[o].x; w.y += out_w[o].y; }
+                            out_w[o] = w;
                         }
                     }
                 }
@@ -796,11 +796,58 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
                 v4i vre = re[c][p], vim = im[c][p];
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) vim[reg] += corr[reg];
-                if (a.dbg & 2) { if (vre[0] == 0x12345678 && vim[1] == 0x7654321) a.part[lane] = vre; continue; }
+                if (a.dbg & 2) { if (vre[0] == 0x12345678 && vim[1] == 0x7654321) part_w[lane] = vre; continue; }
+                if constexpr (!SPLIT && NPOL == 1 && NTT == 4) {
+                    // whole 64-row matrices, one polarisation: neighbouring lanes hold neighbouring baselines of a row, so a lane pair swaps one
+                    // value each and every lane stores 16 bytes (two baselines) of ONE row -- half the store instructions of the 8-byte form
+                    // (the matrix stores of a unit are bound by store issue, not by bytes); on a diagonal tile pair the row's triangle may end
+                    // inside the pair (one baseline, 8 bytes) or before it (nothing)
+                    if (A == 64 && !a.accumulate && !(a.dbg & 2048)) {
+                        if (f >= a.Fout) continue;
+                        const bool odd = (r & 1) != 0;
+                        unsigned mag = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) mag |= xe_mag_bits(vre[k]) | xe_mag_bits(vim[k]);
+                        const bool small = a.k127 && xe_all_small(mag);
+#pragma unroll
+                        for (int rp = 0; rp < 4; rp += 2) {
+                            c32 w[2];
+                            if (small) {
+#pragma unroll
+                                for (int e = 0; e < 2; e++) {
+                                    w[e].x = xe_scale127_small(vre[rp + e]);
+                                    w[e].y = xe_scale127_small(vim[rp + e]);
+                                }
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 2; e++) {
+                                    // int32 wrap-around can only have happened for re == +2^31 (every sample -128 over 65536 frames)
+                                    const double dre = (vre[rp + e] == (int)0x80000000) ? 2147483648.0 : (double)vre[rp + e];
+                                    w[e].x = (float)(dre * a.kd * a.kd);  // the oracle's expression: (double)S * kd * kd, rounded once
+                                    w[e].y = (float)((double)vim[rp + e] * a.kd * a.kd);
+                                }
+                            }
+                            const float sx = odd ? w[0].x : w[1].x, sy = odd ? w[0].y : w[1].y;  // what the neighbour stores of this lane's values
+                            const float gx = __shfl_xor(sx, 1), gy = __shfl_xor(sy, 1);
+                            const int i = 4 * g + rp + (odd ? 1 : 0), j0 = r & ~1;  // this lane stores columns j0, j0 + 1 of row i of the tile pair
+                            const int s1 = bi * 16 + i;
+                            c32 *dst = out_w + (size_t)f * nb + (s1 * (s1 + 1) / 2 + bj * 16 + j0);
+                            const c32 first = odd ? c32{gx, gy} : w[0], second = odd ? w[1] : c32{gx, gy};
+                            if (bi != bj || j0 + 1 <= i) {
+                                typedef float v4f __attribute__((ext_vector_type(4)));
+                                const v4f q4 = (v4f){first.x, first.y, second.x, second.y};
+                                __builtin_memcpy((void *)dst, &q4, 16);
+                            } else if (j0 <= i) {
+                                *dst = first;
+                            }
+                        }
+                        continue;
+                    }
+                }
                 if constexpr (SPLIT) {
                     if (a.compact == 2) {
                         constexpr int OD = NTT * (NTT - 1) / 2;
-                        unsigned char *blk = (unsigned char *)a.part + ((size_t)q * a.F + f) * pk_block_bytes(NTT);
+                        unsigned char *blk = (unsigned char *)part_w + ((size_t)q * a.F + f) * pk_block_bytes(NTT);
                         if (bi == bj) {
                             v4i comb;
 #pragma unroll
@@ -820,7 +867,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
                         // A diagonal tile pair needs re (symmetric) and im (antisymmetric, zero diagonal) of ONE triangle: both go into one
                         // 16 x 16 record, re on and below the diagonal, im above it (im[i][j] = -im[j][i] is rebuilt by the reduction).
                         // 2 NP - NTT records of 1 KiB per channel and time range instead of 2 NP: a fifth less partial-sum traffic at 64 rows.
-                        v4i *dst = a.part + (((size_t)q * a.F + f) * (2 * NP - NTT) + (2 * p - bi)) * 64 + lane;
+                        v4i *dst = part_w + (((size_t)q * a.F + f) * (2 * NP - NTT) + (2 * p - bi)) * 64 + lane;
                         if (bi == bj) {
                             v4i comb;
 #pragma unroll
@@ -831,7 +878,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
                             __builtin_nontemporal_store(vim, dst + 64);
                         }
                     } else {
-                        v4i *dst = a.part + ((((size_t)q * a.F + f) * NP + p) * 2) * 64 + lane;
+                        v4i *dst = part_w + ((((size_t)q * a.F + f) * NP + p) * 2) * 64 + lane;
                         __builtin_nontemporal_store(vre, dst);
                         __builtin_nontemporal_store(vim, dst + 64);
                     }
@@ -849,8 +896,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
                         c32 v;
                         v.x = (float)(dre * a.kd * a.kd);  // the oracle's expression: (double)S * kd * kd, rounded once
                         v.y = (float)((double)vim[reg] * a.kd * a.kd);
-                        if (a.accumulate) { v.x += a.out[o].x; v.y += a.out[o].y; }
-                        a.out[o] = v;
+                        if (a.accumulate) { v.x += out_w[o].x; v.y += out_w[o].y; }
+                        out_w[o] = v;
                     }
                 }
             }
@@ -858,10 +905,95 @@ __global__ __launch_bounds__(kThreads, 2) void k_xe_i8_fused(FuArgs a)
     }
     if (a.ts) {
         stamp(a, 3);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        stamp(a, 4);
+        if (tid == 0 && unit_idx >= 1 && unit_idx < 4) a.ts[(size_t)blockIdx.x * 16 + 9 + 2 * unit_idx] = wall_clock64();  // (later units: stores issued)
+        if (last_unit) {  // (a barrier after an earlier unit would pair with the other ping-pong group's step barrier)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            stamp(a, 4);
+        }
     }
+    }
+    };
+    if constexpr (PP) {
+        // Ping-pong: the two waves of a SIMD (w and w + 4) run half a step apart.  Waves 0-3 read block j and then multiply it; waves 4-7
+        // first multiply block j - 1 (operands kept across the barrier) and then read block j: one wave's matrix products run beside the
+        // other's LDS reads and byte transposes instead of both doing the same thing at the same time.  ONE barrier per step: behind it
+        // block j has landed and nobody reads block j - 1 any more, whose slots take block j + 1.
+        // Both groups run the same body -- read block j, multiply block j -- and differ only in where the step's barrier sits: before the
+        // read (group 0) or between read and multiply (group 1, which therefore multiplies block j while group 0 already reads j + 1).
+        // (waves w and w + 4 share a SIMD: a workgroup's waves are placed round robin over the four SIMDs -- checked with HW_REG_HW_ID.)
+        // The second group gets static priority: the first group's products (older waves win the arbitration) would otherwise hold back
+        // the last few products of the second group's phase for a whole phase, and everybody waits for them at the barrier.
+        const int grp = wave >> 2;
+        if (grp == 1 && !(a.dbg & 32)) __builtin_amdgcn_s_setprio(1);
+        // Persistent form (a.items > 1): the blocks of all units of this workgroup form ONE stream through the ring.  The request for the
+        // first block of unit k + 1 goes out behind the barrier of unit k's last block, the second one behind the next barrier, so the
+        // first-load latency of a unit (8-14 us from HBM) runs under the previous unit's last products and its matrix stores.
+        const int items = SPLIT ? 1 : a.items;  // (time ranges: one unit per workgroup, their workgroups must all be resident)
+        const int total = items * a.steps;
+        auto top = [&](int gb) {  // block gb (counted over all units) has landed for every wave, nobody reads block gb - 1 any more: its slots take block gb + 1
+            if (gb == 0 && total > 1) {
+                if constexpr (PER_STEP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            if (gb == 0) stamp(a, 1);
+            if (gb + 1 < total) {
+                const int jb = (gb + 1) % a.steps;  // the block to request, counted inside its unit
+                if (jb == 0) {  // the next unit of this workgroup: the same slice of a later window (see FuArgs::items)
+#pragma unroll
+                    for (int sh = 0; sh < NSH; sh++) src_lane[sh] += a.unit_in_step;
+                    if (pf_src) pf_src += a.unit_in_step;
+                }
+                if (a.pf_dist > 0) {  // (the slow lines' own requests for blocks 0 and 1 of the first unit go out at launch: nothing to gain there)
+                    if (gb == 0) for (int b2 = 2; b2 < a.pf_dist && b2 < a.steps; b2++) prefetch_slow(b2);
+                    if (jb + a.pf_dist - 1 < a.steps) prefetch_slow(jb + a.pf_dist - 1);
+                }
+                if (gb >= 1) {
+                    issue_stage(2 * jb, 2 * gb + 2);
+                    issue_stage(2 * jb + 1, 2 * gb + 3);
+                }
+            }
+        };
+        int gb = 0;  // blocks counted over all units of this workgroup
+        for (int unit = 0; unit < items; unit++) {
+#pragma unroll
+            for (int c = 0; c < CPW; c++) {
+#pragma unroll
+                for (int p = 0; p < NP; p++) re[c][p] = im[c][p] = (v4i){0, 0, 0, 0};
+#pragma unroll
+                for (int rt = 0; rt < NTT; rt++) rs[c][rt] = 0u;
+            }
+            for (int j = 0; j < a.steps; j++, gb++) {
+                long I[CPW][NTT], Q[CPW][NTT];
+                if (grp == 0 || gb == 0) top(gb);
+                if (!(a.dbg & (1 | 128))) read_block(gb, I, Q);
+                else if (a.dbg & 128) {
+#pragma unroll
+                    for (int c = 0; c < CPW; c++)
+#pragma unroll
+                        for (int rt = 0; rt < NTT; rt++) { I[c][rt] = rs[c][rt]; Q[c][rt] = gb; }
+                }
+                if (grp == 1 && gb + 1 < total) top(gb + 1);
+                if (!(a.dbg & (1 | 64))) mfma32(I, Q);
+                else if (a.dbg & 64) {
+#pragma unroll
+                    for (int c = 0; c < CPW; c++)
+#pragma unroll
+                        for (int rt = 0; rt < NTT; rt++) rs[c][rt] += (unsigned)I[c][rt] ^ (unsigned)Q[c][rt];
+                }
+            }
+            finish_unit(blockIdx.x + unit * gridDim.x, unit, unit + 1 == items);
+        }
+    } else {
+        for (int j = 0; j < a.steps; j++) {
+            long I[CPW][NTT], Q[CPW][NTT];
+            load_block(j, I, Q);
+            if (!(a.dbg & 1)) mfma32(I, Q);
+        }
+        finish_unit(blockIdx.x, 0, true);
     }
 }
 
@@ -984,9 +1116,13 @@ template <int NPOL, int NTT, bool SPLIT, bool PP, bool RS> int launch_fused_s(co
 {
     constexpr int NSH = (NTT * 16 / NPOL > 32) ? 2 : 1;
     constexpr int lds_bytes = kRing * (kStageT * NSH * kChunk + 16) + 1024;  // (+ the scratch the slow lines' early touches land in)
-    MI355_HIP(hipFuncSetAttribute((const void *)k_xe_i8_fused<NPOL, NTT, SPLIT, PP, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    static bool attr_set = false;  // (per instantiation; a second thread setting it again is harmless)
+    if (!attr_set) {
+        MI355_HIP(hipFuncSetAttribute((const void *)k_xe_i8_fused<NPOL, NTT, SPLIT, PP, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        attr_set = true;
+    }
     const int nint = a.nint_launch;
-    hipLaunchKernelGGL((k_xe_i8_fused<NPOL, NTT, SPLIT, PP, RS>), dim3((unsigned)(p.units * p.tsplit * nint)), dim3(kThreads), lds_bytes, st, a);
+    hipLaunchKernelGGL((k_xe_i8_fused<NPOL, NTT, SPLIT, PP, RS>), dim3((unsigned)(p.units * p.tsplit * nint / a.items)), dim3(kThreads), lds_bytes, st, a);
     MI355_HIP(hipGetLastError());
     if (SPLIT && !RS) {
         const int NP = NTT * (NTT + 1) / 2;
@@ -1026,7 +1162,7 @@ template <int NPOL> int launch_by_tiles(const XeFusedPlan &p, const FuArgs &a, h
 // tuning aid (MI355_XE_TS=1): one synchronous launch with per-workgroup phase stamps, summary on stderr
 int launch_with_stamps(const XeFusedPlan &p, FuArgs a, hipStream_t st)
 {
-    const int wgs = p.units * p.tsplit * a.nint_launch;
+    const int wgs = p.units * p.tsplit * a.nint_launch / a.items;
     static unsigned long long *d_ts = nullptr;
     static int cap = 0;
     if (cap < wgs) {
@@ -1062,17 +1198,14 @@ int launch_with_stamps(const XeFusedPlan &p, FuArgs a, hipStream_t st)
             fclose(f);
         }
     }
-    for (int w = 0; w < 2; w++) {
-        double st[3] = {0, 0, 0};
-        int n = 0;
-        for (int b = 0; b < wgs; b++) {
-            const unsigned long long v = h[(size_t)b * 16 + 8 + w];
-            if (!v) continue;
-            st[0] += (double)(v & 0xfffff); st[1] += (double)((v >> 20) & 0xfffff); st[2] += (double)((v >> 40) & 0xfffff);
-            n++;
+    for (int u = 1; u < a.items && u < 4; u++)
+        for (int k = 0; k < 2; k++) {
+            std::vector<double> v;
+            for (int b = 0; b < wgs; b++) if (h[(size_t)b * 16 + 8 + 2 * u + k]) v.push_back((double)(h[(size_t)b * 16 + 8 + 2 * u + k] - t0) * 0.01);
+            if (v.empty()) continue;
+            std::sort(v.begin(), v.end());
+            fprintf(stderr, "  unit %d %-13s %7.2f %7.2f %7.2f\n", u + 1, k ? "stores issued" : "loop end", v.front(), v[v.size() / 2], v.back());
         }
-        if (n) fprintf(stderr, "  wave %d: shader cycles in barrier+wait / read / multiply, mean over workgroups: %.0f / %.0f / %.0f\n", 4 * w, st[0] / n, st[1] / n, st[2] / n);
-    }
     int bad = 0;
     for (int b = 0; b < wgs; b++) bad += ((int)h[(size_t)b * 16 + 7] != (b & 7));
     fprintf(stderr, "  workgroups not on XCD blockIdx %% 8: %d\n", bad);
@@ -1080,6 +1213,38 @@ int launch_with_stamps(const XeFusedPlan &p, FuArgs a, hipStream_t st)
 }
 
 }  // namespace
+
+namespace {
+__global__ __launch_bounds__(256) void k_xe_scale_selftest(unsigned long long *bad)
+{
+    const double kd = 0.007874015748031496063;
+    unsigned long long n = 0;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x - (1L << 24); v <= (1L << 24); v += (long)gridDim.x * 256) {
+        const int S = (int)v;
+        const float want = (float)((double)S * kd * kd), got = xe_scale127_small(S);
+        n += __float_as_uint(want) != __float_as_uint(got) ? 1u : 0u;
+    }
+    if (n) atomicAdd(bad, n);
+}
+}  // namespace
+
+extern "C" int mi355_xengine_selftest_scale(mi355_ctx *ctx, long long *mismatches)
+{
+    MI355_REQUIRE(ctx && mismatches, "NULL argument");
+    MI355_HIP(hipSetDevice(ctx->device));
+    unsigned long long *d = nullptr, h = 0;
+    MI355_HIP(hipMalloc(&d, 8));
+    hipError_t e = hipMemset(d, 0, 8);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_xe_scale_selftest, dim3(2048), dim3(256), 0, 0, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    MI355_HIP(e);
+    *mismatches = (long long)h;
+    return MI355_OK;
+}
 
 XeFusedPlan mi355_xe_fused_plan(int N, int F, int Fout, int npol, int T, int num_cus, int nint)
 {
@@ -1114,8 +1279,8 @@ XeFusedPlan mi355_xe_fused_plan(int N, int F, int Fout, int npol, int T, int num
     const int NP = p.ntt * (p.ntt + 1) / 2;
     p.part_per_window = s > 1 ? (size_t)s * F * NP * 2 * 1024 : 0;
     p.flag_offset = p.part_per_window * (nint > 0 ? nint : 1);
-    // (behind the partial sums: one 8-byte arrival word per slice and window for the in-launch reduction)
-    p.part_bytes = s > 1 ? p.flag_offset + (((size_t)p.units * (nint > 0 ? nint : 1) * 8 + (size_t)p.units * (s + 1) * 4 + 255) & ~(size_t)255) : 0;
+    // (behind the partial sums: two banks of one 8-byte arrival word per slice and window for the in-launch reduction)
+    p.part_bytes = s > 1 ? p.flag_offset + (((size_t)2 * p.units * (nint > 0 ? nint : 1) * 8 + 255) & ~(size_t)255) : 0;
     p.ok = true;
     return p;
 }
@@ -1135,7 +1300,15 @@ int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void 
     const int Tp = (T + 31) / 32 * 32;  // whole K blocks
     const char *rs_env = getenv("MI355_XE_INKERNEL_REDUCE");
     a.rs = (epoch && p.tsplit == 4 && p.ntt == 4 && Tp / 4 <= 256 && (long)p.units * 4 * (nint > 0 ? nint : 1) <= p.cus && !(rs_env && atoi(rs_env) == 0)) ? 1 : 0;
-    if (a.rs) a.epoch = ++*epoch;
+    // (the workspace's epoch is committed only once the kernel is enqueued: a launch that fails before that leaves the words and the count as they were)
+    if (a.rs) a.epoch = *epoch + 1u;
+    a.flag_bank = (unsigned)(p.units * (nint > 0 ? nint : 1));
+    a.k127 = (kd == 0.007874015748031496063 && !getenv("MI355_XE_SCALE_F64")) ? 1 : 0;
+    {
+        const int us = 10 + 6 * (Tp / (32 * p.tsplit));
+        a.wait_ticks = (unsigned)(us < 20 ? 20 : us > 100 ? 100 : us) * 100u;
+        if (const char *e = getenv("MI355_XE_WAIT_US")) a.wait_ticks = (unsigned)atoi(e) * 100u;
+    }
     a.compact = !getenv("MI355_XE_NO_COMPACT") ? 1 : 0;
     // 24-bit planes: time ranges of at most 256 steps, at least two row tiles (a lone diagonal record has nothing to pair with)
     if (a.compact && p.tsplit > 1 && Tp / p.tsplit <= 256 && p.ntt >= 2 && !getenv("MI355_XE_NO_PACK24")) a.compact = 2;
@@ -1168,6 +1341,7 @@ int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void 
     // MI355_XE_PF: distance in K blocks (default 2), + 16: without the 1.15 x line; MI355_XE_NO_PREFETCH: off.
     a.pf_mask = 0;
     a.pf_dist = 0;
+    a.pf_lines = 0;
     if ((a.nlines == 8 || a.nlines == 16 || a.nlines == 32) && p.row_stride == a.nlines * 128 && ((size_t)in & 127) == 0 && T % 32 == 0 && a.steps >= 4 &&
         !getenv("MI355_XE_NO_PREFETCH")) {
         const int key = (int)(((size_t)in >> 7) & 15), tune = getenv("MI355_XE_PF") ? atoi(getenv("MI355_XE_PF")) : 2;
@@ -1176,18 +1350,41 @@ int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void 
             if ((c & 7) == 3 || (c == 15 && a.nlines >= 16 && !(tune & 16))) a.pf_mask |= 1u << l;
         }
         a.pf_dist = (tune & 15) >= 2 ? (tune & 15) : 2;
+        int n = 0;
+        for (int l = 0; l < a.nlines; l++)
+            if ((a.pf_mask >> l) & 1) {
+                if (n < 8) a.pf_lines |= (unsigned long long)l << (8 * n);
+                n++;
+            }
+        if (n > 8) { a.pf_mask = 0; a.pf_dist = 0; }
     }
     a.slow_first = -1;
     if (p.tsplit == 1 && a.nint_launch > 1 && a.nlines % 8 == 0 && p.row_stride % 1024 == 0 && ((size_t)in & 127) == 0 &&
         (long)p.units * a.nint_launch > p.cus && (a.pf_dist == 0 || getenv("MI355_XE_SLOW_FIRST")) && !getenv("MI355_XE_NO_SLOW_FIRST"))
         a.slow_first = (int)(((size_t)in >> 7) & 7);
-    if (getenv("MI355_XE_TS")) return launch_with_stamps(p, a, st);
-    if (p.npol == 1) {
-        if (p.ntt == 1) return launch_fused<1, 1>(p, a, st);
-        if (p.ntt == 2) return launch_fused<1, 2>(p, a, st);
-        return launch_fused<1, 4>(p, a, st);
+    // Persistent form: no time ranges, more units than CUs, the ping-pong schedule -- every workgroup runs total / grid units, one after the
+    // other, the next unit's first K blocks requested under the current unit's matrix stores (MI355_XE_NO_PERSIST: one unit per workgroup)
+    a.items = 1;
+    a.unit_in_step = 0;
+    {
+        const long total = (long)p.units * p.tsplit * a.nint_launch;
+        const int per = (int)((total + p.cus - 1) / p.cus);
+        // workgroup b's unit k is unit b + k * grid of the plain form: with the pinned map (xcd = b % 8, sector = (b / 8) % 4, line and window from
+        // b / 32) that is the same slice of window + k * grid / (4 * nlines) when grid / 4 is a multiple of the lines per row
+        if (p.tsplit == 1 && per > 1 && total % per == 0 && a.steps >= 4 && a.pinned && a.slow_first < 0 && a.ng == N && !(dbg & ((7 << 20) | (3 << 12))) &&
+            ((total / per) % 32) == 0 && ((total / per / 4) % a.nlines) == 0 && !getenv("MI355_XE_NO_PINGPONG") && !getenv("MI355_XE_NO_PERSIST")) {
+            a.items = per;
+            a.unit_in_step = (size_t)(total / per / 4 / a.nlines) * a.in_window;
+        }
     }
-    if (p.ntt == 1) return launch_fused<2, 1>(p, a, st);
-    if (p.ntt == 2) return launch_fused<2, 2>(p, a, st);
-    return launch_fused<2, 4>(p, a, st);
+    // MI355_XE_FAIL_LAUNCH (test switch): fail where a bad stream handle or an exhausted device would -- nothing enqueued, an error returned
+    if (getenv("MI355_XE_FAIL_LAUNCH")) {
+        mi355_set_error("fused X-engine launch failed (MI355_XE_FAIL_LAUNCH)");
+        return MI355_ERR_HIP;
+    }
+    int rc;
+    if (getenv("MI355_XE_TS")) rc = launch_with_stamps(p, a, st);
+    else rc = p.npol == 1 ? launch_by_tiles<1>(p, a, st) : launch_by_tiles<2>(p, a, st);
+    if (rc == MI355_OK && a.rs) *epoch = a.epoch;
+    return rc;
 }

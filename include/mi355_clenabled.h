@@ -271,6 +271,10 @@ int mi355_xengine_submit_acquired(mi355_xengine *h, const void *accumulator_or_n
 /* host gather: copy frames [0,nframes) of each input stream into time slots
  * frame0.. of a frame buffer laid out as the reference's pinned host buffer */
 int mi355_xengine_gather(const mi355_xengine *h, int nframes, int frame0, const void *const *inputs, void *frame_buffer);
+/* Self-test of the IChar scale (lib/clXEngine_impl.cc:859-867: every sample / 127, i.e. every sum / 16129): the device evaluates the
+ * single-precision form the matrix stores use and the double expression (float)((double)S * (1/127) * (1/127)) for EVERY sum S with
+ * |S| <= 2^24 (the range the single-precision form is used in) and counts the sums where the two floats differ; *mismatches must be 0. */
+int mi355_xengine_selftest_scale(mi355_ctx *ctx, long long *mismatches);
 
 /* ---------------------------------------------------------------------------
  * Remaining elementwise family.  One handle type; `kind` selects the block:

@@ -665,3 +665,150 @@ def test_early_touches_of_the_slow_lines(gpu, oracle, N, F, T, npol, nint, W, sh
         finally:
             os.environ.pop("MI355_XE_NO_PREFETCH", None)
         assert np.array_equal(out.cpu().numpy().view(np.complex64).reshape(-1), ref), off
+
+
+def test_in_launch_reduction_recovers_from_failed_and_unfinished_launches(gpu, oracle, monkeypatch):
+    """The arrival words of the in-launch reduction must not carry anything from one launch into the next but the launch count:
+    (1) a call that fails before its kernel is enqueued (MI355_XE_FAIL_LAUNCH stands in for a bad stream handle / an exhausted device) returns
+    an error and the next call on the handle is bit-exact; (2) a launch whose workgroups of some row lines leave before they arrive
+    (MI355_XE_DBG bits 16 / 17: the other units wait, give up or finish alone) leaves counts that are short of full behind -- the
+    following launches, which count in the other bank of words and clear this one, are bit-exact again.
+    Single windows on the handle's workspace (config 5's kernel instance: ping-pong schedule + reduce-scatter tail) and batches of
+    windows on the batch workspace."""
+    import torch
+    N, F, T = 64, 1024, 512  # 64 slices x 4 time ranges = 256 workgroups, 4 K blocks per range
+    rng = np.random.default_rng(91)
+    blk = _xe(gpu, gpu.DTYPE_BYTE, 1, N, F, T)
+    per = blk.get_output_buffer_size()
+    xs = [rng.integers(-128, 128, size=T * N * F * 2, dtype=np.int64).astype(np.int8) for _ in range(2)]
+    refs = [oracle.xengine_ichar(N, F, 1, T, x, exact=True) for x in xs]
+    dx = [torch.from_numpy(x).cuda() for x in xs]
+    count = [0]
+
+    def one(expect_ok=True):
+        k = count[0] & 1
+        count[0] += 1
+        out = torch.full((per, 2), 3.0, device="cuda")
+        blk.xcorrelate_device(dx[k], out)
+        torch.cuda.synchronize()
+        if expect_ok:
+            assert np.array_equal(out.cpu().numpy().view(np.complex64).reshape(-1), refs[k]), count[0]
+
+    one(); one()
+    monkeypatch.setenv("MI355_XE_FAIL_LAUNCH", "1")
+    with pytest.raises(gpu.Mi355Error):
+        one()
+    monkeypatch.delenv("MI355_XE_FAIL_LAUNCH")
+    one(); one(); one()
+    for bits in ("65536", "131072"):  # only / all but the workgroups of lines 3 and 11 run: every slice of the others is left unfinished
+        monkeypatch.setenv("MI355_XE_DBG", bits)
+        monkeypatch.setenv("MI355_XE_WAIT_US", "5")  # (nobody waits tens of microseconds for units that never come)
+        one(expect_ok=False)
+        monkeypatch.delenv("MI355_XE_DBG")
+        monkeypatch.delenv("MI355_XE_WAIT_US")
+        one(); one(); one()
+    # the batch workspace: per-rank geometry, 8 windows x 8 slices x 4 ranges = 256 workgroups
+    Fb, nint = 128, 8
+    bb = _xe(gpu, gpu.DTYPE_BYTE, 1, N, Fb, T)
+    perb = bb.get_output_buffer_size()
+    w = rng.integers(-128, 128, size=(nint, T, N, Fb, 1, 2), dtype=np.int64).astype(np.int8)
+    refb = np.concatenate([oracle.xengine_ichar(N, Fb, 1, T, w[i].reshape(-1), exact=True) for i in range(nint)])
+    dw = torch.from_numpy(w).cuda()
+
+    def batch(expect_ok=True):
+        out = torch.full((nint * perb, 2), 3.0, device="cuda")
+        bb.xcorrelate_n_device(nint, dw, out)
+        torch.cuda.synchronize()
+        if expect_ok:
+            assert np.array_equal(out.cpu().numpy().view(np.complex64).reshape(-1), refb)
+
+    batch(); batch()
+    monkeypatch.setenv("MI355_XE_FAIL_LAUNCH", "1")
+    with pytest.raises(gpu.Mi355Error):
+        batch()
+    monkeypatch.delenv("MI355_XE_FAIL_LAUNCH")
+    batch(); batch()
+    monkeypatch.setenv("MI355_XE_DBG", "131072")
+    monkeypatch.setenv("MI355_XE_WAIT_US", "5")
+    batch(expect_ok=False)
+    monkeypatch.delenv("MI355_XE_DBG")
+    monkeypatch.delenv("MI355_XE_WAIT_US")
+    batch(); batch(); batch()
+
+
+def test_one_handle_on_two_streams_is_ordered_by_the_library(gpu, oracle):
+    """One handle, calls alternating between two streams with no synchronisation by the caller: the launches share the handle's partial-sum
+    workspace (inboxes and arrival words of the in-launch reduction), so the library orders them with an event whenever the stream changes
+    (mi355_xengine::ws_stream).  Single windows and batches; every result bit-exact."""
+    import torch
+    N, F, T = 64, 1024, 512
+    rng = np.random.default_rng(92)
+    xs = [rng.integers(-128, 128, size=(T, N, F, 1, 2), dtype=np.int64).astype(np.int8) for _ in range(3)]
+    refs = [oracle.xengine_ichar(N, F, 1, T, x.reshape(-1), exact=True) for x in xs]
+    dx = [torch.from_numpy(x).cuda() for x in xs]
+    blk = _xe(gpu, gpu.DTYPE_BYTE, 1, N, F, T)
+    per = blk.get_output_buffer_size()
+    rounds = 18
+    outs = [torch.zeros(per, 2, device="cuda") for _ in range(rounds)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for r in range(rounds):
+        with torch.cuda.stream(streams[r & 1]):
+            blk.xcorrelate_device(dx[r % 3], outs[r])
+    torch.cuda.synchronize()
+    for r in range(rounds):
+        assert np.array_equal(outs[r].cpu().numpy().view(np.complex64).reshape(-1), refs[r % 3]), r
+    # batches of the per-rank geometry on the batch workspace, window counts alternating as well (the words move with the count)
+    Fb, T = 128, 256
+    bb = _xe(gpu, gpu.DTYPE_BYTE, 1, N, Fb, T)
+    perb = bb.get_output_buffer_size()
+    w = rng.integers(-128, 128, size=(8, T, N, Fb, 1, 2), dtype=np.int64).astype(np.int8)
+    refb = np.concatenate([oracle.xengine_ichar(N, Fb, 1, T, w[i].reshape(-1), exact=True) for i in range(8)])
+    dw = torch.from_numpy(w).cuda()
+    outb = [torch.zeros(8 * perb, 2, device="cuda") for _ in range(10)]
+    for r in range(10):
+        n = 8 if r % 3 else 4
+        with torch.cuda.stream(streams[r & 1]):
+            bb.xcorrelate_n_device(n, dw, outb[r])
+    torch.cuda.synchronize()
+    for r in range(10):
+        n = 8 if r % 3 else 4
+        assert np.array_equal(outb[r].cpu().numpy().view(np.complex64).reshape(-1)[:n * perb], refb[:n * perb]), r
+
+
+@pytest.mark.parametrize("N,F,T,npol,nint", [(64, 1024, 128, 1, 8), (64, 1024, 128, 1, 12), (64, 512, 160, 1, 16), (64, 256, 128, 1, 48),
+                                             (50, 1024, 128, 1, 8), (32, 1024, 128, 2, 8), (64, 1024, 128, 1, 5)])
+def test_batched_persistent_workgroups(gpu, oracle, monkeypatch, N, F, T, npol, nint):
+    """More whole-integration units than CUs: a workgroup runs its units one after the other (FuArgs::items) -- the same slice of windows
+    w, w + grid / (4 lines), ... -- and requests a unit's first K blocks while it stores the previous unit's matrix.  Every window bit-exact
+    against the oracle and identical to the one-unit-per-workgroup launch (MI355_XE_NO_PERSIST); accumulate; window counts that do not
+    divide evenly fall back to one unit per workgroup."""
+    import torch
+    rng = np.random.default_rng(N * 13 + nint)
+    wins = rng.integers(-128, 128, size=(nint, T, N, F, npol, 2), dtype=np.int64).astype(np.int8)
+    blk = _xe(gpu, gpu.DTYPE_BYTE, npol, N, F, T)
+    per = blk.get_output_buffer_size()
+    ref = np.concatenate([oracle.xengine_ichar(N, F, npol, T, wins[i].reshape(-1), exact=True) for i in range(nint)])
+    x = torch.from_numpy(wins).cuda()
+    out = torch.zeros(nint * per, 2, device="cuda")
+    blk.xcorrelate_n_device(nint, x, out)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.complex64).reshape(-1), ref)
+    monkeypatch.setenv("MI355_XE_NO_PERSIST", "1")
+    plain = torch.zeros(nint * per, 2, device="cuda")
+    blk.xcorrelate_n_device(nint, x, plain)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("MI355_XE_NO_PERSIST")
+    assert torch.equal(out, plain)
+    blk.xcorrelate_n_device(nint, x, out, accumulate=True)
+    torch.cuda.synchronize()
+    ref2 = np.concatenate([oracle.xengine_ichar(N, F, npol, T, wins[i].reshape(-1), exact=True, acc=ref[i * per:(i + 1) * per].copy()) for i in range(nint)])
+    assert np.array_equal(out.cpu().numpy().view(np.complex64).reshape(-1), ref2)
+
+
+def test_ichar_scale_single_precision_is_exact(gpu):
+    """The matrix stores of the fused IChar kernels scale sums below 2^24 in single precision (q = fl(S c), r = S - 16129 q by one fma,
+    fl(q + r c)); the reference's arithmetic is (float)((double)S / 127 / 127) (lib/clXEngine_impl.cc:859-867 applied to every product).
+    The device compares the two for EVERY |S| <= 2^24: no sum may differ in a single bit."""
+    blk = _xe(gpu, gpu.DTYPE_BYTE, 1, 4, 16, 32)
+    assert blk.selftest_scale() == 0
