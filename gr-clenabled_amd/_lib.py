@@ -110,6 +110,17 @@ def lib():
         "mi355_pack3d_dev": (i, [vp, vp, vp, sz, sz, sz, sz, sz, sz, sz, vp]),
         "mi355_xengine_gather": (i, [vp, i, i, pp, vp]),
         "mi355_xengine_selftest_scale": (i, [vp, C.POINTER(C.c_longlong)]),
+        "mi355_xengine_shard_create": (i, [i, C.POINTER(C.c_int), i, i, i, i, i, pp]),
+        "mi355_xengine_shard_destroy": (i, [vp]),
+        "mi355_xengine_shard_world": (i, [vp]),
+        "mi355_xengine_shard_device": (i, [vp, i]),
+        "mi355_xengine_shard_frames_bytes": (sz, [vp]),
+        "mi355_xengine_shard_slab_items": (sz, [vp]),
+        "mi355_xengine_shard_stream": (vp, [vp, i]),
+        "mi355_xengine_shard_submit_dev": (i, [vp, pp, pp, i]),
+        "mi355_xengine_shard_wait_stream": (i, [vp, i, vp]),
+        "mi355_xengine_shard_synchronize": (i, [vp]),
+        "mi355_xengine_shard_xcorrelate": (i, [vp, vp, vp, i]),
         "mi355_xengine_submit": (i, [vp, vp, vp]),
         "mi355_xengine_wait": (i, [vp, vp]),
         "mi355_xengine_pending": (i, [vp]),

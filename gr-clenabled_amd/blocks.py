@@ -457,6 +457,72 @@ class clXEngine(_Block):
         return nframes
 
 
+class clXEngineSharded:
+    """clXEngine over several devices of one process: `world` ranks on devices `device_ids` (mi355_xengine_shard_*, the single-process
+    counterpart of shard.py).  IChar only.  The reference has no such class -- it picks ONE device per block (devId,
+    lib/GRCLBase.cpp:115-134); this is the form a flowgraph (one process) can use.  xcorrelate(): `windows` integration windows in the
+    reference's frame layout in, `windows` triangular-order matrices out (lib/clXEngine_impl.h:179-201 over the devices)."""
+
+    def __init__(self, device_ids, polarization, num_inputs, num_channels, integration, windows=1):
+        self._L = lib()
+        self._h = C.c_void_p()
+        ids = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
+        self.world, self.npol, self.windows = len(device_ids), int(polarization), int(windows)
+        self.num_inputs, self.num_channels, self.integration = int(num_inputs), int(num_channels), int(integration)
+        check(self._L.mi355_xengine_shard_create(self.world, ids, self.npol, self.num_inputs, self.num_channels, self.integration, self.windows,
+                                                 C.byref(self._h)), "mi355_xengine_shard_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.mi355_xengine_shard_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def frames_bytes(self):
+        return self._L.mi355_xengine_shard_frames_bytes(self._h)
+
+    def slab_items(self):
+        return self._L.mi355_xengine_shard_slab_items(self._h)
+
+    def get_output_buffer_size(self):  # items of ONE window's full matrix
+        return self.slab_items() * self.world
+
+    def device(self, rank):
+        return self._L.mi355_xengine_shard_device(self._h, int(rank))
+
+    def stream(self, rank):
+        return self._L.mi355_xengine_shard_stream(self._h, int(rank))
+
+    def xcorrelate(self, input_matrix, cross_correlation, accumulate=False):
+        x = np.ascontiguousarray(input_matrix)
+        need = self.windows * self.integration * self.num_inputs * self.num_channels * self.npol * 2
+        if x.nbytes < need:
+            raise ValueError("xcorrelate: input needs %d bytes" % need)
+        y = _host(cross_correlation, np.complex64, writable=True)
+        if y.size < self.windows * self.get_output_buffer_size():
+            raise ValueError("xcorrelate: output needs %d items" % (self.windows * self.get_output_buffer_size()))
+        check(self._L.mi355_xengine_shard_xcorrelate(self._h, _hp(x), _hp(y), 1 if accumulate else 0), "mi355_xengine_shard_xcorrelate")
+        return self.windows * self.get_output_buffer_size()
+
+    def submit_device(self, frames, outs, accumulate=False):
+        """frames[r] / outs[r]: CUDA tensors on the rank's device (antenna-group frames / windows x slab matrices); enqueue only."""
+        fp = (C.c_void_p * self.world)(*[_dp(t, self.frames_bytes(), "frames").value for t in frames])
+        op = (C.c_void_p * self.world)(*[_dp(t, self.windows * self.slab_items() * 8, "output").value for t in outs])
+        check(self._L.mi355_xengine_shard_submit_dev(self._h, fp, op, 1 if accumulate else 0), "mi355_xengine_shard_submit_dev")
+
+    def wait_current_stream(self, rank):
+        """The rank's compute stream waits for everything enqueued so far on torch's current stream of the rank's device."""
+        check(self._L.mi355_xengine_shard_wait_stream(self._h, int(rank), _torch_stream(self.device(rank))), "mi355_xengine_shard_wait_stream")
+
+    def synchronize(self):
+        check(self._L.mi355_xengine_shard_synchronize(self._h), "mi355_xengine_shard_synchronize")
+
+
 class _Elem(_Block):
     """Remaining elementwise family over mi355_elem_*."""
     _destroy = "mi355_elem_destroy"

@@ -181,6 +181,27 @@ static int xengine_stream_test(const std::string &dir)
         run(xe, 9 * T);
         report("clXEngine pipeline_integration=3 (9 windows -> 3)", (size_t)9 * T * F * N, 1.0, g_handler_calls == 3 && g_handler_ok);
     }
+    {   // the same block over four ranks of this process (here: all on the one device): antenna groups in, channel slabs out, the matrices
+        // identical to the one-device block's -- random samples this time, compared value by value
+        std::vector<char> rnd((size_t)T * N * F * 2);
+        unsigned lcg = 12345u;
+        for (auto &c : rnd) { lcg = lcg * 1664525u + 1013904223u; c = (char)(lcg >> 24); }
+        auto one = clXEngine::make(OCLTYPE_GPU, OCLDEVICESELECTOR_SPECIFIC, 0, g_dev, false, DTYPE_BYTE, 1, N, CLXCORR_TRIANGULAR_ORDER, 0, F, T, {});
+        auto four = clXEngine::make(OCLTYPE_GPU, OCLDEVICESELECTOR_SPECIFIC, 0, g_dev, false, DTYPE_BYTE, 1, N, CLXCORR_TRIANGULAR_ORDER, 0, F, T, {});
+        four->set_shard_devices({g_dev, g_dev, g_dev, g_dev});
+        std::vector<XComplex> a((size_t)one->get_output_buffer_size()), b(a.size());
+        one->xcorrelate(rnd.data(), a.data());
+        four->xcorrelate(rnd.data(), b.data());
+        bool ok = four->shard_devices() == 4 && memcmp(a.data(), b.data(), a.size() * sizeof(XComplex)) == 0;
+        // and through the streaming entry: windows of constant samples, the handler's check
+        T_user = T;
+        g_handler_calls = 0;
+        g_handler_ok = true;
+        four->set_result_handler(on_matrix, &T_user);
+        run(four, 6 * T);
+        ok = ok && g_handler_calls == 6 && g_handler_ok && four->integrations_delivered() == 6;
+        report("clXEngine over 4 ranks of one process (set_shard_devices)", (size_t)7 * T * F * N, 1.0, ok);
+    }
     return g_fail ? 1 : 0;
 }
 

@@ -40,6 +40,13 @@ public:
     virtual long integrations_delivered() const = 0;
     // frames of every input stream -> the frame buffer, lib/clXEngine_impl.cc:987-1061
     virtual int gather_frames(int nframes, int frame0, gr_vector_const_void_star &input_items, void *frame_buffer) = 0;
+    // Not in the reference (one device per block, devId: lib/GRCLBase.cpp:115-134): run THIS block over several devices of the process --
+    // device r ingests antenna group r over its own host link, the devices exchange (corner turn over xGMI) and device r correlates channel
+    // slab r; results are identical to the one-device block's.  IChar input, num_inputs * polarization <= 64, the device count must divide
+    // num_inputs and num_channels.  Also set by the environment variable MI355_XENGINE_DEVICES="0,1,2,3" for flowgraphs that are not edited.
+    // An empty or one-element list returns to the device of make().
+    virtual void set_shard_devices(const std::vector<int> &device_ids) = 0;
+    virtual int shard_devices() const = 0;
     // stream-tag synchroniser state (internal_synchronizer = true, lib/clXEngine_impl.cc:1158-1226)
     virtual bool synchronized() const = 0;
     virtual uint64_t sync_tag() const = 0;

@@ -232,6 +232,10 @@ public:
 
 class clXEngine_impl : public clXEngine, public MI355Base {
     mi355_xengine *d_h = nullptr;
+    // several devices behind ONE block (set_shard_devices / MI355_XENGINE_DEVICES): antenna groups in, channel slabs out, the corner turn
+    // between the devices inside mi355_xengine_shard_* -- the reference has one device per block (devId, lib/GRCLBase.cpp:115-134)
+    mi355_xengine_shard *d_shard = nullptr;
+    int d_data_type;
     int d_npol, d_num_inputs, d_num_channels, d_integration, d_pipeline_integration, d_first_channel;
     long d_in_items;
     size_t d_matrix_len, d_in_bytes;
@@ -321,7 +325,7 @@ public:
                     gr::io_signature::make(2, num_inputs * (data_type == DTYPE_PACKEDXY ? 1 : polarization),
                                            num_channels * (data_type == DTYPE_PACKEDXY ? 2 : item_bytes(data_type))),
                     gr::io_signature::make(0, 0, 0)),
-          MI355Base(p, s, pl, d, dbg), d_npol(data_type == DTYPE_PACKEDXY ? 2 : polarization),
+          MI355Base(p, s, pl, d, dbg), d_data_type(data_type), d_npol(data_type == DTYPE_PACKEDXY ? 2 : polarization),
           d_num_inputs(num_inputs), d_num_channels(num_channels), d_integration(integration),
           d_pipeline_integration(pipeline_integration), d_first_channel(first_channel), d_disable_output(disable_output),
           d_output_file(output_file && !disable_output), d_file_base(file_base), d_object_name(object_name),
@@ -352,12 +356,38 @@ public:
             sched::no_tag_propagation(this);
             set_output_multiple(16);
         }
+        if (const char *e = getenv("MI355_XENGINE_DEVICES")) {  // "0,1,2,3": an unmodified flowgraph's block over several devices
+            std::vector<int> ids;
+            for (const char *q = e; *q;) {
+                char *end = nullptr;
+                const long v = strtol(q, &end, 10);
+                if (end == q) break;
+                ids.push_back((int)v);
+                q = *end == ',' ? end + 1 : end;
+            }
+            if (ids.size() > 1) set_shard_devices(ids);
+        }
     }
     ~clXEngine_impl() override
     {
         try { stop(); } catch (...) {}
+        mi355_xengine_shard_destroy(d_shard);
         mi355_xengine_destroy(d_h);
     }
+    void set_shard_devices(const std::vector<int> &device_ids) override
+    {
+        std::lock_guard<std::mutex> g(d_lock);
+        if (d_tracker != 0 || mi355_xengine_pending(d_h) > 0) throw std::runtime_error("[X-Engine] set_shard_devices: an integration is in progress");
+        if (d_data_type != DTYPE_BYTE) throw std::invalid_argument("[X-Engine] several devices: IChar (byte) input only");
+        mi355_xengine_shard_destroy(d_shard);
+        d_shard = nullptr;
+        if (device_ids.size() < 2) return;  // back to the one device of make()
+        chk(mi355_xengine_shard_create((int)device_ids.size(), device_ids.data(), d_npol, d_num_inputs, d_num_channels, d_integration, 1, &d_shard),
+            "mi355_xengine_shard_create");
+        d_frames_sync.resize(d_in_bytes);
+        if (d_accum.size() != d_matrix_len) d_accum.assign(d_matrix_len, XComplex());
+    }
+    int shard_devices() const override { return d_shard ? mi355_xengine_shard_world(d_shard) : 1; }
     bool stop() override
     {
         std::lock_guard<std::mutex> g(d_lock);
@@ -424,7 +454,7 @@ public:
         const int remaining = d_integration - d_tracker;
         const int n = noutput_items > remaining ? remaining : noutput_items;  // :925-934
         if (d_tracker == 0) {  // a new integration window starts: get the buffer it is gathered into
-            if (d_pipeline_integration > 1) d_frames = d_frames_sync.data();
+            if (d_pipeline_integration > 1 || d_shard) d_frames = d_frames_sync.data();
             else {
                 if (mi355_xengine_pending(d_h) == 2) collect_one();  // previous result goes out before the swap (:1070-1094)
                 void *fb = nullptr;
@@ -437,8 +467,14 @@ public:
         d_frame_counter += n;
         if (d_tracker == d_integration) {
             const long first = d_frame_counter - d_integration;
-            if (d_pipeline_integration > 1) {
+            if (d_shard && d_pipeline_integration <= 1) {
+                // every device takes its antenna group over its own link, the devices turn the corner and correlate their channel slabs
+                chk(mi355_xengine_shard_xcorrelate(d_shard, d_frames, d_result.data(), 0), "mi355_xengine_shard_xcorrelate");
+                deliver(d_result.data(), first);
+            } else if (d_pipeline_integration > 1) {
                 // device "+=" into the running matrix, read back every pipeline_integration windows (:785-796,1250-1285)
+                if (d_shard) chk(mi355_xengine_shard_xcorrelate(d_shard, d_frames, d_accum.data(), 1), "mi355_xengine_shard_xcorrelate");
+                else
                 chk(mi355_xengine_xcorrelate(d_h, d_frames, d_accum.data(), 1), "mi355_xengine_xcorrelate");
                 if (++d_pipe_count >= d_pipeline_integration) {
                     deliver(d_accum.data(), first - (long)d_integration * (d_pipeline_integration - 1));
@@ -464,6 +500,8 @@ public:
     }
     void xcorrelate(char *in, XComplex *out) override
     {
+        if (d_shard) chk(mi355_xengine_shard_xcorrelate(d_shard, in, out, d_pipeline_integration > 1), "mi355_xengine_shard_xcorrelate");
+        else
         chk(mi355_xengine_xcorrelate(d_h, in, out, d_pipeline_integration > 1), "mi355_xengine_xcorrelate");
     }
     void submit(const void *in, const XComplex *acc) override { chk(mi355_xengine_submit(d_h, in, acc), "mi355_xengine_submit"); }

@@ -271,6 +271,34 @@ int mi355_xengine_submit_acquired(mi355_xengine *h, const void *accumulator_or_n
 /* host gather: copy frames [0,nframes) of each input stream into time slots
  * frame0.. of a frame buffer laid out as the reference's pinned host buffer */
 int mi355_xengine_gather(const mi355_xengine *h, int nframes, int frame0, const void *const *inputs, void *frame_buffer);
+/* ---- clXEngine over several devices of ONE process.  The reference picks one device per block (devId,
+ * lib/GRCLBase.cpp:115-134) and a GNU Radio flowgraph is one process: this handle owns `world` device contexts and runs the FX correlator's
+ * corner turn between them.  Rank r = device_ids[r] (a device may appear more than once: the ranks then share it) ingests antenna group r --
+ * frames [window][t][num_inputs/world stations][chan][pol]{I,Q}, the reference's frame layout of lib/clXEngine_impl.cc:987-1061 -- and
+ * produces channels [r F/W, (r+1) F/W) of the reference's [chan][baseline][pol^2] matrix (:786-808) for each of `windows` integration
+ * windows per exchange.  IChar (int8 I/Q) with num_inputs * npol <= 64 rows; world must divide num_inputs and num_channels.
+ * Per exchange: one strided device copy packs a rank's frames into per-destination blocks (mi355_pack3d_dev), `world` peer copies
+ * (hipMemcpyPeerAsync: xGMI) deliver them, and mi355_xengine_xcorrelate_n_dev reads the receive buffer in place; two slots, an exchange and
+ * a compute stream per rank, so exchange k+1 runs under correlation k.  (gr-clenabled_amd/shard.py is the same pipeline with one process per
+ * device and an RCCL all-to-all.) */
+typedef struct mi355_xengine_shard mi355_xengine_shard;
+int mi355_xengine_shard_create(int world, const int *device_ids, int npol, int num_inputs, int num_channels, int integration, int windows,
+                               mi355_xengine_shard **out);
+int mi355_xengine_shard_destroy(mi355_xengine_shard *h);
+int mi355_xengine_shard_world(const mi355_xengine_shard *h);
+int mi355_xengine_shard_device(const mi355_xengine_shard *h, int rank);
+size_t mi355_xengine_shard_frames_bytes(const mi355_xengine_shard *h);  /* bytes of one rank's frames per exchange */
+size_t mi355_xengine_shard_slab_items(const mi355_xengine_shard *h);    /* complex floats of one rank's matrix per window */
+void *mi355_xengine_shard_stream(mi355_xengine_shard *h, int rank);     /* the rank's compute stream (hipStream_t): producers of frames_dev go here */
+/* the rank's compute stream waits for everything enqueued so far on `stream` (hipStream_t of that device): the other way to order a producer */
+int mi355_xengine_shard_wait_stream(mi355_xengine_shard *h, int rank, void *stream);
+/* enqueue one exchange + correlation: frames_dev[r] / out_dev[r] live on device_ids[r] (out: windows x slab_items complex floats);
+ * the frames must stay untouched until the next submit or synchronize on the handle returns */
+int mi355_xengine_shard_submit_dev(mi355_xengine_shard *h, const void *const *frames_dev, void *const *out_dev, int accumulate);
+int mi355_xengine_shard_synchronize(mi355_xengine_shard *h);
+/* host form: `windows` windows in the reference's layout [window][t][station][chan][pol] -> [window][chan][baseline][pol^2]; every rank
+ * copies its antenna group over its own host link and its slab back; blocking (lib/clXEngine_impl.h:179-201 over `world` devices) */
+int mi355_xengine_shard_xcorrelate(mi355_xengine_shard *h, const void *in_host, void *out_host, int accumulate);
 /* Self-test of the IChar scale (lib/clXEngine_impl.cc:859-867: every sample / 127, i.e. every sum / 16129): the device evaluates the
  * single-precision form the matrix stores use and the double expression (float)((double)S * (1/127) * (1/127)) for EVERY sum S with
  * |S| <= 2^24 (the range the single-precision form is used in) and counts the sums where the two floats differ; *mismatches must be 0. */
