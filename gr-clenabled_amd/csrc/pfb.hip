@@ -258,8 +258,15 @@ __global__ __launch_bounds__(M, 2) void k_pfbw(const c32 *__restrict__ in, c32 *
 
     // raw buffer over the readable input; offsets are 32-bit (the launcher guarantees n_in * 8 < 4 GiB - 64 KiB),
     // and a row before the start of the stream wraps to an out-of-range offset, i.e. reads as zero
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)(unsigned)(n_in * 8), 0x00020000);
+    // (the buffer ends with the last row THIS wave's outputs use: the refill of the last iteration -- 16 rows past the wave's range, which the
+    // next wave reads anyway -- is then out of range, i.e. no memory traffic: 6 % of the input bytes at 16 groups per wave)
+    long long n_lim = (long long)g_begin * U * M + K - (long long)PMAX * M + ((long long)(g_end - g_begin) * U + PMAX - 1) * M;
+    if (n_lim > n_in) n_lim = n_in;
+    if (n_lim < 0) n_lim = 0;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)in, 0, (int)(unsigned)(n_lim * 8), 0x00020000);
     const unsigned lane_off = (unsigned)((M - 1 - lane0) * 8);
+    // the output as a range-checked buffer (identity map, critically sampled: rows 0 .. nsteps-1 of M channels; the launcher guarantees < 4 GiB)
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, (int)(unsigned)((size_t)nsteps * M * 8), 0x00020000);
     // sample index of ring row 0 of the first iteration: X[w] = in[n0 + w*M + (M-1-lane)]
     const long long n0 = (long long)g_begin * U * M + K - (long long)PMAX * M;
     auto load_row = [&](long long row) -> f2v {  // row = absolute row index relative to n0
@@ -269,6 +276,9 @@ __global__ __launch_bounds__(M, 2) void k_pfbw(const c32 *__restrict__ in, c32 *
     f2v ring[RS];
 #pragma unroll
     for (int w = 0; w < RS; w++) ring[w] = load_row(w);
+    // (the compiler's wait-count pass merges this path -- RS loads in flight -- with the loop's back edge -- 16 loads + 16 stores -- into a
+    // full drain, vmcnt(0), at the second product of every first-phase iteration; with nothing in flight on entry it keeps the exact counts)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     auto iteration = [&](auto phase_tag, int grp) {
         constexpr int PH = decltype(phase_tag)::value;
@@ -313,7 +323,24 @@ __global__ __launch_bounds__(M, 2) void k_pfbw(const c32 *__restrict__ in, c32 *
         transform_regs<M, 1, false, G>(v, tw, lds, lane);
         constexpr int NP = PL::NP, RL = PL::radix(NP - 1), BL = M / RL;
         const int i0 = grp * U;
-        if constexpr (IDENT) {
+        if constexpr (IDENT && OS == 1) {
+            // Buffer stores with hardware range checking: the steps past the end of the call are dropped by the address unit, so the sixteen
+            // stores are unconditional and straight-line.  With the stores under `if (step < nsteps)` the compiler could not count them (0 .. 16
+            // were in flight at the next iteration's first use of a freshly loaded row) and waited for vmcnt(15): every row load of the previous
+            // iteration AND, one by one, the previous iteration's stores -- a wave stood ~1.5 us per iteration waiting for store
+            // acknowledgements.  Counted, the wait is vmcnt(30 + ...): only the load that is needed.
+#pragma unroll
+            for (int q = 0; q < 16 / RL; q++) {
+                const int g = lane + M * q, fr = g / BL, j = g % BL;
+                const unsigned o8 = (unsigned)(((size_t)(i0 + fr) * M + j) * 8);
+#pragma unroll
+                for (int t = 0; t < RL; t++) {
+                    const c32 z = v[q * RL + t];
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(f2v, z), orsrc, o8 + (unsigned)(orev<RL>(t) * BL * 8), 0, 2);  // (2: nontemporal)
+                }
+            }
+            __syncthreads();
+        } else if constexpr (IDENT) {
 #pragma unroll
             for (int q = 0; q < 16 / RL; q++) {
                 const int g = lane + M * q, fr = g / BL, j = g % BL;
