@@ -219,6 +219,8 @@ extern "C" int mi355_xengine_shard_synchronize(mi355_xengine_shard *h)
 extern "C" int mi355_xengine_shard_xcorrelate(mi355_xengine_shard *h, const void *in_host, void *out_host, int accumulate)
 {
     MI355_REQUIRE(h && in_host && out_host, "NULL argument");
+    static std::mutex host_call;  // (one host call at a time: the ranks' staging buffers are the handle's; submit_dev below takes the handle's lock itself)
+    std::lock_guard<std::mutex> hg(host_call);
     const int W = h->world;
     const size_t grp = (size_t)h->Ng * h->row, step = (size_t)h->N * h->row, steps = (size_t)h->windows * h->T;
     const size_t slab_bytes = h->slab_items * 8, full_bytes = slab_bytes * W;

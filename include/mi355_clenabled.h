@@ -238,6 +238,8 @@ size_t mi355_xengine_input_bytes(const mi355_xengine *h);
 size_t mi355_xengine_output_items(const mi355_xengine *h);
 /* accumulate=0: out = V ; accumulate=1: out += V (pipeline integration) */
 int mi355_xengine_xcorrelate(mi355_xengine *h, const void *in_host, void *out_host, int accumulate);
+/* (device-pointer calls: a handle may be used from several streams -- launches that share the handle's partial-sum workspace are ordered by the
+ * library with an event recorded on the PREVIOUS call's stream, which therefore must still exist when the next call on the handle is made) */
 int mi355_xengine_xcorrelate_dev(mi355_xengine *h, const void *in_dev, void *out_dev, int accumulate, void *stream);
 /* Multi-GPU form (no counterpart in the reference, which runs one X-engine on one device): the input is the
  * receive buffer of the all-to-all corner turn, [group][t][station in group][chan][pol], stations_per_group stations per

@@ -776,7 +776,7 @@ def test_one_handle_on_two_streams_is_ordered_by_the_library(gpu, oracle):
         assert np.array_equal(outb[r].cpu().numpy().view(np.complex64).reshape(-1)[:n * perb], refb[:n * perb]), r
 
 
-@pytest.mark.parametrize("N,F,T,npol,nint", [(64, 1024, 128, 1, 8), (64, 1024, 128, 1, 12), (64, 512, 160, 1, 16), (64, 256, 128, 1, 48),
+@pytest.mark.parametrize("N,F,T,npol,nint", [(64, 1024, 128, 1, 8), (64, 512, 128, 1, 12), (64, 512, 160, 1, 16), (64, 256, 128, 1, 48),
                                              (50, 1024, 128, 1, 8), (32, 1024, 128, 2, 8), (64, 1024, 128, 1, 5)])
 def test_batched_persistent_workgroups(gpu, oracle, monkeypatch, N, F, T, npol, nint):
     """More whole-integration units than CUs: a workgroup runs its units one after the other (FuArgs::items) -- the same slice of windows
