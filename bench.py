@@ -799,6 +799,41 @@ def sharded_xengine(pkg, dev, steps, world, rank, windows=8):
             "overlap": "exchange(i+1) on a side stream under correlate(i); receive buffer read in place"}
 
 
+def sharded_one_process(pkg, dev, windows=8, ranks=2):
+    """The single-process driver of the same pipeline (mi355_xengine_shard_*: what a GNU Radio flowgraph can use) with `ranks` logical ranks
+    on THIS device: config 5 split into antenna groups, packed, exchanged by (here: device-local) peer copies, correlated per channel slab in
+    one launch per rank and exchange, two slots in flight.  One device does all the work of all ranks plus the copies, so the figure is the
+    pipeline's overhead against the batched one-GPU call, not a scaling number."""
+    import time
+    import torch
+    N, F, T = 64, 1024, 1024
+    sh = pkg.clXEngineSharded([dev] * ranks, 1, N, F, T, windows)
+    g = torch.Generator(device="cuda").manual_seed(777)
+    frames = [[torch.randint(-127, 128, (sh.frames_bytes(),), dtype=torch.int8, device="cuda", generator=g) for _ in range(ranks)] for _ in range(2)]
+    outs = [torch.zeros(windows * sh.slab_items(), 2, device="cuda") for _ in range(ranks)]
+    torch.cuda.synchronize()
+    for k in range(2):
+        sh.submit_device(frames[k & 1], outs)
+    sh.synchronize()
+    nex = 6
+    t0 = time.perf_counter()
+    for k in range(nex):
+        sh.submit_device(frames[k & 1], outs)
+    sh.synchronize()
+    dt = (time.perf_counter() - t0) / (nex * windows)
+    del frames, outs
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    sh.close()
+    return {"us_per_integration": round(dt * 1e6, 2), "logical_ranks_on_this_device": ranks, "windows_per_exchange": windows,
+            "timing": "host clock around %d back-to-back submits + synchronize (the handle's own streams)" % nex,
+            "device_bytes_per_integration": {"pack_read_write": 2 * T * N * F * 2, "peer_copies_read_write": 2 * T * N * F * 2,
+                                             "correlation_in_out": T * N * F * 2 + F * (N * (N + 1) // 2) * 8},
+            "note": "one device carries every rank's packing (134 MB read + written per window), the copies that are xGMI transfers on several "
+                    "devices (134 MB read + written here) and both ranks' correlations at once: 4.5 x the bytes of the bare call -- a functional run of "
+                    "the single-process pipeline inside the bench, not a scaling number"}
+
+
 def annotate_sharded_scaling(extras, world):
     """Strong scaling of the 64 x 1024 x 1024 integration stream: efficiency = t(1 GPU) / (N x t(N GPUs)), both sides eight windows per launch
     (like for like), the one-GPU time measured in the SAME line (N > 1: `clXEngine_n1_reference`, every rank's own device; N = 1: the batched
@@ -931,6 +966,10 @@ def main():
         except Exception as exc:  # noqa: BLE001
             extras["clXEngine_sharded"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         if rank == 0 and world == 1:
+            try:
+                extras["clXEngine_shard_one_process"] = sharded_one_process(pkg, local)
+            except Exception as exc:  # noqa: BLE001
+                extras["clXEngine_shard_one_process"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
             try:
                 extras.update(hostpath_blocks(pkg, taps_pair, local))
             except Exception as exc:  # noqa: BLE001
