@@ -166,3 +166,23 @@ def test_work_refuses_buffers_smaller_than_the_call(gpu):
     p = m.clPolyphaseChannelizer(1, 2, 0, 0, [0.1] * 48, 512, 8, 8, list(range(8)))
     with pytest.raises(ValueError):
         p.general_work(512, [np.zeros(512, np.complex64)], [np.zeros(512, np.complex64)])  # forecast() asks for 512 + 40
+
+
+@pytest.mark.gpu
+def test_clxengine_over_several_ranks_through_the_binding(gpu, oracle):
+    """clXEngine.set_shard_devices (not in the reference: several devices behind ONE block, the corner turn inside the C ABI): frames fed through
+    general_work() the way a flowgraph does, four ranks on the one device, one integration delivered; the block without it delivers the same."""
+    m = _mod()
+    N, F, T = 8, 64, 32
+    rng = np.random.default_rng(9)
+    streams = [rng.integers(-128, 128, size=(T, F, 2), dtype=np.int64).astype(np.int8) for _ in range(N)]
+    for devs in ([0, 0, 0, 0], []):
+        xe = m.clXEngine(1, 2, 0, 0, False, 5, 1, N, 1, 0, F, T, [])  # (data_type 5 = DTYPE_BYTE: IChar)
+        if devs:
+            xe.set_shard_devices(devs)
+            assert xe.shard_devices() == 4
+        else:
+            assert xe.shard_devices() == 1
+        assert xe.general_work(T, [s.reshape(-1).view(np.int8) for s in streams], []) == T
+        xe.stop()
+        assert xe.integrations_delivered() == 1
