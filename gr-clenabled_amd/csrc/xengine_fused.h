@@ -35,3 +35,8 @@ XeFusedPlan mi355_xe_fused_plan(int N, int F, int Fout, int npol, int T, int num
 // NULL: the reduce kernel is used.
 int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void *part, int N, int F, int Fout, int T, double kd,
                           int accumulate, hipStream_t st, int stations_per_group = 0, unsigned *epoch = nullptr, int nint = 1);
+
+// Whole-line form (xengine_lines.hip): 64 stations, one polarisation, rows of whole 128-byte lines, enough (window, line, pair group) units to fill
+// the device without time ranges.  mi355_xe_fused_launch routes to it where mi355_xe_lines_ok says so (MI355_XE_NO_LINES=1: never).
+bool mi355_xe_lines_ok(int N, int F, int Fout, int npol, int T, int stations_per_group, int accumulate, int nint, int cus);
+int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int T, double kd, hipStream_t st, int stations_per_group, int nint, int cus);

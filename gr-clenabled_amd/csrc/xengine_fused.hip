@@ -1289,6 +1289,11 @@ XeFusedPlan mi355_xe_fused_plan(int N, int F, int Fout, int npol, int T, int num
 int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void *part, int N, int F, int Fout, int T, double kd, int accumulate,
                           hipStream_t st, int stations_per_group, unsigned *epoch, int nint)
 {
+    // whole 128-byte lines per request, the row-tile pairs split over four workgroups (xengine_lines.hip): where there are enough units without
+    // time ranges; needs neither the partial-sum workspace nor the arrival words
+    if (p.tsplit == 1 && p.npol == 1 && p.row_stride == F * 2 && ((size_t)in & 15) == 0 &&
+        mi355_xe_lines_ok(N, F, Fout, p.npol, T, stations_per_group, accumulate, nint, p.cus))
+        return mi355_xe_lines_launch(in, out, N, F, Fout, T, kd, st, stations_per_group, nint, p.cus);
     FuArgs a;
     a.in = (const unsigned char *)in;
     a.part = (v4i *)part;

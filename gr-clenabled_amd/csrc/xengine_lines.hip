@@ -1,0 +1,445 @@
+// clXEngine, IChar (int8 I/Q) input, 64 stations, one polarisation: corner turn AND correlation in one pass over the input, with WHOLE 128-byte
+// lines per request (round 5).  Reference behaviour: lib/clXEngine_impl.cc:708-817 (CharToComplex + XCorrelate kernels), :859-867 (IChar scale);
+// input layout [t][station][chan]{I,Q} (:766-767,987-1061), output [chan][baseline] (:786-808).
+//
+// Why this shape.  k_xe_i8_fused (xengine_fused.hip) gives a workgroup a 32-byte column slice (16 channels) of every (t, station) row and all ten
+// row-tile pairs; its loop is bound by the number of 128-byte-line REQUESTS a CU can have in flight, not by bytes: one request per row and workgroup,
+// 4.19 M per BASELINE integration, 40 us from HBM.  tools/ubench/xe_colgroup_read.hip measures the alternative: a workgroup takes the WHOLE line
+// (64 channels) of a row but only a GROUP of the ten row-tile pairs,
+//     A = {00, 10, 11} stations 0-31      B = {22, 32, 33} stations 32-63      C = {20, 21} stations 0-47      D = {30, 31} stations 0-31, 48-63
+// 2.5 x the rows, a quarter of the requests per row: 2.62 M requests, and the four workgroups of a line sit on one XCD (blockIdx % 8) and walk the
+// same frames, so HBM still sees every line once (L2 hits for the re-reads).  Request stream alone: 33.6 against 55.8 us per window.
+// Registers: 64 channels x 16 accumulator registers per lane for every group --
+//   off-diagonal pair: re += I_a I_b^T + Q_a Q_b^T,  im' += Q_a I_b^T + I_a (~Q_b)^T,  im = im' + sum_t I_a(t)            (8 registers, as in k_xe_i8_fused)
+//   diagonal pair: all four products into ONE accumulator C = re + im' (4 registers): re is symmetric and im antisymmetric, so
+//                  re[i][j] = (C[i][j] + C[j][i]) / 2,  im[i][j] = (C[i][j] - C[j][i]) / 2 exactly (|C| <= T * 2^16: T <= 16384)
+// so a workgroup of FOUR waves (one per SIMD, up to 512 registers each) holds 16 channels x 16 registers per wave.
+//
+// Data path.  A K block is 32 frames.  The lines of one row tile (16 stations) and 16 frames = 256 lines = one sub-stage, 32 LDS-DMA instructions
+// (global_load_lds_dwordx4), each the line of ONE station for 8 consecutive frames (lane = frame * 8 + 16-byte piece), landing as a 1 KiB chunk; chunk
+// starts are 1040 bytes apart, so the sixteen stations' copies of a piece fall into sixteen different 16-byte bank groups (conflict-free ds_read_b128).
+// Ring of four sub-stages (130 KiB), all four in flight while nothing is read.  Per sub-stage a lane (station r, group g) pulls 4 frames x 32 bytes
+// (its wave's 16 channels) into registers, the slot is handed back to the DMA at once, and the bytes are transposed (v_perm) into the K-major
+// operands of v_mfma_i32_16x16x32_i8: after two sub-stages a lane holds 8 frames of every channel of its wave for one row tile.  The order of the
+// frames inside a K block differs from k_xe_i8_fused's (any order is fine as long as both operands use it).
+#include "xengine_fused.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <type_traits>
+#include <vector>
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+struct c32 { float x, y; };
+
+constexpr int kLnWaves = 4, kLnThreads = kLnWaves * 64, kLnChunk = 1040, kLnSlot = 32 * kLnChunk, kLnRing = 4;
+constexpr int kLnTile = 16 * 20 * 4;  // a wave's scratch for the transposed diagonal tile
+constexpr int kLnLds = kLnRing * kLnSlot + kLnWaves * kLnTile;
+
+struct LnArgs {
+    const unsigned char *in;
+    c32 *out;
+    int Fout, T, ncols, row_stride, ng;  // ncols: 128-byte lines per row; ng: stations per antenna group (64: the reference layout)
+    int units, items, pinned;            // units of the launch = windows x lines x 4 groups; units per workgroup (persistent form)
+    int steps;                           // K blocks (32 frames) per unit
+    size_t in_window, in_group, out_window;
+    double kd;
+    int k127;
+    int dbg;  // tuning aid (MI355_XE_DBG): 1 no products, 2 no matrix stores, 4 no DMA
+    unsigned long long *ts;
+};
+
+__device__ __forceinline__ unsigned perm(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+
+// 4 dwords (bytes b0..b3 of four frames) -> out[j] = byte j of each input dword
+__device__ __forceinline__ void transpose4x4(unsigned i0, unsigned i1, unsigned i2, unsigned i3, unsigned (&out)[4])
+{
+    const unsigned t0 = perm(i1, i0, 0x05010400u), t1 = perm(i1, i0, 0x07030602u);
+    const unsigned t2 = perm(i3, i2, 0x05010400u), t3 = perm(i3, i2, 0x07030602u);
+    out[0] = perm(t2, t0, 0x05040100u);
+    out[1] = perm(t2, t0, 0x07060302u);
+    out[2] = perm(t3, t1, 0x05040100u);
+    out[3] = perm(t3, t1, 0x07060302u);
+}
+
+// the IChar scale in single precision, bit for bit (float)((double)S * kd * kd) at kd = 1 / 127 for |S| < 2^24 (see xengine_fused.hip)
+__device__ __forceinline__ float ln_scale127_small(int S)
+{
+    const float c = 6.2000123e-05f;  // fl(1 / 16129)
+    const float sf = (float)S;
+    const float q = sf * c;
+    const float r = __builtin_fmaf(-q, 16129.0f, sf);
+    return __builtin_fmaf(r, c, q);
+}
+__device__ __forceinline__ unsigned ln_mag_bits(int v) { return (unsigned)(v + 0x1000000); }
+__device__ __forceinline__ bool ln_all_small(unsigned m) { return __builtin_amdgcn_ballot_w64((m >> 25) != 0u) == 0ull; }
+
+__device__ __forceinline__ void ln_dma16(const void *gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+__device__ __forceinline__ long as_long(v2i v) { return __builtin_bit_cast(long, v); }
+__device__ __forceinline__ long not_long(v2i v) { return __builtin_bit_cast(long, (v2i){~v[0], ~v[1]}); }
+
+struct LnUnit { int col, grp, win; };
+
+__device__ __forceinline__ LnUnit ln_map_unit(const LnArgs &a, int n)
+{
+    LnUnit u;
+    int combo;
+    if (a.pinned) {  // the four groups of a (line, window) on one XCD, next to each other in dispatch order
+        const int xcd = n & 7, within = n >> 3;
+        u.grp = within & 3;
+        combo = xcd + 8 * (within >> 2);
+    } else {
+        u.grp = n & 3;
+        combo = n >> 2;
+    }
+    u.col = combo % a.ncols;
+    u.win = combo / a.ncols;
+    return u;
+}
+
+// DIAG: groups A / B (row tiles x < y; pairs xx, yx, yy); otherwise C / D (row tile ra against row tiles 0 and 1)
+template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, unsigned char *lds, const int grp)
+{
+    constexpr int NRT = DIAG ? 2 : 3, NS = 2 * NRT;
+    const unsigned lds0 = (unsigned)(size_t)lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int grid = (int)gridDim.x;
+    const size_t row_bytes = (size_t)a.row_stride, t_stride = (size_t)a.ng * row_bytes;
+    // row tiles in load order
+    const int rt0 = DIAG ? 2 * grp : grp, rt1 = DIAG ? 2 * grp + 1 : 0, rt2 = 1;  // (DIAG: grp 0 -> 0, 1; grp 1 -> 2, 3.  else: grp 2 / 3 -> 2 / 3, then 0, 1)
+
+    // ---- requests.  Wave w issues the chunks of frame octet w / 2 and stations 8 (w % 2) .. + 7 of the row tile: one instruction = one station's
+    // line for 8 frames.  Address = (uniform) unit, row tile, station, K block, half + (per lane) frame and piece.
+    const size_t lane_off = (size_t)((wave >> 1) * 8 + (lane >> 3)) * t_stride + (size_t)(lane & 7) * 16;
+    const unsigned char *hb0 = nullptr, *hb1 = nullptr, *hb2 = nullptr;
+    auto setup_issue = [&](int n) {
+        const LnUnit u = ln_map_unit(a, n);
+        const unsigned char *in_w = a.in + (size_t)u.win * a.in_window + (size_t)u.col * 128;
+        auto half_base = [&](int rt) {
+            const int st = 16 * rt + 8 * (wave & 1);
+            return in_w + (size_t)(st / a.ng) * a.in_group + (size_t)(st % a.ng) * row_bytes;
+        };
+        hb0 = half_base(rt0);
+        hb1 = half_base(rt1);
+        hb2 = half_base(rt2);
+    };
+    const int total_sub = a.items * a.steps * NS;  // sub-stages of this workgroup's stream
+    int issue_unit = 0, issue_kb = -1;             // the unit / K block whose sub-stages are being requested
+    setup_issue(blockIdx.x);
+    // sub-stage number m of the stream (all units of this workgroup), j = m % NS = 2 * (row tile index) + half, known at compile time at every
+    // call site; sub-stages are requested in stream order, so the K block and unit just count up
+    auto issue = [&](int m, int j) {
+        if (j == 0 && ++issue_kb == a.steps) {
+            issue_kb = 0;
+            issue_unit++;
+            setup_issue(blockIdx.x + issue_unit * grid);
+        }
+        const int kb = issue_kb;
+        const int i = j >> 1, h = j & 1;
+        const unsigned char *hb = i == 0 ? hb0 : i == 1 ? hb1 : hb2;
+        const unsigned char *p0 = hb + (size_t)(32 * kb + 16 * h) * t_stride + lane_off;
+        const unsigned dst0 = lds0 + (m & (kLnRing - 1)) * kLnSlot + ((wave >> 1) * 16 + (wave & 1) * 8) * kLnChunk;
+        if (!(a.dbg & 4)) {
+#pragma unroll
+            for (int ii = 0; ii < 8; ii++) ln_dma16(p0 + (size_t)ii * row_bytes, __builtin_amdgcn_readfirstlane(dst0 + ii * kLnChunk));
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (j < total_sub) issue(j, j % NS);
+
+    // operands: X[set][u][k][half]: dword unit u (channels 2u, 2u + 1 of the wave's sixteen), k = I(2u), Q(2u), I(2u+1), Q(2u+1); 4 frames per half
+    v2i X0[8][4], X1[8][4];
+    v4i acc[4][16];
+    const long ones = 0x0101010101010101L;  // I_a x ones^T adds sum_t I_a(t) to every column of row a: the "+ 1" of -q = ~q + 1, no row sums to carry
+    const int lane_lds = ((g & 1) * 16 + r) * kLnChunk + (g >> 1) * 512 + wave * 32;
+
+    // wait until sub-stage m has landed (for every wave), pull this lane's bytes, hand the slot back, transpose into X[.][.][.][H]
+    auto consume = [&](int m, int j, bool drain, v2i (&X)[8][4], auto Hc) {
+        constexpr int H = decltype(Hc)::value;
+        const int younger = total_sub - 1 - m;  // sub-stages requested after this one that may still be in flight
+        if (drain || younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (younger >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __syncthreads();
+        const unsigned char *cb = lds + (m & (kLnRing - 1)) * kLnSlot + lane_lds;
+        v4i raw[4][2];
+#pragma unroll
+        for (int ti = 0; ti < 4; ti++) {
+            raw[ti][0] = *(const v4i *)(cb + ti * 128);
+            raw[ti][1] = *(const v4i *)(cb + ti * 128 + 16);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();  // every wave holds its bytes: the slot takes sub-stage m + 4
+        if (m + 4 < total_sub) issue(m + 4, (j + 4) % NS);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            unsigned o[4];
+            transpose4x4((unsigned)raw[0][u >> 2][u & 3], (unsigned)raw[1][u >> 2][u & 3], (unsigned)raw[2][u >> 2][u & 3], (unsigned)raw[3][u >> 2][u & 3], o);
+#pragma unroll
+            for (int k = 0; k < 4; k++) X[u][k][H] = (int)o[k];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // (the raw dwords die here)
+    };
+    typedef std::integral_constant<int, 0> H0;
+    typedef std::integral_constant<int, 1> H1;
+
+    // The products.  Accumulators are pinned to the accumulation registers and updated IN PLACE by inline assembly: 16 channels x 16 registers are
+    // exactly the 256 AGPRs of a wave, and the compiler's own v_mfma (destination and addend allocated separately) needs spare ones and spills.
+    // What the compiler's hazard pass would have done is done by construction: products are issued type by type over all sixteen channels, so two
+    // products on one accumulator are fifteen products apart; every product is preceded by two idle cycles (a freshly written operand or addend);
+    // the epilogue reads the accumulators after ln_mfma_drain().
+    auto mm = [&](v4i &C, long A, long B) {
+        asm volatile("s_nop 1\n\tv_mfma_i32_16x16x32_i8 %0, %1, %2, %0" : "+a"(C) : "v"(A), "v"(B));
+    };
+    // diagonal pair of row tile X: C += I I^T + Q Q^T + Q I^T + I (~Q)^T + I 1^T
+    auto mfma_diag = [&](v4i (&C)[16], const v2i (&X)[8][4]) {
+#pragma unroll
+        for (int ch = 0; ch < 16; ch++) mm(C[ch], as_long(X[ch >> 1][2 * (ch & 1)]), as_long(X[ch >> 1][2 * (ch & 1)]));
+#pragma unroll
+        for (int ch = 0; ch < 16; ch++) mm(C[ch], as_long(X[ch >> 1][2 * (ch & 1) + 1]), as_long(X[ch >> 1][2 * (ch & 1) + 1]));
+#pragma unroll
+        for (int ch = 0; ch < 16; ch++) mm(C[ch], as_long(X[ch >> 1][2 * (ch & 1) + 1]), as_long(X[ch >> 1][2 * (ch & 1)]));
+#pragma unroll
+        for (int ch = 0; ch < 16; ch++) mm(C[ch], as_long(X[ch >> 1][2 * (ch & 1)]), not_long(X[ch >> 1][2 * (ch & 1) + 1]));
+#pragma unroll
+        for (int ch = 0; ch < 16; ch++) mm(C[ch], as_long(X[ch >> 1][2 * (ch & 1)]), ones);
+    };
+    // off-diagonal pair: rows XA, columns XB
+    auto mfma_off = [&](v4i (&RE)[16], v4i (&IM)[16], const v2i (&XA)[8][4], const v2i (&XB)[8][4]) {
+#pragma unroll
+        for (int ch = 0; ch < 16; ch++) mm(RE[ch], as_long(XA[ch >> 1][2 * (ch & 1)]), as_long(XB[ch >> 1][2 * (ch & 1)]));
+#pragma unroll
+        for (int ch = 0; ch < 16; ch++) mm(IM[ch], as_long(XA[ch >> 1][2 * (ch & 1) + 1]), as_long(XB[ch >> 1][2 * (ch & 1)]));
+#pragma unroll
+        for (int ch = 0; ch < 16; ch++) mm(RE[ch], as_long(XA[ch >> 1][2 * (ch & 1) + 1]), as_long(XB[ch >> 1][2 * (ch & 1) + 1]));
+#pragma unroll
+        for (int ch = 0; ch < 16; ch++) mm(IM[ch], as_long(XA[ch >> 1][2 * (ch & 1)]), not_long(XB[ch >> 1][2 * (ch & 1) + 1]));
+#pragma unroll
+        for (int ch = 0; ch < 16; ch++) mm(IM[ch], as_long(XA[ch >> 1][2 * (ch & 1)]), ones);
+    };
+
+    const int nb = 64 * 65 / 2;
+    int m = 0;  // sub-stage counter of the stream
+    for (int unit = 0; unit < a.items; unit++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int ch = 0; ch < 16; ch++) acc[k][ch] = (v4i){0, 0, 0, 0};
+        for (int kb = 0; kb < a.steps; kb++) {
+            // (the first wait of a unit that follows another one drains everything: that unit's matrix stores share the counter with the DMA and
+            // complete out of order with it)
+            const bool drain = unit > 0 && kb == 0;
+            if constexpr (DIAG) {
+                consume(m, 0, drain, X0, H0{});
+                consume(m + 1, 1, false, X0, H1{});
+                consume(m + 2, 2, false, X1, H0{});
+                mfma_diag(acc[0], X0);
+                consume(m + 3, 3, false, X1, H1{});
+                mfma_off(acc[2], acc[3], X1, X0);
+                mfma_diag(acc[1], X1);
+                m += 4;
+            } else {
+                consume(m, 0, drain, X0, H0{});
+                consume(m + 1, 1, false, X0, H1{});
+                consume(m + 2, 2, false, X1, H0{});
+                consume(m + 3, 3, false, X1, H1{});
+                mfma_off(acc[0], acc[1], X0, X1);
+                consume(m + 4, 4, false, X1, H0{});
+                consume(m + 5, 5, false, X1, H1{});
+                mfma_off(acc[2], acc[3], X0, X1);
+                m += 6;
+            }
+        }
+        // ---- the unit's matrices: scale, scatter into [chan][baseline]
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");  // (the last products have left the pipeline before an accumulator is read)
+        const LnUnit un = ln_map_unit(a, blockIdx.x + unit * grid);
+        c32 *const out_w = a.out + (size_t)un.win * a.out_window;
+        int rr = lane & 15, gg = lane >> 4;
+        asm volatile("" : "+v"(rr), "+v"(gg));  // (keeps the tail's index arithmetic out of the loop's registers)
+        const bool odd = (rr & 1) != 0;
+        int *tile = (int *)(lds + kLnRing * kLnSlot + wave * kLnTile);
+        // two values per lane and row pair -> 16-byte stores of two neighbouring baselines of ONE row (a lane pair swaps a value each)
+        auto store_rows = [&](const int (&vre)[4], const int (&vim)[4], int f, int bi, int bj, bool small) {
+#pragma unroll
+            for (int rp = 0; rp < 4; rp += 2) {
+                c32 w[2];
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    if (small) {
+                        w[e].x = ln_scale127_small(vre[rp + e]);
+                        w[e].y = ln_scale127_small(vim[rp + e]);
+                    } else {
+                        w[e].x = (float)((double)vre[rp + e] * a.kd * a.kd);  // the oracle's expression: (double)S * kd * kd, rounded once
+                        w[e].y = (float)((double)vim[rp + e] * a.kd * a.kd);
+                    }
+                }
+                const float sx = odd ? w[0].x : w[1].x, sy = odd ? w[0].y : w[1].y;  // what the neighbour stores of this lane's values
+                const float gx = __shfl_xor(sx, 1), gy = __shfl_xor(sy, 1);
+                const int i = 4 * gg + rp + (odd ? 1 : 0), j0 = rr & ~1;  // this lane stores columns j0, j0 + 1 of row i of the tile pair
+                const int s1 = bi * 16 + i;
+                c32 *dst = out_w + (size_t)f * nb + (s1 * (s1 + 1) / 2 + bj * 16 + j0);
+                const c32 first = odd ? c32{gx, gy} : w[0], second = odd ? w[1] : c32{gx, gy};
+                if (bi != bj || j0 + 1 <= i) {
+                    const v4f q4 = (v4f){first.x, first.y, second.x, second.y};
+                    __builtin_memcpy((void *)dst, &q4, 16);
+                } else if (j0 <= i) {
+                    *dst = first;
+                }
+            }
+        };
+        auto emit_off = [&](const v4i &RE, const v4i &IM, int f, int bi, int bj) {
+            int vre[4], vim[4];
+            unsigned mag = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                vre[k] = RE[k];
+                vim[k] = IM[k];
+                mag |= ln_mag_bits(vre[k]) | ln_mag_bits(vim[k]);
+            }
+            if (a.dbg & 2) { if (vre[0] == 0x12345678 && vim[1] == 0x7654321) out_w[lane].x = 1.0f; return; }
+            store_rows(vre, vim, f, bi, bj, a.k127 && ln_all_small(mag));
+        };
+        auto emit_diag = [&](const v4i &C, int f, int bi) {
+            int ct[4], vre[4], vim[4];
+            // C[i][j], i = 4 g + reg, j = r; its transpose through this wave's scratch (same wave: no barrier)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                ct[k] = C[k];
+                tile[(4 * gg + k) * 20 + rr] = ct[k];
+            }
+            const v4i trow = *(const v4i *)(tile + rr * 20 + 4 * gg);  // C_true[r][4 g + reg]
+            unsigned mag = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                vre[k] = (ct[k] + trow[k]) >> 1;  // (even: exact)
+                vim[k] = (ct[k] - trow[k]) >> 1;  // 0 on the diagonal
+                mag |= ln_mag_bits(vre[k]) | ln_mag_bits(vim[k]);
+            }
+            if (a.dbg & 2) { if (vre[0] == 0x12345678 && vim[1] == 0x7654321) out_w[lane].x = 1.0f; return; }
+            store_rows(vre, vim, f, bi, bi, a.k127 && ln_all_small(mag));
+        };
+#pragma unroll
+        for (int ch = 0; ch < 16; ch++) {
+            const int f = un.col * 64 + wave * 16 + ch;
+            if (f >= a.Fout) continue;
+            if constexpr (DIAG) {
+                emit_diag(acc[0][ch], f, rt0);
+                emit_off(acc[2][ch], acc[3][ch], f, rt1, rt0);
+                emit_diag(acc[1][ch], f, rt1);
+            } else {
+                emit_off(acc[0][ch], acc[1][ch], f, rt0, 0);
+                emit_off(acc[2][ch], acc[3][ch], f, rt0, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // (one channel's values at a time)
+        }
+    }
+}
+
+__global__ __launch_bounds__(kLnThreads) void k_xe_i8_lines(LnArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    if (a.ts && threadIdx.x == 0) a.ts[(size_t)blockIdx.x * 2] = wall_clock64();
+    // (a workgroup's units are all of one group: the host makes the grid a multiple of 32 -- pinned map -- or of 4)
+    const int grp = ln_map_unit(a, blockIdx.x).grp;
+    if (grp < 2) ln_body<true>(a, lds, grp);
+    else ln_body<false>(a, lds, grp);
+    if (a.ts && threadIdx.x == 0) a.ts[(size_t)blockIdx.x * 2 + 1] = wall_clock64();
+}
+
+}  // namespace
+
+// Geometry the whole-line kernel covers: one polarisation, exactly 64 stations, rows of whole 128-byte lines (a multiple of 64 channels, all of them
+// output), whole K blocks, at most 16384 frames (the combined accumulator of the diagonal pairs), antenna groups of a multiple of 8 stations, enough
+// (window, line, group) units to fill the device WITHOUT time ranges.  MI355_XE_NO_LINES=1: never.
+bool mi355_xe_lines_ok(int N, int F, int Fout, int npol, int T, int stations_per_group, int accumulate, int nint, int cus)
+{
+    if (getenv("MI355_XE_NO_LINES")) return false;
+    const int ng = (stations_per_group > 0 && stations_per_group < N) ? stations_per_group : N;
+    if (npol != 1 || N != 64 || F % 64 != 0 || Fout != F || T % 32 != 0 || T < 32 || T > 16384 || accumulate || ng % 8 != 0) return false;
+    const long units = (long)(nint > 0 ? nint : 1) * (F / 64) * 4;
+    const int min_units = getenv("MI355_XE_LINES_MIN_UNITS") ? atoi(getenv("MI355_XE_LINES_MIN_UNITS")) : cus;
+    return units >= min_units && units % 4 == 0;
+}
+
+int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int T, double kd, hipStream_t st, int stations_per_group, int nint, int cus)
+{
+    LnArgs a;
+    a.in = (const unsigned char *)in;
+    a.out = (c32 *)out;
+    a.Fout = Fout;
+    a.T = T;
+    a.ncols = F / 64;
+    a.row_stride = F * 2;
+    a.ng = (stations_per_group > 0 && stations_per_group < N) ? stations_per_group : N;
+    const int nw = nint > 0 ? nint : 1;
+    a.units = nw * a.ncols * 4;
+    a.steps = T / 32;
+    // reference layout: [window][t][station]; group-major: [group][window][t][station in group]
+    a.in_window = (size_t)T * a.ng * a.row_stride;
+    a.in_group = (size_t)nw * T * a.ng * a.row_stride;
+    a.out_window = (size_t)Fout * ((size_t)N * (N + 1) / 2);
+    a.kd = kd;
+    a.k127 = (kd == 0.007874015748031496063 && !getenv("MI355_XE_SCALE_F64")) ? 1 : 0;
+    a.dbg = getenv("MI355_XE_DBG") ? atoi(getenv("MI355_XE_DBG")) : 0;
+    a.ts = nullptr;
+    // persistent form: units / grid units per workgroup; the grid a multiple of 32 (pinned map: a workgroup keeps its XCD and group) or of 4
+    a.pinned = (a.units % 32 == 0) ? 1 : 0;
+    const int quantum = a.pinned ? 32 : 4;
+    int items = (a.units + cus - 1) / cus;
+    while (items < a.units && (a.units % items != 0 || (a.units / items) % quantum != 0)) items++;
+    if (a.units % items != 0 || (a.units / items) % quantum != 0) items = a.units / quantum;  // (one workgroup quantum: always divides)
+    a.items = items;
+    static bool attr_set = false;
+    if (!attr_set) {
+        MI355_HIP(hipFuncSetAttribute((const void *)k_xe_i8_lines, hipFuncAttributeMaxDynamicSharedMemorySize, kLnLds));
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned)(a.units / a.items);
+    if (getenv("MI355_XE_TS")) {  // tuning aid: one synchronous launch with start / end stamps per workgroup
+        unsigned long long *d_ts = nullptr;
+        MI355_HIP(hipMalloc(&d_ts, (size_t)grid * 16));
+        a.ts = d_ts;
+        hipLaunchKernelGGL(k_xe_i8_lines, dim3(grid), dim3(kLnThreads), kLnLds, st, a);
+        MI355_HIP(hipGetLastError());
+        MI355_HIP(hipStreamSynchronize(st));
+        std::vector<unsigned long long> h((size_t)grid * 2);
+        MI355_HIP(hipMemcpy(h.data(), d_ts, (size_t)grid * 16, hipMemcpyDeviceToHost));
+        (void)hipFree(d_ts);
+        unsigned long long t0 = ~0ull;
+        for (unsigned b = 0; b < grid; b++) t0 = std::min(t0, h[2 * b]);
+        double end_by_grp[4] = {0, 0, 0, 0}, end_by_col[64] = {0}, last = 0;
+        int n_grp[4] = {0, 0, 0, 0}, n_col[64] = {0};
+        for (unsigned b = 0; b < grid; b++) {
+            const int within = a.pinned ? (int)(b >> 3) : (int)b, grp = within & 3, combo = a.pinned ? (int)((b & 7) + 8 * (within >> 2)) : (int)(b >> 2);
+            const double e = (double)(h[2 * b + 1] - t0) * 0.01;
+            end_by_grp[grp] += e; n_grp[grp]++;
+            end_by_col[(combo % a.ncols) & 63] += e; n_col[(combo % a.ncols) & 63]++;
+            last = std::max(last, e);
+        }
+        fprintf(stderr, "[xe lines stamps] %u workgroups x %d units, last end %.1f us; mean end by group:", grid, a.items, last);
+        for (int k = 0; k < 4; k++) fprintf(stderr, " %.1f", n_grp[k] ? end_by_grp[k] / n_grp[k] : 0.0);
+        fprintf(stderr, "; by line:");
+        for (int k = 0; k < a.ncols && k < 64; k++) fprintf(stderr, " %.0f", n_col[k] ? end_by_col[k] / n_col[k] : 0.0);
+        fprintf(stderr, "\n");
+        return MI355_OK;
+    }
+    hipLaunchKernelGGL(k_xe_i8_lines, dim3(grid), dim3(kLnThreads), kLnLds, st, a);
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
+}

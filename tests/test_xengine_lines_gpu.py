@@ -1,0 +1,144 @@
+"""GPU parity: the whole-line form of the fused IChar X-engine (csrc/xengine_lines.hip: 64 stations, one polarisation, whole 128-byte lines per
+request, the ten row-tile pairs split over four workgroups) against the oracle's exact mode, bit for bit, and against the 32-byte-slice kernel
+(MI355_XE_NO_LINES=1).  Reference behaviour: lib/clXEngine_impl.cc:708-817, :859-867.  The path is chosen by mi355_xe_lines_ok (enough units to
+fill the device without time ranges); MI355_XE_LINES_MIN_UNITS lowers that bar so that small geometries reach the kernel too."""
+import os
+import numpy as np
+import pytest
+
+from conftest import GPU_ARGS
+
+pytestmark = pytest.mark.gpu
+
+
+def _xe(gpu, N, F, T):
+    return gpu.clXEngine(*GPU_ARGS, False, gpu.DTYPE_BYTE, 1, N, gpu.CLXCORR_TRIANGULAR_ORDER, 0, F, T, [])
+
+
+def _run(gpu, blk, nint, x, out, ng=0):
+    import torch
+    if ng: blk.xcorrelate_n_device(nint, x, out, stations_per_group=ng)
+    else: blk.xcorrelate_n_device(nint, x, out)
+    torch.cuda.synchronize()
+
+
+@pytest.fixture
+def small_units(monkeypatch):
+    monkeypatch.setenv("MI355_XE_LINES_MIN_UNITS", "4")
+
+
+@pytest.mark.parametrize("F,T,nint", [(64, 32, 1), (64, 64, 2), (128, 96, 3), (192, 160, 1), (256, 32, 8), (512, 64, 16), (1024, 32, 5)])
+def test_whole_line_kernel_bit_exact(gpu, oracle, small_units, F, T, nint):
+    """Every window bit exact against the oracle: one and several K blocks, one unit and several units per workgroup (512 x 16: two), unit counts
+    that are and are not a multiple of 32 (the pinned and the plain workgroup map)."""
+    import torch
+    N = 64
+    rng = np.random.default_rng(F + 7 * T + nint)
+    wins = rng.integers(-128, 128, size=(nint, T, N, F, 1, 2), dtype=np.int64).astype(np.int8)
+    blk = _xe(gpu, N, F, T)
+    per = blk.get_output_buffer_size()
+    ref = np.concatenate([oracle.xengine_ichar(N, F, 1, T, wins[i].reshape(-1), exact=True) for i in range(nint)])
+    x = torch.from_numpy(wins).cuda()
+    out = torch.zeros(nint * per, 2, device="cuda")
+    _run(gpu, blk, nint, x, out)
+    got = out.cpu().numpy().view(np.complex64).reshape(-1)
+    assert np.array_equal(got, ref)
+    # the 32-byte-slice kernel gives the same bits
+    os.environ["MI355_XE_NO_LINES"] = "1"
+    try:
+        old = torch.zeros_like(out)
+        _run(gpu, blk, nint, x, old)
+    finally:
+        os.environ.pop("MI355_XE_NO_LINES", None)
+    assert torch.equal(out, old)
+
+
+@pytest.mark.parametrize("W", [2, 4, 8])
+def test_whole_line_kernel_group_major(gpu, oracle, small_units, W):
+    """The input as one all-to-all delivers it, [group][window][t][station in group][chan]: read in place (groups of 32, 16 and 8 stations)."""
+    import torch
+    N, F, T, nint = 64, 128, 64, 3
+    rng = np.random.default_rng(W)
+    wins = rng.integers(-128, 128, size=(nint, T, N, F, 1, 2), dtype=np.int64).astype(np.int8)
+    blk = _xe(gpu, N, F, T)
+    per = blk.get_output_buffer_size()
+    ref = np.concatenate([oracle.xengine_ichar(N, F, 1, T, wins[i].reshape(-1), exact=True) for i in range(nint)])
+    Ng = N // W
+    x = torch.from_numpy(np.ascontiguousarray(wins.reshape(nint, T, W, Ng, F, 1, 2).transpose(2, 0, 1, 3, 4, 5, 6))).cuda()
+    out = torch.zeros(nint * per, 2, device="cuda")
+    _run(gpu, blk, nint, x, out, ng=Ng)
+    assert np.array_equal(out.cpu().numpy().view(np.complex64).reshape(-1), ref)
+
+
+def test_whole_line_kernel_extremes(gpu, oracle, small_units):
+    """All samples -128 (the value whose negation does not exist in int8), all +127, and alternating signs, over the longest integration the
+    kernel takes (16384 frames: the combined accumulator of a diagonal tile pair holds re + im, |.| <= T * 2^16)."""
+    import torch
+    N, F, T = 64, 64, 16384
+    blk = _xe(gpu, N, F, T)
+    per = blk.get_output_buffer_size()
+    for fill in ("min", "max", "alt"):
+        w = np.empty((T, N, F, 1, 2), np.int8)
+        if fill == "min": w[:] = -128
+        elif fill == "max": w[:] = 127
+        else:
+            w[..., 0] = -128
+            w[..., 1] = 127
+            w[::2, 1::2] = np.array([127, -128], np.int8)
+        ref = oracle.xengine_ichar(N, F, 1, T, w.reshape(-1), exact=True)
+        x = torch.from_numpy(w).cuda()
+        out = torch.zeros(per, 2, device="cuda")
+        _run(gpu, blk, 1, x, out)
+        assert np.array_equal(out.cpu().numpy().view(np.complex64).reshape(-1), ref), fill
+
+
+def test_whole_line_kernel_refusals_fall_back(gpu, oracle, small_units):
+    """Geometries outside the kernel's range still give the oracle's bits through the 32-byte-slice kernel: 60 stations, 96 channels (rows that are
+    not whole lines), a ragged integration, accumulate."""
+    import torch
+    for N, F, T in ((60, 64, 64), (64, 96, 64), (64, 64, 40)):
+        rng = np.random.default_rng(N + F + T)
+        w = rng.integers(-128, 128, size=(2, T, N, F, 1, 2), dtype=np.int64).astype(np.int8)
+        blk = _xe(gpu, N, F, T)
+        per = blk.get_output_buffer_size()
+        ref = np.concatenate([oracle.xengine_ichar(N, F, 1, T, w[i].reshape(-1), exact=True) for i in range(2)])
+        out = torch.zeros(2 * per, 2, device="cuda")
+        _run(gpu, blk, 2, torch.from_numpy(w).cuda(), out)
+        assert np.array_equal(out.cpu().numpy().view(np.complex64).reshape(-1), ref)
+    N, F, T = 64, 64, 64
+    rng = np.random.default_rng(5)
+    w = rng.integers(-128, 128, size=(1, T, N, F, 1, 2), dtype=np.int64).astype(np.int8)
+    blk = _xe(gpu, N, F, T)
+    per = blk.get_output_buffer_size()
+    x = torch.from_numpy(w).cuda()
+    out = torch.zeros(per, 2, device="cuda")
+    _run(gpu, blk, 1, x, out)
+    ref = oracle.xengine_ichar(N, F, 1, T, w.reshape(-1), exact=True)
+    blk.xcorrelate_n_device(1, x, out, accumulate=True)
+    torch.cuda.synchronize()
+    ref2 = oracle.xengine_ichar(N, F, 1, T, w.reshape(-1), exact=True, acc=ref.copy())
+    assert np.array_equal(out.cpu().numpy().view(np.complex64).reshape(-1), ref2)
+
+
+def test_whole_line_kernel_config5_batch(gpu, oracle):
+    """BASELINE config 5 (64 x 1024 x 1024), eight windows per launch -- the default route, two units per workgroup: the first and the last window bit
+    exact against the oracle, every window identical to the 32-byte-slice kernel's."""
+    import torch
+    N, F, T, nint = 64, 1024, 1024, 8
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randint(-128, 128, (nint, T, N, F, 1, 2), dtype=torch.int8, device="cuda", generator=g)
+    blk = _xe(gpu, N, F, T)
+    per = blk.get_output_buffer_size()
+    out = torch.zeros(nint * per, 2, device="cuda")
+    _run(gpu, blk, nint, x, out)
+    os.environ["MI355_XE_NO_LINES"] = "1"
+    try:
+        old = torch.zeros_like(out)
+        _run(gpu, blk, nint, x, old)
+    finally:
+        os.environ.pop("MI355_XE_NO_LINES", None)
+    assert torch.equal(out, old)
+    got = out.cpu().numpy().view(np.complex64).reshape(nint, -1)
+    for i in (0, nint - 1):
+        ref = oracle.xengine_ichar(N, F, 1, T, x[i].cpu().numpy().reshape(-1), exact=True)
+        assert np.array_equal(got[i], ref), i
