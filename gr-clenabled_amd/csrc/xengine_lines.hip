@@ -53,7 +53,14 @@ struct LnArgs {
     unsigned long long *ts;
 };
 
-__device__ __forceinline__ unsigned perm(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+// (asm volatile: the transposes stay where they are written, between the products they are interleaved with -- left to the scheduler they are
+// hoisted and sunk across the products, the raw rows of two sub-stages live at once, and the allocator starts moving accumulators)
+__device__ __forceinline__ unsigned perm(unsigned hi, unsigned lo, unsigned sel)
+{
+    unsigned d;
+    asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(hi), "v"(lo), "s"(sel));
+    return d;
+}
 
 // 4 dwords (bytes b0..b3 of four frames) -> out[j] = byte j of each input dword
 __device__ __forceinline__ void transpose4x4(unsigned i0, unsigned i1, unsigned i2, unsigned i3, unsigned (&out)[4])
@@ -87,8 +94,45 @@ __device__ __forceinline__ void ln_dma16(const void *gsrc, unsigned lds_dst)
                  : "memory");
 }
 
-__device__ __forceinline__ long as_long(v2i v) { return __builtin_bit_cast(long, v); }
-__device__ __forceinline__ long not_long(v2i v) { return __builtin_bit_cast(long, (v2i){~v[0], ~v[1]}); }
+
+// ---- The accumulators are the wave's 256 accumulation registers BY NAME: accumulator (k, ch) = a[(16 k + ch) * 4 .. + 3].  The compiler never sees
+// them as values -- given 256 tied "+a" operands it time-shares AGPRs between accumulators (v_accvgpr_read of a register a product issued one
+// instruction earlier has not written yet: the hazards of an inline-assembly v_mfma are invisible to it) and given its own v_mfma it needs spare
+// AGPRs and spills.  Every statement that touches them clobbers all 256, so nothing of the compiler's lives in an AGPR across any of them, and the
+// file is built with -amdgpu-spill-vgpr-to-agpr=0.  Ordering and hazards by construction (see the K loop).
+#define LN_A8(n) "a" #n "0", "a" #n "1", "a" #n "2", "a" #n "3", "a" #n "4", "a" #n "5", "a" #n "6", "a" #n "7", "a" #n "8", "a" #n "9"
+#define LN_ALL_AGPRS                                                                                                                              \
+    "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", LN_A8(1), LN_A8(2), LN_A8(3), LN_A8(4), LN_A8(5), LN_A8(6), LN_A8(7), LN_A8(8),   \
+        LN_A8(9), LN_A8(10), LN_A8(11), LN_A8(12), LN_A8(13), LN_A8(14), LN_A8(15), LN_A8(16), LN_A8(17), LN_A8(18), LN_A8(19), LN_A8(20),       \
+        LN_A8(21), LN_A8(22), LN_A8(23), LN_A8(24), "a250", "a251", "a252", "a253", "a254", "a255"
+
+template <int I, int N, class F> __device__ __forceinline__ void ln_sfor(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        ln_sfor<I + 1, N>(f);
+    }
+}
+// accumulator at AGPR R += A x B^T (16 x 16 x 64, int8): two idle cycles in front (a freshly written operand)
+template <int R> __device__ __forceinline__ void ln_mm(const v4i &A, const v4i &B)
+{
+    asm volatile("s_nop 1\n\tv_mfma_i32_16x16x64_i8 a[%2:%3], %0, %1, a[%2:%3]" ::"v"(A), "v"(B), "n"(R), "n"(R + 3) : LN_ALL_AGPRS);
+}
+template <int R> __device__ __forceinline__ void ln_acc_zero4()
+{
+    asm volatile("v_accvgpr_write_b32 a[%0], 0\n\tv_accvgpr_write_b32 a[%1], 0\n\tv_accvgpr_write_b32 a[%2], 0\n\tv_accvgpr_write_b32 a[%3], 0" ::"n"(R), "n"(R + 1),
+                 "n"(R + 2), "n"(R + 3)
+                 : LN_ALL_AGPRS);
+}
+template <int R> __device__ __forceinline__ v4i ln_acc_read4()
+{
+    v4i v;
+    asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\tv_accvgpr_read_b32 %2, a[%6]\n\tv_accvgpr_read_b32 %3, a[%7]"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                 : "n"(R), "n"(R + 1), "n"(R + 2), "n"(R + 3));
+    return v;
+}
+constexpr int ln_areg(int k, int ch) { return (16 * k + ch) * 4; }
 
 struct LnUnit { int col, grp, win; };
 
@@ -159,113 +203,166 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
         }
     };
 #pragma unroll
-    for (int j = 0; j < 4; j++)
+    for (int j = 0; j < 3; j++)
         if (j < total_sub) issue(j, j % NS);
 
-    // operands: X[set][u][k][half]: dword unit u (channels 2u, 2u + 1 of the wave's sixteen), k = I(2u), Q(2u), I(2u+1), Q(2u+1); 4 frames per half
-    v2i X0[8][4], X1[8][4];
-    v4i acc[4][16];
-    const long ones = 0x0101010101010101L;  // I_a x ones^T adds sum_t I_a(t) to every column of row a: the "+ 1" of -q = ~q + 1, no row sums to carry
+    // operands: X[u][c] = (I, Q) of channel 2u + c of the wave's sixteen as ONE 16-byte operand of v_mfma_i32_16x16x64_i8: components 0, 1 = I of
+    // the two halves of the K block (4 frames each), 2, 3 = Q; u = the dword unit the two channels share in the raw rows
+    v4i X0[8][2], X1[8][2];
+    v4i raw[4][2];
     const int lane_lds = ((g & 1) * 16 + r) * kLnChunk + (g >> 1) * 512 + wave * 32;
 
-    // wait until sub-stage m has landed (for every wave), pull this lane's bytes, hand the slot back, transpose into X[.][.][.][H]
-    auto consume = [&](int m, int j, bool drain, v2i (&X)[8][4], auto Hc) {
-        constexpr int H = decltype(Hc)::value;
-        const int younger = total_sub - 1 - m;  // sub-stages requested after this one that may still be in flight
+    // ---- One wave per SIMD: nothing hides a latency unless the instruction stream itself does.  A sub-stage is taken in three parts --
+    //   front(m): wait until sub-stage m has landed, ONE barrier (behind it every wave has also finished reading sub-stage m - 1, whose slot takes
+    //             sub-stage m + 3 at once: three sub-stages in flight), the eight 16-byte LDS reads of this lane;
+    //   products that do not touch the operand set about to be written, issued while those reads are in flight;
+    //   perm(u): the byte transpose of dword unit u into X[u][.][half], three products of the pending list after each unit.
+    auto front = [&](int m, int j, bool drain) {
+        const int younger = total_sub - 1 - m;  // sub-stages requested after this one that may still be in flight (at most two)
         if (drain || younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (younger >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        else if (younger == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __syncthreads();
+        if (m + 3 < total_sub) issue(m + 3, (j + 3) % NS);
         const unsigned char *cb = lds + (m & (kLnRing - 1)) * kLnSlot + lane_lds;
-        v4i raw[4][2];
 #pragma unroll
         for (int ti = 0; ti < 4; ti++) {
             raw[ti][0] = *(const v4i *)(cb + ti * 128);
             raw[ti][1] = *(const v4i *)(cb + ti * 128 + 16);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();  // every wave holds its bytes: the slot takes sub-stage m + 4
-        if (m + 4 < total_sub) issue(m + 4, (j + 4) % NS);
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            unsigned o[4];
-            transpose4x4((unsigned)raw[0][u >> 2][u & 3], (unsigned)raw[1][u >> 2][u & 3], (unsigned)raw[2][u >> 2][u & 3], (unsigned)raw[3][u >> 2][u & 3], o);
-#pragma unroll
-            for (int k = 0; k < 4; k++) X[u][k][H] = (int)o[k];
-        }
-        __builtin_amdgcn_sched_barrier(0);  // (the raw dwords die here)
     };
-    typedef std::integral_constant<int, 0> H0;
-    typedef std::integral_constant<int, 1> H1;
-
-    // The products.  Accumulators are pinned to the accumulation registers and updated IN PLACE by inline assembly: 16 channels x 16 registers are
-    // exactly the 256 AGPRs of a wave, and the compiler's own v_mfma (destination and addend allocated separately) needs spare ones and spills.
-    // What the compiler's hazard pass would have done is done by construction: products are issued type by type over all sixteen channels, so two
-    // products on one accumulator are fifteen products apart; every product is preceded by two idle cycles (a freshly written operand or addend);
-    // the epilogue reads the accumulators after ln_mfma_drain().
-    auto mm = [&](v4i &C, long A, long B) {
-        asm volatile("s_nop 1\n\tv_mfma_i32_16x16x32_i8 %0, %1, %2, %0" : "+a"(C) : "v"(A), "v"(B));
+    auto perm_unit = [&](v4i (&X)[8][2], int u, int H) {
+        unsigned o[4];
+        transpose4x4((unsigned)raw[0][u >> 2][u & 3], (unsigned)raw[1][u >> 2][u & 3], (unsigned)raw[2][u >> 2][u & 3], (unsigned)raw[3][u >> 2][u & 3], o);
+        X[u][0][H] = (int)o[0];
+        X[u][0][2 + H] = (int)o[1];
+        X[u][1][H] = (int)o[2];
+        X[u][1][2 + H] = (int)o[3];
     };
-    // diagonal pair of row tile X: C += I I^T + Q Q^T + Q I^T + I (~Q)^T + I 1^T
-    auto mfma_diag = [&](v4i (&C)[16], const v2i (&X)[8][4]) {
-#pragma unroll
-        for (int ch = 0; ch < 16; ch++) mm(C[ch], as_long(X[ch >> 1][2 * (ch & 1)]), as_long(X[ch >> 1][2 * (ch & 1)]));
-#pragma unroll
-        for (int ch = 0; ch < 16; ch++) mm(C[ch], as_long(X[ch >> 1][2 * (ch & 1) + 1]), as_long(X[ch >> 1][2 * (ch & 1) + 1]));
-#pragma unroll
-        for (int ch = 0; ch < 16; ch++) mm(C[ch], as_long(X[ch >> 1][2 * (ch & 1) + 1]), as_long(X[ch >> 1][2 * (ch & 1)]));
-#pragma unroll
-        for (int ch = 0; ch < 16; ch++) mm(C[ch], as_long(X[ch >> 1][2 * (ch & 1)]), not_long(X[ch >> 1][2 * (ch & 1) + 1]));
-#pragma unroll
-        for (int ch = 0; ch < 16; ch++) mm(C[ch], as_long(X[ch >> 1][2 * (ch & 1)]), ones);
+    // The products (accumulators by name, see ln_mm).  What the compiler's hazard pass would do for its own v_mfma is done by construction: the
+    // products of a list are issued type by type over all sixteen channels, so two products on one accumulator are fifteen products apart; every
+    // product is preceded by two idle cycles; the accumulators are read after the pipeline has drained.
+    // 16 x 16 x 64: K = (half, frame, I | Q), so ONE product is sum_t (I_a I_b + Q_a Q_b) -- the whole real part -- and with the second operand
+    // (~Q_b, I_b) the whole of im'; the third, against (1, 0), adds sum_t I_a(t) to every column of row a: the "+ 1" of -q = ~q + 1
+    auto swapped = [&](const v4i &x) { return (v4i){~x[2], ~x[3], x[0], x[1]}; };
+    const v4i ones = (v4i){0x01010101, 0x01010101, 0, 0};
+    // item I (0 .. 47) of a diagonal pair's list, accumulator set KC: C += (I, Q) (I, Q)^T | (I, Q) (~Q, I)^T | (I, Q) (1, 0)^T, sixteen channels each
+    auto diag_item = [&](auto kc, const v4i (&X)[8][2], auto ic) {
+        constexpr int KC = decltype(kc)::value, I = decltype(ic)::value, ty = I >> 4, ch = I & 15;
+        const v4i &x = X[ch >> 1][ch & 1];
+        if constexpr (ty == 0) ln_mm<ln_areg(KC, ch)>(x, x);
+        else if constexpr (ty == 1) ln_mm<ln_areg(KC, ch)>(x, swapped(x));
+        else ln_mm<ln_areg(KC, ch)>(x, ones);
     };
-    // off-diagonal pair: rows XA, columns XB
-    auto mfma_off = [&](v4i (&RE)[16], v4i (&IM)[16], const v2i (&XA)[8][4], const v2i (&XB)[8][4]) {
-#pragma unroll
-        for (int ch = 0; ch < 16; ch++) mm(RE[ch], as_long(XA[ch >> 1][2 * (ch & 1)]), as_long(XB[ch >> 1][2 * (ch & 1)]));
-#pragma unroll
-        for (int ch = 0; ch < 16; ch++) mm(IM[ch], as_long(XA[ch >> 1][2 * (ch & 1) + 1]), as_long(XB[ch >> 1][2 * (ch & 1)]));
-#pragma unroll
-        for (int ch = 0; ch < 16; ch++) mm(RE[ch], as_long(XA[ch >> 1][2 * (ch & 1) + 1]), as_long(XB[ch >> 1][2 * (ch & 1) + 1]));
-#pragma unroll
-        for (int ch = 0; ch < 16; ch++) mm(IM[ch], as_long(XA[ch >> 1][2 * (ch & 1)]), not_long(XB[ch >> 1][2 * (ch & 1) + 1]));
-#pragma unroll
-        for (int ch = 0; ch < 16; ch++) mm(IM[ch], as_long(XA[ch >> 1][2 * (ch & 1)]), ones);
+    // item I of an off-diagonal pair's list (rows XA, columns XB), accumulator sets KR (re) and KR + 1 (im)
+    auto off_item = [&](auto kr, const v4i (&XA)[8][2], const v4i (&XB)[8][2], auto ic) {
+        constexpr int KR = decltype(kr)::value, I = decltype(ic)::value, ty = I >> 4, ch = I & 15;
+        const v4i &xa = XA[ch >> 1][ch & 1], &xb = XB[ch >> 1][ch & 1];
+        if constexpr (ty == 0) ln_mm<ln_areg(KR, ch)>(xa, xb);
+        else if constexpr (ty == 1) ln_mm<ln_areg(KR + 1, ch)>(xa, swapped(xb));
+        else ln_mm<ln_areg(KR + 1, ch)>(xa, ones);
     };
+    typedef std::integral_constant<int, 0> K0;
+    typedef std::integral_constant<int, 1> K1;
+    typedef std::integral_constant<int, 2> K2;
+    auto diag_range = [&](auto kc, const v4i (&X)[8][2], auto lo, auto hi) {
+        ln_sfor<decltype(lo)::value, decltype(hi)::value>([&](auto ic) { diag_item(kc, X, ic); });
+    };
+    // a sub-stage's eight transposes into half H of X with a stretch of a diagonal pair's list (all of whose operands are complete) spread over
+    // them: the items of unit u FIRST (the first ones run under the latency of the LDS reads), CUM = the cumulative counts per unit
+    auto perms_with_diag = [&](v4i (&X)[8][2], auto hc, auto kc, const v4i (&XD)[8][2], auto basec, auto cumc) {
+        ln_sfor<0, 8>([&](auto uc) {
+            constexpr int u = decltype(uc)::value, H = decltype(hc)::value, B = decltype(basec)::value;
+            typedef decltype(cumc) CUM;
+            diag_range(kc, XD, std::integral_constant<int, B + CUM::at(u)>{}, std::integral_constant<int, B + CUM::at(u + 1)>{});
+            perm_unit(X, u, H);
+        });
+    };
+    // the LAST sub-stage of an operand set: unit u completes channels 2u, 2u + 1 of X, whose products against the other, complete set follow at
+    // once -- real part and im' of both channels, and the row-sum product of the PREVIOUS unit's channels (same accumulator as im': kept four
+    // products apart).  ROWS: X holds the rows (XO the columns), else the columns.
+    auto perms_with_off = [&](v4i (&X)[8][2], auto kr, const v4i (&XO)[8][2], auto rowsc) {
+        constexpr bool ROWS = decltype(rowsc)::value != 0;
+        auto item = [&](auto tyc, auto chc) {
+            constexpr int I = decltype(tyc)::value * 16 + decltype(chc)::value;
+            if constexpr (ROWS) off_item(kr, X, XO, std::integral_constant<int, I>{});
+            else off_item(kr, XO, X, std::integral_constant<int, I>{});
+        };
+        typedef std::integral_constant<int, 0> T0;
+        typedef std::integral_constant<int, 1> T1;
+        typedef std::integral_constant<int, 2> T2;
+        ln_sfor<0, 8>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            perm_unit(X, u, 1);
+            item(T0{}, std::integral_constant<int, 2 * u>{});
+            item(T0{}, std::integral_constant<int, 2 * u + 1>{});
+            item(T1{}, std::integral_constant<int, 2 * u>{});
+            item(T1{}, std::integral_constant<int, 2 * u + 1>{});
+            if constexpr (u > 0) {
+                item(T2{}, std::integral_constant<int, 2 * u - 2>{});
+                item(T2{}, std::integral_constant<int, 2 * u - 1>{});
+            }
+        });
+        item(T2{}, std::integral_constant<int, 14>{});
+        item(T2{}, std::integral_constant<int, 15>{});
+    };
+    struct Cum24 { static constexpr int at(int u) { constexpr int c[9] = {0, 6, 9, 12, 15, 18, 20, 22, 24}; return c[u]; } };
+    struct Cum40 { static constexpr int at(int u) { constexpr int c[9] = {0, 8, 13, 18, 23, 28, 32, 36, 40}; return c[u]; } };
+    typedef std::integral_constant<int, 24> C24;
+    typedef std::integral_constant<int, 40> C40;
+    typedef std::integral_constant<int, 48> C48;
+    typedef K0 H0;
+    typedef K1 H1;
 
     const int nb = 64 * 65 / 2;
     int m = 0;  // sub-stage counter of the stream
     for (int unit = 0; unit < a.items; unit++) {
+        ln_sfor<0, 64>([&](auto qc) { ln_acc_zero4<4 * decltype(qc)::value>(); });
+        // (the loop carries the pair yy of a K block into the next one; before the first K block it runs on zeros)
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-#pragma unroll
-            for (int ch = 0; ch < 16; ch++) acc[k][ch] = (v4i){0, 0, 0, 0};
+        for (int u = 0; u < 8; u++) X1[u][0] = X1[u][1] = (v4i){0, 0, 0, 0};
         for (int kb = 0; kb < a.steps; kb++) {
             // (the first wait of a unit that follows another one drains everything: that unit's matrix stores share the counter with the DMA and
             // complete out of order with it)
             const bool drain = unit > 0 && kb == 0;
             if constexpr (DIAG) {
-                consume(m, 0, drain, X0, H0{});
-                consume(m + 1, 1, false, X0, H1{});
-                consume(m + 2, 2, false, X1, H0{});
-                mfma_diag(acc[0], X0);
-                consume(m + 3, 3, false, X1, H1{});
-                mfma_off(acc[2], acc[3], X1, X0);
-                mfma_diag(acc[1], X1);
+                // X0 = row tile x, X1 = row tile y; accumulator sets 0 = xx, 1 = yy, 2 / 3 = re / im of yx.  Every product runs between the
+                // transposes of some sub-stage: the pair yy of the PREVIOUS K block (reads X1 only) under the two sub-stages of x, the pair xx under
+                // the first of y, the pair yx channel by channel as the second of y completes X1.
+                front(m, 0, drain);
+                perms_with_diag(X0, H0{}, K1{}, X1, K0{}, Cum24{});
+                front(m + 1, 1, false);
+                perms_with_diag(X0, H1{}, K1{}, X1, C24{}, Cum24{});
+                front(m + 2, 2, false);
+                perms_with_diag(X1, H0{}, K0{}, X0, K0{}, Cum40{});
+                front(m + 3, 3, false);
+                diag_range(K0{}, X0, C40{}, C48{});
+                perms_with_off(X1, K2{}, X0, K1{});
                 m += 4;
             } else {
-                consume(m, 0, drain, X0, H0{});
-                consume(m + 1, 1, false, X0, H1{});
-                consume(m + 2, 2, false, X1, H0{});
-                consume(m + 3, 3, false, X1, H1{});
-                mfma_off(acc[0], acc[1], X0, X1);
-                consume(m + 4, 4, false, X1, H0{});
-                consume(m + 5, 5, false, X1, H1{});
-                mfma_off(acc[2], acc[3], X0, X1);
+                // X0 = row tile a, X1 = row tile 0, then 1; accumulator sets 0 / 1 = re / im of (a, 0), 2 / 3 of (a, 1): each pair channel by channel
+                // as the second sub-stage of its column tile completes X1
+                front(m, 0, drain);
+#pragma unroll
+                for (int u = 0; u < 8; u++) perm_unit(X0, u, 0);
+                front(m + 1, 1, false);
+#pragma unroll
+                for (int u = 0; u < 8; u++) perm_unit(X0, u, 1);
+                front(m + 2, 2, false);
+#pragma unroll
+                for (int u = 0; u < 8; u++) perm_unit(X1, u, 0);
+                front(m + 3, 3, false);
+                perms_with_off(X1, K0{}, X0, K0{});
+                front(m + 4, 4, false);
+#pragma unroll
+                for (int u = 0; u < 8; u++) perm_unit(X1, u, 0);
+                front(m + 5, 5, false);
+                perms_with_off(X1, K2{}, X0, K0{});
                 m += 6;
             }
         }
+        // the products the loop carries: the pair yy of the last K block
+        if constexpr (DIAG) diag_range(K1{}, X1, K0{}, C48{});
         // ---- the unit's matrices: scale, scatter into [chan][baseline]
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");  // (the last products have left the pipeline before an accumulator is read)
         const LnUnit un = ln_map_unit(a, blockIdx.x + unit * grid);
@@ -334,20 +431,21 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
             if (a.dbg & 2) { if (vre[0] == 0x12345678 && vim[1] == 0x7654321) out_w[lane].x = 1.0f; return; }
             store_rows(vre, vim, f, bi, bi, a.k127 && ln_all_small(mag));
         };
-#pragma unroll
-        for (int ch = 0; ch < 16; ch++) {
+        ln_sfor<0, 16>([&](auto chc) {
+            constexpr int ch = decltype(chc)::value;
             const int f = un.col * 64 + wave * 16 + ch;
-            if (f >= a.Fout) continue;
-            if constexpr (DIAG) {
-                emit_diag(acc[0][ch], f, rt0);
-                emit_off(acc[2][ch], acc[3][ch], f, rt1, rt0);
-                emit_diag(acc[1][ch], f, rt1);
-            } else {
-                emit_off(acc[0][ch], acc[1][ch], f, rt0, 0);
-                emit_off(acc[2][ch], acc[3][ch], f, rt0, 1);
+            if (f < a.Fout) {
+                if constexpr (DIAG) {
+                    emit_diag(ln_acc_read4<ln_areg(0, ch)>(), f, rt0);
+                    emit_off(ln_acc_read4<ln_areg(2, ch)>(), ln_acc_read4<ln_areg(3, ch)>(), f, rt1, rt0);
+                    emit_diag(ln_acc_read4<ln_areg(1, ch)>(), f, rt1);
+                } else {
+                    emit_off(ln_acc_read4<ln_areg(0, ch)>(), ln_acc_read4<ln_areg(1, ch)>(), f, rt0, 0);
+                    emit_off(ln_acc_read4<ln_areg(2, ch)>(), ln_acc_read4<ln_areg(3, ch)>(), f, rt0, 1);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);  // (one channel's values at a time)
-        }
+        });
     }
 }
 
