@@ -36,9 +36,11 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 struct c32 { float x, y; };
 
-constexpr int kLnWaves = 4, kLnThreads = kLnWaves * 64, kLnChunk = 1040, kLnSlot = 32 * kLnChunk, kLnRing = 4;
+constexpr int kLnWaves = 8, kLnCh = 8, kLnU = 4;  // eight waves (two per SIMD), eight channels = one 16-byte piece = four dword units per wave
+constexpr int kLnThreads = kLnWaves * 64, kLnChunk = 1040, kLnSlot = 32 * kLnChunk, kLnRing = 4;
 constexpr int kLnTile = 16 * 20 * 4;  // a wave's scratch for the transposed diagonal tile
-constexpr int kLnLds = kLnRing * kLnSlot + kLnWaves * kLnTile;
+constexpr int kLnPoll = kLnRing * kLnSlot + kLnWaves * kLnTile;  // 256 bytes: where the partners' progress words land (pacing)
+constexpr int kLnLds = kLnPoll + 256;
 
 struct LnArgs {
     const unsigned char *in;
@@ -49,7 +51,9 @@ struct LnArgs {
     size_t in_window, in_group, out_window;
     double kd;
     int k127;
-    int dbg;  // tuning aid (MI355_XE_DBG): 1 no products, 2 no matrix stores, 4 no DMA
+    int dbg;  // tuning aid (MI355_XE_DBG): 2 no matrix stores, 4 no DMA, 8 no pacing
+    unsigned tag;   // launch number (pacing of the four workgroups of a line: ln_progress)
+    int pace;       // K blocks a workgroup may run ahead of the slowest of its three partners (0: no pacing)
     unsigned long long *ts;
 };
 
@@ -103,8 +107,7 @@ __device__ __forceinline__ void ln_dma16(const void *gsrc, unsigned lds_dst)
 #define LN_A8(n) "a" #n "0", "a" #n "1", "a" #n "2", "a" #n "3", "a" #n "4", "a" #n "5", "a" #n "6", "a" #n "7", "a" #n "8", "a" #n "9"
 #define LN_ALL_AGPRS                                                                                                                              \
     "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", LN_A8(1), LN_A8(2), LN_A8(3), LN_A8(4), LN_A8(5), LN_A8(6), LN_A8(7), LN_A8(8),   \
-        LN_A8(9), LN_A8(10), LN_A8(11), LN_A8(12), LN_A8(13), LN_A8(14), LN_A8(15), LN_A8(16), LN_A8(17), LN_A8(18), LN_A8(19), LN_A8(20),       \
-        LN_A8(21), LN_A8(22), LN_A8(23), LN_A8(24), "a250", "a251", "a252", "a253", "a254", "a255"
+        LN_A8(9), LN_A8(10), LN_A8(11), "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"
 
 template <int I, int N, class F> __device__ __forceinline__ void ln_sfor(F &&f)
 {
@@ -132,9 +135,13 @@ template <int R> __device__ __forceinline__ v4i ln_acc_read4()
                  : "n"(R), "n"(R + 1), "n"(R + 2), "n"(R + 3));
     return v;
 }
-constexpr int ln_areg(int k, int ch) { return (16 * k + ch) * 4; }
+constexpr int ln_areg(int k, int ch) { return (8 * k + ch) * 4; }
 
 struct LnUnit { int col, grp, win; };
+
+// The four workgroups of a (line, window) re-read each other's lines from the XCD's L2 only while they walk the same frames: the K block a
+// workgroup has reached, {launch tag << 12 | K blocks done}, for its three partners to see (pinned map, every workgroup resident)
+__device__ unsigned ln_progress[8192];
 
 __device__ __forceinline__ LnUnit ln_map_unit(const LnArgs &a, int n)
 {
@@ -168,13 +175,13 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
 
     // ---- requests.  Wave w issues the chunks of frame octet w / 2 and stations 8 (w % 2) .. + 7 of the row tile: one instruction = one station's
     // line for 8 frames.  Address = (uniform) unit, row tile, station, K block, half + (per lane) frame and piece.
-    const size_t lane_off = (size_t)((wave >> 1) * 8 + (lane >> 3)) * t_stride + (size_t)(lane & 7) * 16;
+    const size_t lane_off = (size_t)((wave >> 2) * 8 + (lane >> 3)) * t_stride + (size_t)(lane & 7) * 16;
     const unsigned char *hb0 = nullptr, *hb1 = nullptr, *hb2 = nullptr;
     auto setup_issue = [&](int n) {
         const LnUnit u = ln_map_unit(a, n);
         const unsigned char *in_w = a.in + (size_t)u.win * a.in_window + (size_t)u.col * 128;
         auto half_base = [&](int rt) {
-            const int st = 16 * rt + 8 * (wave & 1);
+            const int st = 16 * rt + 4 * (wave & 3);
             return in_w + (size_t)(st / a.ng) * a.in_group + (size_t)(st % a.ng) * row_bytes;
         };
         hb0 = half_base(rt0);
@@ -186,7 +193,10 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
     setup_issue(blockIdx.x);
     // sub-stage number m of the stream (all units of this workgroup), j = m % NS = 2 * (row tile index) + half, known at compile time at every
     // call site; sub-stages are requested in stream order, so the K block and unit just count up
-    auto issue = [&](int m, int j) {
+    const unsigned char *iss_p0 = nullptr;  // the sub-stage being requested: this lane's source of the wave's first chunk, the chunk's LDS address
+    unsigned iss_dst0 = 0;
+    bool iss_on = false;
+    auto issue_prep = [&](int m, int j) {
         if (j == 0 && ++issue_kb == a.steps) {
             issue_kb = 0;
             issue_unit++;
@@ -195,49 +205,103 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
         const int kb = issue_kb;
         const int i = j >> 1, h = j & 1;
         const unsigned char *hb = i == 0 ? hb0 : i == 1 ? hb1 : hb2;
-        const unsigned char *p0 = hb + (size_t)(32 * kb + 16 * h) * t_stride + lane_off;
-        const unsigned dst0 = lds0 + (m & (kLnRing - 1)) * kLnSlot + ((wave >> 1) * 16 + (wave & 1) * 8) * kLnChunk;
-        if (!(a.dbg & 4)) {
-#pragma unroll
-            for (int ii = 0; ii < 8; ii++) ln_dma16(p0 + (size_t)ii * row_bytes, __builtin_amdgcn_readfirstlane(dst0 + ii * kLnChunk));
-        }
+        iss_p0 = hb + (size_t)(32 * kb + 16 * h) * t_stride + lane_off;
+        iss_dst0 = lds0 + (m & (kLnRing - 1)) * kLnSlot + ((wave >> 2) * 16 + (wave & 3) * 4) * kLnChunk;
+    };
+    // the wave's ii-th request of that sub-stage (one station's line of 8 frames).  The four requests of a sub-stage are issued one at a time
+    // between the transposes: back to back, the eight waves' 32 instructions queue at the CU's address unit and every wave stands ~330 clocks
+    auto issue_one = [&](int ii) {
+        if (iss_on && !(a.dbg & 4)) ln_dma16(iss_p0 + (size_t)ii * row_bytes, __builtin_amdgcn_readfirstlane(iss_dst0 + ii * kLnChunk));
     };
 #pragma unroll
     for (int j = 0; j < 3; j++)
-        if (j < total_sub) issue(j, j % NS);
+        if (j < total_sub) {
+            iss_on = true;
+            issue_prep(j, j % NS);
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++) issue_one(ii);
+        }
 
     // operands: X[u][c] = (I, Q) of channel 2u + c of the wave's sixteen as ONE 16-byte operand of v_mfma_i32_16x16x64_i8: components 0, 1 = I of
     // the two halves of the K block (4 frames each), 2, 3 = Q; u = the dword unit the two channels share in the raw rows
-    v4i X0[8][2], X1[8][2];
-    v4i raw[4][2];
-    const int lane_lds = ((g & 1) * 16 + r) * kLnChunk + (g >> 1) * 512 + wave * 32;
+    v4i X0[kLnU][2], X1[kLnU][2];
+    v4i raw[4];
+    const int lane_lds = ((g & 1) * 16 + r) * kLnChunk + (g >> 1) * 512 + wave * 16;
 
     // ---- One wave per SIMD: nothing hides a latency unless the instruction stream itself does.  A sub-stage is taken in three parts --
     //   front(m): wait until sub-stage m has landed, ONE barrier (behind it every wave has also finished reading sub-stage m - 1, whose slot takes
     //             sub-stage m + 3 at once: three sub-stages in flight), the eight 16-byte LDS reads of this lane;
     //   products that do not touch the operand set about to be written, issued while those reads are in flight;
     //   perm(u): the byte transpose of dword unit u into X[u][.][half], three products of the pending list after each unit.
+    int kb_done = 0;                 // K blocks of this workgroup's stream that have been started
+    long long pace_budget = 20000;   // 100 MHz ticks this workgroup may spend waiting for partners in all (200 us): a partner that is not resident is not waited for for ever
+    unsigned long long t_pace = 0;
+    const int my_slot = (int)((blockIdx.x >> 3) & 3), partner0 = (int)((blockIdx.x & 7) + 32 * (blockIdx.x >> 5));
+    unsigned long long t_wait = 0, t_bar1 = 0;  // (tuning aid, MI355_XE_TS: shader clocks wave 0 spends waiting for the DMA / at the barrier)
+    //   front(m): wait until sub-stage m has landed, ONE barrier -- behind it every wave has also finished reading sub-stage m - 1, whose slot takes
+    //             sub-stage m + 3 (requested piecemeal by the transposes that follow: issue_one) -- and the four 16-byte LDS reads of this lane
     auto front = [&](int m, int j, bool drain) {
         const int younger = total_sub - 1 - m;  // sub-stages requested after this one that may still be in flight (at most two)
+        const unsigned long long c0 = a.ts ? __builtin_readcyclecounter() : 0;
         if (drain || younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        const unsigned long long c1 = a.ts ? __builtin_readcyclecounter() : 0;
         __syncthreads();
-        if (m + 3 < total_sub) issue(m + 3, (j + 3) % NS);
+        if (a.ts) {
+            t_wait += c1 - c0;
+            t_bar1 += __builtin_readcyclecounter() - c1;
+        }
+        iss_on = m + 3 < total_sub;
+        if (iss_on) issue_prep(m + 3, (j + 3) % NS);
+        // ---- pacing.  At a K block's first sub-stage wave 0 publishes the K blocks this workgroup has done and asks for its partners' counts (three
+        // loads: older than the requests of sub-stage m + 3, so the vmcnt(8) of the front two sub-stages later has seen them land); there, a workgroup
+        // more than `pace` K blocks ahead of its slowest partner waits (bounded) -- the laggard's lines would otherwise have left the L2.
+        if (a.pace > 0 && wave == 0) {
+            if (j == 0) {
+                kb_done++;
+                if (lane == 0) __hip_atomic_store(&ln_progress[blockIdx.x], (a.tag << 12) | (unsigned)kb_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane < 3) {
+                    // (by LDS-DMA: a load into a register would be the compiler's to copy or spill before the data is there)
+                    const unsigned *q = &ln_progress[partner0 + 8 * ((my_slot + 1 + lane) & 3)];
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off sc1\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep)
+                                 : "v"(q), "s"(lds0 + kLnPoll)
+                                 : "memory");
+                }
+            } else if (j == 2) {
+                const unsigned seen = lane < 3 ? *(const unsigned *)(lds + kLnPoll + lane * 4) : 0u;  // (the words have landed: see above)
+                unsigned mine = (unsigned)kb_done;
+                auto behind = [&](unsigned v) { return lane < 3 && (v >> 12) == a.tag && (v & 0xfffu) + (unsigned)a.pace < mine; };
+                if (__builtin_amdgcn_ballot_w64(behind(seen)) != 0ull && pace_budget > 0) {
+                    const unsigned long long t0 = wall_clock64();
+                    unsigned long long waited = 0;
+                    bool lag = true;
+                    while (lag && waited < (unsigned long long)pace_budget) {
+                        __builtin_amdgcn_s_sleep(16);
+                        unsigned v = 0;
+                        if (lane < 3) v = __hip_atomic_load(&ln_progress[partner0 + 8 * ((my_slot + 1 + lane) & 3)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        lag = __builtin_amdgcn_ballot_w64(behind(v)) != 0ull;
+                        waited = wall_clock64() - t0;
+                    }
+                    pace_budget -= (long long)waited;
+                    t_pace += waited;
+                }
+            }
+        }
         const unsigned char *cb = lds + (m & (kLnRing - 1)) * kLnSlot + lane_lds;
 #pragma unroll
-        for (int ti = 0; ti < 4; ti++) {
-            raw[ti][0] = *(const v4i *)(cb + ti * 128);
-            raw[ti][1] = *(const v4i *)(cb + ti * 128 + 16);
-        }
+        for (int ti = 0; ti < 4; ti++) raw[ti] = *(const v4i *)(cb + ti * 128);
     };
-    auto perm_unit = [&](v4i (&X)[8][2], int u, int H) {
+    auto perm_unit = [&](v4i (&X)[kLnU][2], int u, int H) {
         unsigned o[4];
-        transpose4x4((unsigned)raw[0][u >> 2][u & 3], (unsigned)raw[1][u >> 2][u & 3], (unsigned)raw[2][u >> 2][u & 3], (unsigned)raw[3][u >> 2][u & 3], o);
+        transpose4x4((unsigned)raw[0][u], (unsigned)raw[1][u], (unsigned)raw[2][u], (unsigned)raw[3][u], o);
         X[u][0][H] = (int)o[0];
         X[u][0][2 + H] = (int)o[1];
         X[u][1][H] = (int)o[2];
         X[u][1][2 + H] = (int)o[3];
+        issue_one(u);
     };
     // The products (accumulators by name, see ln_mm).  What the compiler's hazard pass would do for its own v_mfma is done by construction: the
     // products of a list are issued type by type over all sixteen channels, so two products on one accumulator are fifteen products apart; every
@@ -247,16 +311,16 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
     auto swapped = [&](const v4i &x) { return (v4i){~x[2], ~x[3], x[0], x[1]}; };
     const v4i ones = (v4i){0x01010101, 0x01010101, 0, 0};
     // item I (0 .. 47) of a diagonal pair's list, accumulator set KC: C += (I, Q) (I, Q)^T | (I, Q) (~Q, I)^T | (I, Q) (1, 0)^T, sixteen channels each
-    auto diag_item = [&](auto kc, const v4i (&X)[8][2], auto ic) {
-        constexpr int KC = decltype(kc)::value, I = decltype(ic)::value, ty = I >> 4, ch = I & 15;
+    auto diag_item = [&](auto kc, const v4i (&X)[kLnU][2], auto ic) {
+        constexpr int KC = decltype(kc)::value, I = decltype(ic)::value, ty = I / kLnCh, ch = I % kLnCh;
         const v4i &x = X[ch >> 1][ch & 1];
         if constexpr (ty == 0) ln_mm<ln_areg(KC, ch)>(x, x);
         else if constexpr (ty == 1) ln_mm<ln_areg(KC, ch)>(x, swapped(x));
         else ln_mm<ln_areg(KC, ch)>(x, ones);
     };
     // item I of an off-diagonal pair's list (rows XA, columns XB), accumulator sets KR (re) and KR + 1 (im)
-    auto off_item = [&](auto kr, const v4i (&XA)[8][2], const v4i (&XB)[8][2], auto ic) {
-        constexpr int KR = decltype(kr)::value, I = decltype(ic)::value, ty = I >> 4, ch = I & 15;
+    auto off_item = [&](auto kr, const v4i (&XA)[kLnU][2], const v4i (&XB)[kLnU][2], auto ic) {
+        constexpr int KR = decltype(kr)::value, I = decltype(ic)::value, ty = I / kLnCh, ch = I % kLnCh;
         const v4i &xa = XA[ch >> 1][ch & 1], &xb = XB[ch >> 1][ch & 1];
         if constexpr (ty == 0) ln_mm<ln_areg(KR, ch)>(xa, xb);
         else if constexpr (ty == 1) ln_mm<ln_areg(KR + 1, ch)>(xa, swapped(xb));
@@ -265,13 +329,13 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
     typedef std::integral_constant<int, 0> K0;
     typedef std::integral_constant<int, 1> K1;
     typedef std::integral_constant<int, 2> K2;
-    auto diag_range = [&](auto kc, const v4i (&X)[8][2], auto lo, auto hi) {
+    auto diag_range = [&](auto kc, const v4i (&X)[kLnU][2], auto lo, auto hi) {
         ln_sfor<decltype(lo)::value, decltype(hi)::value>([&](auto ic) { diag_item(kc, X, ic); });
     };
     // a sub-stage's eight transposes into half H of X with a stretch of a diagonal pair's list (all of whose operands are complete) spread over
     // them: the items of unit u FIRST (the first ones run under the latency of the LDS reads), CUM = the cumulative counts per unit
-    auto perms_with_diag = [&](v4i (&X)[8][2], auto hc, auto kc, const v4i (&XD)[8][2], auto basec, auto cumc) {
-        ln_sfor<0, 8>([&](auto uc) {
+    auto perms_with_diag = [&](v4i (&X)[kLnU][2], auto hc, auto kc, const v4i (&XD)[kLnU][2], auto basec, auto cumc) {
+        ln_sfor<0, kLnU>([&](auto uc) {
             constexpr int u = decltype(uc)::value, H = decltype(hc)::value, B = decltype(basec)::value;
             typedef decltype(cumc) CUM;
             diag_range(kc, XD, std::integral_constant<int, B + CUM::at(u)>{}, std::integral_constant<int, B + CUM::at(u + 1)>{});
@@ -281,17 +345,17 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
     // the LAST sub-stage of an operand set: unit u completes channels 2u, 2u + 1 of X, whose products against the other, complete set follow at
     // once -- real part and im' of both channels, and the row-sum product of the PREVIOUS unit's channels (same accumulator as im': kept four
     // products apart).  ROWS: X holds the rows (XO the columns), else the columns.
-    auto perms_with_off = [&](v4i (&X)[8][2], auto kr, const v4i (&XO)[8][2], auto rowsc) {
+    auto perms_with_off = [&](v4i (&X)[kLnU][2], auto kr, const v4i (&XO)[kLnU][2], auto rowsc) {
         constexpr bool ROWS = decltype(rowsc)::value != 0;
         auto item = [&](auto tyc, auto chc) {
-            constexpr int I = decltype(tyc)::value * 16 + decltype(chc)::value;
+            constexpr int I = decltype(tyc)::value * kLnCh + decltype(chc)::value;
             if constexpr (ROWS) off_item(kr, X, XO, std::integral_constant<int, I>{});
             else off_item(kr, XO, X, std::integral_constant<int, I>{});
         };
         typedef std::integral_constant<int, 0> T0;
         typedef std::integral_constant<int, 1> T1;
         typedef std::integral_constant<int, 2> T2;
-        ln_sfor<0, 8>([&](auto uc) {
+        ln_sfor<0, kLnU>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
             perm_unit(X, u, 1);
             item(T0{}, std::integral_constant<int, 2 * u>{});
@@ -303,24 +367,25 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
                 item(T2{}, std::integral_constant<int, 2 * u - 1>{});
             }
         });
-        item(T2{}, std::integral_constant<int, 14>{});
-        item(T2{}, std::integral_constant<int, 15>{});
+        item(T2{}, std::integral_constant<int, kLnCh - 2>{});
+        item(T2{}, std::integral_constant<int, kLnCh - 1>{});
     };
-    struct Cum24 { static constexpr int at(int u) { constexpr int c[9] = {0, 6, 9, 12, 15, 18, 20, 22, 24}; return c[u]; } };
-    struct Cum40 { static constexpr int at(int u) { constexpr int c[9] = {0, 8, 13, 18, 23, 28, 32, 36, 40}; return c[u]; } };
-    typedef std::integral_constant<int, 24> C24;
-    typedef std::integral_constant<int, 40> C40;
-    typedef std::integral_constant<int, 48> C48;
+    // (a list = 3 x 8 = 24 items; half a list per sub-stage of x, 20 of the pair xx under the first sub-stage of y and its last 4 in front of the second)
+    struct Cum24 { static constexpr int at(int u) { constexpr int c[5] = {0, 4, 7, 10, 12}; return c[u]; } };
+    struct Cum40 { static constexpr int at(int u) { constexpr int c[5] = {0, 6, 11, 16, 20}; return c[u]; } };
+    typedef std::integral_constant<int, 12> C24;
+    typedef std::integral_constant<int, 20> C40;
+    typedef std::integral_constant<int, 24> C48;
     typedef K0 H0;
     typedef K1 H1;
 
     const int nb = 64 * 65 / 2;
     int m = 0;  // sub-stage counter of the stream
     for (int unit = 0; unit < a.items; unit++) {
-        ln_sfor<0, 64>([&](auto qc) { ln_acc_zero4<4 * decltype(qc)::value>(); });
+        ln_sfor<0, 4 * kLnCh>([&](auto qc) { ln_acc_zero4<4 * decltype(qc)::value>(); });
         // (the loop carries the pair yy of a K block into the next one; before the first K block it runs on zeros)
 #pragma unroll
-        for (int u = 0; u < 8; u++) X1[u][0] = X1[u][1] = (v4i){0, 0, 0, 0};
+        for (int u = 0; u < kLnU; u++) X1[u][0] = X1[u][1] = (v4i){0, 0, 0, 0};
         for (int kb = 0; kb < a.steps; kb++) {
             // (the first wait of a unit that follows another one drains everything: that unit's matrix stores share the counter with the DMA and
             // complete out of order with it)
@@ -344,18 +409,18 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
                 // as the second sub-stage of its column tile completes X1
                 front(m, 0, drain);
 #pragma unroll
-                for (int u = 0; u < 8; u++) perm_unit(X0, u, 0);
+                for (int u = 0; u < kLnU; u++) perm_unit(X0, u, 0);
                 front(m + 1, 1, false);
 #pragma unroll
-                for (int u = 0; u < 8; u++) perm_unit(X0, u, 1);
+                for (int u = 0; u < kLnU; u++) perm_unit(X0, u, 1);
                 front(m + 2, 2, false);
 #pragma unroll
-                for (int u = 0; u < 8; u++) perm_unit(X1, u, 0);
+                for (int u = 0; u < kLnU; u++) perm_unit(X1, u, 0);
                 front(m + 3, 3, false);
                 perms_with_off(X1, K0{}, X0, K0{});
                 front(m + 4, 4, false);
 #pragma unroll
-                for (int u = 0; u < 8; u++) perm_unit(X1, u, 0);
+                for (int u = 0; u < kLnU; u++) perm_unit(X1, u, 0);
                 front(m + 5, 5, false);
                 perms_with_off(X1, K2{}, X0, K0{});
                 m += 6;
@@ -431,9 +496,9 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
             if (a.dbg & 2) { if (vre[0] == 0x12345678 && vim[1] == 0x7654321) out_w[lane].x = 1.0f; return; }
             store_rows(vre, vim, f, bi, bi, a.k127 && ln_all_small(mag));
         };
-        ln_sfor<0, 16>([&](auto chc) {
+        ln_sfor<0, kLnCh>([&](auto chc) {
             constexpr int ch = decltype(chc)::value;
-            const int f = un.col * 64 + wave * 16 + ch;
+            const int f = un.col * 64 + wave * kLnCh + ch;
             if (f < a.Fout) {
                 if constexpr (DIAG) {
                     emit_diag(ln_acc_read4<ln_areg(0, ch)>(), f, rt0);
@@ -447,17 +512,23 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
             __builtin_amdgcn_sched_barrier(0);  // (one channel's values at a time)
         });
     }
+    if (a.ts && tid == 0) {
+        a.ts[(size_t)blockIdx.x * 8 + 2] = t_wait;
+        a.ts[(size_t)blockIdx.x * 8 + 3] = t_bar1;
+        a.ts[(size_t)blockIdx.x * 8 + 4] = t_pace;
+        a.ts[(size_t)blockIdx.x * 8 + 6] = __builtin_readcyclecounter();
+    }
 }
 
 __global__ __launch_bounds__(kLnThreads) void k_xe_i8_lines(LnArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    if (a.ts && threadIdx.x == 0) a.ts[(size_t)blockIdx.x * 2] = wall_clock64();
+    if (a.ts && threadIdx.x == 0) a.ts[(size_t)blockIdx.x * 8] = wall_clock64();
     // (a workgroup's units are all of one group: the host makes the grid a multiple of 32 -- pinned map -- or of 4)
     const int grp = ln_map_unit(a, blockIdx.x).grp;
     if (grp < 2) ln_body<true>(a, lds, grp);
     else ln_body<false>(a, lds, grp);
-    if (a.ts && threadIdx.x == 0) a.ts[(size_t)blockIdx.x * 2 + 1] = wall_clock64();
+    if (a.ts && threadIdx.x == 0) a.ts[(size_t)blockIdx.x * 8 + 1] = wall_clock64();
 }
 
 }  // namespace
@@ -471,8 +542,11 @@ bool mi355_xe_lines_ok(int N, int F, int Fout, int npol, int T, int stations_per
     const int ng = (stations_per_group > 0 && stations_per_group < N) ? stations_per_group : N;
     if (npol != 1 || N != 64 || F % 64 != 0 || Fout != F || T % 32 != 0 || T < 32 || T > 16384 || accumulate || ng % 8 != 0) return false;
     const long units = (long)(nint > 0 ? nint : 1) * (F / 64) * 4;
-    const int min_units = getenv("MI355_XE_LINES_MIN_UNITS") ? atoi(getenv("MI355_XE_LINES_MIN_UNITS")) : cus;
-    return units >= min_units && units % 4 == 0;
+    // MI355_XE_LINES_MIN_UNITS (test switch): any unit count.  Otherwise: enough units to fill the device, at most two per workgroup (measured at
+    // config 5, windows per launch 4 / 8 / 16: 196 / 367 / 800 us against 204 / 397 / 780 for the 32-byte-slice kernel), a multiple of 32 (the
+    // pinned map, which the pacing of a line's four workgroups needs)
+    if (getenv("MI355_XE_LINES_MIN_UNITS")) return units >= atoi(getenv("MI355_XE_LINES_MIN_UNITS")) && units % 4 == 0;
+    return units >= cus && units <= 2L * cus && units % 32 == 0 && (units <= cus || (units / 2) % 32 == 0);
 }
 
 int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int T, double kd, hipStream_t st, int stations_per_group, int nint, int cus)
@@ -496,6 +570,8 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
     a.k127 = (kd == 0.007874015748031496063 && !getenv("MI355_XE_SCALE_F64")) ? 1 : 0;
     a.dbg = getenv("MI355_XE_DBG") ? atoi(getenv("MI355_XE_DBG")) : 0;
     a.ts = nullptr;
+    static unsigned launch_seq = 0;
+    a.tag = (++launch_seq) & 0xfffffu;
     // persistent form: units / grid units per workgroup; the grid a multiple of 32 (pinned map: a workgroup keeps its XCD and group) or of 4
     a.pinned = (a.units % 32 == 0) ? 1 : 0;
     const int quantum = a.pinned ? 32 : 4;
@@ -503,6 +579,11 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
     while (items < a.units && (a.units % items != 0 || (a.units / items) % quantum != 0)) items++;
     if (a.units % items != 0 || (a.units / items) % quantum != 0) items = a.units / quantum;  // (one workgroup quantum: always divides)
     a.items = items;
+    // pacing needs the pinned map, every workgroup resident (one per CU) and partners that can be told apart
+    {
+        const int pace = getenv("MI355_XE_LINES_PACE") ? atoi(getenv("MI355_XE_LINES_PACE")) : 2;
+        a.pace = (a.pinned && a.units / a.items <= cus && a.units / a.items <= 8192 && (long)a.items * a.steps < 4096 && !(a.dbg & 8)) ? pace : 0;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         MI355_HIP(hipFuncSetAttribute((const void *)k_xe_i8_lines, hipFuncAttributeMaxDynamicSharedMemorySize, kLnLds));
@@ -511,21 +592,22 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
     const unsigned grid = (unsigned)(a.units / a.items);
     if (getenv("MI355_XE_TS")) {  // tuning aid: one synchronous launch with start / end stamps per workgroup
         unsigned long long *d_ts = nullptr;
-        MI355_HIP(hipMalloc(&d_ts, (size_t)grid * 16));
+        MI355_HIP(hipMalloc(&d_ts, (size_t)grid * 64));
+        MI355_HIP(hipMemsetAsync(d_ts, 0, (size_t)grid * 64, st));
         a.ts = d_ts;
         hipLaunchKernelGGL(k_xe_i8_lines, dim3(grid), dim3(kLnThreads), kLnLds, st, a);
         MI355_HIP(hipGetLastError());
         MI355_HIP(hipStreamSynchronize(st));
-        std::vector<unsigned long long> h((size_t)grid * 2);
-        MI355_HIP(hipMemcpy(h.data(), d_ts, (size_t)grid * 16, hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> h((size_t)grid * 8);
+        MI355_HIP(hipMemcpy(h.data(), d_ts, (size_t)grid * 64, hipMemcpyDeviceToHost));
         (void)hipFree(d_ts);
         unsigned long long t0 = ~0ull;
-        for (unsigned b = 0; b < grid; b++) t0 = std::min(t0, h[2 * b]);
+        for (unsigned b = 0; b < grid; b++) t0 = std::min(t0, h[8 * b]);
         double end_by_grp[4] = {0, 0, 0, 0}, end_by_col[64] = {0}, last = 0;
         int n_grp[4] = {0, 0, 0, 0}, n_col[64] = {0};
         for (unsigned b = 0; b < grid; b++) {
             const int within = a.pinned ? (int)(b >> 3) : (int)b, grp = within & 3, combo = a.pinned ? (int)((b & 7) + 8 * (within >> 2)) : (int)(b >> 2);
-            const double e = (double)(h[2 * b + 1] - t0) * 0.01;
+            const double e = (double)(h[8 * b + 1] - t0) * 0.01;
             end_by_grp[grp] += e; n_grp[grp]++;
             end_by_col[(combo % a.ncols) & 63] += e; n_col[(combo % a.ncols) & 63]++;
             last = std::max(last, e);
@@ -535,6 +617,18 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
         fprintf(stderr, "; by line:");
         for (int k = 0; k < a.ncols && k < 64; k++) fprintf(stderr, " %.0f", n_col[k] ? end_by_col[k] / n_col[k] : 0.0);
         fprintf(stderr, "\n");
+        // shader clocks of wave 0 in the parts of front(), by group type (diagonal groups 0 / 1, off-diagonal 2 / 3), as a share of the kernel's clocks
+        for (int ty = 0; ty < 2; ty++) {
+            double w = 0, b1 = 0, pc = 0, dur = 0; int n = 0;
+            for (unsigned b = 0; b < grid; b++) {
+                const int within = a.pinned ? (int)(b >> 3) : (int)b, grp = within & 3;
+                if ((grp >> 1) != ty) continue;
+                w += (double)h[8 * b + 2]; b1 += (double)h[8 * b + 3]; pc += (double)h[8 * b + 4];
+                dur += (double)(h[8 * b + 1] - h[8 * b]) * 0.01; n++;
+            }
+            if (n) fprintf(stderr, "  %s groups: %.0f us per workgroup; clocks of wave 0 (k): DMA wait %.0f, barrier %.0f; paced %.1f us\n",
+                           ty ? "off-diagonal" : "diagonal", dur / n, w / n / 1e3, b1 / n / 1e3, pc / n * 0.01);
+        }
         return MI355_OK;
     }
     hipLaunchKernelGGL(k_xe_i8_lines, dim3(grid), dim3(kLnThreads), kLnLds, st, a);
