@@ -8,20 +8,29 @@
 // (64 channels) of a row but only a GROUP of the ten row-tile pairs,
 //     A = {00, 10, 11} stations 0-31      B = {22, 32, 33} stations 32-63      C = {20, 21} stations 0-47      D = {30, 31} stations 0-31, 48-63
 // 2.5 x the rows, a quarter of the requests per row: 2.62 M requests, and the four workgroups of a line sit on one XCD (blockIdx % 8) and walk the
-// same frames, so HBM still sees every line once (L2 hits for the re-reads).  Request stream alone: 33.6 against 55.8 us per window.
+// same frames, so the re-reads can hit that XCD's L2.  Request stream alone: 33.6 against 55.8 us per window (eight windows per launch, from HBM).
 // Registers: 64 channels x 16 accumulator registers per lane for every group --
-//   off-diagonal pair: re += I_a I_b^T + Q_a Q_b^T,  im' += Q_a I_b^T + I_a (~Q_b)^T,  im = im' + sum_t I_a(t)            (8 registers, as in k_xe_i8_fused)
-//   diagonal pair: all four products into ONE accumulator C = re + im' (4 registers): re is symmetric and im antisymmetric, so
+//   off-diagonal pair: re += I_a I_b^T + Q_a Q_b^T,  im += Q_a I_b^T + I_a (~Q_b)^T + I_a 1^T   (-q = ~q + 1 exactly, -128 included)     8 registers
+//   diagonal pair: everything into ONE accumulator C = re + im (4 registers): re is symmetric and im antisymmetric, so
 //                  re[i][j] = (C[i][j] + C[j][i]) / 2,  im[i][j] = (C[i][j] - C[j][i]) / 2 exactly (|C| <= T * 2^16: T <= 16384)
-// so a workgroup of FOUR waves (one per SIMD, up to 512 registers each) holds 16 channels x 16 registers per wave.
+// Workgroup = EIGHT waves, two per SIMD: wave w owns the w-th 16-byte piece of every line = 8 channels = 128 accumulation registers, addressed BY
+// NAME from inline assembly (see ln_mm), + at most 128 vector registers.  (One wave per SIMD with 16 channels was built first: a wave's own
+// VALU instructions do not overlap its own matrix products -- tools/ubench/mfma_i8_rate.hip: 17.5 + 8 k clocks per product with k v_perm behind it
+// -- so the byte transposes and the products of a K block add up; two waves per SIMD overlap each other's.)
 //
 // Data path.  A K block is 32 frames.  The lines of one row tile (16 stations) and 16 frames = 256 lines = one sub-stage, 32 LDS-DMA instructions
 // (global_load_lds_dwordx4), each the line of ONE station for 8 consecutive frames (lane = frame * 8 + 16-byte piece), landing as a 1 KiB chunk; chunk
 // starts are 1040 bytes apart, so the sixteen stations' copies of a piece fall into sixteen different 16-byte bank groups (conflict-free ds_read_b128).
-// Ring of four sub-stages (130 KiB), all four in flight while nothing is read.  Per sub-stage a lane (station r, group g) pulls 4 frames x 32 bytes
-// (its wave's 16 channels) into registers, the slot is handed back to the DMA at once, and the bytes are transposed (v_perm) into the K-major
-// operands of v_mfma_i32_16x16x32_i8: after two sub-stages a lane holds 8 frames of every channel of its wave for one row tile.  The order of the
-// frames inside a K block differs from k_xe_i8_fused's (any order is fine as long as both operands use it).
+// Ring of four sub-stages (130 KiB): one being read, three in flight.  Per sub-stage a lane (station r, group g) pulls 4 frames x 16 bytes (its
+// wave's 8 channels) into registers and byte-transposes them (v_perm) into the operands of v_mfma_i32_16x16x64_i8: operand = (I | Q) of one channel,
+// 8 frames each, K = 64 -- ONE product is the whole real part of a tile pair and K block.  The order of the frames inside a K block differs
+// from k_xe_i8_fused's (any order is fine as long as both operands use it).  Products are issued BETWEEN the transposes (the pair yy of the previous
+// K block under the sub-stages of x, xx under the first of y, yx channel by channel as the second of y completes its operands), the four requests
+// of the sub-stage three ahead one at a time between them as well.
+// Pacing.  The four workgroups of a line re-read each other's lines from L2 only while they walk the same frames; groups C / D take six
+// sub-stages per K block, A / B four, so A / B run ahead until their partners' lines have left the L2 again (read traffic 1.8 x the input).  Every
+// workgroup publishes the K blocks it has done (ln_progress) and one that is more than `pace` ahead of its slowest partner waits: 383 -> 364 us per
+// eight windows, and the slow address class (lines 3 and 11 of a row: 1.6 x the latency from HBM) disappears from the per-line end times.
 #include "xengine_fused.h"
 
 #include <algorithm>
@@ -99,10 +108,10 @@ __device__ __forceinline__ void ln_dma16(const void *gsrc, unsigned lds_dst)
 }
 
 
-// ---- The accumulators are the wave's 256 accumulation registers BY NAME: accumulator (k, ch) = a[(16 k + ch) * 4 .. + 3].  The compiler never sees
-// them as values -- given 256 tied "+a" operands it time-shares AGPRs between accumulators (v_accvgpr_read of a register a product issued one
+// ---- The accumulators are 128 accumulation registers BY NAME: accumulator (k, ch) = a[(8 k + ch) * 4 .. + 3], k = 0 .. 3, ch = 0 .. 7.  The compiler never sees
+// them as values -- given tied "+a" operands that fill the AGPR file it time-shares AGPRs between accumulators (v_accvgpr_read of a register a product issued one
 // instruction earlier has not written yet: the hazards of an inline-assembly v_mfma are invisible to it) and given its own v_mfma it needs spare
-// AGPRs and spills.  Every statement that touches them clobbers all 256, so nothing of the compiler's lives in an AGPR across any of them, and the
+// AGPRs and spills.  Every statement that touches them clobbers all 128, so nothing of the compiler's lives in an AGPR across any of them, and the
 // file is built with -amdgpu-spill-vgpr-to-agpr=0.  Ordering and hazards by construction (see the K loop).
 #define LN_A8(n) "a" #n "0", "a" #n "1", "a" #n "2", "a" #n "3", "a" #n "4", "a" #n "5", "a" #n "6", "a" #n "7", "a" #n "8", "a" #n "9"
 #define LN_ALL_AGPRS                                                                                                                              \
@@ -222,17 +231,13 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
             for (int ii = 0; ii < 4; ii++) issue_one(ii);
         }
 
-    // operands: X[u][c] = (I, Q) of channel 2u + c of the wave's sixteen as ONE 16-byte operand of v_mfma_i32_16x16x64_i8: components 0, 1 = I of
+    // operands: X[u][c] = (I, Q) of channel 2u + c of the wave's eight as ONE 16-byte operand of v_mfma_i32_16x16x64_i8: components 0, 1 = I of
     // the two halves of the K block (4 frames each), 2, 3 = Q; u = the dword unit the two channels share in the raw rows
     v4i X0[kLnU][2], X1[kLnU][2];
     v4i raw[4];
     const int lane_lds = ((g & 1) * 16 + r) * kLnChunk + (g >> 1) * 512 + wave * 16;
 
-    // ---- One wave per SIMD: nothing hides a latency unless the instruction stream itself does.  A sub-stage is taken in three parts --
-    //   front(m): wait until sub-stage m has landed, ONE barrier (behind it every wave has also finished reading sub-stage m - 1, whose slot takes
-    //             sub-stage m + 3 at once: three sub-stages in flight), the eight 16-byte LDS reads of this lane;
-    //   products that do not touch the operand set about to be written, issued while those reads are in flight;
-    //   perm(u): the byte transpose of dword unit u into X[u][.][half], three products of the pending list after each unit.
+    // ---- A sub-stage is taken in two parts: front(m), then the byte transposes of its four dword units with products and requests between them --
     int kb_done = 0;                 // K blocks of this workgroup's stream that have been started
     long long pace_budget = 20000;   // 100 MHz ticks this workgroup may spend waiting for partners in all (200 us): a partner that is not resident is not waited for for ever
     unsigned long long t_pace = 0;
@@ -304,13 +309,14 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
         issue_one(u);
     };
     // The products (accumulators by name, see ln_mm).  What the compiler's hazard pass would do for its own v_mfma is done by construction: the
-    // products of a list are issued type by type over all sixteen channels, so two products on one accumulator are fifteen products apart; every
+    // products of a list are issued type by type over the wave's eight channels (two products on one accumulator are seven products apart; in the
+    // channel-by-channel order of perms_with_off at least four); every
     // product is preceded by two idle cycles; the accumulators are read after the pipeline has drained.
     // 16 x 16 x 64: K = (half, frame, I | Q), so ONE product is sum_t (I_a I_b + Q_a Q_b) -- the whole real part -- and with the second operand
     // (~Q_b, I_b) the whole of im'; the third, against (1, 0), adds sum_t I_a(t) to every column of row a: the "+ 1" of -q = ~q + 1
     auto swapped = [&](const v4i &x) { return (v4i){~x[2], ~x[3], x[0], x[1]}; };
     const v4i ones = (v4i){0x01010101, 0x01010101, 0, 0};
-    // item I (0 .. 47) of a diagonal pair's list, accumulator set KC: C += (I, Q) (I, Q)^T | (I, Q) (~Q, I)^T | (I, Q) (1, 0)^T, sixteen channels each
+    // item I (0 .. 23) of a diagonal pair's list, accumulator set KC: C += (I, Q) (I, Q)^T | (I, Q) (~Q, I)^T | (I, Q) (1, 0)^T, eight channels each
     auto diag_item = [&](auto kc, const v4i (&X)[kLnU][2], auto ic) {
         constexpr int KC = decltype(kc)::value, I = decltype(ic)::value, ty = I / kLnCh, ch = I % kLnCh;
         const v4i &x = X[ch >> 1][ch & 1];
