@@ -674,15 +674,20 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank, out=None):
         # A stream of integrations handed over eight or sixteen at a time (mi355_xengine_xcorrelate_n_dev): every unit is a whole integration of
         # its 32-byte slice (no time ranges, no partial sums), 512 / 1024 units on 256 CUs, the slow lines' units first.  Inputs in rotation.
         row = {}
-        for nint in (8, 16):
+        for nint in (4, 8, 16):
             vb = torch.zeros(nint * xe.get_output_buffer_size(), 2, device="cuda")
             fn_rot, bufs = rotate(lambda: torch.randint(-127, 128, (nint, T, N, Fw, 1, 2), dtype=torch.int8, device="cuda", generator=g),
                                   nint * T * N * Fw * 2, lambda x: xe.xcorrelate_n_device(nint, x, vb))
             rb = rate(fn_rot, nint * N * Fw * T, 2)
             tw = rb["us_per_launch"] / nint
+            # (which kernel: mi355_xe_lines_ok -- 64 stations, whole-line rows, enough (window, line, pair group) units to fill the device and at
+            # most two per workgroup: the whole-line kernel of csrc/xengine_lines.hip; otherwise the 32-byte-slice kernel, persistent workgroups)
+            units = nint * (Fw // 64) * 4
+            lines = N == 64 and Fw % 64 == 0 and 256 <= units <= 512 and not os.environ.get("MI355_XE_NO_LINES")
             row["windows_per_launch_%d" % nint] = {"us_per_window": round(tw, 2), "MSamples_per_s": rb["MSamples_per_s"],
                                                   "hbm_frac_algorithmic": round(alg_bytes / (tw * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                                  "distinct_inputs_in_rotation": len(bufs)}
+                                                  "distinct_inputs_in_rotation": len(bufs),
+                                                  "kernel": "k_xe_i8_lines" if lines else "k_xe_i8_fused"}
             del bufs, fn_rot, vb
             torch.cuda.empty_cache()
         out["clXEngine_64ant_1024ch_1024t_ichar_batched"] = row

@@ -34,6 +34,7 @@
 #include "xengine_fused.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <type_traits>
 #include <vector>
@@ -576,8 +577,8 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
     a.k127 = (kd == 0.007874015748031496063 && !getenv("MI355_XE_SCALE_F64")) ? 1 : 0;
     a.dbg = getenv("MI355_XE_DBG") ? atoi(getenv("MI355_XE_DBG")) : 0;
     a.ts = nullptr;
-    static unsigned launch_seq = 0;
-    a.tag = (++launch_seq) & 0xfffffu;
+    static std::atomic<unsigned> launch_seq{0};
+    a.tag = (launch_seq.fetch_add(1u) + 1u) & 0xfffffu;
     // persistent form: units / grid units per workgroup; the grid a multiple of 32 (pinned map: a workgroup keeps its XCD and group) or of 4
     a.pinned = (a.units % 32 == 0) ? 1 : 0;
     const int quantum = a.pinned ? 32 : 4;
