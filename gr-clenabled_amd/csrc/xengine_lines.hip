@@ -63,7 +63,9 @@ struct LnArgs {
     int k127;
     int dbg;  // tuning aid (MI355_XE_DBG): 2 no matrix stores, 4 no DMA, 8 no pacing
     unsigned tag;   // launch number (pacing of the four workgroups of a line: ln_progress)
-    int pace;       // K blocks a workgroup may run ahead of the slowest of its three partners (0: no pacing)
+    int pace;       // half K blocks a workgroup may run ahead of the slowest of its three partners (0: no pacing)
+    int rot, grid;  // line rotation per unit of a workgroup (0: none); workgroups of the launch
+    int pub_local;  // progress words by plain stores, kept in the XCD's L2 (0: agent-scope stores, MI355_XE_LINES_PUB=0)
     unsigned long long *ts;
 };
 
@@ -150,7 +152,8 @@ constexpr int ln_areg(int k, int ch) { return (8 * k + ch) * 4; }
 struct LnUnit { int col, grp, win; };
 
 // The four workgroups of a (line, window) re-read each other's lines from the XCD's L2 only while they walk the same frames: the K block a
-// workgroup has reached, {launch tag << 12 | K blocks done}, for its three partners to see (pinned map, every workgroup resident)
+// workgroup has reached, {launch tag << 12 | K blocks done}, for its three partners to see (pinned map, every workgroup resident);
+// word of workgroup b: (b % 8) * 1024 + b / 8 -- an XCD's words are its own 4 KiB, a team's four are neighbours
 __device__ unsigned ln_progress[8192];
 
 __device__ __forceinline__ LnUnit ln_map_unit(const LnArgs &a, int n)
@@ -167,6 +170,9 @@ __device__ __forceinline__ LnUnit ln_map_unit(const LnArgs &a, int n)
     }
     u.col = combo % a.ncols;
     u.win = combo / a.ncols;
+    // a workgroup's k-th unit is rot * k lines further on than its first: the units of the slow lines (address bits 7..9 == 3: 1.25 x the time from HBM)
+    // go to twice as many workgroups, one each, instead of two each to the same ones (the host sets rot only where every k covers whole windows)
+    if (a.rot) u.col = (u.col + a.rot * (n / a.grid)) % a.ncols;
     return u;
 }
 
@@ -239,10 +245,16 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
     const int lane_lds = ((g & 1) * 16 + r) * kLnChunk + (g >> 1) * 512 + wave * 16;
 
     // ---- A sub-stage is taken in two parts: front(m), then the byte transposes of its four dword units with products and requests between them --
-    int kb_done = 0;                 // K blocks of this workgroup's stream that have been started
+    int kb_done = 0;                 // half K blocks of this workgroup's stream that have been started
     long long pace_budget = 20000;   // 100 MHz ticks this workgroup may spend waiting for partners in all (200 us): a partner that is not resident is not waited for for ever
     unsigned long long t_pace = 0;
-    const int my_slot = (int)((blockIdx.x >> 3) & 3), partner0 = (int)((blockIdx.x & 7) + 32 * (blockIdx.x >> 5));
+    // The four workgroups of a line are neighbours in dispatch order on ONE XCD (blockIdx % 8 under round-robin dispatch): their progress words are four
+    // adjacent words of that XCD's own 4 KiB of ln_progress.  pub_local: written by PLAIN stores (the line stays in the XCD's L2) and read by
+    // L1-bypassing loads (L2 hits); agent-scope (sc1) stores drop the line from the L2, so that every publish and every poll crosses the fabric to
+    // the word's home.  A workgroup that finds itself on another XCD than its index says (HW_REG_XCC_ID) publishes at agent scope and waits for nobody.
+    const int my_slot = (int)((blockIdx.x >> 3) & 3), team0 = (int)((blockIdx.x & 7) * 1024 + 4 * (blockIdx.x >> 5));
+    const bool on_xcd = (int)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7) == (int)(blockIdx.x & 7);
+    const bool xcd_local = a.pub_local && on_xcd, pace_wait = !a.pub_local || on_xcd;
     unsigned long long t_wait = 0, t_bar1 = 0;  // (tuning aid, MI355_XE_TS: shader clocks wave 0 spends waiting for the DMA / at the barrier)
     //   front(m): wait until sub-stage m has landed, ONE barrier -- behind it every wave has also finished reading sub-stage m - 1, whose slot takes
     //             sub-stage m + 3 (requested piecemeal by the transposes that follow: issue_one) -- and the four 16-byte LDS reads of this lane
@@ -260,23 +272,13 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
         }
         iss_on = m + 3 < total_sub;
         if (iss_on) issue_prep(m + 3, (j + 3) % NS);
-        // ---- pacing.  At a K block's first sub-stage wave 0 publishes the K blocks this workgroup has done and asks for its partners' counts (three
-        // loads: older than the requests of sub-stage m + 3, so the vmcnt(8) of the front two sub-stages later has seen them land); there, a workgroup
-        // more than `pace` K blocks ahead of its slowest partner waits (bounded) -- the laggard's lines would otherwise have left the L2.
+        // ---- pacing.  Twice per K block (its first and its middle sub-stage) wave 0 publishes the half K blocks this workgroup has started and asks
+        // for its partners' counts (three loads: older than the requests of sub-stage m + 3, so the vmcnt(8) of the front two sub-stages later has
+        // seen them land); there, a workgroup more than `pace` half K blocks ahead of its slowest partner waits (bounded) -- the laggard's lines would
+        // otherwise have left the L2.  (The check of one half and the publication of the next may fall on the same sub-stage: check first.)
         if (a.pace > 0 && wave == 0) {
-            if (j == 0) {
-                kb_done++;
-                if (lane == 0) __hip_atomic_store(&ln_progress[blockIdx.x], (a.tag << 12) | (unsigned)kb_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (lane < 3) {
-                    // (by LDS-DMA: a load into a register would be the compiler's to copy or spill before the data is there)
-                    const unsigned *q = &ln_progress[partner0 + 8 * ((my_slot + 1 + lane) & 3)];
-                    unsigned keep;
-                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off sc1\n\ts_mov_b32 m0, %0"
-                                 : "=&s"(keep)
-                                 : "v"(q), "s"(lds0 + kLnPoll)
-                                 : "memory");
-                }
-            } else if (j == 2) {
+            const bool pub = j == 0 || j == NS / 2, chk = j == 2 || j == (NS / 2 + 2) % NS;
+            if (chk && pace_wait && kb_done > 0) {
                 const unsigned seen = lane < 3 ? *(const unsigned *)(lds + kLnPoll + lane * 4) : 0u;  // (the words have landed: see above)
                 unsigned mine = (unsigned)kb_done;
                 auto behind = [&](unsigned v) { return lane < 3 && (v >> 12) == a.tag && (v & 0xfffu) + (unsigned)a.pace < mine; };
@@ -287,12 +289,30 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
                     while (lag && waited < (unsigned long long)pace_budget) {
                         __builtin_amdgcn_s_sleep(16);
                         unsigned v = 0;
-                        if (lane < 3) v = __hip_atomic_load(&ln_progress[partner0 + 8 * ((my_slot + 1 + lane) & 3)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (lane < 3) v = __hip_atomic_load(&ln_progress[team0 + ((my_slot + 1 + lane) & 3)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         lag = __builtin_amdgcn_ballot_w64(behind(v)) != 0ull;
                         waited = wall_clock64() - t0;
                     }
                     pace_budget -= (long long)waited;
                     t_pace += waited;
+                }
+            }
+            if (pub) {
+                kb_done++;
+                if (lane == 0) {
+                    const unsigned word = (a.tag << 12) | (unsigned)kb_done;
+                    // (a plain store: the line stays in the XCD's L2, where the partners' loads find it; "volatile" in C++ would be a system-scope store and a wait)
+                    if (xcd_local) asm volatile("global_store_dword %0, %1, off" ::"v"(&ln_progress[team0 + my_slot]), "v"(word) : "memory");
+                    else __hip_atomic_store(&ln_progress[team0 + my_slot], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (lane < 3) {
+                    // (by LDS-DMA: a load into a register would be the compiler's to copy or spill before the data is there)
+                    const unsigned *q = &ln_progress[team0 + ((my_slot + 1 + lane) & 3)];
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off sc1\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep)
+                                 : "v"(q), "s"(lds0 + kLnPoll)
+                                 : "memory");
                 }
             }
         }
@@ -588,15 +608,18 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
     a.items = items;
     // pacing needs the pinned map, every workgroup resident (one per CU) and partners that can be told apart
     {
-        const int pace = getenv("MI355_XE_LINES_PACE") ? atoi(getenv("MI355_XE_LINES_PACE")) : 2;
-        a.pace = (a.pinned && a.units / a.items <= cus && a.units / a.items <= 8192 && (long)a.items * a.steps < 4096 && !(a.dbg & 8)) ? pace : 0;
+        const int pace = getenv("MI355_XE_LINES_PACE") ? atoi(getenv("MI355_XE_LINES_PACE")) : 2;  // in half K blocks
+        a.pace = (a.pinned && a.units / a.items <= cus && a.units / a.items <= 8192 && (long)a.items * a.steps < 2048 && !(a.dbg & 8)) ? pace : 0;
     }
+    a.pub_local = (getenv("MI355_XE_LINES_PUB") && atoi(getenv("MI355_XE_LINES_PUB")) == 0) ? 0 : 1;
     static bool attr_set = false;
     if (!attr_set) {
         MI355_HIP(hipFuncSetAttribute((const void *)k_xe_i8_lines, hipFuncAttributeMaxDynamicSharedMemorySize, kLnLds));
         attr_set = true;
     }
     const unsigned grid = (unsigned)(a.units / a.items);
+    a.grid = (int)grid;
+    a.rot = (a.pinned && a.items > 1 && (grid / 4) % (unsigned)a.ncols == 0) ? (getenv("MI355_XE_LINES_ROT") ? atoi(getenv("MI355_XE_LINES_ROT")) : 1) : 0;
     if (getenv("MI355_XE_TS")) {  // tuning aid: one synchronous launch with start / end stamps per workgroup
         unsigned long long *d_ts = nullptr;
         MI355_HIP(hipMalloc(&d_ts, (size_t)grid * 64));
