@@ -671,19 +671,23 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank, out=None):
                                             "scaling_efficiency_vs_n1_batched": round(t1b / (world * tw), 3), "n1_us_per_window_batched": round(t1b, 2),
                                             "collective": "none (every rank ingests all antennas of its F/W channels)"}
     if world == 1:
-        # A stream of integrations handed over eight or sixteen at a time (mi355_xengine_xcorrelate_n_dev): every unit is a whole integration of
-        # its 32-byte slice (no time ranges, no partial sums), 512 / 1024 units on 256 CUs, the slow lines' units first.  Inputs in rotation.
+        # A stream of integrations handed over 4 ... 32 at a time (mi355_xengine_xcorrelate_n_dev): every unit is a whole integration of one line's
+        # pair group (no time ranges, no partial sums), 256 ... 2048 units on 256 CUs.  Inputs in rotation (every launch reads HBM).
         row = {}
-        for nint in (4, 8, 16):
+        def lines_kernel(units, cus=256, max_items=16):  # mi355_xe_lines_ok's rule for this geometry (csrc/xengine_lines.hip)
+            if os.environ.get("MI355_XE_NO_LINES") or N != 64 or Fw % 64 or units < cus or units % 32:
+                return False
+            return any(units % it == 0 and (units // it) % 32 == 0 for it in range(-(-units // cus), max_items + 1))
+        for nint in (4, 8, 16, 32):
             vb = torch.zeros(nint * xe.get_output_buffer_size(), 2, device="cuda")
             fn_rot, bufs = rotate(lambda: torch.randint(-127, 128, (nint, T, N, Fw, 1, 2), dtype=torch.int8, device="cuda", generator=g),
                                   nint * T * N * Fw * 2, lambda x: xe.xcorrelate_n_device(nint, x, vb))
             rb = rate(fn_rot, nint * N * Fw * T, 2)
             tw = rb["us_per_launch"] / nint
-            # (which kernel: mi355_xe_lines_ok -- 64 stations, whole-line rows, enough (window, line, pair group) units to fill the device and at
-            # most two per workgroup: the whole-line kernel of csrc/xengine_lines.hip; otherwise the 32-byte-slice kernel, persistent workgroups)
+            # (which kernel: mi355_xe_lines_ok -- 64 stations, whole-line rows, enough (window, line, pair group) units to fill the device in equal
+            # shares of at most 16 per workgroup: the whole-line kernel of csrc/xengine_lines.hip; otherwise the 32-byte-slice kernel)
             units = nint * (Fw // 64) * 4
-            lines = N == 64 and Fw % 64 == 0 and 256 <= units <= 512 and not os.environ.get("MI355_XE_NO_LINES")
+            lines = lines_kernel(units)
             row["windows_per_launch_%d" % nint] = {"us_per_window": round(tw, 2), "MSamples_per_s": rb["MSamples_per_s"],
                                                   "hbm_frac_algorithmic": round(alg_bytes / (tw * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                                   "distinct_inputs_in_rotation": len(bufs),

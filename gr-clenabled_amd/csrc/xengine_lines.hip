@@ -29,8 +29,11 @@
 // of the sub-stage three ahead one at a time between them as well.
 // Pacing.  The four workgroups of a line re-read each other's lines from L2 only while they walk the same frames; groups C / D take six
 // sub-stages per K block, A / B four, so A / B run ahead until their partners' lines have left the L2 again (read traffic 1.8 x the input).  Every
-// workgroup publishes the K blocks it has done (ln_progress) and one that is more than `pace` ahead of its slowest partner waits: 383 -> 364 us per
-// eight windows, and the slow address class (lines 3 and 11 of a row: 1.6 x the latency from HBM) disappears from the per-line end times.
+// workgroup publishes the half K blocks it has started (ln_progress) and one that is more than `pace` ahead of its slowest partner waits.  The words
+// stay in the XCD's L2 (plain stores, L1-bypassing loads): published at agent scope they cross the fabric to the array's home, the launch time then
+// follows where that home is (the first paced form: 360 us in one process, 400 in the next) -- now 347-362 us per eight windows in every process, reads
+// 1.44 x the input.  A workgroup's k-th unit is k lines further on than its first (the slow address class, lines 3 and 11 of a row, 1.25 x the time
+// from HBM, spread over twice the workgroups); any equal share of up to 16 units per workgroup: ~80 us per launch + 34.5 us per window.
 #include "xengine_fused.h"
 
 #include <algorithm>
@@ -246,7 +249,7 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
 
     // ---- A sub-stage is taken in two parts: front(m), then the byte transposes of its four dword units with products and requests between them --
     int kb_done = 0;                 // half K blocks of this workgroup's stream that have been started
-    long long pace_budget = 20000;   // 100 MHz ticks this workgroup may spend waiting for partners in all (200 us): a partner that is not resident is not waited for for ever
+    long long pace_budget = 10000LL * a.items;  // 100 MHz ticks this workgroup may spend waiting for partners in all (100 us per unit): a partner that is not resident is not waited for for ever
     unsigned long long t_pace = 0;
     // The four workgroups of a line are neighbours in dispatch order on ONE XCD (blockIdx % 8 under round-robin dispatch): their progress words are four
     // adjacent words of that XCD's own 4 KiB of ln_progress.  pub_local: written by PLAIN stores (the line stays in the XCD's L2) and read by
@@ -569,11 +572,16 @@ bool mi355_xe_lines_ok(int N, int F, int Fout, int npol, int T, int stations_per
     const int ng = (stations_per_group > 0 && stations_per_group < N) ? stations_per_group : N;
     if (npol != 1 || N != 64 || F % 64 != 0 || Fout != F || T % 32 != 0 || T < 32 || T > 16384 || accumulate || ng % 8 != 0) return false;
     const long units = (long)(nint > 0 ? nint : 1) * (F / 64) * 4;
-    // MI355_XE_LINES_MIN_UNITS (test switch): any unit count.  Otherwise: enough units to fill the device, at most two per workgroup (measured at
-    // config 5, windows per launch 4 / 8 / 16: 196 / 367 / 800 us against 204 / 397 / 780 for the 32-byte-slice kernel), a multiple of 32 (the
-    // pinned map, which the pacing of a line's four workgroups needs)
+    // MI355_XE_LINES_MIN_UNITS (test switch): any unit count.  Otherwise: enough units to fill the device and a multiple of 32 (the pinned map, which
+    // the pacing of a line's four workgroups needs) that splits into equal shares of at most MI355_XE_LINES_MAX_ITEMS (default 16) units per workgroup
+    // over a grid that is a multiple of 32 (measured at config 5, windows per launch 4 / 8 / 16: 180 / 350 / 637 us against 204 / 397 / 780 for the
+    // 32-byte-slice kernel: the more units per workgroup, the smaller the share of the last units' matrix stores, which nothing overlaps)
     if (getenv("MI355_XE_LINES_MIN_UNITS")) return units >= atoi(getenv("MI355_XE_LINES_MIN_UNITS")) && units % 4 == 0;
-    return units >= cus && units <= 2L * cus && units % 32 == 0 && (units <= cus || (units / 2) % 32 == 0);
+    if (units < cus || units % 32 != 0) return false;
+    const long max_items = getenv("MI355_XE_LINES_MAX_ITEMS") ? atol(getenv("MI355_XE_LINES_MAX_ITEMS")) : 16;
+    for (long items = (units + cus - 1) / cus; items <= max_items; items++)
+        if (units % items == 0 && (units / items) % 32 == 0) return true;  // (the share mi355_xe_lines_launch will find)
+    return false;
 }
 
 int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int T, double kd, hipStream_t st, int stations_per_group, int nint, int cus)

@@ -120,6 +120,33 @@ def test_whole_line_kernel_refusals_fall_back(gpu, oracle, small_units):
     assert np.array_equal(out.cpu().numpy().view(np.complex64).reshape(-1), ref2)
 
 
+@pytest.mark.parametrize("nint,pub", [(8, "1"), (24, "1"), (12, "0"), (64, "1")])
+def test_whole_line_kernel_default_route_many_units(gpu, oracle, monkeypatch, nint, pub):
+    """The default route (no test switch) at 1024 channels x 64 frames: 2, 6, 3 and 16 units per workgroup, paced through the progress words (kept in
+    the XCD's L2, or -- MI355_XE_LINES_PUB=0 -- published at agent scope), a workgroup's k-th unit k lines further on: bit exact against the oracle
+    and, window for window, against the 32-byte-slice kernel."""
+    import torch
+    monkeypatch.setenv("MI355_XE_LINES_PUB", pub)
+    N, F, T = 64, 1024, 64
+    rng = np.random.default_rng(nint)
+    wins = rng.integers(-128, 128, size=(nint, T, N, F, 1, 2), dtype=np.int64).astype(np.int8)
+    blk = _xe(gpu, N, F, T)
+    per = blk.get_output_buffer_size()
+    x = torch.from_numpy(wins).cuda()
+    out = torch.zeros(nint * per, 2, device="cuda")
+    _run(gpu, blk, nint, x, out)
+    got = out.cpu().numpy().view(np.complex64).reshape(nint, -1)
+    for i in (range(nint) if nint <= 12 else sorted(set(range(0, nint, 5)) | {nint - 1})):  # (the rest: through the other kernel, below)
+        assert np.array_equal(got[i], oracle.xengine_ichar(N, F, 1, T, wins[i].reshape(-1), exact=True)), i
+    os.environ["MI355_XE_NO_LINES"] = "1"
+    try:
+        old = torch.zeros_like(out)
+        _run(gpu, blk, nint, x, old)
+    finally:
+        os.environ.pop("MI355_XE_NO_LINES", None)
+    assert torch.equal(out, old)
+
+
 def test_whole_line_kernel_config5_batch(gpu, oracle):
     """BASELINE config 5 (64 x 1024 x 1024), eight windows per launch -- the default route, two units per workgroup: the first and the last window bit
     exact against the oracle, every window identical to the 32-byte-slice kernel's."""
