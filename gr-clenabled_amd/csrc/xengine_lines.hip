@@ -251,13 +251,14 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
     int kb_done = 0;                 // half K blocks of this workgroup's stream that have been started
     long long pace_budget = 10000LL * a.items;  // 100 MHz ticks this workgroup may spend waiting for partners in all (100 us per unit): a partner that is not resident is not waited for for ever
     unsigned long long t_pace = 0;
-    // The four workgroups of a line are neighbours in dispatch order on ONE XCD (blockIdx % 8 under round-robin dispatch): their progress words are four
-    // adjacent words of that XCD's own 4 KiB of ln_progress.  pub_local: written by PLAIN stores (the line stays in the XCD's L2) and read by
-    // L1-bypassing loads (L2 hits); agent-scope (sc1) stores drop the line from the L2, so that every publish and every poll crosses the fabric to
-    // the word's home.  A workgroup that finds itself on another XCD than its index says (HW_REG_XCC_ID) publishes at agent scope and waits for nobody.
+    // The four workgroups of a line are neighbours in dispatch order on ONE XCD (blockIdx % 8 plus whatever offset the dispatcher's round robin starts
+    // this launch with): their progress words are four adjacent words of one 4 KiB page of ln_progress per (blockIdx % 8).  pub_local: written by PLAIN
+    // stores (the line stays in the XCD's L2) and read by L1-bypassing loads (L2 hits); agent-scope (sc1) stores drop the line from the L2, so that every
+    // publication and every poll crosses the fabric to the word's home.  Nothing checks the placement: a partner on ANOTHER XCD never sees this launch's
+    // tag in the words it reads (a word with another tag is nobody's progress), so it is not waited for -- pacing is performance only, and every wait
+    // is bounded.  (HW_REG_XCC_ID == blockIdx % 8 does NOT hold in general: the round robin goes on from where the previous dispatch stopped.)
     const int my_slot = (int)((blockIdx.x >> 3) & 3), team0 = (int)((blockIdx.x & 7) * 1024 + 4 * (blockIdx.x >> 5));
-    const bool on_xcd = (int)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7) == (int)(blockIdx.x & 7);
-    const bool xcd_local = a.pub_local && on_xcd, pace_wait = !a.pub_local || on_xcd;
+    const bool xcd_local = a.pub_local != 0, pace_wait = true;
     unsigned long long t_wait = 0, t_bar1 = 0;  // (tuning aid, MI355_XE_TS: shader clocks wave 0 spends waiting for the DMA / at the barrier)
     //   front(m): wait until sub-stage m has landed, ONE barrier -- behind it every wave has also finished reading sub-stage m - 1, whose slot takes
     //             sub-stage m + 3 (requested piecemeal by the transposes that follow: issue_one) -- and the four 16-byte LDS reads of this lane

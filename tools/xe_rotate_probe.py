@@ -11,8 +11,11 @@ nbuf = int(os.environ.get("PROBE_NBUF", "4")); it = int(os.environ.get("PROBE_IT
 xe = pkg.clXEngine(1, 2, 0, 0, False, pkg.DTYPE_BYTE, NPOL, N, 1, 0, F, T, [])
 xs = [torch.randint(-127, 128, (nint, T, N, F, NPOL, 2), dtype=torch.int8, device="cuda") for _ in range(nbuf)]
 outs = [torch.zeros(nint * xe.get_output_buffer_size(), 2, device="cuda") for _ in range(nbuf)]
+shift = int(os.environ.get("PROBE_SHIFT", "0"))  # > 0: a small kernel of `shift` workgroups in front of every launch (the dispatcher's round robin over the XCDs goes on from there)
+junk = torch.zeros(shift * 256, device="cuda") if shift else None
 def run():
     for k in range(nbuf):
+        if shift: junk.add_(1.0)
         if nint > 1: xe.xcorrelate_n_device(nint, xs[k], outs[k])
         else: xe.xcorrelate_device(xs[k], outs[k])
 fresh = int(os.environ.get("PROBE_FRESH", "0"))  # 1: every window is written by a device copy right before its launch (a producer kernel)
