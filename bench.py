@@ -677,7 +677,10 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank, out=None):
         def lines_kernel(units, cus=256, max_items=16):  # mi355_xe_lines_ok's rule for this geometry (csrc/xengine_lines.hip)
             if os.environ.get("MI355_XE_NO_LINES") or N != 64 or Fw % 64 or units < cus or units % 32:
                 return False
-            return any(units % it == 0 and (units // it) % 32 == 0 for it in range(-(-units // cus), max_items + 1))
+            for it in range(-(-units // cus), max_items + 1):
+                if units % it == 0 and (units // it) % 32 == 0:
+                    return (units // it) * 8 >= cus * 7
+            return False
         for nint in (4, 8, 16, 32):
             vb = torch.zeros(nint * xe.get_output_buffer_size(), 2, device="cuda")
             fn_rot, bufs = rotate(lambda: torch.randint(-127, 128, (nint, T, N, Fw, 1, 2), dtype=torch.int8, device="cuda", generator=g),

@@ -575,14 +575,14 @@ bool mi355_xe_lines_ok(int N, int F, int Fout, int npol, int T, int stations_per
     const long units = (long)(nint > 0 ? nint : 1) * (F / 64) * 4;
     // MI355_XE_LINES_MIN_UNITS (test switch): any unit count.  Otherwise: enough units to fill the device and a multiple of 32 (the pinned map, which
     // the pacing of a line's four workgroups needs) that splits into equal shares of at most MI355_XE_LINES_MAX_ITEMS (default 16) units per workgroup
-    // over a grid that is a multiple of 32 (measured at config 5, windows per launch 4 / 8 / 16: 180 / 350 / 637 us against 204 / 397 / 780 for the
+    // over a grid that is a multiple of 32 and at least 7/8 of the CUs (6 or 10 windows of config 5 would run on 192 / 160 workgroups) (measured at config 5, windows per launch 4 / 8 / 16: 180 / 350 / 637 us against 204 / 397 / 780 for the
     // 32-byte-slice kernel: the more units per workgroup, the smaller the share of the last units' matrix stores, which nothing overlaps)
     if (getenv("MI355_XE_LINES_MIN_UNITS")) return units >= atoi(getenv("MI355_XE_LINES_MIN_UNITS")) && units % 4 == 0;
     if (units < cus || units % 32 != 0) return false;
     const long max_items = getenv("MI355_XE_LINES_MAX_ITEMS") ? atol(getenv("MI355_XE_LINES_MAX_ITEMS")) : 16;
     for (long items = (units + cus - 1) / cus; items <= max_items; items++)
-        if (units % items == 0 && (units / items) % 32 == 0) return true;  // (the share mi355_xe_lines_launch will find)
-    return false;
+        if (units % items == 0 && (units / items) % 32 == 0) return (units / items) * 8 >= (long)cus * 7;  // (the share mi355_xe_lines_launch will find:
+    return false;                                                                                     //  on at least 7/8 of the CUs, or the other kernel is faster)
 }
 
 int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int T, double kd, hipStream_t st, int stations_per_group, int nint, int cus)
