@@ -53,7 +53,8 @@ constexpr int kLnWaves = 8, kLnCh = 8, kLnU = 4;  // eight waves (two per SIMD),
 constexpr int kLnThreads = kLnWaves * 64, kLnChunk = 1040, kLnSlot = 32 * kLnChunk, kLnRing = 4;
 constexpr int kLnTile = 16 * 20 * 4;  // a wave's scratch for the transposed diagonal tile
 constexpr int kLnPoll = kLnRing * kLnSlot + kLnWaves * kLnTile;  // 256 bytes: where the partners' progress words land (pacing)
-constexpr int kLnLds = kLnPoll + 256;
+constexpr int kLnTouch = kLnPoll + 256;  // 1 KiB: where the early touches of the slow lines land (never read)
+constexpr int kLnLds = kLnTouch + 1024;
 
 struct LnArgs {
     const unsigned char *in;
@@ -68,6 +69,10 @@ struct LnArgs {
     unsigned tag;   // launch number (pacing of the four workgroups of a line: ln_progress)
     int pace;       // half K blocks a workgroup may run ahead of the slowest of its three partners (0: no pacing)
     int rot, grid;  // line rotation per unit of a workgroup (0: none); workgroups of the launch
+    // early touches of the slow lines (address bits 7..9 == 3: ~1.7 x the latency from HBM): the diagonal groups of the OTHER lines, which wait for their
+    // partners anyway, request 16 bytes of every slow line's rows pf_dist K blocks ahead (the lines are in the Infinity Cache when their own workgroups ask)
+    int pf_dist, pf_lg, pf_per, pf_items;  // 0: off; log2(slow lines per row); (row, slow line) items per K block and toucher; items per K block
+    unsigned pf_mask, pf_lines;            // bit l: line l of a row is slow; the slow lines' numbers, one byte each
     int pub_local;  // progress words by plain stores, kept in the XCD's L2 (0: agent-scope stores, MI355_XE_LINES_PUB=0)
     unsigned long long *ts;
 };
@@ -196,6 +201,9 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
     // line for 8 frames.  Address = (uniform) unit, row tile, station, K block, half + (per lane) frame and piece.
     const size_t lane_off = (size_t)((wave >> 2) * 8 + (lane >> 3)) * t_stride + (size_t)(lane & 7) * 16;
     const unsigned char *hb0 = nullptr, *hb1 = nullptr, *hb2 = nullptr;
+    bool pf_on = false;
+    int pf_first = 0;
+    const unsigned char *pf_win = nullptr;
     auto setup_issue = [&](int n) {
         const LnUnit u = ln_map_unit(a, n);
         const unsigned char *in_w = a.in + (size_t)u.win * a.in_window + (size_t)u.col * 128;
@@ -206,6 +214,11 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
         hb0 = half_base(rt0);
         hb1 = half_base(rt1);
         hb2 = half_base(rt2);
+        if constexpr (DIAG) {
+            pf_on = a.pf_dist > 0 && !((a.pf_mask >> u.col) & 1u);
+            pf_first = (__builtin_popcount(~a.pf_mask & ((1u << u.col) - 1u)) * 2 + grp) * a.pf_per;  // this workgroup among the touchers of its window
+            pf_win = a.in + (size_t)u.win * a.in_window;
+        }
     };
     const int total_sub = a.items * a.steps * NS;  // sub-stages of this workgroup's stream
     int issue_unit = 0, issue_kb = -1;             // the unit / K block whose sub-stages are being requested
@@ -226,6 +239,19 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
         const unsigned char *hb = i == 0 ? hb0 : i == 1 ? hb1 : hb2;
         iss_p0 = hb + (size_t)(32 * kb + 16 * h) * t_stride + lane_off;
         iss_dst0 = lds0 + (m & (kLnRing - 1)) * kLnSlot + ((wave >> 2) * 16 + (wave & 3) * 4) * kLnChunk;
+        // early touches: wave j, at the K block's j-th sub-stage, one instruction = up to 64 (row, slow line) items of the K block pf_dist further on.
+        // (In front of the sub-stage's own requests: older than they are, so the waits that count them have seen it land -- like wave 0's poll; a
+        // touch that takes long holds up a diagonal group, which has the time.)
+        if constexpr (DIAG) {
+            if (pf_on && wave == j && kb + a.pf_dist < a.steps) {
+                const int k = wave * 64 + lane, i = pf_first + k;
+                if (k < a.pf_per && i < a.pf_items) {
+                    const int which = i & ((1 << a.pf_lg) - 1), row = i >> a.pf_lg, t = row >> 6, st = row & 63;
+                    const unsigned ln = (a.pf_lines >> (8 * which)) & 0xffu;
+                    ln_dma16(pf_win + ((size_t)(32 * (kb + a.pf_dist) + t) * 64 + (size_t)st) * row_bytes + (size_t)ln * 128, lds0 + kLnTouch);
+                }
+            }
+        }
     };
     // the wave's ii-th request of that sub-stage (one station's line of 8 frames).  The four requests of a sub-stage are issued one at a time
     // between the transposes: back to back, the eight waves' 32 instructions queue at the CU's address unit and every wave stands ~330 clocks
@@ -621,6 +647,27 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
         a.pace = (a.pinned && a.units / a.items <= cus && a.units / a.items <= 8192 && (long)a.items * a.steps < 2048 && !(a.dbg & 8)) ? pace : 0;
     }
     a.pub_local = (getenv("MI355_XE_LINES_PUB") && atoi(getenv("MI355_XE_LINES_PUB")) == 0) ? 0 : 1;
+    // early touches (MI355_XE_LINES_PF: distance in K blocks, default 4 -- 2 ... 8 within 1 %, 12 slower --, 0: off): rows of 8, 16 or 32 whole lines in the reference layout
+    a.pf_dist = a.pf_lg = a.pf_per = a.pf_items = 0;
+    a.pf_mask = a.pf_lines = 0;
+    {
+        const int pf = getenv("MI355_XE_LINES_PF") ? atoi(getenv("MI355_XE_LINES_PF")) : 4;
+        if (pf > 0 && (a.ncols == 8 || a.ncols == 16 || a.ncols == 32) && a.ng == N && ((size_t)in & 127) == 0 && a.steps > pf) {
+            const int key = (int)(((size_t)in >> 7) & 15);
+            int n = 0;
+            for (int l = 0; l < a.ncols; l++)
+                if ((((l + key) & 15) & 7) == 3) {
+                    a.pf_mask |= 1u << l;
+                    a.pf_lines |= (unsigned)l << (8 * n);
+                    n++;
+                }
+            const int touchers = (a.ncols - n) * 2;  // the diagonal groups of the other lines
+            a.pf_items = 32 * 64 * n;
+            a.pf_per = (a.pf_items + touchers - 1) / touchers;
+            a.pf_lg = n == 1 ? 0 : n == 2 ? 1 : 2;
+            if ((n == 1 || n == 2 || n == 4) && a.pf_per <= 256) a.pf_dist = pf;
+        }
+    }
     static bool attr_set = false;
     if (!attr_set) {
         MI355_HIP(hipFuncSetAttribute((const void *)k_xe_i8_lines, hipFuncAttributeMaxDynamicSharedMemorySize, kLnLds));
