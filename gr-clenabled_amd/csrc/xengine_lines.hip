@@ -33,7 +33,10 @@
 // stay in the XCD's L2 (plain stores, L1-bypassing loads): published at agent scope they cross the fabric to the array's home, the launch time then
 // follows where that home is (the first paced form: 360 us in one process, 400 in the next) -- now 347-362 us per eight windows in every process, reads
 // 1.44 x the input.  A workgroup's k-th unit is k lines further on than its first (the slow address class, lines 3 and 11 of a row, 1.25 x the time
-// from HBM, spread over twice the workgroups); any equal share of up to 16 units per workgroup: ~80 us per launch + 34.5 us per window.
+// from HBM, spread over twice the workgroups); any equal share of up to 16 units per workgroup.
+// Early touches.  The diagonal groups of the other lines -- which wait for their partners 13 % of the time anyway -- request 16 bytes of every row of
+// the slow lines four K blocks ahead (one instruction per wave 0 ... 3 and K block): the slow lines' own workgroups then find them in the Infinity
+// Cache.  bench.py: 4 / 8 windows per launch 42.1 / 38.7 -> 36.9 / 37.1 us per window, 16 and 32 unchanged (35.4 / 35.6).
 #include "xengine_fused.h"
 
 #include <algorithm>
