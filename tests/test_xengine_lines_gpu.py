@@ -147,6 +147,30 @@ def test_whole_line_kernel_default_route_many_units(gpu, oracle, monkeypatch, ni
     assert torch.equal(out, old)
 
 
+@pytest.mark.parametrize("F,T,nint", [(512, 256, 8), (2048, 192, 2), (1024, 320, 4)])
+def test_whole_line_kernel_early_touches(gpu, oracle, F, T, nint):
+    """The default route with the early touches of the slow lines on (rows of 8, 32 and 16 lines, more K blocks than the touch distance): requests for
+    data nobody reads must change nothing -- the first and the last window bit exact against the oracle, all of them identical with the touches off."""
+    import torch
+    N = 64
+    g = torch.Generator(device="cuda").manual_seed(F + T)
+    x = torch.randint(-128, 128, (nint, T, N, F, 1, 2), dtype=torch.int8, device="cuda", generator=g)
+    blk = _xe(gpu, N, F, T)
+    per = blk.get_output_buffer_size()
+    out = torch.zeros(nint * per, 2, device="cuda")
+    _run(gpu, blk, nint, x, out)
+    os.environ["MI355_XE_LINES_PF"] = "0"
+    try:
+        off = torch.zeros_like(out)
+        _run(gpu, blk, nint, x, off)
+    finally:
+        os.environ.pop("MI355_XE_LINES_PF", None)
+    assert torch.equal(out, off)
+    got = out.cpu().numpy().view(np.complex64).reshape(nint, -1)
+    for i in (0, nint - 1):
+        assert np.array_equal(got[i], oracle.xengine_ichar(N, F, 1, T, x[i].cpu().numpy().reshape(-1), exact=True)), i
+
+
 def test_whole_line_kernel_config5_batch(gpu, oracle):
     """BASELINE config 5 (64 x 1024 x 1024), eight windows per launch -- the default route, two units per workgroup: the first and the last window bit
     exact against the oracle, every window identical to the 32-byte-slice kernel's."""
