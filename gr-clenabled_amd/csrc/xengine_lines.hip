@@ -57,7 +57,8 @@ constexpr int kLnThreads = kLnWaves * 64, kLnChunk = 1040, kLnSlot = 32 * kLnChu
 constexpr int kLnTile = 16 * 20 * 4;  // a wave's scratch for the transposed diagonal tile
 constexpr int kLnPoll = kLnRing * kLnSlot + kLnWaves * kLnTile;  // 256 bytes: where the partners' progress words land (pacing)
 constexpr int kLnTouch = kLnPoll + 256;  // 1 KiB: where the early touches of the slow lines land (never read)
-constexpr int kLnLds = kLnTouch + 1024;
+constexpr int kLnRs = kLnTouch + 1024;   // off-diagonal groups: a wave's row sums, [channel][lane] (2 KiB per wave)
+constexpr int kLnLds = kLnRs + kLnWaves * kLnCh * 64 * 4;
 
 struct LnArgs {
     const unsigned char *in;
@@ -422,13 +423,29 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
             item(T0{}, std::integral_constant<int, 2 * u + 1>{});
             item(T1{}, std::integral_constant<int, 2 * u>{});
             item(T1{}, std::integral_constant<int, 2 * u + 1>{});
-            if constexpr (u > 0) {
+            if constexpr (DIAG && u > 0) {
                 item(T2{}, std::integral_constant<int, 2 * u - 2>{});
                 item(T2{}, std::integral_constant<int, 2 * u - 1>{});
             }
         });
-        item(T2{}, std::integral_constant<int, kLnCh - 2>{});
-        item(T2{}, std::integral_constant<int, kLnCh - 1>{});
+        if constexpr (DIAG) {
+            item(T2{}, std::integral_constant<int, kLnCh - 2>{});
+            item(T2{}, std::integral_constant<int, kLnCh - 1>{});
+        }
+    };
+    // Off-diagonal groups: both pairs have their rows in ONE row tile (X0), so the "+ 1" of -q = ~q + 1 -- sum_t I_a(t) on every column of row a -- is
+    // the same vector for both.  It is not a third product there (a third of the matrix pipe's time in the groups that set the pace) but a byte sum
+    // of the lane's own I planes (station r, frame group g), added into the wave's 2 KiB of LDS per K block; the epilogue sums the four frame groups
+    // and hands row i its total (as k_xe_i8_fused does with its row sums).
+    int *const rs_lds = (int *)(lds + kLnRs) + wave * (kLnCh * 64) + lane;
+    auto row_sums = [&]() {
+#pragma unroll
+        for (int ch = 0; ch < kLnCh; ch++) {
+            const v4i &x = X0[ch >> 1][ch & 1];
+            int t = __builtin_amdgcn_sdot4(x[0], 0x01010101, 0, false);
+            t = __builtin_amdgcn_sdot4(x[1], 0x01010101, t, false);
+            __hip_atomic_fetch_add(rs_lds + ch * 64, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     };
     // (a list = 3 x 8 = 24 items; half a list per sub-stage of x, 20 of the pair xx under the first sub-stage of y and its last 4 in front of the second)
     struct Cum24 { static constexpr int at(int u) { constexpr int c[5] = {0, 4, 7, 10, 12}; return c[u]; } };
@@ -446,6 +463,10 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
         // (the loop carries the pair yy of a K block into the next one; before the first K block it runs on zeros)
 #pragma unroll
         for (int u = 0; u < kLnU; u++) X1[u][0] = X1[u][1] = (v4i){0, 0, 0, 0};
+        if constexpr (!DIAG) {
+#pragma unroll
+            for (int ch = 0; ch < kLnCh; ch++) rs_lds[ch * 64] = 0;
+        }
         for (int kb = 0; kb < a.steps; kb++) {
             // (the first wait of a unit that follows another one drains everything: that unit's matrix stores share the counter with the DMA and
             // complete out of order with it)
@@ -473,6 +494,7 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
                 front(m + 1, 1, false);
 #pragma unroll
                 for (int u = 0; u < kLnU; u++) perm_unit(X0, u, 1);
+                row_sums();
                 front(m + 2, 2, false);
 #pragma unroll
                 for (int u = 0; u < kLnU; u++) perm_unit(X1, u, 0);
@@ -565,8 +587,19 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
                     emit_off(ln_acc_read4<ln_areg(2, ch)>(), ln_acc_read4<ln_areg(3, ch)>(), f, rt1, rt0);
                     emit_diag(ln_acc_read4<ln_areg(1, ch)>(), f, rt1);
                 } else {
-                    emit_off(ln_acc_read4<ln_areg(0, ch)>(), ln_acc_read4<ln_areg(1, ch)>(), f, rt0, 0);
-                    emit_off(ln_acc_read4<ln_areg(2, ch)>(), ln_acc_read4<ln_areg(3, ch)>(), f, rt0, 1);
+                    // row i = 4 g + reg of the tile pair: the sum over the four frame groups of station i's I bytes
+                    int v = rs_lds[ch * 64];
+                    v += __shfl_xor(v, 16);
+                    v += __shfl_xor(v, 32);
+                    v4i im0 = ln_acc_read4<ln_areg(1, ch)>(), im1 = ln_acc_read4<ln_areg(3, ch)>();
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int c = __shfl(v, 4 * gg + k);
+                        im0[k] += c;
+                        im1[k] += c;
+                    }
+                    emit_off(ln_acc_read4<ln_areg(0, ch)>(), im0, f, rt0, 0);
+                    emit_off(ln_acc_read4<ln_areg(2, ch)>(), im1, f, rt0, 1);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);  // (one channel's values at a time)
