@@ -20,6 +20,7 @@
 //   im   = im' + sum_t I_a(t)             (row sums via v_sad_u8 on the operand bytes)
 // so a channel needs 2 accumulators per tile pair (80 registers for 64 rows) + 4 row-sum registers.
 #include "xengine_fused.h"
+#include <atomic>
 
 #include <algorithm>
 #include <cstdio>
@@ -1117,10 +1118,17 @@ template <int NPOL, int NTT, bool SPLIT, bool PP, bool RS> int launch_fused_s(co
 {
     constexpr int NSH = (NTT * 16 / NPOL > 32) ? 2 : 1;
     constexpr int lds_bytes = kRing * (kStageT * NSH * kChunk + 16) + 1024;  // (+ the scratch the slow lines' early touches land in)
-    static bool attr_set = false;  // (per instantiation; a second thread setting it again is harmless)
-    if (!attr_set) {
-        MI355_HIP(hipFuncSetAttribute((const void *)k_xe_i8_fused<NPOL, NTT, SPLIT, PP, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        attr_set = true;
+    // (per instantiation AND per device: a function's attributes belong to the device that is current when they are set -- the single-process
+    // multi-GPU form launches this kernel on every device of the handle; a second thread setting it again is harmless)
+    static std::atomic<unsigned long long> attr_devs{0};
+    {
+        int dev = 0;
+        MI355_HIP(hipGetDevice(&dev));
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(attr_devs.load(std::memory_order_relaxed) & bit)) {
+            MI355_HIP(hipFuncSetAttribute((const void *)k_xe_i8_fused<NPOL, NTT, SPLIT, PP, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+            attr_devs.fetch_or(bit, std::memory_order_relaxed);
+        }
     }
     const int nint = a.nint_launch;
     hipLaunchKernelGGL((k_xe_i8_fused<NPOL, NTT, SPLIT, PP, RS>), dim3((unsigned)(p.units * p.tsplit * nint / a.items)), dim3(kThreads), lds_bytes, st, a);

@@ -704,10 +704,15 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
             if ((n == 1 || n == 2 || n == 4) && a.pf_per <= 256) a.pf_dist = pf;
         }
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        MI355_HIP(hipFuncSetAttribute((const void *)k_xe_i8_lines, hipFuncAttributeMaxDynamicSharedMemorySize, kLnLds));
-        attr_set = true;
+    static std::atomic<unsigned long long> attr_devs{0};  // (per device: a function's attributes belong to the device that is current when they are set)
+    {
+        int dev = 0;
+        MI355_HIP(hipGetDevice(&dev));
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(attr_devs.load(std::memory_order_relaxed) & bit)) {
+            MI355_HIP(hipFuncSetAttribute((const void *)k_xe_i8_lines, hipFuncAttributeMaxDynamicSharedMemorySize, kLnLds));
+            attr_devs.fetch_or(bit, std::memory_order_relaxed);
+        }
     }
     const unsigned grid = (unsigned)(a.units / a.items);
     a.grid = (int)grid;
