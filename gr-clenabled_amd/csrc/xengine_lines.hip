@@ -36,7 +36,8 @@
 // from HBM, spread over twice the workgroups); any equal share of up to 16 units per workgroup.
 // Early touches.  The diagonal groups of the other lines -- which wait for their partners 13 % of the time anyway -- request 16 bytes of every row of
 // the slow lines four K blocks ahead (one instruction per wave 0 ... 3 and K block): the slow lines' own workgroups then find them in the Infinity
-// Cache.  bench.py: 4 / 8 windows per launch 42.1 / 38.7 -> 36.9 / 37.1 us per window, 16 and 32 unchanged (35.4 / 35.6).
+// Cache.  bench.py: 4 / 8 windows per launch 42.1 / 38.7 -> 36.9 / 37.1 us per window, 16 and 32 unchanged (35.4 / 35.6).  With the touches the
+// pacing is OFF by default: issuing them and waiting for their answers holds the diagonal groups back enough (35.9 / 35.5 / 35.2 / 35.1 us per window).
 #include "xengine_fused.h"
 
 #include <algorithm>
@@ -677,11 +678,6 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
     while (items < a.units && (a.units % items != 0 || (a.units / items) % quantum != 0)) items++;
     if (a.units % items != 0 || (a.units / items) % quantum != 0) items = a.units / quantum;  // (one workgroup quantum: always divides)
     a.items = items;
-    // pacing needs the pinned map, every workgroup resident (one per CU) and partners that can be told apart
-    {
-        const int pace = getenv("MI355_XE_LINES_PACE") ? atoi(getenv("MI355_XE_LINES_PACE")) : 2;  // in half K blocks
-        a.pace = (a.pinned && a.units / a.items <= cus && a.units / a.items <= 8192 && (long)a.items * a.steps < 2048 && !(a.dbg & 8)) ? pace : 0;
-    }
     a.pub_local = (getenv("MI355_XE_LINES_PUB") && atoi(getenv("MI355_XE_LINES_PUB")) == 0) ? 0 : 1;
     // early touches (MI355_XE_LINES_PF: distance in K blocks, default 4 -- 2 ... 8 within 1 %, 12 slower --, 0: off): rows of 8, 16 or 32 whole lines in the reference layout
     a.pf_dist = a.pf_lg = a.pf_per = a.pf_items = 0;
@@ -703,6 +699,14 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
             a.pf_lg = n == 1 ? 0 : n == 2 ? 1 : 2;
             if ((n == 1 || n == 2 || n == 4) && a.pf_per <= 256) a.pf_dist = pf;
         }
+    }
+    // pacing needs the pinned map, every workgroup resident (one per CU) and partners that can be told apart.  Default: OFF where the early touches
+    // are on -- the diagonal groups that would run ahead are the ones that issue the touches and wait for their answers, which holds them back enough
+    // (sustained, 4 / 8 / 16 / 32 windows per launch: 36.0 / 35.5 / 35.2 / 35.1 us per window unpaced against 37.4-38.5 / 36.7-37.1 / 36.2-36.8 / 35.9-36.5
+    // paced by 2 half K blocks; without touches AND without pacing 45 / 40 / 43-47 / 46-52) -- and 2 half K blocks where they are not
+    {
+        const int pace = getenv("MI355_XE_LINES_PACE") ? atoi(getenv("MI355_XE_LINES_PACE")) : (a.pf_dist > 0 ? 0 : 2);
+        a.pace = (a.pinned && a.units / a.items <= cus && a.units / a.items <= 8192 && (long)a.items * a.steps < 2048 && !(a.dbg & 8)) ? pace : 0;
     }
     static std::atomic<unsigned long long> attr_devs{0};  // (per device: a function's attributes belong to the device that is current when they are set)
     {

@@ -147,11 +147,13 @@ def test_whole_line_kernel_default_route_many_units(gpu, oracle, monkeypatch, ni
     assert torch.equal(out, old)
 
 
-@pytest.mark.parametrize("F,T,nint", [(512, 256, 8), (2048, 192, 2), (1024, 320, 4)])
-def test_whole_line_kernel_early_touches(gpu, oracle, F, T, nint):
-    """The default route with the early touches of the slow lines on (rows of 8, 32 and 16 lines, more K blocks than the touch distance): requests for
-    data nobody reads must change nothing -- the first and the last window bit exact against the oracle, all of them identical with the touches off."""
+@pytest.mark.parametrize("F,T,nint,pace", [(512, 256, 8, None), (2048, 192, 2, None), (1024, 320, 4, None), (1024, 320, 8, "2")])
+def test_whole_line_kernel_early_touches(gpu, oracle, monkeypatch, F, T, nint, pace):
+    """The default route with the early touches of the slow lines on (rows of 8, 32 and 16 lines, more K blocks than the touch distance; unpaced --
+    the default with touches -- and paced): requests for data nobody reads must change nothing -- the first and the last window bit exact against the
+    oracle, all of them identical with the touches off."""
     import torch
+    if pace is not None: monkeypatch.setenv("MI355_XE_LINES_PACE", pace)
     N = 64
     g = torch.Generator(device="cuda").manual_seed(F + T)
     x = torch.randint(-128, 128, (nint, T, N, F, 1, 2), dtype=torch.int8, device="cuda", generator=g)
