@@ -674,7 +674,7 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank, out=None):
         # A stream of integrations handed over 4 ... 32 at a time (mi355_xengine_xcorrelate_n_dev): every unit is a whole integration of one line's
         # pair group (no time ranges, no partial sums), 256 ... 2048 units on 256 CUs.  Inputs in rotation (every launch reads HBM).
         row = {}
-        def lines_kernel(units, cus=256, max_items=16):  # mi355_xe_lines_ok's rule for this geometry (csrc/xengine_lines.hip)
+        def lines_kernel(units, cus=256, max_items=64):  # mi355_xe_lines_ok's rule for this geometry (csrc/xengine_lines.hip)
             if os.environ.get("MI355_XE_NO_LINES") or N != 64 or Fw % 64 or units < cus or units % 32:
                 return False
             for it in range(-(-units // cus), max_items + 1):
@@ -688,7 +688,7 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank, out=None):
             rb = rate(fn_rot, nint * N * Fw * T, 2)
             tw = rb["us_per_launch"] / nint
             # (which kernel: mi355_xe_lines_ok -- 64 stations, whole-line rows, enough (window, line, pair group) units to fill the device in equal
-            # shares of at most 16 per workgroup: the whole-line kernel of csrc/xengine_lines.hip; otherwise the 32-byte-slice kernel)
+            # shares of at most 64 per workgroup: the whole-line kernel of csrc/xengine_lines.hip; otherwise the 32-byte-slice kernel)
             units = nint * (Fw // 64) * 4
             lines = lines_kernel(units)
             row["windows_per_launch_%d" % nint] = {"us_per_window": round(tw, 2), "MSamples_per_s": rb["MSamples_per_s"],

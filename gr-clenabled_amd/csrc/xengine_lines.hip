@@ -33,7 +33,7 @@
 // stay in the XCD's L2 (plain stores, L1-bypassing loads): published at agent scope they cross the fabric to the array's home, the launch time then
 // follows where that home is (the first paced form: 360 us in one process, 400 in the next) -- now 347-362 us per eight windows in every process, reads
 // 1.44 x the input.  A workgroup's k-th unit is k lines further on than its first (the slow address class, lines 3 and 11 of a row, 1.25 x the time
-// from HBM, spread over twice the workgroups); any equal share of up to 16 units per workgroup.
+// from HBM, spread over twice the workgroups); any equal share of up to 64 units per workgroup (128 windows per launch: 34.4 us per window).
 // Early touches.  The diagonal groups of the other lines -- which wait for their partners 13 % of the time anyway -- request 16 bytes of every row of
 // the slow lines four K blocks ahead (one instruction per wave 0 ... 3 and K block): the slow lines' own workgroups then find them in the Infinity
 // Cache.  bench.py: 4 / 8 windows per launch 42.1 / 38.7 -> 36.9 / 37.1 us per window, 16 and 32 unchanged (35.4 / 35.6).  With the touches the
@@ -637,12 +637,12 @@ bool mi355_xe_lines_ok(int N, int F, int Fout, int npol, int T, int stations_per
     if (npol != 1 || N != 64 || F % 64 != 0 || Fout != F || T % 32 != 0 || T < 32 || T > 16384 || accumulate || ng % 8 != 0) return false;
     const long units = (long)(nint > 0 ? nint : 1) * (F / 64) * 4;
     // MI355_XE_LINES_MIN_UNITS (test switch): any unit count.  Otherwise: enough units to fill the device and a multiple of 32 (the pinned map, which
-    // the pacing of a line's four workgroups needs) that splits into equal shares of at most MI355_XE_LINES_MAX_ITEMS (default 16) units per workgroup
+    // the pacing of a line's four workgroups needs) that splits into equal shares of at most MI355_XE_LINES_MAX_ITEMS (default 64) units per workgroup
     // over a grid that is a multiple of 32 and at least 7/8 of the CUs (6 or 10 windows of config 5 would run on 192 / 160 workgroups) (measured at config 5, windows per launch 4 / 8 / 16: 180 / 350 / 637 us against 204 / 397 / 780 for the
     // 32-byte-slice kernel: the more units per workgroup, the smaller the share of the last units' matrix stores, which nothing overlaps)
     if (getenv("MI355_XE_LINES_MIN_UNITS")) return units >= atoi(getenv("MI355_XE_LINES_MIN_UNITS")) && units % 4 == 0;
     if (units < cus || units % 32 != 0) return false;
-    const long max_items = getenv("MI355_XE_LINES_MAX_ITEMS") ? atol(getenv("MI355_XE_LINES_MAX_ITEMS")) : 16;
+    const long max_items = getenv("MI355_XE_LINES_MAX_ITEMS") ? atol(getenv("MI355_XE_LINES_MAX_ITEMS")) : 64;
     for (long items = (units + cus - 1) / cus; items <= max_items; items++)
         if (units % items == 0 && (units / items) % 32 == 0) return (units / items) * 8 >= (long)cus * 7;  // (the share mi355_xe_lines_launch will find:
     return false;                                                                                     //  on at least 7/8 of the CUs, or the other kernel is faster)
