@@ -1452,19 +1452,9 @@ extern "C" int mi355_xengine_xcorrelate_grouped_dev(mi355_xengine *h, const void
     return launch_xe(h, in_dev, out_dev, accumulate, mi355_pick_stream(h->ctx, stream), h->d_tiles, h->d_pad, stations_per_group);
 }
 
-extern "C" int mi355_xengine_xcorrelate_n_dev(mi355_xengine *h, int nint, const void *in_dev, void *out_dev, int accumulate, int stations_per_group,
-                                              void *stream)
+// nint windows in ONE launch where the geometry has such a kernel (the caller holds dev_lock)
+static int xe_n_dev_launch(mi355_xengine *h, int nint, const void *in_dev, void *out_dev, int accumulate, int stations_per_group, hipStream_t st)
 {
-    MI355_REQUIRE(h && in_dev && out_dev, "NULL argument");
-    MI355_REQUIRE(nint >= 1, "nint must be >= 1");
-    MI355_REQUIRE(stations_per_group == 0 || (stations_per_group >= 1 && h->g.N % stations_per_group == 0),
-                  "stations_per_group must be 0 (reference layout) or divide the number of inputs");
-    MI355_REQUIRE((reinterpret_cast<uintptr_t>(in_dev) & (h->data_type == MI355_DTYPE_COMPLEX ? 7u : 3u)) == 0 &&
-                      (reinterpret_cast<uintptr_t>(out_dev) & 7u) == 0,
-                  "device buffers must be 4-byte (int8 / packed input) or 8-byte (complex input, output) aligned");
-    MI355_HIP(hipSetDevice(h->ctx->device));
-    hipStream_t st = mi355_pick_stream(h->ctx, stream);
-    std::lock_guard<std::mutex> dl(h->dev_lock);
     const XeGeo &g = h->g;
     const bool grouped = stations_per_group > 0 && stations_per_group < g.N;
     // one launch for all windows: the fused IChar path (<= 64 rows, rows of whole 16-byte pieces, 16-byte aligned input)
@@ -1512,6 +1502,52 @@ extern "C" int mi355_xengine_xcorrelate_n_dev(mi355_xengine *h, int nint, const 
         if (rc != MI355_OK) return rc;
     }
     return MI355_OK;
+}
+
+extern "C" int mi355_xengine_xcorrelate_n_dev(mi355_xengine *h, int nint, const void *in_dev, void *out_dev, int accumulate, int stations_per_group,
+                                              void *stream)
+{
+    MI355_REQUIRE(h && in_dev && out_dev, "NULL argument");
+    MI355_REQUIRE(nint >= 1, "nint must be >= 1");
+    MI355_REQUIRE(stations_per_group == 0 || (stations_per_group >= 1 && h->g.N % stations_per_group == 0),
+                  "stations_per_group must be 0 (reference layout) or divide the number of inputs");
+    MI355_REQUIRE((reinterpret_cast<uintptr_t>(in_dev) & (h->data_type == MI355_DTYPE_COMPLEX ? 7u : 3u)) == 0 &&
+                      (reinterpret_cast<uintptr_t>(out_dev) & 7u) == 0,
+                  "device buffers must be 4-byte (int8 / packed input) or 8-byte (complex input, output) aligned");
+    MI355_HIP(hipSetDevice(h->ctx->device));
+    hipStream_t st = mi355_pick_stream(h->ctx, stream);
+    std::lock_guard<std::mutex> dl(h->dev_lock);
+    const XeGeo &g = h->g;
+    const bool grouped = stations_per_group > 0 && stations_per_group < g.N;
+    // Window counts between the good ones.  The whole-line kernel takes the counts whose units split into equal shares over (nearly) all CUs -- at
+    // BASELINE config 5: 4, 7, 8, 12, 14, 16, ... -- and runs them at 35-37 us per window; in between the 32-byte-slice kernel needs a second round of
+    // workgroups for a few units (5 / 6 / 10 windows per launch: 71 / 62 / 55 us per window).  Such a call is cut into stream-ordered launches of good
+    // counts, the rest in twos and ones (5 = 4 + 1, 6 = 4 + 2, 10 = 8 + 2, 11 = 8 + 2 + 1); windows are independent, so nothing else changes.
+    // (Reference layout only: in the group-major layout a window's address depends on the call's window count.  MI355_XE_NO_SPLIT=1: one launch.)
+    if (nint > 2 && !grouped && h->data_type == MI355_DTYPE_BYTE && !h->pad && !getenv("MI355_XE_NO_SPLIT")) {
+        auto good = [&](int c) { return mi355_xe_lines_ok(g.N, g.F, g.Fout, g.npol, g.T, 0, accumulate, c, h->ctx->num_cus); };
+        int top = 0;
+        for (int c = nint; c >= 1 && !top; c--)
+            if (good(c)) top = c;
+        if (top > 0 && !good(nint)) {
+            const size_t out_bytes = h->out_items * 8;
+            int done = 0;
+            while (done < nint) {
+                const int rem = nint - done;
+                int c = 0;
+                for (int k = rem; k >= 1 && !c; k--)
+                    if (good(k)) c = k;
+                // (the rest: at most two windows per launch where one window is a quarter of the device or more -- config 5: one / two / three windows
+                // in one launch 62 / 117 / 208 us -- otherwise all of it in one)
+                if (!c) c = ((long)(g.F / 64) * 4 * 4 >= h->ctx->num_cus && rem > 2) ? 2 : rem;
+                const int rc = xe_n_dev_launch(h, c, (const char *)in_dev + (size_t)done * h->in_bytes, (char *)out_dev + (size_t)done * out_bytes, accumulate, 0, st);
+                if (rc != MI355_OK) return rc;
+                done += c;
+            }
+            return MI355_OK;
+        }
+    }
+    return xe_n_dev_launch(h, nint, in_dev, out_dev, accumulate, stations_per_group, st);
 }
 
 extern "C" int mi355_xengine_xcorrelate_dev(mi355_xengine *h, const void *in_dev, void *out_dev, int accumulate, void *stream)

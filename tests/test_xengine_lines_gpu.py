@@ -173,6 +173,35 @@ def test_whole_line_kernel_early_touches(gpu, oracle, monkeypatch, F, T, nint, p
         assert np.array_equal(got[i], oracle.xengine_ichar(N, F, 1, T, x[i].cpu().numpy().reshape(-1), exact=True)), i
 
 
+@pytest.mark.parametrize("F,T,nint", [(1024, 64, 5), (1024, 64, 11), (512, 96, 13), (1024, 32, 3)])
+def test_window_counts_between_the_good_ones_are_split(gpu, oracle, monkeypatch, F, T, nint):
+    """mi355_xengine_xcorrelate_n_dev cuts a call whose window count the whole-line kernel does not take (5 = 4 + 1, 11 = 8 + 2 + 1, 13 = 8 + 5) into
+    stream-ordered launches: every window bit exact, and identical to the one-launch form (MI355_XE_NO_SPLIT=1)."""
+    import torch
+    N = 64
+    rng = np.random.default_rng(100 + nint)
+    wins = rng.integers(-128, 128, size=(nint, T, N, F, 1, 2), dtype=np.int64).astype(np.int8)
+    blk = _xe(gpu, N, F, T)
+    per = blk.get_output_buffer_size()
+    x = torch.from_numpy(wins).cuda()
+    out = torch.zeros(nint * per, 2, device="cuda")
+    _run(gpu, blk, nint, x, out)
+    got = out.cpu().numpy().view(np.complex64).reshape(nint, -1)
+    for i in range(nint):
+        assert np.array_equal(got[i], oracle.xengine_ichar(N, F, 1, T, wins[i].reshape(-1), exact=True)), i
+    monkeypatch.setenv("MI355_XE_NO_SPLIT", "1")
+    one = torch.zeros_like(out)
+    _run(gpu, blk, nint, x, one)
+    assert torch.equal(out, one)
+    # accumulate: the whole-line kernel does not take it, so the call is one launch of the 32-byte-slice kernel as before
+    monkeypatch.delenv("MI355_XE_NO_SPLIT")
+    blk.xcorrelate_n_device(nint, x, out, accumulate=True)
+    torch.cuda.synchronize()
+    got2 = out.cpu().numpy().view(np.complex64).reshape(nint, -1)
+    ref2 = oracle.xengine_ichar(N, F, 1, T, wins[0].reshape(-1), exact=True, acc=got[0].copy())
+    assert np.array_equal(got2[0], ref2)
+
+
 def test_whole_line_kernel_config5_batch(gpu, oracle):
     """BASELINE config 5 (64 x 1024 x 1024), eight windows per launch -- the default route, two units per workgroup: the first and the last window bit
     exact against the oracle, every window identical to the 32-byte-slice kernel's."""

@@ -19,7 +19,7 @@ for nint in nints:
     for rep in range(2):
         for v in vals:
             os.environ[var] = v
-            if var == "MI355_XE_NO_LINES" and v == "0": os.environ.pop(var)
+            if var in ("MI355_XE_NO_LINES", "MI355_XE_NO_SPLIT") and v == "0": os.environ.pop(var)
             for k in range(4): xe.xcorrelate_n_device(nint, xs[k % nbuf], out)
             torch.cuda.synchronize()
             n = max(20, int(0.08 / (nint * 40e-6)))
