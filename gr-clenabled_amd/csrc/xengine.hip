@@ -1529,7 +1529,9 @@ extern "C" int mi355_xengine_xcorrelate_n_dev(mi355_xengine *h, int nint, const 
         int top = 0;
         for (int c = nint; c >= 1 && !top; c--)
             if (good(c)) top = c;
-        if (top > 0 && !good(nint)) {
+        for (int c = nint + 1; c <= 64 && !top; c++)  // (fewer windows than the smallest good count: the rest rule below still applies -- 3 = 2 + 1)
+            if (good(c)) top = -1;
+        if (top != 0 && !good(nint)) {
             const size_t out_bytes = h->out_items * 8;
             int done = 0;
             while (done < nint) {

@@ -173,9 +173,9 @@ def test_whole_line_kernel_early_touches(gpu, oracle, monkeypatch, F, T, nint, p
         assert np.array_equal(got[i], oracle.xengine_ichar(N, F, 1, T, x[i].cpu().numpy().reshape(-1), exact=True)), i
 
 
-@pytest.mark.parametrize("F,T,nint", [(1024, 64, 5), (1024, 64, 11), (512, 96, 13), (1024, 32, 3)])
+@pytest.mark.parametrize("F,T,nint", [(1024, 64, 5), (1024, 64, 11), (512, 96, 13), (1024, 32, 3), (512, 64, 3)])
 def test_window_counts_between_the_good_ones_are_split(gpu, oracle, monkeypatch, F, T, nint):
-    """mi355_xengine_xcorrelate_n_dev cuts a call whose window count the whole-line kernel does not take (5 = 4 + 1, 11 = 8 + 2 + 1, 13 = 8 + 5) into
+    """mi355_xengine_xcorrelate_n_dev cuts a call whose window count the whole-line kernel does not take (5 = 4 + 1, 11 = 8 + 2 + 1, 13 = 8 + 5, 3 = 2 + 1 where a window is a quarter of the device) into
     stream-ordered launches: every window bit exact, and identical to the one-launch form (MI355_XE_NO_SPLIT=1)."""
     import torch
     N = 64
