@@ -618,6 +618,9 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank, out=None):
     fn_rot, bufs = rotate(mk, x8.numel(), lambda x: xe.xcorrelate_device(x, vis))
     r = rate(fn_rot, N * Fw * T, 2, xe_extra)
     r.pop("hbm_frac", None)
+    rt = xe.last_route()  # which kernel that was (mi355_xengine_last_route): the route depends on geometry, alignment and environment
+    r["kernel"] = rt["kernel"]
+    r["route"] = {k: rt[k] for k in ("workgroups", "tsplit", "in_launch_reduce", "touches")}
     r["inputs"] = "%d distinct windows in rotation (%.0f MB): every launch reads its input from HBM" % (len(bufs), len(bufs) * x8.numel() / 1e6)
     del bufs, fn_rot
     # the same call on ONE buffer over and over (what rounds 1-3 quoted): an input below 256 MiB stays in the Infinity Cache between launches
@@ -690,7 +693,8 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank, out=None):
             # (which kernel: mi355_xe_lines_ok -- 64 stations, whole-line rows, enough (window, line, pair group) units to fill the device in equal
             # shares of at most 64 per workgroup: the whole-line kernel of csrc/xengine_lines.hip; otherwise the 32-byte-slice kernel)
             units = nint * (Fw // 64) * 4
-            lines = lines_kernel(units)
+            lines = xe.last_route()["kernel"] == "k_xe_i8_lines"
+            assert lines == lines_kernel(units), (xe.last_route(), units)
             row["windows_per_launch_%d" % nint] = {"us_per_window": round(tw, 2), "MSamples_per_s": rb["MSamples_per_s"],
                                                   "hbm_frac_algorithmic": round(alg_bytes / (tw * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                                   "distinct_inputs_in_rotation": len(bufs),
@@ -865,6 +869,54 @@ def annotate_sharded_scaling(extras, world):
     return extras
 
 
+def baseline_summary(line):
+    """The five BASELINE.json configs in ONE compact object (< 2 KB), the LAST key of the line: whatever tail of the line a log keeps, these survive.
+    us = HIP-event time per launch; frac = algorithmic bytes / us / 8 TB/s; tx = HBM bytes moved (PMC, profiles/<tag>_baseline_configs.txt) /
+    algorithmic bytes; cpu = the oracle's restatement on ONE host core, MSamples/s."""
+    b = line.get("blocks") or {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "baseline_configs_pmc.json")) as fh:
+            pmc = json.load(fh)
+    except Exception:  # noqa: BLE001
+        pmc = {}
+
+    def tx(k):
+        return (pmc.get(k) or {}).get("traffic_ratio")
+
+    def row(key, **kw):
+        r = b.get(key)
+        return r if isinstance(r, dict) else None
+
+    out = {"keys": "us per launch (HIP events), frac of 8 TB/s on algorithmic bytes, tx = PMC bytes / algorithmic (%s), cpu = oracle 1 core MS/s"
+                   % pmc.get("source", "no pmc file")}
+    c1 = row("config1_clMathOp_testCPU_8192")
+    if c1:
+        out["1_clMathOp_cmul_8192_testCPU"] = {"cpu_us_per_call": c1.get("us_per_call"), "cpu": c1.get("MSamples_per_s")}
+    rf, cb = line.get("roofline") or {}, line.get("cpu_baseline") or {}
+    out["2_clFFT_4096_fwd_blackman_shift"] = {"kernel": "k_fft<4096>", "us": rf.get("kernel_us"), "frac": rf.get("frac"), "tx": tx("2"),
+                                             "cpu": cb.get("value")}
+    r = row("clFilter_fft_65taps")
+    if r:
+        h = row("clFilter_fft_65taps_32768_hostpath") or {}
+        out["3_clFilter_fft_65taps"] = {"kernel": "k_ols<%s>" % r.get("fft_size"), "us": r["us_per_launch"], "frac": r["hbm_frac"], "tx": tx("3"),
+                                        "cpu": r.get("cpu_1core_MSamples_per_s"), "host_32768_call_us": h.get("us_per_call_median")}
+    r = row("clPolyphaseChannelizer_64x32_stream")
+    if r:
+        s = row("clPolyphaseChannelizer_64x32_buf65536") or {}
+        out["4_clPolyphaseChannelizer_64x32"] = {"kernel": "k_pfbw<64,32>", "us": r["us_per_launch"], "frac": r["hbm_frac"], "tx": tx("4"),
+                                                 "cpu": r.get("cpu_1core_MSamples_per_s"), "buf65536_call_us": s.get("us_per_launch"),
+                                                 "per_gpu_MSps": r.get("per_gpu_MSamples_per_s")}
+    r = row("clXEngine_64ant_1024ch_1024t_ichar")
+    if r:
+        d = {"kernel": r.get("kernel"), "us": r["us_per_launch"], "frac": r.get("hbm_frac_algorithmic"), "frac_i8_5POPS": r.get("mfma_frac_i8_5POPS"),
+             "tx": tx("5"), "cpu": r.get("cpu_1core_MSamples_per_s")}
+        w8 = (row("clXEngine_64ant_1024ch_1024t_ichar_batched") or {}).get("windows_per_launch_8")
+        if w8:
+            d["x8_us_per_window"], d["x8_frac"], d["x8_kernel"], d["x8_tx"] = w8["us_per_window"], w8["hbm_frac_algorithmic"], w8["kernel"], tx("5b")
+        out["5_clXEngine_64x1024x1024_ichar"] = d
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -952,6 +1004,10 @@ def main():
         emitted.set()
         if note:
             line["watchdog"] = note
+        try:
+            line["baseline_configs"] = baseline_summary(line)  # the last key of the line
+        except Exception as exc:  # noqa: BLE001
+            line["baseline_configs"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         if rank == 0:
             print(json.dumps(line), flush=True)
 

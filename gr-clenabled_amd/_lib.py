@@ -110,6 +110,7 @@ def lib():
         "mi355_pack3d_dev": (i, [vp, vp, vp, sz, sz, sz, sz, sz, sz, sz, vp]),
         "mi355_xengine_gather": (i, [vp, i, i, pp, vp]),
         "mi355_xengine_selftest_scale": (i, [vp, C.POINTER(C.c_longlong)]),
+        "mi355_xengine_last_route": (i, [vp, vp]),
         "mi355_xengine_shard_create": (i, [i, C.POINTER(C.c_int), i, i, i, i, i, pp]),
         "mi355_xengine_shard_destroy": (i, [vp]),
         "mi355_xengine_shard_world": (i, [vp]),

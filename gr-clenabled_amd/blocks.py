@@ -443,6 +443,17 @@ class clXEngine(_Block):
                                        int(src_block_stride), int(dst_pitch), int(dst_block_stride), _torch_stream(self.device)),
               "mi355_pack3d_dev")
 
+    def last_route(self):
+        """Which kernels the last device-side call ran (mi355_xengine_last_route): a dict of mi355_xe_route's fields."""
+        class Route(C.Structure):
+            _fields_ = [("kernel", C.c_char * 64)] + [(k, C.c_int) for k in ("launches", "windows", "workgroups", "units_per_workgroup", "tsplit",
+                                                                           "in_launch_reduce", "touches", "pace")]
+        r = Route()
+        check(self._L.mi355_xengine_last_route(self._h, C.byref(r)), "mi355_xengine_last_route")
+        d = {k: int(getattr(r, k)) for k, _ in Route._fields_[1:]}
+        d["kernel"] = r.kernel.decode()
+        return d
+
     def selftest_scale(self):
         """Sums S in [-2^24, 2^24] whose single-precision IChar scale differs from (float)((double)S / 127 / 127): must be 0."""
         n = C.c_longlong(-1)

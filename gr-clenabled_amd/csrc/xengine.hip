@@ -1082,12 +1082,34 @@ struct mi355_xengine {
     hipStream_t ws_stream[3] = {nullptr, nullptr, nullptr};
     bool ws_used[3] = {false, false, false};
     hipEvent_t ws_event = nullptr;
+    mi355_xe_route route = {};      // kernels of the last device-side call (mi355_xengine_last_route)
+    char routes_seen[8][64] = {};   // routes already logged once
     int pad = 0;            // one zero channel appended on the device (odd channel count of 2-byte samples)
     size_t pad_bytes = 0;
     unsigned char *d_pad = nullptr;
 };
 
+thread_local mi355_xe_route mi355_xe_route_tls = {};
+void mi355_xe_route_set(const char *kernel, int windows, int workgroups, int units_per_workgroup, int tsplit, int in_launch_reduce, int touches, int pace)
+{
+    mi355_xe_route &r = mi355_xe_route_tls;
+    snprintf(r.kernel, sizeof(r.kernel), "%s", kernel);
+    r.launches += 1;
+    r.windows = windows; r.workgroups = workgroups; r.units_per_workgroup = units_per_workgroup; r.tsplit = tsplit;
+    r.in_launch_reduce = in_launch_reduce; r.touches = touches; r.pace = pace;
+}
+
 namespace {
+
+// the calling thread's route record starts a call at zero launches; at the end of the call it becomes the handle's (under dev_lock); a route the
+// handle has not taken before is logged once
+void xe_route_begin() { mi355_xe_route_tls = mi355_xe_route{}; }
+void xe_route_commit(mi355_xengine *h);
+struct XeRouteScope {  // (declared after the lock guard of an entry point: committed before the lock is released)
+    mi355_xengine *h;
+    explicit XeRouteScope(mi355_xengine *hh) : h(hh) { xe_route_begin(); }
+    ~XeRouteScope() { xe_route_commit(h); }
+};
 
 // rows of (t, station) with an odd number of 2-byte channels: copy into rows padded by one zero channel (4-byte units)
 __global__ __launch_bounds__(256) void k_xe_pad_rows(const unsigned short *__restrict__ in, unsigned short *__restrict__ out, size_t rows,
@@ -1201,6 +1223,7 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
             if (blocks > cap) blocks = cap;
             hipLaunchKernelGGL(k_xe_reduce, dim3((unsigned)blocks), dim3(256), 0, st, (const c32 *)tiles, (c32 *)out, real_items, out_items, tsplit, accumulate);
             MI355_HIP(hipGetLastError());
+            mi355_xe_route_set("k_xe_f32_fused+k_xe_reduce", 1, (int)grid.x, 1, tsplit, 0, 0, 0);
             return MI355_OK;
         }
         if (mfma) {
@@ -1226,12 +1249,14 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
             else CORR_F32(16, 4, 9);
 #undef CORR_F32
             MI355_HIP(hipGetLastError());
+            mi355_xe_route_set("k_xe_turn_f32+k_xe_corr_f32", 1, 0, 1, 1, 0, 0, 0);
             return MI355_OK;
         }
         const int nblk = (g.A + kCfBlk - 1) / kCfBlk;
         dim3 grid((g.Fout + 255) / 256, nblk * (nblk + 1) / 2);
         hipLaunchKernelGGL(k_xe_cf32, grid, dim3(256), 0, st, (const c32 *)in, (c32 *)out, g, nblk, accumulate);
         MI355_HIP(hipGetLastError());
+        mi355_xe_route_set("k_xe_cf32", 1, 0, 1, 1, 0, 0, 0);
         return MI355_OK;
     }
     // The integration can be processed in channel slabs that reuse one tile workspace.  Measured on
@@ -1318,14 +1343,19 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
             else if (g.NT == 8) CORR_SB(8);
             else CORR_SB(6);
 #undef CORR_SB
+            mi355_xe_route_set(fast_turn ? "k_xe_turn_lds+k_xe_corr_sb" : "k_xe_turn+k_xe_corr_sb", 1, (int)grid, sa.chan_per_wg, 1, 0, 0, 0);
         }
-        else if (lds_corr && g.NT == 2) CORR_LDS(2, 4, 1);        //  3 pairs
-        else if (lds_corr && g.NT == 4) CORR_LDS(4, 4, 3);   // 10 pairs
-        else if (lds_corr && g.NT == 6) CORR_LDS(6, 4, 6);   // 21 pairs
-        else if (lds_corr && g.NT == 8) CORR_LDS(8, 8, 5);   // 36 pairs: one workgroup per channel
-        else
+        else if (lds_corr && (g.NT == 2 || g.NT == 4 || g.NT == 6 || g.NT == 8)) {
+            if (g.NT == 2) CORR_LDS(2, 4, 1);        //  3 pairs
+            else if (g.NT == 4) CORR_LDS(4, 4, 3);   // 10 pairs
+            else if (g.NT == 6) CORR_LDS(6, 4, 6);   // 21 pairs
+            else CORR_LDS(8, 8, 5);                  // 36 pairs: one workgroup per channel
+            mi355_xe_route_set("k_xe_turn+k_xe_corr_lds", 1, 0, 1, 1, 0, 0, 0);
+        } else {
             hipLaunchKernelGGL(k_xe_corr, dim3(gs.Fs, (npairs + kPairsPerWG - 1) / kPairsPerWG), dim3(256), 0, st,
                                (const unsigned char *)tiles, (c32 *)out, gs, npairs, kd, accumulate);
+            mi355_xe_route_set("k_xe_turn+k_xe_corr", 1, 0, 1, 1, 0, 0, 0);
+        }
 #undef CORR_LDS
         MI355_HIP(hipGetLastError());
     }
@@ -1333,7 +1363,34 @@ int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipSt
     return MI355_OK;
 }
 
+void xe_route_commit(mi355_xengine *h)
+{
+    const mi355_xe_route &r = mi355_xe_route_tls;
+    if (r.launches == 0) return;  // (nothing was enqueued: the handle keeps what its last launch recorded)
+    h->route = r;
+    char key[64];
+    snprintf(key, sizeof(key), "%.40s/%d/%d/%d", r.kernel, r.windows, r.tsplit, r.units_per_workgroup);
+    for (auto &seen : h->routes_seen) {
+        if (!strcmp(seen, key)) return;
+        if (!seen[0]) {
+            snprintf(seen, sizeof(seen), "%s", key);
+            mi355_log(h->ctx, MI355_LOG_DEBUG, "clXEngine %d x %d x %d frames: %s, %d window(s) per launch, %d workgroups x %d unit(s), %d time range(s)%s, touches %d, pace %d",
+                      h->g.N, h->g.Fout, h->g.T, r.kernel, r.windows, r.workgroups, r.units_per_workgroup, r.tsplit,
+                      r.in_launch_reduce ? " combined in the launch" : "", r.touches, r.pace);
+            return;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int mi355_xengine_last_route(const mi355_xengine *h, mi355_xe_route *out)
+{
+    MI355_REQUIRE(h && out, "NULL argument");
+    std::lock_guard<std::mutex> dl(const_cast<mi355_xengine *>(h)->dev_lock);
+    *out = h->route;
+    return MI355_OK;
+}
 
 extern "C" int mi355_xengine_destroy(mi355_xengine *h)
 {
@@ -1449,7 +1506,10 @@ extern "C" int mi355_xengine_xcorrelate_grouped_dev(mi355_xengine *h, const void
     MI355_REQUIRE(h->data_type == MI355_DTYPE_BYTE && !h->pad, "group-major input: IChar with an even channel count only");
     MI355_HIP(hipSetDevice(h->ctx->device));
     std::lock_guard<std::mutex> dl(h->dev_lock);
-    return launch_xe(h, in_dev, out_dev, accumulate, mi355_pick_stream(h->ctx, stream), h->d_tiles, h->d_pad, stations_per_group);
+    xe_route_begin();
+    const int rc = launch_xe(h, in_dev, out_dev, accumulate, mi355_pick_stream(h->ctx, stream), h->d_tiles, h->d_pad, stations_per_group);
+    xe_route_commit(h);
+    return rc;
 }
 
 // nint windows in ONE launch where the geometry has such a kernel (the caller holds dev_lock)
@@ -1517,6 +1577,7 @@ extern "C" int mi355_xengine_xcorrelate_n_dev(mi355_xengine *h, int nint, const 
     MI355_HIP(hipSetDevice(h->ctx->device));
     hipStream_t st = mi355_pick_stream(h->ctx, stream);
     std::lock_guard<std::mutex> dl(h->dev_lock);
+    XeRouteScope route_scope(h);
     const XeGeo &g = h->g;
     const bool grouped = stations_per_group > 0 && stations_per_group < g.N;
     // Window counts between the good ones.  The whole-line kernel takes the counts whose units split into equal shares over (nearly) all CUs -- at
@@ -1560,7 +1621,10 @@ extern "C" int mi355_xengine_xcorrelate_dev(mi355_xengine *h, const void *in_dev
                   "device buffers must be 4-byte (int8 / packed input) or 8-byte (complex input, output) aligned");
     MI355_HIP(hipSetDevice(h->ctx->device));
     std::lock_guard<std::mutex> dl(h->dev_lock);
-    return launch_xe(h, in_dev, out_dev, accumulate, mi355_pick_stream(h->ctx, stream), h->d_tiles, h->d_pad);
+    xe_route_begin();
+    const int rc = launch_xe(h, in_dev, out_dev, accumulate, mi355_pick_stream(h->ctx, stream), h->d_tiles, h->d_pad);
+    xe_route_commit(h);
+    return rc;
 }
 
 namespace {
@@ -1618,7 +1682,10 @@ static int xe_submit_slot(mi355_xengine *h, const void *in_host /* nullptr: the 
         mi355_copy(sl.h_out, acc_host, outb);
         MI355_HIP(hipMemcpyAsync(sl.d_out, sl.h_out, outb, hipMemcpyHostToDevice, st));
     }
-    rc = launch_xe(h, sl.d_in, sl.d_out, acc_host != nullptr, st, sl.d_tiles, sl.d_pad);
+    {
+        XeRouteScope route_scope(h);  // (callers hold dev_lock)
+        rc = launch_xe(h, sl.d_in, sl.d_out, acc_host != nullptr, st, sl.d_tiles, sl.d_pad);
+    }
     if (rc) return rc;
     MI355_HIP(hipMemcpyAsync(sl.h_out, sl.d_out, outb, hipMemcpyDeviceToHost, st));
     MI355_HIP(hipEventRecord(sl.done, st));

@@ -4,6 +4,10 @@
 
 #include "common.h"
 
+// what the launch functions of this thread did last (mi355_xengine copies it into the handle under its lock: mi355_xengine_last_route)
+extern thread_local mi355_xe_route mi355_xe_route_tls;
+void mi355_xe_route_set(const char *kernel, int windows, int workgroups, int units_per_workgroup, int tsplit, int in_launch_reduce, int touches, int pace);
+
 struct XeFusedPlan {
     bool ok = false;     // geometry supported by the fused kernels
     int npol = 1, ntt = 0;
@@ -39,4 +43,10 @@ int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void 
 // Whole-line form (xengine_lines.hip): 64 stations, one polarisation, rows of whole 128-byte lines, enough (window, line, pair group) units to fill
 // the device without time ranges.  mi355_xe_fused_launch routes to it where mi355_xe_lines_ok says so (MI355_XE_NO_LINES=1: never).
 bool mi355_xe_lines_ok(int N, int F, int Fout, int npol, int T, int stations_per_group, int accumulate, int nint, int cus);
-int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int T, double kd, hipStream_t st, int stations_per_group, int nint, int cus);
+// Fewer units than compute units (one window of BASELINE config 5 -- the reference's xcorrelate(char*, XComplex*) shape, lib/clXEngine_impl.h:184-201): the
+// integration is cut into 2 or 4 time ranges (mi355_xe_lines_split, 0: not this geometry) whose partial sums the kernel's tail combines inside the launch
+// through `part` (inboxes of teams x 4 x tsplit x 64 KiB, then at flag_offset two banks of one 8-byte arrival word per team; both fit the workspace
+// mi355_xe_fused_plan sizes when its tsplit equals this one).  *epoch: the workspace's launch counter, advanced once the kernel is enqueued.
+int mi355_xe_lines_split(int N, int F, int Fout, int npol, int T, int stations_per_group, int accumulate, int nint, int cus);
+int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int T, double kd, hipStream_t st, int stations_per_group, int nint, int cus,
+                          int tsplit = 1, void *part = nullptr, size_t flag_offset = 0, unsigned *epoch = nullptr);

@@ -1302,6 +1302,12 @@ int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void 
     if (p.tsplit == 1 && p.npol == 1 && p.row_stride == F * 2 && ((size_t)in & 15) == 0 &&
         mi355_xe_lines_ok(N, F, Fout, p.npol, T, stations_per_group, accumulate, nint, p.cus))
         return mi355_xe_lines_launch(in, out, N, F, Fout, T, kd, st, stations_per_group, nint, p.cus);
+    // the same kernel with time ranges where the units alone do not fill the device (one or two windows of config 5): the tail combines the ranges
+    // inside the launch through the plan's workspace (same size rule: the plan's tsplit is this one's)
+    if (p.tsplit > 1 && p.npol == 1 && p.row_stride == F * 2 && ((size_t)in & 15) == 0 && epoch && part &&
+        mi355_xe_lines_split(N, F, Fout, p.npol, T, stations_per_group, accumulate, nint, p.cus) == p.tsplit &&
+        (size_t)(nint > 0 ? nint : 1) * (F / 64) * 4 * 4 * p.tsplit * 65536 <= p.flag_offset)
+        return mi355_xe_lines_launch(in, out, N, F, Fout, T, kd, st, stations_per_group, nint, p.cus, p.tsplit, part, p.flag_offset, epoch);
     FuArgs a;
     a.in = (const unsigned char *)in;
     a.part = (v4i *)part;
@@ -1396,6 +1402,8 @@ int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void 
         mi355_set_error("fused X-engine launch failed (MI355_XE_FAIL_LAUNCH)");
         return MI355_ERR_HIP;
     }
+    mi355_xe_route_set(a.rs || p.tsplit == 1 ? "k_xe_i8_fused" : "k_xe_i8_fused+k_xe_i8_reduce", a.nint_launch, p.units * p.tsplit * a.nint_launch / a.items, a.items,
+                       p.tsplit, a.rs, a.pf_dist, 0);
     int rc;
     if (getenv("MI355_XE_TS")) rc = launch_with_stamps(p, a, st);
     else rc = p.npol == 1 ? launch_by_tiles<1>(p, a, st) : launch_by_tiles<2>(p, a, st);

@@ -79,6 +79,13 @@ struct LnArgs {
     int pf_dist, pf_lg, pf_per, pf_items;  // 0: off; log2(slow lines per row); (row, slow line) items per K block and toucher; items per K block
     unsigned pf_mask, pf_lines;            // bit l: line l of a row is slow; the slow lines' numbers, one byte each
     int pub_local;  // progress words by plain stores, kept in the XCD's L2 (0: agent-scope stores, MI355_XE_LINES_PUB=0)
+    // time ranges (k_xe_i8_lines<true>): a (window, line, pair group) TEAM of tsplit workgroups, one per time range, whose exact int32 partial matrices are
+    // combined inside the launch (ln_tail).  part: the teams' inboxes; flags: two banks of flag_bank 8-byte arrival words, one per team:
+    // {arrival count (high 32 bits) | launch tag << 4 | give-up bits (low)}; launch e counts in bank e % 2 and clears the other bank's word
+    int tsplit;
+    unsigned char *part;
+    unsigned long long *flags;
+    unsigned epoch, flag_bank, wait_ticks;
     unsigned long long *ts;
 };
 
@@ -124,6 +131,36 @@ __device__ __forceinline__ void ln_dma16(const void *gsrc, unsigned lds_dst)
 }
 
 
+// partial-sum traffic between the workgroups of a team (time ranges): the hand-off recipe of cdna_hip_programming.md (Guideline 16): write-through (sc1)
+// 16-byte stores, every storing wave drains them, one lane raises the team's count; the consumer polls that word relaxed and reads the pieces with
+// sc1 loads.  (s_nop: a store of more than 8 bytes reads its data a cycle or two after it issues and the hazard pass does not look inside an asm.)
+__device__ __forceinline__ void ln_st_sys(unsigned char *p, v4i v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(p), "v"(v) : "memory");
+}
+// loads AND their wait in one statement (an asm's outputs may be moved or spilled right behind it -- for a bare load, before the data is there)
+__device__ __forceinline__ void ln_ld4(const unsigned char *p, v4i (&x)[4])
+{
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:1024 sc1\n\tglobal_load_dwordx4 %2, %4, off offset:2048 sc1\n\t"
+                 "global_load_dwordx4 %3, %4, off offset:3072 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3])
+                 : "v"(p)
+                 : "memory");
+}
+__device__ __forceinline__ void ln_ld12(const unsigned char *p0, const unsigned char *p1, const unsigned char *p2, v4i (&x)[3][4])
+{
+    asm volatile("global_load_dwordx4 %0, %12, off sc1\n\tglobal_load_dwordx4 %1, %12, off offset:1024 sc1\n\tglobal_load_dwordx4 %2, %12, off offset:2048 sc1\n\t"
+                 "global_load_dwordx4 %3, %12, off offset:3072 sc1\n\t"
+                 "global_load_dwordx4 %4, %13, off sc1\n\tglobal_load_dwordx4 %5, %13, off offset:1024 sc1\n\tglobal_load_dwordx4 %6, %13, off offset:2048 sc1\n\t"
+                 "global_load_dwordx4 %7, %13, off offset:3072 sc1\n\t"
+                 "global_load_dwordx4 %8, %14, off sc1\n\tglobal_load_dwordx4 %9, %14, off offset:1024 sc1\n\tglobal_load_dwordx4 %10, %14, off offset:2048 sc1\n\t"
+                 "global_load_dwordx4 %11, %14, off offset:3072 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(x[0][0]), "=&v"(x[0][1]), "=&v"(x[0][2]), "=&v"(x[0][3]), "=&v"(x[1][0]), "=&v"(x[1][1]), "=&v"(x[1][2]), "=&v"(x[1][3]), "=&v"(x[2][0]),
+                   "=&v"(x[2][1]), "=&v"(x[2][2]), "=&v"(x[2][3])
+                 : "v"(p0), "v"(p1), "v"(p2)
+                 : "memory");
+}
+
 // ---- The accumulators are 128 accumulation registers BY NAME: accumulator (k, ch) = a[(8 k + ch) * 4 .. + 3], k = 0 .. 3, ch = 0 .. 7.  The compiler never sees
 // them as values -- given tied "+a" operands that fill the AGPR file it time-shares AGPRs between accumulators (v_accvgpr_read of a register a product issued one
 // instruction earlier has not written yet: the hazards of an inline-assembly v_mfma are invisible to it) and given its own v_mfma it needs spare
@@ -162,7 +199,7 @@ template <int R> __device__ __forceinline__ v4i ln_acc_read4()
 }
 constexpr int ln_areg(int k, int ch) { return (8 * k + ch) * 4; }
 
-struct LnUnit { int col, grp, win; };
+struct LnUnit { int col, grp, win, q; };
 
 // The four workgroups of a (line, window) re-read each other's lines from the XCD's L2 only while they walk the same frames: the K block a
 // workgroup has reached, {launch tag << 12 | K blocks done}, for its three partners to see (pinned map, every workgroup resident);
@@ -183,6 +220,11 @@ __device__ __forceinline__ LnUnit ln_map_unit(const LnArgs &a, int n)
     }
     u.col = combo % a.ncols;
     u.win = combo / a.ncols;
+    u.q = 0;
+    if (a.tsplit > 1) {  // (line, time range, window): the four pair groups of a line AND time range are neighbours on one XCD (they read the same rows);
+        u.q = u.win % a.tsplit;  // with 8 | ncols the ranges of a team land on one XCD as well (speed only: the exchange is placement independent)
+        u.win /= a.tsplit;
+    }
     // a workgroup's k-th unit is rot * k lines further on than its first: the units of the slow lines (address bits 7..9 == 3: 1.25 x the time from HBM)
     // go to twice as many workgroups, one each, instead of two each to the same ones (the host sets rot only where every k covers whole windows)
     if (a.rot) u.col = (u.col + a.rot * (n / a.grid)) % a.ncols;
@@ -190,7 +232,7 @@ __device__ __forceinline__ LnUnit ln_map_unit(const LnArgs &a, int n)
 }
 
 // DIAG: groups A / B (row tiles x < y; pairs xx, yx, yy); otherwise C / D (row tile ra against row tiles 0 and 1)
-template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, unsigned char *lds, const int grp)
+template <bool DIAG, bool SPLIT> __device__ __forceinline__ void ln_body(const LnArgs &a, unsigned char *lds, const int grp)
 {
     constexpr int NRT = DIAG ? 2 : 3, NS = 2 * NRT;
     const unsigned lds0 = (unsigned)(size_t)lds;
@@ -212,6 +254,7 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
     auto setup_issue = [&](int n) {
         const LnUnit u = ln_map_unit(a, n);
         const unsigned char *in_w = a.in + (size_t)u.win * a.in_window + (size_t)u.col * 128;
+        if constexpr (SPLIT) in_w += (size_t)u.q * (size_t)(32 * a.steps) * t_stride;  // this workgroup's time range
         auto half_base = [&](int rt) {
             const int st = 16 * rt + 4 * (wave & 3);
             return in_w + (size_t)(st / a.ng) * a.in_group + (size_t)(st % a.ng) * row_bytes;
@@ -223,6 +266,7 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
             pf_on = a.pf_dist > 0 && !((a.pf_mask >> u.col) & 1u);
             pf_first = (__builtin_popcount(~a.pf_mask & ((1u << u.col) - 1u)) * 2 + grp) * a.pf_per;  // this workgroup among the touchers of its window
             pf_win = a.in + (size_t)u.win * a.in_window;
+            if constexpr (SPLIT) pf_win += (size_t)u.q * (size_t)(32 * a.steps) * t_stride;  // (touches stay inside the own time range; ng == 64 there)
         }
     };
     const int total_sub = a.items * a.steps * NS;  // sub-stages of this workgroup's stream
@@ -579,32 +623,187 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
             if (a.dbg & 2) { if (vre[0] == 0x12345678 && vim[1] == 0x7654321) out_w[lane].x = 1.0f; return; }
             store_rows(vre, vim, f, bi, bi, a.k127 && ln_all_small(mag));
         };
-        ln_sfor<0, kLnCh>([&](auto chc) {
-            constexpr int ch = decltype(chc)::value;
-            const int f = un.col * 64 + wave * kLnCh + ch;
-            if (f < a.Fout) {
-                if constexpr (DIAG) {
-                    emit_diag(ln_acc_read4<ln_areg(0, ch)>(), f, rt0);
-                    emit_off(ln_acc_read4<ln_areg(2, ch)>(), ln_acc_read4<ln_areg(3, ch)>(), f, rt1, rt0);
-                    emit_diag(ln_acc_read4<ln_areg(1, ch)>(), f, rt1);
+        if constexpr (SPLIT) {
+            // ---- Time ranges: the tsplit workgroups of a team hold exact partial sums of the same 32 tiles per wave.  A wave's tiles form four PIECES
+            // of eight (diagonal groups: xx | yy | re, im of yx for channels 0-3 | 4-7; off-diagonal groups: re, im of (a, 0) for channels 0-3 | 4-7, of
+            // (a, 1) for 0-3 | 4-7; the row sums are added to im' first, so every piece is a plain sum over the ranges); piece p belongs to range
+            // p * tsplit / 4.  Every workgroup sends the pieces of the other ranges lane for lane (one 1 KiB store per tile and wave) to the owners'
+            // inboxes, drains, raises the team's arrival count and, once all have arrived, adds what it received to its own pieces, scales and
+            // scatters them: every workgroup emits 1 / tsplit of the team's matrix.  Placement independent (sc1 stores, sc1 loads, count raised after
+            // the stores have completed); bounded wait: a workgroup that gives up stores its own pieces too, sets its bit and leaves, the LAST
+            // to arrive sees the bits with its own arrival and finishes those pieces -- complete for any dispatch order (as in k_xe_i8_fused).
+            const int S = a.tsplit, QC = un.q;
+            const int team = (un.win * a.ncols + un.col) * 4 + grp;
+            unsigned char *const box = a.part + (size_t)team * ((size_t)4 * S * 65536) + (size_t)wave * 8192 + (size_t)lane * 16;
+            auto slot = [&](int p, int src) { return box + (size_t)(p * S + src) * 65536; };
+            const int f0 = un.col * 64 + wave * kLnCh;
+            // half H (tiles 4 H .. 4 H + 3) of piece P out of the accumulators
+            auto get_half = [&](auto pc, auto hc, v4i (&v)[4]) {
+                constexpr int P = decltype(pc)::value, H = decltype(hc)::value;
+                if constexpr (DIAG && P < 2) {
+                    ln_sfor<0, 4>([&](auto jc) { v[decltype(jc)::value] = ln_acc_read4<ln_areg(P, 4 * H + decltype(jc)::value)>(); });
                 } else {
-                    // row i = 4 g + reg of the tile pair: the sum over the four frame groups of station i's I bytes
-                    int v = rs_lds[ch * 64];
-                    v += __shfl_xor(v, 16);
-                    v += __shfl_xor(v, 32);
-                    v4i im0 = ln_acc_read4<ln_areg(1, ch)>(), im1 = ln_acc_read4<ln_areg(3, ch)>();
+                    ln_sfor<0, 2>([&](auto cc) {
+                        constexpr int c = decltype(cc)::value;
+                        constexpr int ch = DIAG ? 4 * (P - 2) + 2 * H + c : 4 * (P & 1) + 2 * H + c, k0 = DIAG ? 2 : 2 * (P >> 1);
+                        v[2 * c] = ln_acc_read4<ln_areg(k0, ch)>();
+                        v[2 * c + 1] = ln_acc_read4<ln_areg(k0 + 1, ch)>();
+                        if constexpr (!DIAG) {  // im = im' + sum_t I_a(t): this range's share of the row sums
+                            int rsv = rs_lds[ch * 64];
+                            rsv += __shfl_xor(rsv, 16);
+                            rsv += __shfl_xor(rsv, 32);
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const int c = __shfl(v, 4 * gg + k);
-                        im0[k] += c;
-                        im1[k] += c;
+                            for (int k = 0; k < 4; k++) v[2 * c + 1][k] += __shfl(rsv, 4 * gg + k);
+                        }
+                    });
+                }
+            };
+            auto emit_half = [&](int p, int H, const v4i (&v)[4]) {
+                if (DIAG && p < 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) emit_diag(v[j], f0 + 4 * H + j, p == 0 ? rt0 : rt1);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        if constexpr (DIAG) emit_off(v[2 * c], v[2 * c + 1], f0 + 4 * (p - 2) + 2 * H + c, rt1, rt0);
+                        else emit_off(v[2 * c], v[2 * c + 1], f0 + 4 * (p & 1) + 2 * H + c, rt0, p >> 1);
                     }
-                    emit_off(ln_acc_read4<ln_areg(0, ch)>(), im0, f, rt0, 0);
-                    emit_off(ln_acc_read4<ln_areg(2, ch)>(), im1, f, rt0, 1);
+                }
+            };
+            auto send_piece = [&](auto pc) {  // this range's share of piece P -> slot (P, QC)
+                unsigned char *d = slot(decltype(pc)::value, QC);
+                ln_sfor<0, 2>([&](auto hc) {
+                    v4i v[4];
+                    get_half(pc, hc, v);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) ln_st_sys(d + (4 * decltype(hc)::value + j) * 1024, v[j]);
+                });
+            };
+            if (a.ts && tid == 0) a.ts[(size_t)blockIdx.x * 8 + 5] = wall_clock64();  // loop end
+            ln_sfor<0, 4>([&](auto pc) {
+                if (decltype(pc)::value * S / 4 != QC) send_piece(pc);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            unsigned long long *state = a.flags + (size_t)(a.epoch & 1u) * a.flag_bank + (size_t)team;
+            const unsigned full = (unsigned)S, tag = a.epoch & 0x0fffffffu;
+            int *const s_mode = (int *)(lds + kLnPoll), *const s_mask = s_mode + 1;  // (the pacing words' place: there is no pacing in this form)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have completed
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned long long old = __hip_atomic_fetch_add(state, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int mode = 0, mask = 0;
+                if ((unsigned)(old >> 32) + 1u == full) {  // the last to arrive: the give-up bits are final (they can only be set while the count is short)
+                    mode = 2;
+                    if (((unsigned)old >> 4) == tag) mask = (int)((unsigned)old & 15u);
+                } else {
+                    // bounded by time (100 MHz wall clock; about one loop of this geometry -- LnArgs::wait_ticks); dbg 512: give up at once (tests)
+                    const unsigned long long t_w = wall_clock64(), limit = (a.dbg & 512) ? 0 : (unsigned long long)a.wait_ticks;
+                    do {
+                        const unsigned long long cur = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((unsigned)(cur >> 32) == full) mode = 1;
+                        else __builtin_amdgcn_s_sleep(8);
+                    } while (!mode && wall_clock64() - t_w < limit);
+                    if (!mode) mode = 3;
+                }
+                *s_mode = mode;
+                *s_mask = mask;
+            }
+            __syncthreads();
+            if (*s_mode == 3) {  // waited long enough: hand the own pieces over as well, then say so -- unless everybody has arrived meanwhile
+                ln_sfor<0, 4>([&](auto pc) {
+                    if (decltype(pc)::value * S / 4 == QC) send_piece(pc);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    int mode = -1;
+                    while (mode < 0) {
+                        unsigned long long cur = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((unsigned)(cur >> 32) == full) { mode = 1; break; }
+                        const unsigned bits = (((unsigned)cur >> 4) == tag ? ((unsigned)cur & 15u) : 0u) | (1u << QC);
+                        const unsigned long long want = (cur & 0xffffffff00000000ull) | (unsigned long long)((tag << 4) | bits);
+                        if (__hip_atomic_compare_exchange_strong(state, &cur, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) mode = 0;
+                    }
+                    *s_mode = mode;
+                }
+                __syncthreads();
+                if (*s_mode == 0) {
+                    if (a.ts && tid == 0) a.ts[(size_t)blockIdx.x * 8 + 7] = wall_clock64();
+                    continue;  // (items == 1 in this form: the workgroup is done)
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);  // (one channel's values at a time)
-        });
+            if (a.ts && tid == 0) a.ts[(size_t)blockIdx.x * 8 + 7] = wall_clock64();  // all ranges in
+            // this range's pieces: own share out of the accumulators + the other ranges' from the inbox, half a piece (four tiles) at a time
+            ln_sfor<0, 4>([&](auto pc) {
+                constexpr int P = decltype(pc)::value;
+                if (P * S / 4 == QC) {
+                    ln_sfor<0, 2>([&](auto hc) {
+                        constexpr int H = decltype(hc)::value;
+                        v4i v[4];
+                        if (S == 4) {
+                            v4i x[3][4];
+                            ln_ld12(slot(P, (QC + 1) & 3) + H * 4096, slot(P, (QC + 2) & 3) + H * 4096, slot(P, (QC + 3) & 3) + H * 4096, x);
+                            get_half(pc, hc, v);
+#pragma unroll
+                            for (int j = 0; j < 4; j++) v[j] += x[0][j] + x[1][j] + x[2][j];
+                        } else {
+                            v4i x[4];
+                            ln_ld4(slot(P, QC ^ 1) + H * 4096, x);
+                            get_half(pc, hc, v);
+#pragma unroll
+                            for (int j = 0; j < 4; j++) v[j] += x[j];
+                        }
+                        emit_half(P, H, v);
+                    });
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            // (last arriver only, and only after a bounded wait ran out somewhere) the pieces of the ranges that gave up: every share from the inbox
+            const int todo = *s_mode == 2 ? (*s_mask & ~(1 << QC)) : 0;
+            if (todo) {
+                for (int p = 0; p < 4; p++) {
+                    if (!((todo >> (p * S / 4)) & 1)) continue;
+                    for (int H = 0; H < 2; H++) {
+                        v4i v[4] = {(v4i){0, 0, 0, 0}, (v4i){0, 0, 0, 0}, (v4i){0, 0, 0, 0}, (v4i){0, 0, 0, 0}};
+                        for (int src = 0; src < S; src++) {
+                            v4i x[4];
+                            ln_ld4(slot(p, src) + H * 4096, x);
+#pragma unroll
+                            for (int j = 0; j < 4; j++) v[j] += x[j];
+                        }
+                        emit_half(p, H, v);
+                    }
+                }
+            }
+        } else {
+            ln_sfor<0, kLnCh>([&](auto chc) {
+                constexpr int ch = decltype(chc)::value;
+                const int f = un.col * 64 + wave * kLnCh + ch;
+                if (f < a.Fout) {
+                    if constexpr (DIAG) {
+                        emit_diag(ln_acc_read4<ln_areg(0, ch)>(), f, rt0);
+                        emit_off(ln_acc_read4<ln_areg(2, ch)>(), ln_acc_read4<ln_areg(3, ch)>(), f, rt1, rt0);
+                        emit_diag(ln_acc_read4<ln_areg(1, ch)>(), f, rt1);
+                    } else {
+                        // row i = 4 g + reg of the tile pair: the sum over the four frame groups of station i's I bytes
+                        int v = rs_lds[ch * 64];
+                        v += __shfl_xor(v, 16);
+                        v += __shfl_xor(v, 32);
+                        v4i im0 = ln_acc_read4<ln_areg(1, ch)>(), im1 = ln_acc_read4<ln_areg(3, ch)>();
+    #pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int c = __shfl(v, 4 * gg + k);
+                            im0[k] += c;
+                            im1[k] += c;
+                        }
+                        emit_off(ln_acc_read4<ln_areg(0, ch)>(), im0, f, rt0, 0);
+                        emit_off(ln_acc_read4<ln_areg(2, ch)>(), im1, f, rt0, 1);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);  // (one channel's values at a time)
+            });
+        }
     }
     if (a.ts && tid == 0) {
         a.ts[(size_t)blockIdx.x * 8 + 2] = t_wait;
@@ -614,14 +813,23 @@ template <bool DIAG> __device__ __forceinline__ void ln_body(const LnArgs &a, un
     }
 }
 
-__global__ __launch_bounds__(kLnThreads) void k_xe_i8_lines(LnArgs a)
+// SPLIT: time ranges, combined inside the launch (its own kernel: with both endings in one kernel the loop's register allocation suffers)
+template <bool SPLIT> __global__ __launch_bounds__(kLnThreads) void k_xe_i8_lines(LnArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     if (a.ts && threadIdx.x == 0) a.ts[(size_t)blockIdx.x * 8] = wall_clock64();
     // (a workgroup's units are all of one group: the host makes the grid a multiple of 32 -- pinned map -- or of 4)
-    const int grp = ln_map_unit(a, blockIdx.x).grp;
-    if (grp < 2) ln_body<true>(a, lds, grp);
-    else ln_body<false>(a, lds, grp);
+    const LnUnit u0 = ln_map_unit(a, blockIdx.x);
+    const int grp = u0.grp;
+    if constexpr (SPLIT) {
+        // the arrival words come in two banks: launch e counts in bank e % 2 from zero and first clears the OTHER bank's word of its team, so whatever
+        // an unfinished launch left there is gone before launch e + 1 -- stream-ordered behind this one -- looks at it
+        if (threadIdx.x == 0 && u0.q == 0)
+            __hip_atomic_store(a.flags + (size_t)((a.epoch + 1u) & 1u) * a.flag_bank + (size_t)((u0.win * a.ncols + u0.col) * 4 + grp), 0ull, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (grp < 2) ln_body<true, SPLIT>(a, lds, grp);
+    else ln_body<false, SPLIT>(a, lds, grp);
     if (a.ts && threadIdx.x == 0) a.ts[(size_t)blockIdx.x * 8 + 1] = wall_clock64();
 }
 
@@ -648,9 +856,35 @@ bool mi355_xe_lines_ok(int N, int F, int Fout, int npol, int T, int stations_per
     return false;                                                                                     //  on at least 7/8 of the CUs, or the other kernel is faster)
 }
 
-int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int T, double kd, hipStream_t st, int stations_per_group, int nint, int cus)
+// Time ranges (k_xe_i8_lines<true>): the geometry of mi355_xe_lines_ok with FEWER units than compute units -- one window of BASELINE config 5 is 64
+// (line, pair group) teams on 256 CUs, the shape of the reference's own one-integration-per-call operator (lib/clXEngine_impl.h:184-201).  Returns the
+// number of time ranges (2 or 4: the tail's pieces are quarters of a wave's tiles) or 0.  teams x ranges must fill at least 7/8 of the device and
+// never exceed it (every workgroup of a team has to be resident for the in-launch exchange to be the fast path; it is correct either way).
+int mi355_xe_lines_split(int N, int F, int Fout, int npol, int T, int stations_per_group, int accumulate, int nint, int cus)
+{
+    if (getenv("MI355_XE_NO_LINES") || getenv("MI355_XE_NO_LINES_SPLIT")) return 0;
+    const int ng = (stations_per_group > 0 && stations_per_group < N) ? stations_per_group : N;
+    if (npol != 1 || N != 64 || F % 64 != 0 || Fout != F || T % 32 != 0 || T > 16384 || accumulate || ng % 8 != 0) return 0;
+    const long teams = (long)(nint > 0 ? nint : 1) * (F / 64) * 4;
+    if (getenv("MI355_XE_LINES_SPLIT_ANY")) {  // test switch: the range count MI355_XE_TSPLIT forces on the plan, whatever the unit count
+        const int S = getenv("MI355_XE_TSPLIT") ? atoi(getenv("MI355_XE_TSPLIT")) : 0;
+        return ((S == 2 || S == 4) && T % (32 * S) == 0) ? S : 0;
+    }
+    for (int S = 2; S <= 4; S *= 2)
+        if (teams * S <= cus && teams * S * 8 >= (long)cus * 7 && (teams * S) % 32 == 0 && T % (32 * S) == 0 && T / (32 * S) >= 2) return S;
+    return 0;
+}
+
+int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int T, double kd, hipStream_t st, int stations_per_group, int nint, int cus,
+                          int tsplit, void *part, size_t flag_offset, unsigned *epoch)
 {
     LnArgs a;
+    a.tsplit = tsplit > 1 ? tsplit : 1;
+    a.part = (unsigned char *)part;
+    a.flags = (unsigned long long *)((unsigned char *)part + flag_offset);
+    a.epoch = (tsplit > 1 && epoch) ? *epoch + 1u : 1u;  // (committed only once the kernel is enqueued)
+    a.flag_bank = 0;
+    a.wait_ticks = 0;
     a.in = (const unsigned char *)in;
     a.out = (c32 *)out;
     a.Fout = Fout;
@@ -659,8 +893,14 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
     a.row_stride = F * 2;
     a.ng = (stations_per_group > 0 && stations_per_group < N) ? stations_per_group : N;
     const int nw = nint > 0 ? nint : 1;
-    a.units = nw * a.ncols * 4;
-    a.steps = T / 32;
+    a.units = nw * a.ncols * 4 * a.tsplit;
+    a.steps = T / (32 * a.tsplit);
+    a.flag_bank = (unsigned)(nw * a.ncols * 4);
+    {
+        const int us = 10 + 6 * a.steps;  // about one loop of this geometry (see k_xe_i8_fused's tail)
+        a.wait_ticks = (unsigned)(us < 20 ? 20 : us > 100 ? 100 : us) * 100u;
+        if (const char *e = getenv("MI355_XE_WAIT_US")) a.wait_ticks = (unsigned)atoi(e) * 100u;
+    }
     // reference layout: [window][t][station]; group-major: [group][window][t][station in group]
     a.in_window = (size_t)T * a.ng * a.row_stride;
     a.in_group = (size_t)nw * T * a.ng * a.row_stride;
@@ -677,6 +917,7 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
     int items = (a.units + cus - 1) / cus;
     while (items < a.units && (a.units % items != 0 || (a.units / items) % quantum != 0)) items++;
     if (a.units % items != 0 || (a.units / items) % quantum != 0) items = a.units / quantum;  // (one workgroup quantum: always divides)
+    if (a.tsplit > 1) items = 1;  // (time ranges: one unit per workgroup, every workgroup of a team resident where the device is free)
     a.items = items;
     a.pub_local = (getenv("MI355_XE_LINES_PUB") && atoi(getenv("MI355_XE_LINES_PUB")) == 0) ? 0 : 1;
     // early touches (MI355_XE_LINES_PF: distance in K blocks, default 4 -- 2 ... 8 within 1 %, 12 slower --, 0: off): rows of 8, 16 or 32 whole lines in the reference layout
@@ -707,6 +948,7 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
     {
         const int pace = getenv("MI355_XE_LINES_PACE") ? atoi(getenv("MI355_XE_LINES_PACE")) : (a.pf_dist > 0 ? 0 : 2);
         a.pace = (a.pinned && a.units / a.items <= cus && a.units / a.items <= 8192 && (long)a.items * a.steps < 2048 && !(a.dbg & 8)) ? pace : 0;
+        if (a.tsplit > 1) a.pace = 0;  // (the tail keeps its two words where the partners' progress words land)
     }
     static std::atomic<unsigned long long> attr_devs{0};  // (per device: a function's attributes belong to the device that is current when they are set)
     {
@@ -714,20 +956,24 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
         MI355_HIP(hipGetDevice(&dev));
         const unsigned long long bit = 1ull << (dev & 63);
         if (!(attr_devs.load(std::memory_order_relaxed) & bit)) {
-            MI355_HIP(hipFuncSetAttribute((const void *)k_xe_i8_lines, hipFuncAttributeMaxDynamicSharedMemorySize, kLnLds));
+            MI355_HIP(hipFuncSetAttribute((const void *)k_xe_i8_lines<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLnLds));
+            MI355_HIP(hipFuncSetAttribute((const void *)k_xe_i8_lines<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLnLds));
             attr_devs.fetch_or(bit, std::memory_order_relaxed);
         }
     }
     const unsigned grid = (unsigned)(a.units / a.items);
     a.grid = (int)grid;
     a.rot = (a.pinned && a.items > 1 && (grid / 4) % (unsigned)a.ncols == 0) ? (getenv("MI355_XE_LINES_ROT") ? atoi(getenv("MI355_XE_LINES_ROT")) : 1) : 0;
+    mi355_xe_route_set(a.tsplit > 1 ? "k_xe_i8_lines<split>" : "k_xe_i8_lines", nw, (int)grid, a.items, a.tsplit, a.tsplit > 1 ? 1 : 0, a.pf_dist, a.pace);
     if (getenv("MI355_XE_TS")) {  // tuning aid: one synchronous launch with start / end stamps per workgroup
         unsigned long long *d_ts = nullptr;
         MI355_HIP(hipMalloc(&d_ts, (size_t)grid * 64));
         MI355_HIP(hipMemsetAsync(d_ts, 0, (size_t)grid * 64, st));
         a.ts = d_ts;
-        hipLaunchKernelGGL(k_xe_i8_lines, dim3(grid), dim3(kLnThreads), kLnLds, st, a);
+        if (a.tsplit > 1) hipLaunchKernelGGL(k_xe_i8_lines<true>, dim3(grid), dim3(kLnThreads), kLnLds, st, a);
+        else hipLaunchKernelGGL(k_xe_i8_lines<false>, dim3(grid), dim3(kLnThreads), kLnLds, st, a);
         MI355_HIP(hipGetLastError());
+        if (a.tsplit > 1 && epoch) *epoch = a.epoch;
         MI355_HIP(hipStreamSynchronize(st));
         std::vector<unsigned long long> h((size_t)grid * 8);
         MI355_HIP(hipMemcpy(h.data(), d_ts, (size_t)grid * 64, hipMemcpyDeviceToHost));
@@ -762,7 +1008,9 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
         }
         return MI355_OK;
     }
-    hipLaunchKernelGGL(k_xe_i8_lines, dim3(grid), dim3(kLnThreads), kLnLds, st, a);
+    if (a.tsplit > 1) hipLaunchKernelGGL(k_xe_i8_lines<true>, dim3(grid), dim3(kLnThreads), kLnLds, st, a);
+    else hipLaunchKernelGGL(k_xe_i8_lines<false>, dim3(grid), dim3(kLnThreads), kLnLds, st, a);
     MI355_HIP(hipGetLastError());
+    if (a.tsplit > 1 && epoch) *epoch = a.epoch;
     return MI355_OK;
 }

@@ -256,6 +256,21 @@ int mi355_xengine_xcorrelate_grouped_dev(mi355_xengine *h, const void *in_dev, v
  * Other sample formats / geometries run the windows one after the other (group-major input of several windows: UNSUPPORTED). */
 int mi355_xengine_xcorrelate_n_dev(mi355_xengine *h, int nint, const void *in_dev, void *out_dev, int accumulate,
                                    int stations_per_group, void *stream);
+/* Which kernels the handle's LAST device-side call ran (no counterpart in the reference, whose one kernel per data type is fixed at construction,
+ * lib/clXEngine_impl.cc:605-916): the routes differ 2 x in speed and depend on geometry, alignment, window count and environment switches, so a
+ * caller (and the tests) can assert the one it expects.  The first use of a route on a handle is also logged at MI355_LOG_DEBUG. */
+typedef struct mi355_xe_route {
+    char kernel[64];          /* e.g. "k_xe_i8_lines", "k_xe_i8_lines<split>", "k_xe_i8_fused", "k_xe_i8_fused+k_xe_i8_reduce", "k_xe_turn_lds+k_xe_corr_sb" */
+    int launches;             /* launches the last call was cut into (mi355_xengine_xcorrelate_n_dev splits window counts between the good ones) */
+    int windows;              /* integration windows of the last launch */
+    int workgroups;           /* of the last launch (0: not recorded for this route) */
+    int units_per_workgroup;  /* persistent forms: units a workgroup runs one after the other */
+    int tsplit;               /* time ranges per window (1: none) */
+    int in_launch_reduce;     /* the time ranges are combined by the kernel's own tail (0: by a second kernel, or no ranges) */
+    int touches;              /* early touches of the slow lines: distance in K blocks (0: off) */
+    int pace;                 /* pacing of a line's workgroups, half K blocks (0: off) */
+} mi355_xe_route;
+int mi355_xengine_last_route(const mi355_xengine *h, mi355_xe_route *out);
 /* Double-buffered asynchronous form of the host path: replaces the reference's pinned double
  * buffers + worker thread (lib/clXEngine_impl.cc:304-382 start(), :1234-1299 runThread()).
  * submit() copies the integration window into a pinned slot and enqueues H2D + kernels + D2H on that

@@ -213,10 +213,17 @@ def test_whole_line_kernel_config5_batch(gpu, oracle):
     per = blk.get_output_buffer_size()
     out = torch.zeros(nint * per, 2, device="cuda")
     _run(gpu, blk, nint, x, out)
+    # the route this call must take (a wrong one is 1.4 x slower and was once only visible in bench.py): the whole-line kernel, one launch, two units per
+    # workgroup on 256 workgroups, early touches of the slow lines on, no pacing
+    r = blk.last_route()
+    assert r["kernel"] == "k_xe_i8_lines" and r["launches"] == 1 and r["windows"] == nint and r["workgroups"] == 256 and r["units_per_workgroup"] == 2, r
+    assert r["touches"] > 0 and r["pace"] == 0 and r["tsplit"] == 1, r
     os.environ["MI355_XE_NO_LINES"] = "1"
     try:
         old = torch.zeros_like(out)
         _run(gpu, blk, nint, x, old)
+        r = blk.last_route()
+        assert r["kernel"] == "k_xe_i8_fused" and r["windows"] == nint, r
     finally:
         os.environ.pop("MI355_XE_NO_LINES", None)
     assert torch.equal(out, old)
@@ -224,3 +231,113 @@ def test_whole_line_kernel_config5_batch(gpu, oracle):
     for i in (0, nint - 1):
         ref = oracle.xengine_ichar(N, F, 1, T, x[i].cpu().numpy().reshape(-1), exact=True)
         assert np.array_equal(got[i], ref), i
+
+
+# ---- time ranges (k_xe_i8_lines<true>): fewer (window, line, pair group) units than compute units -- the reference's one-integration-per-call shape
+@pytest.fixture
+def split_any(monkeypatch):
+    monkeypatch.setenv("MI355_XE_LINES_SPLIT_ANY", "1")
+
+
+def _route(gpu, blk):
+    return blk.last_route()
+
+
+@pytest.mark.parametrize("F,T,nint,S", [(64, 128, 1, 4), (64, 64, 1, 2), (128, 256, 2, 4), (192, 192, 1, 2), (256, 512, 1, 4), (512, 128, 3, 2)])
+def test_time_ranges_bit_exact(gpu, oracle, split_any, monkeypatch, F, T, nint, S):
+    """Two and four time ranges per team, combined inside the launch: bit exact against the oracle and against the 32-byte-slice kernel; unit counts
+    that are and are not multiples of 32; a second launch on the same workspace (the other bank of arrival words)."""
+    import torch
+    monkeypatch.setenv("MI355_XE_TSPLIT", str(S))
+    N = 64
+    rng = np.random.default_rng(F + 3 * T + nint + S)
+    wins = rng.integers(-128, 128, size=(nint, T, N, F, 1, 2), dtype=np.int64).astype(np.int8)
+    blk = _xe(gpu, N, F, T)
+    per = blk.get_output_buffer_size()
+    ref = np.concatenate([oracle.xengine_ichar(N, F, 1, T, wins[i].reshape(-1), exact=True) for i in range(nint)])
+    x = torch.from_numpy(wins).cuda()
+    for rep in range(3):
+        out = torch.zeros(nint * per, 2, device="cuda")
+        _run(gpu, blk, nint, x, out)
+        assert np.array_equal(out.cpu().numpy().view(np.complex64).reshape(-1), ref), rep
+    r = _route(gpu, blk)
+    if r is not None:
+        assert r["kernel"] == "k_xe_i8_lines<split>" and r["tsplit"] == S, r
+    if nint == 1:  # the one-window entry point takes the same route
+        out = torch.zeros(per, 2, device="cuda")
+        blk.xcorrelate_device(x[0], out)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.complex64).reshape(-1), ref)
+
+
+@pytest.mark.parametrize("S", [2, 4])
+def test_time_ranges_fallback_when_waits_run_out(gpu, oracle, split_any, monkeypatch, S):
+    """MI355_XE_DBG=512: every bounded wait runs out at once, so every workgroup but the last of its team hands its own pieces over and leaves, and
+    the last one finishes the whole team -- the path a team takes when its workgroups are not resident together."""
+    import torch
+    monkeypatch.setenv("MI355_XE_TSPLIT", str(S))
+    monkeypatch.setenv("MI355_XE_DBG", "512")
+    N, F, T = 64, 128, 256
+    rng = np.random.default_rng(S)
+    w = rng.integers(-128, 128, size=(1, T, N, F, 1, 2), dtype=np.int64).astype(np.int8)
+    blk = _xe(gpu, N, F, T)
+    ref = oracle.xengine_ichar(N, F, 1, T, w.reshape(-1), exact=True)
+    x = torch.from_numpy(w).cuda()
+    for rep in range(2):
+        out = torch.zeros(blk.get_output_buffer_size(), 2, device="cuda")
+        _run(gpu, blk, 1, x, out)
+        assert np.array_equal(out.cpu().numpy().view(np.complex64).reshape(-1), ref), rep
+
+
+def test_time_ranges_group_major_and_extremes(gpu, oracle, split_any, monkeypatch):
+    """Group-major input (an all-to-all's receive buffer) through the time-range form; all -128 over 16384 frames in four ranges."""
+    import torch
+    monkeypatch.setenv("MI355_XE_TSPLIT", "4")
+    N, F, T, nint, W = 64, 128, 128, 2, 4
+    rng = np.random.default_rng(99)
+    wins = rng.integers(-128, 128, size=(nint, T, N, F, 1, 2), dtype=np.int64).astype(np.int8)
+    blk = _xe(gpu, N, F, T)
+    per = blk.get_output_buffer_size()
+    ref = np.concatenate([oracle.xengine_ichar(N, F, 1, T, wins[i].reshape(-1), exact=True) for i in range(nint)])
+    Ng = N // W
+    x = torch.from_numpy(np.ascontiguousarray(wins.reshape(nint, T, W, Ng, F, 1, 2).transpose(2, 0, 1, 3, 4, 5, 6))).cuda()
+    out = torch.zeros(nint * per, 2, device="cuda")
+    _run(gpu, blk, nint, x, out, ng=Ng)
+    assert np.array_equal(out.cpu().numpy().view(np.complex64).reshape(-1), ref)
+    N, F, T = 64, 64, 16384
+    blk = _xe(gpu, N, F, T)
+    w = np.full((T, N, F, 1, 2), -128, np.int8)
+    ref = oracle.xengine_ichar(N, F, 1, T, w.reshape(-1), exact=True)
+    out = torch.zeros(blk.get_output_buffer_size(), 2, device="cuda")
+    _run(gpu, blk, 1, torch.from_numpy(w).cuda(), out)
+    assert np.array_equal(out.cpu().numpy().view(np.complex64).reshape(-1), ref)
+
+
+def test_config5_one_and_two_windows_take_the_time_range_form(gpu):
+    """BASELINE config 5 as the reference's operator is called -- ONE integration per call (lib/clXEngine_impl.h:184-201) -- and two windows per call:
+    the whole-line kernel with four / two time ranges, identical to the 32-byte-slice kernel's bits (which test_xengine_gpu.py pins on the oracle)."""
+    import torch
+    N, F, T = 64, 1024, 1024
+    g = torch.Generator(device="cuda").manual_seed(5)
+    blk = _xe(gpu, N, F, T)
+    per = blk.get_output_buffer_size()
+    for nint in (1, 2):
+        x = torch.randint(-128, 128, (nint, T, N, F, 1, 2), dtype=torch.int8, device="cuda", generator=g)
+        out = torch.zeros(nint * per, 2, device="cuda")
+        for rep in range(3):
+            out.zero_()
+            if nint == 1: blk.xcorrelate_device(x, out)
+            else: blk.xcorrelate_n_device(nint, x, out)
+            torch.cuda.synchronize()
+            r = _route(gpu, blk)
+            if r is not None:
+                assert r["kernel"] == "k_xe_i8_lines<split>" and r["tsplit"] == 4 // nint, r
+            os.environ["MI355_XE_NO_LINES"] = "1"
+            try:
+                old = torch.zeros_like(out)
+                if nint == 1: blk.xcorrelate_device(x, old)
+                else: blk.xcorrelate_n_device(nint, x, old)
+                torch.cuda.synchronize()
+            finally:
+                os.environ.pop("MI355_XE_NO_LINES", None)
+            assert torch.equal(out, old), (nint, rep)
