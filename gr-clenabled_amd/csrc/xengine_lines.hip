@@ -292,13 +292,14 @@ template <bool DIAG, bool SPLIT> __device__ __forceinline__ void ln_body(const L
         // (In front of the sub-stage's own requests: older than they are, so the waits that count them have seen it land -- like wave 0's poll; a
         // touch that takes long holds up a diagonal group, which has the time.)
         if constexpr (DIAG) {
-            if (pf_on && wave == j && kb + a.pf_dist < a.steps) {
+            if (pf_on && wave == j) {
                 const int k = wave * 64 + lane, i = pf_first + k;
-                if (k < a.pf_per && i < a.pf_items) {
-                    const int which = i & ((1 << a.pf_lg) - 1), row = i >> a.pf_lg, t = row >> 6, st = row & 63;
-                    const unsigned ln = (a.pf_lines >> (8 * which)) & 0xffu;
-                    ln_dma16(pf_win + ((size_t)(32 * (kb + a.pf_dist) + t) * 64 + (size_t)st) * row_bytes + (size_t)ln * 128, lds0 + kLnTouch);
-                }
+                const bool mine = k < a.pf_per && i < a.pf_items;
+                const int which = i & ((1 << a.pf_lg) - 1), row = i >> a.pf_lg, t = row >> 6, st = row & 63;
+                const unsigned ln = (a.pf_lines >> (8 * which)) & 0xffu;
+                const unsigned char *p0 = pf_win + ((size_t)t * 64 + (size_t)st) * row_bytes + (size_t)ln * 128;
+                if (mine && kb + a.pf_dist < a.steps) ln_dma16(p0 + (size_t)(32 * (kb + a.pf_dist)) * 64 * row_bytes, lds0 + kLnTouch);
+                // (time ranges: touching the K blocks nearer than the distance as well, at the range's start, measured 57.5 against 57.4 us: not done)
             }
         }
     };
@@ -689,6 +690,7 @@ template <bool DIAG, bool SPLIT> __device__ __forceinline__ void ln_body(const L
             int *const s_mode = (int *)(lds + kLnPoll), *const s_mask = s_mode + 1;  // (the pacing words' place: there is no pacing in this form)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have completed
             __syncthreads();
+            if (a.ts && tid == 0) a.ts[(size_t)blockIdx.x * 8 + 6] = wall_clock64();  // pieces sent
             if (tid == 0) {
                 const unsigned long long old = __hip_atomic_fetch_add(state, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 int mode = 0, mask = 0;
@@ -809,7 +811,7 @@ template <bool DIAG, bool SPLIT> __device__ __forceinline__ void ln_body(const L
         a.ts[(size_t)blockIdx.x * 8 + 2] = t_wait;
         a.ts[(size_t)blockIdx.x * 8 + 3] = t_bar1;
         a.ts[(size_t)blockIdx.x * 8 + 4] = t_pace;
-        a.ts[(size_t)blockIdx.x * 8 + 6] = __builtin_readcyclecounter();
+        if constexpr (!SPLIT) a.ts[(size_t)blockIdx.x * 8 + 6] = __builtin_readcyclecounter();
     }
 }
 
@@ -988,6 +990,23 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
             end_by_grp[grp] += e; n_grp[grp]++;
             end_by_col[(combo % a.ncols) & 63] += e; n_col[(combo % a.ncols) & 63]++;
             last = std::max(last, e);
+        }
+        if (a.tsplit > 1) {  // time ranges: the phases of a workgroup, us after the first start (min / median / max)
+            static const char *names[5] = {"start", "loop end", "pieces sent", "all ranges in", "end"};
+            const int idx[5] = {0, 5, 6, 7, 1};
+            for (int k = 0; k < 5; k++) {
+                std::vector<double> v;
+                for (unsigned b = 0; b < grid; b++) if (h[8 * b + idx[k]]) v.push_back((double)(h[8 * b + idx[k]] - t0) * 0.01);
+                if (v.empty()) continue;
+                std::sort(v.begin(), v.end());
+                fprintf(stderr, "  %-14s %7.2f %7.2f %7.2f\n", names[k], v.front(), v[v.size() / 2], v.back());
+            }
+            for (int ty = 0; ty < 2; ty++) {
+                std::vector<double> v;
+                for (unsigned b = 0; b < grid; b++) if ((((a.pinned ? (b >> 3) : b) & 3) >> 1) == (unsigned)ty && h[8 * b + 5]) v.push_back((double)(h[8 * b + 5] - t0) * 0.01);
+                std::sort(v.begin(), v.end());
+                if (!v.empty()) fprintf(stderr, "  loop end, %s groups: %7.2f %7.2f %7.2f\n", ty ? "off-diagonal" : "diagonal", v.front(), v[v.size() / 2], v.back());
+            }
         }
         fprintf(stderr, "[xe lines stamps] %u workgroups x %d units, last end %.1f us; mean end by group:", grid, a.items, last);
         for (int k = 0; k < 4; k++) fprintf(stderr, " %.1f", n_grp[k] ? end_by_grp[k] / n_grp[k] : 0.0);
