@@ -1081,7 +1081,7 @@ struct mi355_xengine {
     // anyway; when a call arrives on ANOTHER stream than the workspace's last one, an event recorded on the old stream is waited for on the new one.
     hipStream_t ws_stream[3] = {nullptr, nullptr, nullptr};
     bool ws_used[3] = {false, false, false};
-    hipEvent_t ws_event = nullptr;
+    hipEvent_t ws_done[3] = {nullptr, nullptr, nullptr};
     mi355_xe_route route = {};      // kernels of the last device-side call (mi355_xengine_last_route)
     char routes_seen[8][64] = {};   // routes already logged once
     int pad = 0;            // one zero channel appended on the device (odd channel count of 2-byte samples)
@@ -1135,27 +1135,44 @@ __global__ __launch_bounds__(256) void k_xe_pad_rows8(const unsigned long long *
     }
 }
 
-// stream-order this call on workspace ws behind the workspace's previous launch (see mi355_xengine::ws_stream); called under dev_lock
+// Stream-order this call on workspace ws behind the workspace's previous launch (see mi355_xengine::ws_stream); called under dev_lock.
+// The previous stream is only ever touched when it is one of the context's own (they live as long as the context): an event recorded on it now is
+// waited for on the new stream.  A CALLER's stream may have been destroyed since its launch -- handing the runtime a dead handle crashes it
+// (tests/test_xengine_gpu.py::test_handle_survives_a_destroyed_stream) -- so behind a caller's stream the call waits for the device instead.  (An event
+// behind EVERY launch on the launch's own stream would avoid that wait, and was measured: 2-4 us per launch at BASELINE config 5, 60.9 against 57.4 us
+// for one window per call -- every caller would pay for a stream change that almost none makes.)
 int xe_order_workspace(mi355_xengine *h, int ws, hipStream_t st)
 {
     if (h->ws_used[ws] && h->ws_stream[ws] != st) {
-        if (!h->ws_event) MI355_HIP(hipEventCreateWithFlags(&h->ws_event, hipEventDisableTiming));
-        MI355_HIP(hipEventRecord(h->ws_event, h->ws_stream[ws]));
-        MI355_HIP(hipStreamWaitEvent(st, h->ws_event, 0));
+        const hipStream_t old = h->ws_stream[ws];
+        if (old == h->ctx->stream[0] || old == h->ctx->stream[1]) {
+            if (!h->ws_done[ws]) MI355_HIP(hipEventCreateWithFlags(&h->ws_done[ws], hipEventDisableTiming));
+            MI355_HIP(hipEventRecord(h->ws_done[ws], old));
+            MI355_HIP(hipStreamWaitEvent(st, h->ws_done[ws], 0));
+        } else {
+            MI355_HIP(hipDeviceSynchronize());
+        }
     }
     h->ws_stream[ws] = st;
     h->ws_used[ws] = true;
     return MI355_OK;
 }
 
+int launch_xe_body(mi355_xengine *h, const void *in, void *out, int accumulate, hipStream_t st, unsigned char *tiles, unsigned char *padbuf,
+                   int stations_per_group);
 int launch_xe(mi355_xengine *h, const void *in, void *out, int accumulate, hipStream_t st, unsigned char *tiles, unsigned char *padbuf,
               int stations_per_group = 0)
 {
-    const XeGeo &g = h->g;
     if (tiles) {
         const int rc = xe_order_workspace(h, tiles == h->d_tiles ? 0 : 1, st);
         if (rc != MI355_OK) return rc;
     }
+    return launch_xe_body(h, in, out, accumulate, st, tiles, padbuf, stations_per_group);
+}
+int launch_xe_body(mi355_xengine *h, const void *in, void *out, int accumulate, hipStream_t st, unsigned char *tiles, unsigned char *padbuf,
+                   int stations_per_group)
+{
+    const XeGeo &g = h->g;
     // complex float: is this launch the fused kernel's?  (decided first: that kernel reads rows which end inside a 128-byte line as they
     // are, every other complex-float kernel needs them padded to whole lines)
     int tsplit = 1;
@@ -1408,7 +1425,8 @@ extern "C" int mi355_xengine_destroy(mi355_xengine *h)
     }
     if (h->d_pad) (void)hipFree(h->d_pad);
     if (h->d_batch) (void)hipFree(h->d_batch);
-    if (h->ws_event) (void)hipEventDestroy(h->ws_event);
+    for (auto &e : h->ws_done)
+        if (e) (void)hipEventDestroy(e);
     delete h;
     return MI355_OK;
 }
@@ -1535,7 +1553,7 @@ static int xe_n_dev_launch(mi355_xengine *h, int nint, const void *in_dev, void 
                 h->batch_bytes = fp.part_bytes;
                 h->batch_nint = 0;
             }
-            {
+            if (fp.part_bytes > 0) {  // (no time ranges -- the whole-line kernel, the persistent form -- no workspace: nothing to order, streams stay independent)
                 const int rc = xe_order_workspace(h, 2, st);  // (before the fill below: it must not run under a launch still in flight on another stream)
                 if (rc != MI355_OK) return rc;
             }

@@ -239,7 +239,9 @@ size_t mi355_xengine_output_items(const mi355_xengine *h);
 /* accumulate=0: out = V ; accumulate=1: out += V (pipeline integration) */
 int mi355_xengine_xcorrelate(mi355_xengine *h, const void *in_host, void *out_host, int accumulate);
 /* (device-pointer calls: a handle may be used from several streams -- launches that share the handle's partial-sum workspace are ordered by the
- * library with an event recorded on the PREVIOUS call's stream, which therefore must still exist when the next call on the handle is made) */
+ * library when the stream changes: behind one of the context's own streams with an event, behind a caller's stream -- which may have been
+ * destroyed since, and is therefore never touched again -- by waiting for the device.  A stream may be destroyed as soon as the caller is done
+ * with it.  Batched launches that need no workspace -- no time ranges -- are not ordered at all.) */
 int mi355_xengine_xcorrelate_dev(mi355_xengine *h, const void *in_dev, void *out_dev, int accumulate, void *stream);
 /* Multi-GPU form (no counterpart in the reference, which runs one X-engine on one device): the input is the
  * receive buffer of the all-to-all corner turn, [group][t][station in group][chan][pol], stations_per_group stations per

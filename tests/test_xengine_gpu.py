@@ -812,3 +812,43 @@ def test_ichar_scale_single_precision_is_exact(gpu):
     The device compares the two for EVERY |S| <= 2^24: no sum may differ in a single bit."""
     blk = _xe(gpu, gpu.DTYPE_BYTE, 1, 4, 16, 32)
     assert blk.selftest_scale() == 0
+
+
+_DEAD_STREAM_SCRIPT = r'''
+import ctypes, os, sys
+sys.path.insert(0, os.environ["MI355_REPO"])
+import numpy as np, torch
+import __graft_entry__ as e
+pkg, o = e.load_package(), e.load_oracle()
+path = [l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l][0]
+hip = ctypes.CDLL(path)
+N, F, T = 64, 128, 256   # four time ranges: the launches share the handle's partial-sum workspace
+rng = np.random.default_rng(4)
+x = rng.integers(-128, 128, size=(T, N, F, 1, 2), dtype=np.int64).astype(np.int8)
+ref = o.xengine_ichar(N, F, 1, T, x.reshape(-1), exact=True)
+blk = pkg.clXEngine(1, 2, 0, 0, False, pkg.DTYPE_BYTE, 1, N, 1, 0, F, T, [])
+dx = torch.from_numpy(x).cuda()
+outs = [torch.zeros(blk.get_output_buffer_size(), 2, device="cuda") for _ in range(6)]
+torch.cuda.synchronize()
+for r in range(3):
+    s = ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(s)) == 0
+    with torch.cuda.stream(torch.cuda.ExternalStream(s.value)):
+        blk.xcorrelate_device(dx, outs[2 * r])
+    assert hip.hipStreamDestroy(s) == 0      # (not synchronised: the launch may still be in flight)
+    blk.xcorrelate_device(dx, outs[2 * r + 1])  # torch's current stream: another one than the workspace's last, which no longer exists
+torch.cuda.synchronize()
+for r, v in enumerate(outs):
+    assert np.array_equal(v.cpu().numpy().view(np.complex64).reshape(-1), ref), r
+print("dead-stream ok")
+'''
+
+
+def test_handle_survives_a_destroyed_stream(gpu):
+    """The workspace's previous stream was destroyed before the next call on the handle (a per-call stream): the library must not fail (and must
+    not stay broken), it waits for the device instead of the dead stream.  Run in a child process -- the test hands the runtime a dead handle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _DEAD_STREAM_SCRIPT], capture_output=True, text=True, timeout=300, env=dict(os.environ, MI355_REPO=root))
+    assert r.returncode == 0 and "dead-stream ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
