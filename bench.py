@@ -850,6 +850,38 @@ def sharded_one_process(pkg, dev, windows=8, ranks=2):
                     "the single-process pipeline inside the bench, not a scaling number"}
 
 
+def sharded_host_ingest(pkg, dev, windows=4, exchanges=5):
+    """The streaming HOST path of the single-process sharded block (mi355_xengine_shard_acquire / submit_acquired / wait: pinned frame slots, every
+    rank uploads its antenna group on its own stream, two exchanges in flight -- what clXEngine::work_test uses after set_shard_devices), config 5,
+    for 1, 2 and 4 logical ranks on THIS device.  All ranks share the one host link here, so the time per integration cannot drop with the rank
+    count; the check is that it does not GROW (serialised uploads or a synchronisation per call would show as W x).  PCIe inclusive, never `value`."""
+    import time
+    N, F, T = 64, 1024, 1024
+    out = {"windows_per_exchange": windows, "exchanges_timed": exchanges, "what": "host clock around acquire + submit_acquired (+ wait once two are in flight) "
+           "per exchange, frames already in the pinned slot (the block's gather is not in it); 134 MB up, 17 MB down per integration"}
+    for ranks in (1, 2, 4):
+        sh = pkg.clXEngineSharded([dev] * ranks, 1, N, F, T, windows)
+        res = np.empty(windows * sh.get_output_buffer_size(), np.complex64)
+        for _ in range(2):  # both pinned slots, every rank's device buffers
+            sh.acquire()[:1] = 1
+            sh.submit_acquired()
+        while sh.pending():
+            sh.wait(res)
+        t0 = time.perf_counter()
+        for _ in range(exchanges):
+            if sh.pending() == 2:
+                sh.wait(res)
+            sh.acquire()
+            sh.submit_acquired()
+        while sh.pending():
+            sh.wait(res)
+        dt = (time.perf_counter() - t0) / (exchanges * windows)
+        out["ranks_%d" % ranks] = {"us_per_integration": round(dt * 1e6, 1), "host_GBps_up": round(T * N * F * 2 / dt / 1e9, 1)}
+        sh.close()
+    out["grows_with_ranks"] = out["ranks_4"]["us_per_integration"] > 1.15 * out["ranks_1"]["us_per_integration"]
+    return out
+
+
 def annotate_sharded_scaling(extras, world):
     """Strong scaling of the 64 x 1024 x 1024 integration stream: efficiency = t(1 GPU) / (N x t(N GPUs)), both sides eight windows per launch
     (like for like), the one-GPU time measured in the SAME line (N > 1: `clXEngine_n1_reference`, every rank's own device; N = 1: the batched
@@ -1038,6 +1070,10 @@ def main():
                 extras["clXEngine_shard_one_process"] = sharded_one_process(pkg, local)
             except Exception as exc:  # noqa: BLE001
                 extras["clXEngine_shard_one_process"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            try:
+                extras["clXEngine_shard_host_ingest"] = sharded_host_ingest(pkg, local)
+            except Exception as exc:  # noqa: BLE001
+                extras["clXEngine_shard_host_ingest"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
             try:
                 extras.update(hostpath_blocks(pkg, taps_pair, local))
             except Exception as exc:  # noqa: BLE001

@@ -122,6 +122,12 @@ def lib():
         "mi355_xengine_shard_wait_stream": (i, [vp, i, vp]),
         "mi355_xengine_shard_synchronize": (i, [vp]),
         "mi355_xengine_shard_xcorrelate": (i, [vp, vp, vp, i]),
+        "mi355_xengine_shard_windows": (i, [vp]),
+        "mi355_xengine_shard_input_bytes": (sz, [vp]),
+        "mi355_xengine_shard_acquire": (i, [vp, pp]),
+        "mi355_xengine_shard_submit_acquired": (i, [vp]),
+        "mi355_xengine_shard_wait": (i, [vp, vp]),
+        "mi355_xengine_shard_pending": (i, [vp]),
         "mi355_xengine_submit": (i, [vp, vp, vp]),
         "mi355_xengine_wait": (i, [vp, vp]),
         "mi355_xengine_pending": (i, [vp]),

@@ -520,6 +520,31 @@ class clXEngineSharded:
         check(self._L.mi355_xengine_shard_xcorrelate(self._h, _hp(x), _hp(y), 1 if accumulate else 0), "mi355_xengine_shard_xcorrelate")
         return self.windows * self.get_output_buffer_size()
 
+    def input_bytes(self):
+        return self._L.mi355_xengine_shard_input_bytes(self._h)
+
+    def acquire(self):
+        """Streaming host path: the pinned frame buffer of the next free slot (`windows` integration windows in the reference's frame layout,
+        lib/clXEngine_impl.cc:325-362) as a writable int8 numpy view; fill it, then submit_acquired()."""
+        p = C.c_void_p()
+        check(self._L.mi355_xengine_shard_acquire(self._h, C.byref(p)), "mi355_xengine_shard_acquire")
+        return np.frombuffer((C.c_int8 * self.input_bytes()).from_address(p.value), dtype=np.int8)
+
+    def submit_acquired(self):
+        """Per rank, on its own stream: upload of its antenna group out of the pinned buffer, exchange, correlation, download -- enqueue only."""
+        check(self._L.mi355_xengine_shard_submit_acquired(self._h), "mi355_xengine_shard_submit_acquired")
+
+    def wait(self, cross_correlation):
+        """Block for the oldest submitted exchange; `windows` matrices."""
+        y = _host(cross_correlation, np.complex64, writable=True)
+        if y.size < self.windows * self.get_output_buffer_size():
+            raise ValueError("wait: output needs %d items" % (self.windows * self.get_output_buffer_size()))
+        check(self._L.mi355_xengine_shard_wait(self._h, _hp(y)), "mi355_xengine_shard_wait")
+        return self.windows * self.get_output_buffer_size()
+
+    def pending(self):
+        return self._L.mi355_xengine_shard_pending(self._h)
+
     def submit_device(self, frames, outs, accumulate=False):
         """frames[r] / outs[r]: CUDA tensors on the rank's device (antenna-group frames / windows x slab matrices); enqueue only."""
         fp = (C.c_void_p * self.world)(*[_dp(t, self.frames_bytes(), "frames").value for t in frames])

@@ -830,6 +830,12 @@ template <bool SPLIT> __global__ __launch_bounds__(kLnThreads) void k_xe_i8_line
             __hip_atomic_store(a.flags + (size_t)((a.epoch + 1u) & 1u) * a.flag_bank + (size_t)((u0.win * a.ncols + u0.col) * 4 + grp), 0ull, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
     }
+    if constexpr (SPLIT) {
+        // test switch (MI355_XE_DBG bits 16 / 17): only / all but the first time range of every team runs -- the others leave before they arrive, so
+        // every team's count stays short of full (the units that do run wait, give up, and nobody finishes): what an aborted launch leaves behind
+        const int m = (a.dbg >> 16) & 3;
+        if (m && ((m == 1) != (u0.q == 0))) return;
+    }
     if (grp < 2) ln_body<true, SPLIT>(a, lds, grp);
     else ln_body<false, SPLIT>(a, lds, grp);
     if (a.ts && threadIdx.x == 0) a.ts[(size_t)blockIdx.x * 8 + 1] = wall_clock64();
@@ -966,6 +972,11 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
     const unsigned grid = (unsigned)(a.units / a.items);
     a.grid = (int)grid;
     a.rot = (a.pinned && a.items > 1 && (grid / 4) % (unsigned)a.ncols == 0) ? (getenv("MI355_XE_LINES_ROT") ? atoi(getenv("MI355_XE_LINES_ROT")) : 1) : 0;
+    // MI355_XE_FAIL_LAUNCH (test switch): fail where a bad stream handle or an exhausted device would -- nothing enqueued, an error returned
+    if (a.tsplit > 1 && getenv("MI355_XE_FAIL_LAUNCH")) {
+        mi355_set_error("whole-line X-engine launch failed (MI355_XE_FAIL_LAUNCH)");
+        return MI355_ERR_HIP;
+    }
     mi355_xe_route_set(a.tsplit > 1 ? "k_xe_i8_lines<split>" : "k_xe_i8_lines", nw, (int)grid, a.items, a.tsplit, a.tsplit > 1 ? 1 : 0, a.pf_dist, a.pace);
     if (getenv("MI355_XE_TS")) {  // tuning aid: one synchronous launch with start / end stamps per workgroup
         unsigned long long *d_ts = nullptr;

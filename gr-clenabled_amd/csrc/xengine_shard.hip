@@ -33,10 +33,24 @@ struct mi355_xengine_shard {
         // host path: device copies of the rank's frames / matrices
         unsigned char *d_frames = nullptr;
         void *d_out = nullptr;
+        // streaming host path (acquire / submit_acquired / wait): per host slot the rank's frames and matrices on the device, "slot's matrices are in
+        // the pinned result buffer" on the compute stream
+        unsigned char *hd_frames[2] = {nullptr, nullptr};
+        void *hd_out[2] = {nullptr, nullptr};
+        hipEvent_t h_done[2] = {nullptr, nullptr};
     };
     std::vector<Rank> rk;
     int next_slot = 0;
     std::mutex lock;
+    std::mutex host_call;  // the synchronous host form, one call at a time per handle (its staging buffers are the handle's)
+    // streaming host path: two slots of PINNED host memory (hipHostMallocPortable: every rank's device reads its antenna group out of the same
+    // buffer over its own link, truly asynchronously) -- the reference pins its frame buffers too (lib/clXEngine_impl.cc:325-362)
+    struct HostSlot {
+        void *h_in = nullptr, *h_out = nullptr;
+        bool busy = false;
+    } hs[2];
+    int host_next_submit = 0, host_next_wait = 0, host_pending = 0;
+    bool host_acquired = false;
 };
 
 namespace {
@@ -53,10 +67,19 @@ void shard_free(mi355_xengine_shard *h)
         if (r.mark) (void)hipEventDestroy(r.mark);
         if (r.d_frames) (void)hipFree(r.d_frames);
         if (r.d_out) (void)hipFree(r.d_out);
+        for (int s = 0; s < 2; s++) {
+            if (r.hd_frames[s]) (void)hipFree(r.hd_frames[s]);
+            if (r.hd_out[s]) (void)hipFree(r.hd_out[s]);
+            if (r.h_done[s]) (void)hipEventDestroy(r.h_done[s]);
+        }
         if (r.xs) (void)hipStreamDestroy(r.xs);
         if (r.cs) (void)hipStreamDestroy(r.cs);
         if (r.xe) mi355_xengine_destroy(r.xe);
         if (r.ctx) mi355_ctx_destroy(r.ctx);
+    }
+    for (auto &sl : h->hs) {
+        if (sl.h_in) (void)hipHostFree(sl.h_in);
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
     }
     delete h;
 }
@@ -162,10 +185,15 @@ extern "C" int mi355_xengine_shard_wait_stream(mi355_xengine_shard *h, int rank,
 // (frames_bytes() long, 16-byte aligned); they are read by the packing copy on the rank's exchange stream, which first waits for
 // everything enqueued so far on the rank's compute stream (mi355_xengine_shard_stream: enqueue the producer of the frames there); they must
 // stay untouched until the next submit / synchronize on this handle returns.  out_dev[r]: windows x slab_items() complex floats on device r.
+static int shard_submit_locked(mi355_xengine_shard *h, const void *const *frames_dev, void *const *out_dev, int accumulate);
 extern "C" int mi355_xengine_shard_submit_dev(mi355_xengine_shard *h, const void *const *frames_dev, void *const *out_dev, int accumulate)
 {
     MI355_REQUIRE(h && frames_dev && out_dev, "NULL argument");
     std::lock_guard<std::mutex> g(h->lock);
+    return shard_submit_locked(h, frames_dev, out_dev, accumulate);
+}
+static int shard_submit_locked(mi355_xengine_shard *h, const void *const *frames_dev, void *const *out_dev, int accumulate)
+{
     const int W = h->world, s = h->next_slot;
     for (int r = 0; r < W; r++) MI355_REQUIRE(frames_dev[r] && out_dev[r] && (reinterpret_cast<uintptr_t>(frames_dev[r]) & 15u) == 0, "NULL or misaligned rank buffer");
     const size_t rows = (size_t)h->windows * h->T * h->Ng;
@@ -219,8 +247,7 @@ extern "C" int mi355_xengine_shard_synchronize(mi355_xengine_shard *h)
 extern "C" int mi355_xengine_shard_xcorrelate(mi355_xengine_shard *h, const void *in_host, void *out_host, int accumulate)
 {
     MI355_REQUIRE(h && in_host && out_host, "NULL argument");
-    static std::mutex host_call;  // (one host call at a time: the ranks' staging buffers are the handle's; submit_dev below takes the handle's lock itself)
-    std::lock_guard<std::mutex> hg(host_call);
+    std::lock_guard<std::mutex> hg(h->host_call);  // (one host call at a time per handle; submit_dev below takes the handle's lock itself)
     const int W = h->world;
     const size_t grp = (size_t)h->Ng * h->row, step = (size_t)h->N * h->row, steps = (size_t)h->windows * h->T;
     const size_t slab_bytes = h->slab_items * 8, full_bytes = slab_bytes * W;
@@ -247,4 +274,113 @@ extern "C" int mi355_xengine_shard_xcorrelate(mi355_xengine_shard *h, const void
                                    hipMemcpyDeviceToHost, k.cs));
     }
     return mi355_xengine_shard_synchronize(h);
+}
+
+
+// ---- Streaming host path: the sharded counterpart of mi355_xengine_acquire / submit_acquired / wait (and of the reference's pinned double buffers +
+// worker thread, lib/clXEngine_impl.cc:325-362, :1234-1299).  acquire() hands out a PINNED buffer for `windows` integration windows in the reference's
+// frame layout [window][t][station][chan][pol]{I,Q}; the block gathers its frames straight into it; submit_acquired() enqueues, per rank and on the
+// rank's own compute stream, the 2-D copy of its antenna group out of that buffer (asynchronous -- pinned memory -- so the W ranks' uploads run at
+// once over W host links), the exchange, the correlation and the copy of the rank's slab into a pinned result buffer, and returns; wait() blocks for
+// the OLDEST submitted exchange and writes its `windows` matrices [window][chan][baseline][pol^2].  At most two exchanges are in flight: the gather
+// of exchange k+1 (the caller's) and its uploads run under the devices' work on exchange k.
+extern "C" int mi355_xengine_shard_windows(const mi355_xengine_shard *h) { return h ? h->windows : MI355_ERR_INVALID_ARG; }
+extern "C" size_t mi355_xengine_shard_input_bytes(const mi355_xengine_shard *h)
+{
+    return h ? (size_t)h->windows * h->T * h->N * h->row : 0;
+}
+extern "C" int mi355_xengine_shard_pending(const mi355_xengine_shard *h) { return h ? h->host_pending : MI355_ERR_INVALID_ARG; }
+
+extern "C" int mi355_xengine_shard_acquire(mi355_xengine_shard *h, void **frame_buffer)
+{
+    MI355_REQUIRE(h && frame_buffer, "NULL argument");
+    std::lock_guard<std::mutex> g(h->lock);
+    if (h->host_pending >= 2) {
+        mi355_set_error("two exchanges in flight: wait() for the oldest first");
+        return MI355_ERR_STATE;
+    }
+    auto &sl = h->hs[h->host_next_submit];
+    if (!sl.h_in) {
+        const size_t in_bytes = (size_t)h->windows * h->T * h->N * h->row, out_bytes = (size_t)h->windows * h->slab_items * 8 * h->world;
+        MI355_HIP(hipSetDevice(h->rk[0].dev));
+        hipError_t e = hipHostMalloc(&sl.h_in, in_bytes, hipHostMallocPortable);
+        if (e == hipSuccess) e = hipHostMalloc(&sl.h_out, out_bytes, hipHostMallocPortable);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            if (sl.h_in) (void)hipHostFree(sl.h_in);
+            sl.h_in = sl.h_out = nullptr;
+            mi355_set_error("cannot pin %zu + %zu bytes of host memory for the sharded X-engine: %s", in_bytes, out_bytes, hipGetErrorString(e));
+            return MI355_ERR_NOMEM;
+        }
+    }
+    h->host_acquired = true;
+    *frame_buffer = sl.h_in;
+    return MI355_OK;
+}
+
+extern "C" int mi355_xengine_shard_submit_acquired(mi355_xengine_shard *h)
+{
+    MI355_REQUIRE(h != nullptr, "NULL argument");
+    std::lock_guard<std::mutex> g(h->lock);
+    if (!h->host_acquired) {
+        mi355_set_error("submit_acquired without acquire");
+        return MI355_ERR_STATE;
+    }
+    const int W = h->world, s = h->host_next_submit;
+    auto &sl = h->hs[s];
+    const size_t grp = (size_t)h->Ng * h->row, step = (size_t)h->N * h->row, steps = (size_t)h->windows * h->T;
+    const size_t slab_bytes = h->slab_items * 8, full_bytes = slab_bytes * W;
+    std::vector<const void *> fr((size_t)W);
+    std::vector<void *> ou((size_t)W);
+    for (int r = 0; r < W; r++) {
+        auto &k = h->rk[(size_t)r];
+        MI355_HIP(hipSetDevice(k.dev));
+        if (!k.hd_frames[s]) MI355_HIP(hipMalloc((void **)&k.hd_frames[s], h->frames_bytes));
+        if (!k.hd_out[s]) MI355_HIP(hipMalloc(&k.hd_out[s], slab_bytes * h->windows));
+        if (!k.h_done[s]) MI355_HIP(hipEventCreateWithFlags(&k.h_done[s], hipEventDisableTiming));
+        // (the device buffer's last reader, the packing copy two exchanges ago, is ordered in front of this copy through that exchange's correlation,
+        // which waited for every rank's `sent` event and ran on this stream)
+        MI355_HIP(hipMemcpy2DAsync(k.hd_frames[s], grp, (const char *)sl.h_in + (size_t)r * grp, step, grp, steps, hipMemcpyHostToDevice, k.cs));
+        fr[(size_t)r] = k.hd_frames[s];
+        ou[(size_t)r] = k.hd_out[s];
+    }
+    const int rc = shard_submit_locked(h, fr.data(), ou.data(), 0);
+    if (rc != MI355_OK) return rc;
+    for (int r = 0; r < W; r++) {
+        auto &k = h->rk[(size_t)r];
+        MI355_HIP(hipSetDevice(k.dev));
+        MI355_HIP(hipMemcpy2DAsync((char *)sl.h_out + (size_t)r * slab_bytes, full_bytes, k.hd_out[s], slab_bytes, slab_bytes, (size_t)h->windows,
+                                   hipMemcpyDeviceToHost, k.cs));
+        MI355_HIP(hipEventRecord(k.h_done[s], k.cs));
+    }
+    sl.busy = true;
+    h->host_acquired = false;
+    h->host_next_submit ^= 1;
+    h->host_pending++;
+    return MI355_OK;
+}
+
+extern "C" int mi355_xengine_shard_wait(mi355_xengine_shard *h, void *out_host)
+{
+    MI355_REQUIRE(h && out_host, "NULL argument");
+    int s;
+    {
+        std::lock_guard<std::mutex> g(h->lock);
+        if (h->host_pending == 0) {
+            mi355_set_error("wait without a submitted exchange");
+            return MI355_ERR_STATE;
+        }
+        s = h->host_next_wait;
+    }
+    // (not under the lock: another thread may gather into and submit the other slot meanwhile; waits are single-consumer)
+    for (auto &k : h->rk) {
+        MI355_HIP(hipSetDevice(k.dev));
+        MI355_HIP(hipEventSynchronize(k.h_done[s]));
+    }
+    mi355_copy(out_host, h->hs[s].h_out, (size_t)h->windows * h->slab_items * 8 * h->world);
+    std::lock_guard<std::mutex> g(h->lock);
+    h->hs[s].busy = false;
+    h->host_next_wait ^= 1;
+    h->host_pending--;
+    return MI355_OK;
 }

@@ -198,9 +198,19 @@ static int xengine_stream_test(const std::string &dir)
         g_handler_calls = 0;
         g_handler_ok = true;
         four->set_result_handler(on_matrix, &T_user);
-        run(four, 6 * T);
-        ok = ok && g_handler_calls == 6 && g_handler_ok && four->integrations_delivered() == 6;
-        report("clXEngine over 4 ranks of one process (set_shard_devices)", (size_t)7 * T * F * N, 1.0, ok);
+        // 11 windows = two exchanges of four (pinned slots, one exchange in flight under the gather of the next) + three that stop() flushes
+        run(four, 11 * T);
+        ok = ok && g_handler_calls == 11 && g_handler_ok && four->integrations_delivered() == 11;
+        // the same with one and with three windows per exchange, on two ranks
+        for (int wpe : {1, 3}) {
+            auto two = clXEngine::make(OCLTYPE_GPU, OCLDEVICESELECTOR_SPECIFIC, 0, g_dev, false, DTYPE_BYTE, 1, N, CLXCORR_TRIANGULAR_ORDER, 0, F, T, {});
+            two->set_shard_devices({g_dev, g_dev}, wpe);
+            g_handler_calls = 0;
+            two->set_result_handler(on_matrix, &T_user);
+            run(two, 7 * T + 3);
+            ok = ok && g_handler_calls == 7 && g_handler_ok && two->integrations_delivered() == 7;
+        }
+        report("clXEngine over 4 / 2 ranks of one process (set_shard_devices), streamed", (size_t)26 * T * F * N, 1.0, ok);
     }
     return g_fail ? 1 : 0;
 }

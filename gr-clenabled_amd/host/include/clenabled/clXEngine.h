@@ -44,8 +44,10 @@ public:
     // device r ingests antenna group r over its own host link, the devices exchange (corner turn over xGMI) and device r correlates channel
     // slab r; results are identical to the one-device block's.  IChar input, num_inputs * polarization <= 64, the device count must divide
     // num_inputs and num_channels.  Also set by the environment variable MI355_XENGINE_DEVICES="0,1,2,3" for flowgraphs that are not edited.
-    // An empty or one-element list returns to the device of make().
-    virtual void set_shard_devices(const std::vector<int> &device_ids) = 0;
+    // An empty or one-element list returns to the device of make().  Streamed frames (work / work_test) go to the devices windows_per_exchange
+    // integration windows at a time (MI355_XENGINE_SHARD_WINDOWS overrides): gathered straight into pinned memory, uploaded by every device over its
+    // own link while the next windows are gathered; results come out in order, windows_per_exchange at a time (stop() flushes a partial batch).
+    virtual void set_shard_devices(const std::vector<int> &device_ids, int windows_per_exchange = 4) = 0;
     virtual int shard_devices() const = 0;
     // stream-tag synchroniser state (internal_synchronizer = true, lib/clXEngine_impl.cc:1158-1226)
     virtual bool synchronized() const = 0;

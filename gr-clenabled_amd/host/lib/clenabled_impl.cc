@@ -234,7 +234,17 @@ class clXEngine_impl : public clXEngine, public MI355Base {
     mi355_xengine *d_h = nullptr;
     // several devices behind ONE block (set_shard_devices / MI355_XENGINE_DEVICES): antenna groups in, channel slabs out, the corner turn
     // between the devices inside mi355_xengine_shard_* -- the reference has one device per block (devId, lib/GRCLBase.cpp:115-134)
-    mi355_xengine_shard *d_shard = nullptr;
+    mi355_xengine_shard *d_shard = nullptr;         // one window per call: xcorrelate(char*, XComplex*), pipeline integration
+    // the STREAMING path of work_test(): d_shard_windows integration windows per exchange, gathered straight into the handle's pinned frame slots
+    // (mi355_xengine_shard_acquire / submit_acquired / wait: every device uploads its antenna group over its own link, asynchronously, while the next
+    // windows are gathered) -- created at the first streamed window
+    mi355_xengine_shard *d_shard_stream = nullptr;
+    std::vector<int> d_shard_ids;
+    int d_shard_windows = 4, d_batch_fill = 0;
+    char *d_batch_base = nullptr;
+    std::vector<long> d_batch_first;                // first frame numbers of the windows gathered into the current batch
+    std::vector<std::vector<long>> d_shard_pending_first;  // ... of the exchanges in flight
+    std::vector<XComplex> d_result_batch;
     int d_data_type;
     int d_npol, d_num_inputs, d_num_channels, d_integration, d_pipeline_integration, d_first_channel;
     long d_in_items;
@@ -307,6 +317,14 @@ class clXEngine_impl : public clXEngine, public MI355Base {
             if (d_publish) sched::publish_c32vector(this, "xcorr", "triang_matrix", (const gr_complex *)m, d_matrix_len);
         }
     }
+    void collect_shard()
+    {
+        chk(mi355_xengine_shard_wait(d_shard_stream, d_result_batch.data()), "mi355_xengine_shard_wait");
+        const std::vector<long> firsts = d_shard_pending_first.front();
+        d_shard_pending_first.erase(d_shard_pending_first.begin());
+        for (size_t w = 0; w < firsts.size(); w++) deliver(d_result_batch.data() + w * d_matrix_len, firsts[w]);
+    }
+    bool shard_streaming() const { return d_shard && d_pipeline_integration <= 1; }
     void collect_one()
     {
         chk(mi355_xengine_wait(d_h, d_result.data()), "mi355_xengine_wait");
@@ -365,22 +383,40 @@ public:
                 ids.push_back((int)v);
                 q = *end == ',' ? end + 1 : end;
             }
-            if (ids.size() > 1) set_shard_devices(ids);
+            if (ids.size() > 1) {
+                // the variable is process-wide ("flowgraphs that are not edited"): a block it does not fit -- complex input, more than 64 rows, counts the
+                // ranks do not divide -- keeps its one device and says so; only the explicit call throws
+                try { set_shard_devices(ids); }
+                catch (const std::exception &ex) {
+                    mi355_xengine_shard_destroy(d_shard);
+                    d_shard = nullptr;
+                    log_sink(nullptr, MI355_LOG_WARN, (std::string("MI355_XENGINE_DEVICES ignored for this clXEngine block: ") + ex.what()).c_str());
+                }
+            }
         }
     }
     ~clXEngine_impl() override
     {
         try { stop(); } catch (...) {}
+        mi355_xengine_shard_destroy(d_shard_stream);
         mi355_xengine_shard_destroy(d_shard);
         mi355_xengine_destroy(d_h);
     }
-    void set_shard_devices(const std::vector<int> &device_ids) override
+    void set_shard_devices(const std::vector<int> &device_ids, int windows_per_exchange = 4) override
     {
         std::lock_guard<std::mutex> g(d_lock);
         if (d_tracker != 0 || mi355_xengine_pending(d_h) > 0) throw std::runtime_error("[X-Engine] set_shard_devices: an integration is in progress");
         if (d_data_type != DTYPE_BYTE) throw std::invalid_argument("[X-Engine] several devices: IChar (byte) input only");
+        if (d_batch_fill != 0 || (d_shard_stream && mi355_xengine_shard_pending(d_shard_stream) > 0))
+            throw std::runtime_error("[X-Engine] set_shard_devices: an exchange is in progress (stop() first)");
+        if (windows_per_exchange < 1) throw std::invalid_argument("[X-Engine] set_shard_devices: windows_per_exchange must be >= 1");
+        mi355_xengine_shard_destroy(d_shard_stream);
+        d_shard_stream = nullptr;
         mi355_xengine_shard_destroy(d_shard);
         d_shard = nullptr;
+        d_shard_ids = device_ids;
+        d_shard_windows = windows_per_exchange;
+        if (const char *e = getenv("MI355_XENGINE_SHARD_WINDOWS")) d_shard_windows = atoi(e) > 0 ? atoi(e) : d_shard_windows;
         if (device_ids.size() < 2) return;  // back to the one device of make()
         chk(mi355_xengine_shard_create((int)device_ids.size(), device_ids.data(), d_npol, d_num_inputs, d_num_channels, d_integration, 1, &d_shard),
             "mi355_xengine_shard_create");
@@ -392,6 +428,16 @@ public:
     {
         std::lock_guard<std::mutex> g(d_lock);
         while (mi355_xengine_pending(d_h) > 0) collect_one();
+        if (d_shard_stream) {
+            while (mi355_xengine_shard_pending(d_shard_stream) > 0) collect_shard();
+            // whole windows of a batch that did not fill up: through the block's one device, from the pinned buffer they were gathered into
+            for (int w = 0; w < d_batch_fill; w++) {
+                chk(mi355_xengine_xcorrelate(d_h, d_batch_base + (size_t)w * d_in_bytes, d_result.data(), 0), "mi355_xengine_xcorrelate");
+                deliver(d_result.data(), d_batch_first[(size_t)w]);
+            }
+            d_batch_fill = 0;
+            d_batch_first.clear();
+        }
         if (d_fp) { fclose(d_fp); d_fp = nullptr; }
         return true;
     }
@@ -454,7 +500,21 @@ public:
         const int remaining = d_integration - d_tracker;
         const int n = noutput_items > remaining ? remaining : noutput_items;  // :925-934
         if (d_tracker == 0) {  // a new integration window starts: get the buffer it is gathered into
-            if (d_pipeline_integration > 1 || d_shard) d_frames = d_frames_sync.data();
+            if (shard_streaming()) {
+                if (d_batch_fill == 0) {  // ... and a new exchange: the next pinned frame slot of the sharded handle
+                    if (!d_shard_stream) {
+                        chk(mi355_xengine_shard_create((int)d_shard_ids.size(), d_shard_ids.data(), d_npol, d_num_inputs, d_num_channels, d_integration,
+                                                       d_shard_windows, &d_shard_stream), "mi355_xengine_shard_create");
+                        d_result_batch.resize((size_t)d_shard_windows * d_matrix_len);
+                    }
+                    if (mi355_xengine_shard_pending(d_shard_stream) == 2) collect_shard();
+                    void *fb = nullptr;
+                    chk(mi355_xengine_shard_acquire(d_shard_stream, &fb), "mi355_xengine_shard_acquire");
+                    d_batch_base = (char *)fb;
+                    d_batch_first.clear();
+                }
+                d_frames = d_batch_base + (size_t)d_batch_fill * d_in_bytes;
+            } else if (d_pipeline_integration > 1 || d_shard) d_frames = d_frames_sync.data();
             else {
                 if (mi355_xengine_pending(d_h) == 2) collect_one();  // previous result goes out before the swap (:1070-1094)
                 void *fb = nullptr;
@@ -467,10 +527,17 @@ public:
         d_frame_counter += n;
         if (d_tracker == d_integration) {
             const long first = d_frame_counter - d_integration;
-            if (d_shard && d_pipeline_integration <= 1) {
-                // every device takes its antenna group over its own link, the devices turn the corner and correlate their channel slabs
-                chk(mi355_xengine_shard_xcorrelate(d_shard, d_frames, d_result.data(), 0), "mi355_xengine_shard_xcorrelate");
-                deliver(d_result.data(), first);
+            if (shard_streaming()) {
+                // every device takes its antenna group over its own link out of the pinned slot (asynchronous uploads on the ranks' streams), the
+                // devices turn the corner and correlate their channel slabs, d_shard_windows windows per exchange; one exchange stays in flight
+                // under the gather of the next (the reference overlaps with a worker thread, lib/clXEngine_impl.cc:1234-1299)
+                d_batch_first.push_back(first);
+                if (++d_batch_fill == d_shard_windows) {
+                    chk(mi355_xengine_shard_submit_acquired(d_shard_stream), "mi355_xengine_shard_submit_acquired");
+                    d_shard_pending_first.push_back(d_batch_first);
+                    d_batch_fill = 0;
+                    if (mi355_xengine_shard_pending(d_shard_stream) == 2) collect_shard();
+                }
             } else if (d_pipeline_integration > 1) {
                 // device "+=" into the running matrix, read back every pipeline_integration windows (:785-796,1250-1285)
                 if (d_shard) chk(mi355_xengine_shard_xcorrelate(d_shard, d_frames, d_accum.data(), 1), "mi355_xengine_shard_xcorrelate");

@@ -171,7 +171,7 @@ PYBIND11_MODULE(clenabled_python, m)
         .def("get_input_buffer_size", &clXEngine::get_input_buffer_size)
         .def("get_output_buffer_size", &clXEngine::get_output_buffer_size)
         .def("integrations_delivered", &clXEngine::integrations_delivered)
-        .def("set_shard_devices", &clXEngine::set_shard_devices, py::arg("device_ids"))  // not in the reference: several devices behind one block
+        .def("set_shard_devices", &clXEngine::set_shard_devices, py::arg("device_ids"), py::arg("windows_per_exchange") = 4)  // not in the reference: several devices behind one block
         .def("shard_devices", &clXEngine::shard_devices)
         .def("synchronized", &clXEngine::synchronized)
         .def("general_work", &call_general_work<clXEngine>, py::arg("noutput_items"), py::arg("input_items"), py::arg("output_items"))

@@ -318,6 +318,19 @@ int mi355_xengine_shard_synchronize(mi355_xengine_shard *h);
 /* host form: `windows` windows in the reference's layout [window][t][station][chan][pol] -> [window][chan][baseline][pol^2]; every rank
  * copies its antenna group over its own host link and its slab back; blocking (lib/clXEngine_impl.h:179-201 over `world` devices) */
 int mi355_xengine_shard_xcorrelate(mi355_xengine_shard *h, const void *in_host, void *out_host, int accumulate);
+/* Streaming host form -- what a block that gathers frames all the time uses; the sharded counterpart of mi355_xengine_acquire / submit_acquired /
+ * wait, i.e. of the reference's pinned frame buffers (lib/clXEngine_impl.cc:325-362) and worker thread (:1234-1299).  acquire(): a PINNED buffer of
+ * input_bytes() = `windows` integration windows in the reference's frame layout, to be filled by the caller (mi355_xengine_gather writes this
+ * layout); submit_acquired(): per rank, on the rank's own stream, the asynchronous upload of its antenna group out of that buffer (W host links at
+ * once), exchange, correlation, download of its slab into a pinned result -- enqueue only; wait(): blocks for the OLDEST exchange, writes `windows`
+ * matrices [window][chan][baseline][pol^2].  Two exchanges may be in flight (MI355_ERR_STATE beyond that), so the gather and upload of exchange
+ * k+1 overlap the devices' work on exchange k. */
+int mi355_xengine_shard_windows(const mi355_xengine_shard *h);
+size_t mi355_xengine_shard_input_bytes(const mi355_xengine_shard *h);
+int mi355_xengine_shard_acquire(mi355_xengine_shard *h, void **frame_buffer);
+int mi355_xengine_shard_submit_acquired(mi355_xengine_shard *h);
+int mi355_xengine_shard_wait(mi355_xengine_shard *h, void *out_host);
+int mi355_xengine_shard_pending(const mi355_xengine_shard *h);
 /* Self-test of the IChar scale (lib/clXEngine_impl.cc:859-867: every sample / 127, i.e. every sum / 16129): the device evaluates the
  * single-precision form the matrix stores use and the double expression (float)((double)S * (1/127) * (1/127)) for EVERY sum S with
  * |S| <= 2^24 (the range the single-precision form is used in) and counts the sums where the two floats differ; *mismatches must be 0. */

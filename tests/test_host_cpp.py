@@ -123,12 +123,13 @@ def test_blocks_against_a_scheduler(gpu):
 def test_xengine_streaming_file_sink_and_json(gpu, tmp_path):
     """work_test() streaming with ragged calls: result-handler delivery, file sink with 1 MB rollover and
     JSON sidecars (format of lib/clXEngine_impl.cc:438-465), pipeline integration, and the same block over four ranks of the process
-    (clXEngine::set_shard_devices: matrices identical to the one-device block's, streaming entry included)."""
+    (clXEngine::set_shard_devices: matrices identical to the one-device block's; the streaming entry through the pinned frame slots, 1 / 3 / 4 windows per
+    exchange, a partial batch flushed by stop())."""
     import json
     import numpy as np
     r = subprocess.run([CLI, "--xengine-stream=%s" % tmp_path], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count(" ok") == 4 and "over 4 ranks of one process" in r.stdout, r.stdout
+    assert r.stdout.count(" ok") == 4 and "over 4 / 2 ranks of one process (set_shard_devices), streamed" in r.stdout, r.stdout
     N, F, T, nint = 8, 64, 16, 60
     block = F * (N * (N + 1) // 2)
     files = sorted(p for p in os.listdir(tmp_path) if not p.endswith(".json"))

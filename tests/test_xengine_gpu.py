@@ -667,8 +667,10 @@ def test_early_touches_of_the_slow_lines(gpu, oracle, N, F, T, npol, nint, W, sh
         assert np.array_equal(out.cpu().numpy().view(np.complex64).reshape(-1), ref), off
 
 
-def test_in_launch_reduction_recovers_from_failed_and_unfinished_launches(gpu, oracle, monkeypatch):
-    """The arrival words of the in-launch reduction must not carry anything from one launch into the next but the launch count:
+@pytest.mark.parametrize("route", ["k_xe_i8_lines<split>", "k_xe_i8_fused"])
+def test_in_launch_reduction_recovers_from_failed_and_unfinished_launches(gpu, oracle, monkeypatch, route):
+    """Both kernels that combine time ranges inside the launch (the whole-line kernel's tail, the default at these geometries, and the 32-byte-slice
+    kernel's, MI355_XE_NO_LINES_SPLIT=1).  The arrival words of the in-launch reduction must not carry anything from one launch into the next but the launch count:
     (1) a call that fails before its kernel is enqueued (MI355_XE_FAIL_LAUNCH stands in for a bad stream handle / an exhausted device) returns
     an error and the next call on the handle is bit-exact; (2) a launch whose workgroups of some row lines leave before they arrive
     (MI355_XE_DBG bits 16 / 17: the other units wait, give up or finish alone) leaves counts that are short of full behind -- the
@@ -676,6 +678,8 @@ def test_in_launch_reduction_recovers_from_failed_and_unfinished_launches(gpu, o
     Single windows on the handle's workspace (config 5's kernel instance: ping-pong schedule + reduce-scatter tail) and batches of
     windows on the batch workspace."""
     import torch
+    if route == "k_xe_i8_fused":
+        monkeypatch.setenv("MI355_XE_NO_LINES_SPLIT", "1")
     N, F, T = 64, 1024, 512  # 64 slices x 4 time ranges = 256 workgroups, 4 K blocks per range
     rng = np.random.default_rng(91)
     blk = _xe(gpu, gpu.DTYPE_BYTE, 1, N, F, T)
@@ -695,6 +699,8 @@ def test_in_launch_reduction_recovers_from_failed_and_unfinished_launches(gpu, o
             assert np.array_equal(out.cpu().numpy().view(np.complex64).reshape(-1), refs[k]), count[0]
 
     one(); one()
+    r = blk.last_route()
+    assert r["kernel"] == route and r["tsplit"] == 4 and r["in_launch_reduce"] == 1, r
     monkeypatch.setenv("MI355_XE_FAIL_LAUNCH", "1")
     with pytest.raises(gpu.Mi355Error):
         one()
@@ -723,6 +729,8 @@ def test_in_launch_reduction_recovers_from_failed_and_unfinished_launches(gpu, o
             assert np.array_equal(out.cpu().numpy().view(np.complex64).reshape(-1), refb)
 
     batch(); batch()
+    r = bb.last_route()
+    assert r["kernel"] == route and r["tsplit"] == 4 and r["in_launch_reduce"] == 1, r
     monkeypatch.setenv("MI355_XE_FAIL_LAUNCH", "1")
     with pytest.raises(gpu.Mi355Error):
         batch()

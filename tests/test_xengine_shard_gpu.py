@@ -68,3 +68,41 @@ def test_sharded_constructor_errors(gpu):
         gpu.clXEngineSharded([0, 0], 1, 16, 12, 32)          # 6 channels per rank: not whole 16-byte pieces
     with pytest.raises(gpu.Mi355Error):
         gpu.clXEngineSharded([0, 99], 1, 16, 64, 32)         # no such device
+
+
+@pytest.mark.parametrize("W,windows", [(1, 1), (2, 2), (4, 4), (8, 1)])
+def test_sharded_streaming_host_path(gpu, oracle, W, windows):
+    """acquire / submit_acquired / wait: the pinned frame slots of the handle, two exchanges in flight, results in submission order, bit exact; a
+    third submit without a wait is refused (MI355_ERR_STATE), as is a wait with nothing submitted."""
+    N, F, T = 64, 128, 64
+    rng = np.random.default_rng(W * 10 + windows)
+    sh = gpu.clXEngineSharded([0] * W, 1, N, F, T, windows)
+    per = sh.get_output_buffer_size()
+    assert sh.input_bytes() == windows * T * N * F * 2 and sh.pending() == 0
+    with pytest.raises(gpu.Mi355Error):
+        sh.wait(np.empty(windows * per, np.complex64))
+    rounds = 5
+    xs = [rng.integers(-128, 128, size=(windows, T, N, F, 1, 2), dtype=np.int64).astype(np.int8) for _ in range(rounds)]
+    refs = [np.concatenate([oracle.xengine_ichar(N, F, 1, T, x[w].reshape(-1), exact=True) for w in range(windows)]) for x in xs]
+    got = []
+    out = np.empty(windows * per, np.complex64)
+    for k in range(rounds):
+        if sh.pending() == 2:
+            sh.wait(out)
+            got.append(out.copy())
+        buf = sh.acquire()
+        buf[:] = xs[k].reshape(-1)
+        sh.submit_acquired()
+    assert sh.pending() == 2
+    with pytest.raises(gpu.Mi355Error):
+        sh.acquire()
+    while sh.pending():
+        sh.wait(out)
+        got.append(out.copy())
+    assert len(got) == rounds
+    for k in range(rounds):
+        assert np.array_equal(got[k], refs[k]), k
+    # the synchronous host call still works on the same handle afterwards
+    sh.xcorrelate(xs[0], out)
+    assert np.array_equal(out, refs[0])
+    sh.close()
