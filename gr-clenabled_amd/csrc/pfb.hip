@@ -838,7 +838,11 @@ int launch_fast(mi355_pfb *h, const void *in, void *out, hipStream_t st, int nst
     if constexpr ((M == 64 || M == 128 || M == 256) && PMAX <= 32) {
         static const bool wave = getenv("MI355_PFB_WAVE") ? atoi(getenv("MI355_PFB_WAVE")) != 0 : true;
         const long long n_in = (long long)buf_items - h->R + h->K;
-        if (wave && n_in * 8 < (4ll << 30) - (64 << 10)) return launch_wave<M, PMAX>(h, in, out, st, nsteps, buf_items);
+        // 32-bit byte offsets: the input as it is read (n_in * 8) and the OUTPUT including the rows the last group's unconditional, range-checked stores
+        // overshoot by (up to 16 rows + the reversed row order inside a group: < 32 rows of M channels) -- an offset that wrapped past 2^32 would be
+        // back in range and overwrite the first output rows
+        if (wave && n_in * 8 < (4ll << 30) - (64 << 10) && ((long long)nsteps + 32) * M * 8 < (4ll << 30))
+            return launch_wave<M, PMAX>(h, in, out, st, nsteps, buf_items);
     }
     constexpr int T = 4096 / M;
     int ngroups = (nsteps + T - 1) / T;

@@ -312,7 +312,10 @@ void *mi355_xengine_shard_stream(mi355_xengine_shard *h, int rank);     /* the r
 /* the rank's compute stream waits for everything enqueued so far on `stream` (hipStream_t of that device): the other way to order a producer */
 int mi355_xengine_shard_wait_stream(mi355_xengine_shard *h, int rank, void *stream);
 /* enqueue one exchange + correlation: frames_dev[r] / out_dev[r] live on device_ids[r] (out: windows x slab_items complex floats);
- * the frames must stay untouched until the next submit or synchronize on the handle returns */
+ * submit only ENQUEUES, so the packing copy of this exchange may still be reading frames_dev[r] after the next submit has returned: rewrite a
+ * rank's frames only from work enqueued on mi355_xengine_shard_stream(rank) AFTER that next submit (it is ordered behind the next correlation,
+ * which is behind this exchange's copies), or after mi355_xengine_shard_synchronize -- a producer on any other stream is not ordered behind the
+ * pack.  An error return may leave the exchange half enqueued: synchronize and resubmit. */
 int mi355_xengine_shard_submit_dev(mi355_xengine_shard *h, const void *const *frames_dev, void *const *out_dev, int accumulate);
 int mi355_xengine_shard_synchronize(mi355_xengine_shard *h);
 /* host form: `windows` windows in the reference's layout [window][t][station][chan][pol] -> [window][chan][baseline][pol^2]; every rank
