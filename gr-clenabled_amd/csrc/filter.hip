@@ -796,6 +796,96 @@ __global__ __launch_bounds__(kDlThreads) void k_fir_dec_lds(const c32 *__restric
     }
 }
 
+
+// Round 6: the same staging for EVEN decimations with everything 16 bytes wide.  k_fir_dec_lds spends its time in the staging loop (8-byte loads, one
+// LDS slot computed and written per sample: ~ 3.7 ps per input sample, "reads every sample once" at a third of the read bandwidth) and in a tap loop that
+// mixes scalar tap loads with the LDS reads on one counter.  Here a thread stages sample PAIRS (global_load_dwordx4, all of a thread's loads in
+// flight before the first LDS write), pair p sits at 16-byte unit p + p / 16 (an output's window starts on a pair since D is even; lanes D samples
+// apart then meet different bank quads for every even D), the taps sit in LDS as well, padded with zeros to a multiple of eight (broadcast reads),
+// and a tap step is eight samples: four 16-byte sample reads, two (real taps) or four (complex taps) 16-byte tap reads, 16 / 32 FMAs in the
+// reference's order (lib/fir_filter.cc:222-241: one running sum over k).  Samples past the input's end are staged as zeros.
+typedef float v4f_ __attribute__((ext_vector_type(4)));
+constexpr int kD2Threads = 256;
+__host__ __device__ inline int d2_unit(int p) { return p + (p >> 4); }
+
+template <bool CTAPS>
+__global__ __launch_bounds__(kD2Threads) void k_fir_dec2(const c32 *__restrict__ in, c32 *__restrict__ out, const float *__restrict__ taps_rev, int K, int KP,
+                                                         int decim, long long n_out, int tile_out, int tap_units /* 16-byte units of taps */)
+{
+    extern __shared__ __attribute__((aligned(16))) v4f_ d2_lds[];
+    v4f_ *const tl = d2_lds;                 // taps: KP floats (real) / 2 KP floats (complex), zero padded
+    v4f_ *const xl = d2_lds + tap_units;     // sample pairs
+    const int tid = threadIdx.x;
+    for (int i = tid; i < tap_units * 4; i += kD2Threads) {
+        const int nt = CTAPS ? 2 * K : K;
+        ((float *)tl)[i] = i < nt ? taps_rev[i] : 0.f;
+    }
+    const long long n_in = (n_out - 1) * decim + K;  // the samples the outputs need
+    const long long ntiles = (n_out + tile_out - 1) / tile_out;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long o0 = tile * tile_out, left = n_out - o0;
+        const int no = left < tile_out ? (int)left : tile_out;
+        const long long s0 = o0 * decim;  // even
+        const v4f_ *__restrict__ src = (const v4f_ *)(in + s0);
+        const int pairs = ((no - 1) * decim + KP + 1) / 2;
+        const long long avail = n_in - s0;  // valid samples from s0 on
+        __syncthreads();  // the previous tile's reads are done (and, the first time, nothing)
+        for (int p0 = 0; p0 < pairs; p0 += 8 * kD2Threads) {
+            v4f_ v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int p = p0 + j * kD2Threads + tid;
+                v[j] = (v4f_){0.f, 0.f, 0.f, 0.f};
+                if (p < pairs) {
+                    if (2LL * p + 1 < avail) v[j] = __builtin_nontemporal_load(src + p);
+                    else if (2LL * p < avail) {
+                        const c32 a = in[s0 + 2LL * p];
+                        v[j] = (v4f_){a.x, a.y, 0.f, 0.f};
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int p = p0 + j * kD2Threads + tid;
+                if (p < pairs) xl[d2_unit(p)] = v[j];
+            }
+        }
+        __syncthreads();
+        for (int o = tid; o < no; o += kD2Threads) {
+            const int pb = (o * decim) >> 1;
+            float ax = 0.f, ay = 0.f;
+            for (int k = 0; k < KP; k += 8) {
+                v4f_ sm[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) sm[j] = xl[d2_unit(pb + (k >> 1) + j)];
+                if constexpr (CTAPS) {
+                    v4f_ t[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) t[j] = tl[(k >> 1) + j];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        ax += t[j][0] * sm[j][0] - t[j][1] * sm[j][1];
+                        ay += t[j][0] * sm[j][1] + t[j][1] * sm[j][0];
+                        ax += t[j][2] * sm[j][2] - t[j][3] * sm[j][3];
+                        ay += t[j][2] * sm[j][3] + t[j][3] * sm[j][2];
+                    }
+                } else {
+                    const v4f_ t0 = tl[k >> 2], t1 = tl[(k >> 2) + 1];
+                    ax += t0[0] * sm[0][0]; ay += t0[0] * sm[0][1];
+                    ax += t0[1] * sm[0][2]; ay += t0[1] * sm[0][3];
+                    ax += t0[2] * sm[1][0]; ay += t0[2] * sm[1][1];
+                    ax += t0[3] * sm[1][2]; ay += t0[3] * sm[1][3];
+                    ax += t1[0] * sm[2][0]; ay += t1[0] * sm[2][1];
+                    ax += t1[1] * sm[2][2]; ay += t1[1] * sm[2][3];
+                    ax += t1[2] * sm[3][0]; ay += t1[2] * sm[3][1];
+                    ax += t1[3] * sm[3][2]; ay += t1[3] * sm[3][3];
+                }
+            }
+            out[o0 + o] = mk(ax, ay);
+        }
+    }
+}
+
 template <bool CTAPS>
 __global__ __launch_bounds__(256) void k_fir_td_dec(const c32 *__restrict__ in, c32 *__restrict__ out,
                                                     const float *__restrict__ taps_rev, int K, int decim, long long n_out)
@@ -1166,6 +1256,13 @@ int launch_filter(mi355_filter *h, size_t nout, const void *in, void *out, hipSt
     double r_lds = h->decim / ((h->complex_taps ? 0.00022 : 0.00017) * h->ntaps + 0.0037 * h->decim);
     if (r_all > (h->complex_taps ? 210.0 : 300.0)) r_all = h->complex_taps ? 210.0 : 300.0;
     if (r_lds > 250.0) r_lds = 250.0;
+    // even decimations of a 16-byte aligned input: the 16-byte-wide form k_fir_dec2 (round 6), time per output ~ 0.10 K + 1.5 D ps (65 taps 304 / 603 /
+    // 637 / 653 GS/s of input at D = 10 / 16 / 32 / 64, 200 taps 404 / 467 / 505 at D = 16 / 32 / 64, 400 taps 242 / 331 / 363)
+    const bool dec2_ok = h->decim % 2 == 0 && (reinterpret_cast<uintptr_t>(in) & 15u) == 0 && h->ntaps <= 1024 && !getenv("MI355_FIR_DEC2_OFF");
+    if (dec2_ok) {
+        r_lds = h->decim / ((h->complex_taps ? 0.00012 : 0.00010) * h->ntaps + 0.0015 * h->decim);
+        if (r_lds > 700.0) r_lds = 700.0;
+    }
     // (a decimation above eight filter lengths skips most of the input: neither of the two, the per-output kernel reads only what it needs --
     // 33 taps at D = 600: 277 GS/s of input with every undecimated output on the matrix cores, several thousand per output)
     // ... or the per-output kernel (k_fir_td_dec), which reads only the K samples an output needs: since its tap loop requests eight samples
@@ -1235,6 +1332,31 @@ int launch_filter(mi355_filter *h, size_t nout, const void *in, void *out, hipSt
         if (h->complex_taps) LAUNCH_TD(true);
         else LAUNCH_TD(false);
 #undef LAUNCH_TD
+    } else if (lds_ok && !per_output && dec2_ok) {
+        // even decimations, 16-byte aligned input: the 16-byte-wide form of the LDS-staged kernel
+        const int KP = (h->ntaps + 7) / 8 * 8;
+        const int tap_units = (h->complex_taps ? 2 : 1) * KP / 4;
+        static const int span_env = getenv("MI355_FIR_DEC2_SPAN") ? atoi(getenv("MI355_FIR_DEC2_SPAN")) : 0;
+        // samples staged per tile: 3072 (26 KiB: five or six workgroups per CU) up to 128 taps, 4096 above -- measured at 65 taps, D = 16: spans of
+        // 2048 / 3072 / 4096 / 6144 / 8192 samples 489 / 603 / 550 / 464 / 377 GS/s of input; 400 taps 194 / 223 / 242 / 168 / 194 -- and whole rounds of
+        // 256 outputs where a tile holds more than one (390 outputs per tile at D = 10 ran the second round of threads half empty)
+        const int span_max = span_env > 0 ? span_env : (h->ntaps <= 128 ? 3072 : 4096);
+        int tile_out = span_max > KP ? (span_max - KP) / h->decim + 1 : 1;
+        if (tile_out > 2048) tile_out = 2048;
+        if (tile_out > kD2Threads) tile_out = tile_out / kD2Threads * kD2Threads;
+        const int pairs = ((tile_out - 1) * h->decim + KP + 1) / 2;
+        const size_t smem = (size_t)(tap_units + d2_unit(pairs) + 2) * 16;
+        const long long ntiles = ((long long)nout + tile_out - 1) / tile_out;
+        const long long grid = ntiles < (long long)cus * 8 ? ntiles : (long long)cus * 8;
+#define LAUNCH_D2(CT)                                                                                                        \
+    do {                                                                                                                     \
+        MI355_HIP(hipFuncSetAttribute((const void *)k_fir_dec2<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL((k_fir_dec2<CT>), dim3((unsigned)grid), dim3(kD2Threads), smem, st, (const c32 *)in, (c32 *)out,   \
+                           h->d_taps_rev, h->ntaps, KP, h->decim, (long long)nout, tile_out, tap_units);                     \
+    } while (0)
+        if (h->complex_taps) LAUNCH_D2(true);
+        else LAUNCH_D2(false);
+#undef LAUNCH_D2
     } else if (lds_ok && !per_output) {
         // (a decimation far above the filter length skips most of the input: the per-output kernel reads only what it needs)
         int tile_out = (kDlSpan - h->ntaps) / h->decim + 1;
