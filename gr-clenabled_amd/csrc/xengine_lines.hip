@@ -36,8 +36,12 @@
 // from HBM, spread over twice the workgroups); any equal share of up to 64 units per workgroup (128 windows per launch: 34.4 us per window).
 // Early touches.  The diagonal groups of the other lines -- which wait for their partners 13 % of the time anyway -- request 16 bytes of every row of
 // the slow lines four K blocks ahead (one instruction per wave 0 ... 3 and K block): the slow lines' own workgroups then find them in the Infinity
-// Cache.  bench.py: 4 / 8 windows per launch 42.1 / 38.7 -> 36.9 / 37.1 us per window, 16 and 32 unchanged (35.4 / 35.6).  With the touches the
-// pacing is OFF by default: issuing them and waiting for their answers holds the diagonal groups back enough (35.9 / 35.5 / 35.2 / 35.1 us per window).
+// Cache.  bench.py: 4 / 8 windows per launch 42.1 / 38.7 -> 36.9 / 37.1 us per window, 16 and 32 unchanged (35.4 / 35.6).  Round 5 ran
+// unpaced with the touches on (35.9 / 35.5 / 35.2 / 35.1 us per window on its boxes); round 6 found processes in which the unpaced form runs every
+// launch at 37-41 us per window with 1.6 x the input read, and none for the form paced by 2: pacing by 2 half K blocks is the default again
+// (35.0 / 34.7 / 34.5 / 34.1 us per window at 4 / 8 / 16 / 32 windows per launch; see mi355_xe_lines_launch).
+// Time ranges (round 6, k_xe_i8_lines<true>): fewer units than compute units -- one window of BASELINE config 5, the reference's one-integration-per-call
+// shape -- cut into 2 or 4 ranges per (window, line, pair group) team, the ranges' exact partial sums combined by the kernel's own tail (see ln_body).
 #include "xengine_fused.h"
 
 #include <algorithm>
@@ -949,12 +953,16 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
             if ((n == 1 || n == 2 || n == 4) && a.pf_per <= 256) a.pf_dist = pf;
         }
     }
-    // pacing needs the pinned map, every workgroup resident (one per CU) and partners that can be told apart.  Default: OFF where the early touches
-    // are on -- the diagonal groups that would run ahead are the ones that issue the touches and wait for their answers, which holds them back enough
-    // (sustained, 4 / 8 / 16 / 32 windows per launch: 36.0 / 35.5 / 35.2 / 35.1 us per window unpaced against 37.4-38.5 / 36.7-37.1 / 36.2-36.8 / 35.9-36.5
-    // paced by 2 half K blocks; without touches AND without pacing 45 / 40 / 43-47 / 46-52) -- and 2 half K blocks where they are not
+    // pacing needs the pinned map, every workgroup resident (one per CU) and partners that can be told apart.  Default: 2 half K blocks, with or
+    // without the early touches.  Round 5 left it OFF where the touches are on (its boxes: 36.0 / 35.5 / 35.2 / 35.1 us per window unpaced at 4 / 8 /
+    // 16 / 32 windows per launch against 37.4-38.5 / 36.7-37.1 / 36.2-36.8 / 35.9-36.5 paced by 2); round 6's boxes say the opposite, and the unpaced
+    // form has a bad mode there that the paced one has not: some processes run every launch at 37-41 us per window with 1.6 x the input read
+    // (FETCH_SIZE 810-857 K KiB per 8 windows against 620-672 K) -- the diagonal groups drift ahead of their partners and out of the L2; paced by
+    // 0 / 1 / 2 / 3 / 4: 35.8 / 35.4 / 35.0 / 35.5 / 35.5 (4 windows), 35.3 / 35.1 / 34.7 / 35.1 / 35.2 (8), 35.0 / 34.8 / 34.5 / 34.7 / 34.8 (16),
+    // 37.1 / 34.1 / 34.1 / 34.8 / 35.3 (32), two processes alike (tools/r06_lines_pace_probe.py).  Bounded downside either way: pacing is the choice.
+    // (Without touches AND without pacing: 45 / 40 / 43-47 / 46-52.)
     {
-        const int pace = getenv("MI355_XE_LINES_PACE") ? atoi(getenv("MI355_XE_LINES_PACE")) : (a.pf_dist > 0 ? 0 : 2);
+        const int pace = getenv("MI355_XE_LINES_PACE") ? atoi(getenv("MI355_XE_LINES_PACE")) : 2;
         a.pace = (a.pinned && a.units / a.items <= cus && a.units / a.items <= 8192 && (long)a.items * a.steps < 2048 && !(a.dbg & 8)) ? pace : 0;
         if (a.tsplit > 1) a.pace = 0;  // (the tail keeps its two words where the partners' progress words land)
     }

@@ -214,10 +214,10 @@ def test_whole_line_kernel_config5_batch(gpu, oracle):
     out = torch.zeros(nint * per, 2, device="cuda")
     _run(gpu, blk, nint, x, out)
     # the route this call must take (a wrong one is 1.4 x slower and was once only visible in bench.py): the whole-line kernel, one launch, two units per
-    # workgroup on 256 workgroups, early touches of the slow lines on, no pacing
+    # workgroup on 256 workgroups, early touches of the slow lines on, the four workgroups of a line paced by two half K blocks
     r = blk.last_route()
     assert r["kernel"] == "k_xe_i8_lines" and r["launches"] == 1 and r["windows"] == nint and r["workgroups"] == 256 and r["units_per_workgroup"] == 2, r
-    assert r["touches"] > 0 and r["pace"] == 0 and r["tsplit"] == 1, r
+    assert r["touches"] > 0 and r["pace"] == 2 and r["tsplit"] == 1, r
     os.environ["MI355_XE_NO_LINES"] = "1"
     try:
         old = torch.zeros_like(out)

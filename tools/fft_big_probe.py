@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import __graft_entry__ as e
 pkg = e.load_package()
-N = 1 << 26
+N = 1 << int(os.environ.get("FFT_PROBE_LOG2", "26"))
 a = torch.randn(N, 2, device="cuda"); c = torch.empty_like(a)
 def ev(fn, it=10):
     for _ in range(2): fn()

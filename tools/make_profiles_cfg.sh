@@ -12,10 +12,10 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for k in $cfgs; do
   CMD="python $R/tools/baseline_cfg.py $k"
-  timeout 300 $CMD 40 > $O/${tag}_cfg${k}_run.json 2> $O/${tag}_cfg${k}_run.err
-  timeout 300 rocprofv3 --kernel-trace --stats -d $O/${tag}_cfg${k}_stats -o r -- $CMD 40 > $O/${tag}_cfg${k}_stats.log 2>&1
-  timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/${tag}_cfg${k}_fetch -o r -- $CMD 6 > $O/${tag}_cfg${k}_fetch.log 2>&1
-  timeout 300 rocprofv3 --pmc WRITE_SIZE -d $O/${tag}_cfg${k}_write -o r -- $CMD 6 > $O/${tag}_cfg${k}_write.log 2>&1
+  timeout 300 $CMD 100 > $O/${tag}_cfg${k}_run.json 2> $O/${tag}_cfg${k}_run.err
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/${tag}_cfg${k}_stats -o r -- $CMD 100 > $O/${tag}_cfg${k}_stats.log 2>&1
+  BASELINE_CFG_WARM_S=0.2 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/${tag}_cfg${k}_fetch -o r -- $CMD 10 > $O/${tag}_cfg${k}_fetch.log 2>&1
+  BASELINE_CFG_WARM_S=0.2 timeout 300 rocprofv3 --pmc WRITE_SIZE -d $O/${tag}_cfg${k}_write -o r -- $CMD 10 > $O/${tag}_cfg${k}_write.log 2>&1
   for p in stats fetch write; do
     python $R/tools/prof_summary.py $O/${tag}_cfg${k}_$p/r_results.db > $O/${tag}_cfg${k}_$p.txt 2>&1
     rm -rf $O/${tag}_cfg${k}_$p
