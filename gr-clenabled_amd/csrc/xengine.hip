@@ -1283,6 +1283,11 @@ int launch_xe_body(mi355_xengine *h, const void *in, void *out, int accumulate, 
     const size_t row_bytes = (g.mode == 0) ? (size_t)g.F * g.npol * 2 : (size_t)g.F * 2;
     // IChar with at most 64 rows and whole 128-byte lines per row: corner turn and correlation fused in one pass
     // (xengine_fused.hip); the tile workspace then only holds the int32 partial sums of the time ranges.
+    // 64 stations x two polarisations (128 rows -- the reference CLI's default geometry, lib/test-clxengine.cc:66): the whole-line kernel reads the
+    // reference layout directly, no corner-turn kernel and no tile workspace (k_xe_i8_lines<false, 2>)
+    if (g.mode == 0 && g.npol == 2 && !h->pad && (reinterpret_cast<uintptr_t>(in) & 15u) == 0 &&
+        mi355_xe_lines_ok(g.N, g.F, g.Fout, 2, g.T, stations_per_group, accumulate, 1, h->ctx->num_cus))
+        return mi355_xe_lines_launch(in, out, g.N, g.F, g.Fout, g.T, 0.007874015748031496063, st, stations_per_group, 1, h->ctx->num_cus, 1, nullptr, 0, nullptr, 2);
     if (g.mode == 0 && (reinterpret_cast<uintptr_t>(in) & 15u) == 0) {
         const XeFusedPlan fp = mi355_xe_fused_plan(g.N, g.F, g.Fout, g.npol, g.T, h->ctx->num_cus);
         if (fp.ok && (fp.part_bytes == 0 || (tiles && fp.part_bytes <= h->tile_bytes))) {

@@ -40,7 +40,8 @@ XeFusedPlan mi355_xe_fused_plan(int N, int F, int Fout, int npol, int T, int num
 int mi355_xe_fused_launch(const XeFusedPlan &p, const void *in, void *out, void *part, int N, int F, int Fout, int T, double kd,
                           int accumulate, hipStream_t st, int stations_per_group = 0, unsigned *epoch = nullptr, int nint = 1);
 
-// Whole-line form (xengine_lines.hip): 64 stations, one polarisation, rows of whole 128-byte lines, enough (window, line, pair group) units to fill
+// Whole-line form (xengine_lines.hip): 64 stations, one polarisation (or two -- 128 rows, the reference CLI's default, lib/test-clxengine.cc:66: lines
+// of 32 channels, eight pair groups per line; launch with npol = 2), rows of whole 128-byte lines, enough (window, line, pair group) units to fill
 // the device without time ranges.  mi355_xe_fused_launch routes to it where mi355_xe_lines_ok says so (MI355_XE_NO_LINES=1: never).
 bool mi355_xe_lines_ok(int N, int F, int Fout, int npol, int T, int stations_per_group, int accumulate, int nint, int cus);
 // Fewer units than compute units (one window of BASELINE config 5 -- the reference's xcorrelate(char*, XComplex*) shape, lib/clXEngine_impl.h:184-201): the
@@ -49,4 +50,4 @@ bool mi355_xe_lines_ok(int N, int F, int Fout, int npol, int T, int stations_per
 // mi355_xe_fused_plan sizes when its tsplit equals this one).  *epoch: the workspace's launch counter, advanced once the kernel is enqueued.
 int mi355_xe_lines_split(int N, int F, int Fout, int npol, int T, int stations_per_group, int accumulate, int nint, int cus);
 int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int T, double kd, hipStream_t st, int stations_per_group, int nint, int cus,
-                          int tsplit = 1, void *part = nullptr, size_t flag_offset = 0, unsigned *epoch = nullptr);
+                          int tsplit = 1, void *part = nullptr, size_t flag_offset = 0, unsigned *epoch = nullptr, int npol = 1);

@@ -86,6 +86,7 @@ struct LnArgs {
     // time ranges (k_xe_i8_lines<true>): a (window, line, pair group) TEAM of tsplit workgroups, one per time range, whose exact int32 partial matrices are
     // combined inside the launch (ln_tail).  part: the teams' inboxes; flags: two banks of flag_bank 8-byte arrival words, one per team:
     // {arrival count (high 32 bits) | launch tag << 4 | give-up bits (low)}; launch e counts in bank e % 2 and clears the other bank's word
+    int npol;  // 2: k_xe_i8_lines<false, 2> -- 64 stations x two polarisations, a line = 32 channels x {X, Y}, eight pair groups per line
     int tsplit;
     unsigned char *part;
     unsigned long long *flags;
@@ -214,13 +215,14 @@ __device__ __forceinline__ LnUnit ln_map_unit(const LnArgs &a, int n)
 {
     LnUnit u;
     int combo;
-    if (a.pinned) {  // the four groups of a (line, window) on one XCD, next to each other in dispatch order
+    const int gb = a.npol == 2 ? 3 : 2;  // log2(pair groups per line)
+    if (a.pinned) {  // the four (two polarisations: eight) groups of a (line, window) on one XCD, next to each other in dispatch order
         const int xcd = n & 7, within = n >> 3;
-        u.grp = within & 3;
-        combo = xcd + 8 * (within >> 2);
+        u.grp = within & ((1 << gb) - 1);
+        combo = xcd + 8 * (within >> gb);
     } else {
-        u.grp = n & 3;
-        combo = n >> 2;
+        u.grp = n & ((1 << gb) - 1);
+        combo = n >> gb;
     }
     u.col = combo % a.ncols;
     u.win = combo / a.ncols;
@@ -236,9 +238,22 @@ __device__ __forceinline__ LnUnit ln_map_unit(const LnArgs &a, int n)
 }
 
 // DIAG: groups A / B (row tiles x < y; pairs xx, yx, yy); otherwise C / D (row tile ra against row tiles 0 and 1)
-template <bool DIAG, bool SPLIT> __device__ __forceinline__ void ln_body(const LnArgs &a, unsigned char *lds, const int grp)
+// NP == 2 (two polarisations, 64 stations): a line is 32 channels x {X, Y} x {I, Q}, so a wave's 16-byte piece is FOUR channels and the operand
+// X[u][c] is channel u, polarisation c.  The 128 rows (station, polarisation) make eight row tiles but only four STATION tiles have to be loaded:
+//   DIAG groups 0 / 1: station tiles (0, 1) / (2, 3); per station tile s the pairs (sX, sX), (sY, sY) -- diagonal, one combined accumulator each --
+//                      and (sY, sX): the single-polarisation body with "channel ch" = (u, c) for the diagonal sets and the pair "yx" re-aimed at
+//                      (sY, sX) of station tile x (even ch) and y (odd ch)
+//   other groups 2 .. 7: station tile pairs (1,0) (2,0) (2,1) (3,0) (3,1) (3,2): rows a, columns b, all four polarisation products;
+//                      accumulator sets 2 p2 / 2 p2 + 1 = re / im against column polarisation p2, "channel ch" = (u, row polarisation)
+// Every group loads 32 stations x 32 frames per K block (four sub-stages): 256 station rows per frame and line, eight groups per line.
+template <bool DIAG, bool SPLIT, int NP> __device__ __forceinline__ void ln_body(const LnArgs &a, unsigned char *lds, const int grp)
 {
-    constexpr int NRT = DIAG ? 2 : 3, NS = 2 * NRT;
+    static_assert(NP == 1 || !SPLIT, "time ranges: one polarisation only");
+    // who issues the early touches of the slow lines: the groups with time to spare -- one polarisation: the two diagonal groups of a line (four
+    // sub-stages per K block against six); two polarisations: the six station-tile pairs (32 products per wave and K block against 72)
+    constexpr bool TOUCHER = NP == 2 ? !DIAG : DIAG;
+    constexpr int TPL = NP == 2 ? 6 : 2;  // touchers per line
+    constexpr int NRT = (DIAG || NP == 2) ? 2 : 3, NS = 2 * NRT;
     const unsigned lds0 = (unsigned)(size_t)lds;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -246,7 +261,9 @@ template <bool DIAG, bool SPLIT> __device__ __forceinline__ void ln_body(const L
     const int grid = (int)gridDim.x;
     const size_t row_bytes = (size_t)a.row_stride, t_stride = (size_t)a.ng * row_bytes;
     // row tiles in load order
-    const int rt0 = DIAG ? 2 * grp : grp, rt1 = DIAG ? 2 * grp + 1 : 0, rt2 = 1;  // (DIAG: grp 0 -> 0, 1; grp 1 -> 2, 3.  else: grp 2 / 3 -> 2 / 3, then 0, 1)
+    // (DIAG: grp 0 -> 0, 1; grp 1 -> 2, 3.  else: grp 2 / 3 -> 2 / 3, then 0, 1; two polarisations: grp 2 .. 7 -> (1,0) (2,0) (2,1) (3,0) (3,1) (3,2))
+    const int pa = grp - 2, pr = pa < 1 ? 1 : pa < 3 ? 2 : 3;
+    const int rt0 = DIAG ? 2 * grp : (NP == 2 ? pr : grp), rt1 = DIAG ? 2 * grp + 1 : (NP == 2 ? pa - pr * (pr - 1) / 2 : 0), rt2 = 1;
 
     // ---- requests.  Wave w issues the chunks of frame octet w / 2 and stations 8 (w % 2) .. + 7 of the row tile: one instruction = one station's
     // line for 8 frames.  Address = (uniform) unit, row tile, station, K block, half + (per lane) frame and piece.
@@ -266,9 +283,9 @@ template <bool DIAG, bool SPLIT> __device__ __forceinline__ void ln_body(const L
         hb0 = half_base(rt0);
         hb1 = half_base(rt1);
         hb2 = half_base(rt2);
-        if constexpr (DIAG) {
+        if constexpr (TOUCHER) {
             pf_on = a.pf_dist > 0 && !((a.pf_mask >> u.col) & 1u);
-            pf_first = (__builtin_popcount(~a.pf_mask & ((1u << u.col) - 1u)) * 2 + grp) * a.pf_per;  // this workgroup among the touchers of its window
+            pf_first = (__builtin_popcount(~a.pf_mask & ((1u << u.col) - 1u)) * TPL + (NP == 2 ? grp - 2 : grp)) * a.pf_per;  // this workgroup among the touchers of its window
             pf_win = a.in + (size_t)u.win * a.in_window;
             if constexpr (SPLIT) pf_win += (size_t)u.q * (size_t)(32 * a.steps) * t_stride;  // (touches stay inside the own time range; ng == 64 there)
         }
@@ -295,7 +312,7 @@ template <bool DIAG, bool SPLIT> __device__ __forceinline__ void ln_body(const L
         // early touches: wave j, at the K block's j-th sub-stage, one instruction = up to 64 (row, slow line) items of the K block pf_dist further on.
         // (In front of the sub-stage's own requests: older than they are, so the waits that count them have seen it land -- like wave 0's poll; a
         // touch that takes long holds up a diagonal group, which has the time.)
-        if constexpr (DIAG) {
+        if constexpr (TOUCHER) {
             if (pf_on && wave == j) {
                 const int k = wave * 64 + lane, i = pf_first + k;
                 const bool mine = k < a.pf_per && i < a.pf_items;
@@ -432,7 +449,11 @@ template <bool DIAG, bool SPLIT> __device__ __forceinline__ void ln_body(const L
     // item I of an off-diagonal pair's list (rows XA, columns XB), accumulator sets KR (re) and KR + 1 (im)
     auto off_item = [&](auto kr, const v4i (&XA)[kLnU][2], const v4i (&XB)[kLnU][2], auto ic) {
         constexpr int KR = decltype(kr)::value, I = decltype(ic)::value, ty = I / kLnCh, ch = I % kLnCh;
-        const v4i &xa = XA[ch >> 1][ch & 1], &xb = XB[ch >> 1][ch & 1];
+        // (two polarisations, diagonal groups -- called with XA = station tile y, XB = station tile x: rows = polarisation Y, columns = polarisation X of
+        // ONE station tile and channel ch / 2, x for even ch, y for odd ch)
+        constexpr bool D2 = DIAG && NP == 2;
+        const v4i &xa = D2 ? ((ch & 1) ? XA[ch >> 1][1] : XB[ch >> 1][1]) : XA[ch >> 1][ch & 1];
+        const v4i &xb = D2 ? ((ch & 1) ? XA[ch >> 1][0] : XB[ch >> 1][0]) : XB[ch >> 1][ch & 1];
         if constexpr (ty == 0) ln_mm<ln_areg(KR, ch)>(xa, xb);
         else if constexpr (ty == 1) ln_mm<ln_areg(KR + 1, ch)>(xa, swapped(xb));
         else ln_mm<ln_areg(KR + 1, ch)>(xa, ones);
@@ -497,6 +518,22 @@ template <bool DIAG, bool SPLIT> __device__ __forceinline__ void ln_body(const L
             __hip_atomic_fetch_add(rs_lds + ch * 64, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
+    // two polarisations, station tile pair (a, b): the last sub-stage of b completes channel u (both polarisations) of X1, whose eight products
+    // against X0 follow at once: rows (a, p1), columns (b, p2), re into set 2 p2 and im' into set 2 p2 + 1 of "channel" 2 u + p1
+    auto perms_with_off2 = [&]() {
+        ln_sfor<0, kLnU>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            perm_unit(X1, u, 1);
+            ln_sfor<0, 4>([&](auto qc) {
+                constexpr int p2 = decltype(qc)::value >> 1, p1 = decltype(qc)::value & 1;
+                ln_mm<ln_areg(2 * p2, 2 * u + p1)>(X0[u][p1], X1[u][p2]);
+            });
+            ln_sfor<0, 4>([&](auto qc) {
+                constexpr int p2 = decltype(qc)::value >> 1, p1 = decltype(qc)::value & 1;
+                ln_mm<ln_areg(2 * p2 + 1, 2 * u + p1)>(X0[u][p1], swapped(X1[u][p2]));
+            });
+        });
+    };
     // (a list = 3 x 8 = 24 items; half a list per sub-stage of x, 20 of the pair xx under the first sub-stage of y and its last 4 in front of the second)
     struct Cum24 { static constexpr int at(int u) { constexpr int c[5] = {0, 4, 7, 10, 12}; return c[u]; } };
     struct Cum40 { static constexpr int at(int u) { constexpr int c[5] = {0, 6, 11, 16, 20}; return c[u]; } };
@@ -534,6 +571,21 @@ template <bool DIAG, bool SPLIT> __device__ __forceinline__ void ln_body(const L
                 front(m + 3, 3, false);
                 diag_range(K0{}, X0, C40{}, C48{});
                 perms_with_off(X1, K2{}, X0, K1{});
+                m += 4;
+            } else if constexpr (NP == 2) {
+                // X0 = station tile a (rows), X1 = station tile b (columns)
+                front(m, 0, drain);
+#pragma unroll
+                for (int u = 0; u < kLnU; u++) perm_unit(X0, u, 0);
+                front(m + 1, 1, false);
+#pragma unroll
+                for (int u = 0; u < kLnU; u++) perm_unit(X0, u, 1);
+                row_sums();
+                front(m + 2, 2, false);
+#pragma unroll
+                for (int u = 0; u < kLnU; u++) perm_unit(X1, u, 0);
+                front(m + 3, 3, false);
+                perms_with_off2();
                 m += 4;
             } else {
                 // X0 = row tile a, X1 = row tile 0, then 1; accumulator sets 0 / 1 = re / im of (a, 0), 2 / 3 of (a, 1): each pair channel by channel
@@ -782,6 +834,89 @@ template <bool DIAG, bool SPLIT> __device__ __forceinline__ void ln_body(const L
                     }
                 }
             }
+        } else if constexpr (NP == 2) {
+            // ---- two polarisations: [chan][baseline][XX, XY, YX, YY] (first letter: the polarisation of station s1 >= s2, lib/clXEngine_impl.cc:786-808).
+            // A lane holds element (i = 4 g + reg, j = r) of all four products of a station pair: 32 contiguous bytes per baseline, two 16-byte stores,
+            // sixteen lanes a 512-byte run.
+            auto store4 = [&](c32 *dst, const int (&re)[4], const int (&im)[4], bool small, bool on) {
+                float w[8];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    w[2 * q] = small ? ln_scale127_small(re[q]) : (float)((double)re[q] * a.kd * a.kd);  // (the oracle's expression, rounded once)
+                    w[2 * q + 1] = small ? ln_scale127_small(im[q]) : (float)((double)im[q] * a.kd * a.kd);
+                }
+                if (a.dbg & 2) { if (re[0] == 0x12345678 && im[1] == 0x7654321) out_w[lane].x = w[0]; return; }
+                if (on) {
+                    const v4f q0 = (v4f){w[0], w[1], w[2], w[3]}, q1 = (v4f){w[4], w[5], w[6], w[7]};
+                    __builtin_memcpy((void *)dst, &q0, 16);
+                    __builtin_memcpy((void *)(dst + 2), &q1, 16);
+                }
+            };
+            auto transposed = [&](const v4i &C) {  // C[i][j] -> C[j][i] through this wave's scratch (same wave: no barrier)
+#pragma unroll
+                for (int k = 0; k < 4; k++) tile[(4 * gg + k) * 20 + rr] = C[k];
+                return *(const v4i *)(tile + rr * 20 + 4 * gg);
+            };
+            ln_sfor<0, kLnU>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                const int f = un.col * 32 + wave * kLnU + u;
+                if constexpr (DIAG) {
+                    ln_sfor<0, 2>([&](auto sc) {
+                        constexpr int S2 = decltype(sc)::value;  // 0: station tile x (rt0), 1: y (rt1)
+                        const int bt = S2 ? rt1 : rt0;
+                        const v4i cxx = ln_acc_read4<ln_areg(S2, 2 * u)>(), cyy = ln_acc_read4<ln_areg(S2, 2 * u + 1)>();
+                        const v4i yre = ln_acc_read4<ln_areg(2, 2 * u + S2)>(), yim = ln_acc_read4<ln_areg(3, 2 * u + S2)>();
+                        const v4i txx = transposed(cxx), tyy = transposed(cyy), tre = transposed(yre), tim = transposed(yim);
+                        int re[4][4], im[4][4];
+                        unsigned mag = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            re[k][0] = (cxx[k] + txx[k]) >> 1; im[k][0] = (cxx[k] - txx[k]) >> 1;  // XX: re symmetric, im antisymmetric (exact halves)
+                            re[k][1] = tre[k];                 im[k][1] = -tim[k];                  // XY[i][j] = conj(YX[j][i])
+                            re[k][2] = yre[k];                 im[k][2] = yim[k];                   // YX
+                            re[k][3] = (cyy[k] + tyy[k]) >> 1; im[k][3] = (cyy[k] - tyy[k]) >> 1;  // YY
+#pragma unroll
+                            for (int q = 0; q < 4; q++) mag |= ln_mag_bits(re[k][q]) | ln_mag_bits(im[k][q]);
+                        }
+                        const bool small = a.k127 && ln_all_small(mag);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int i = 4 * gg + k, s1 = bt * 16 + i;
+                            store4(out_w + ((size_t)f * nb + (s1 * (s1 + 1) / 2 + bt * 16 + rr)) * 4, re[k], im[k], small, rr <= i);
+                        }
+                    });
+                } else {
+                    // rows (a, p1) of the station tile pair: the sum over the four frame groups of station i's I bytes, per row polarisation
+                    int corr[2][4];
+#pragma unroll
+                    for (int p1 = 0; p1 < 2; p1++) {
+                        int v = rs_lds[(2 * u + p1) * 64];
+                        v += __shfl_xor(v, 16);
+                        v += __shfl_xor(v, 32);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) corr[p1][k] = __shfl(v, 4 * gg + k);
+                    }
+                    int re[4][4], im[4][4];
+                    unsigned mag = 0;
+                    ln_sfor<0, 4>([&](auto qc) {
+                        constexpr int q = decltype(qc)::value, p1 = q >> 1, p2 = q & 1;
+                        const v4i vr = ln_acc_read4<ln_areg(2 * p2, 2 * u + p1)>(), vi = ln_acc_read4<ln_areg(2 * p2 + 1, 2 * u + p1)>();
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            re[k][q] = vr[k];
+                            im[k][q] = vi[k] + corr[p1][k];
+                            mag |= ln_mag_bits(re[k][q]) | ln_mag_bits(im[k][q]);
+                        }
+                    });
+                    const bool small = a.k127 && ln_all_small(mag);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int s1 = rt0 * 16 + 4 * gg + k;
+                        store4(out_w + ((size_t)f * nb + (s1 * (s1 + 1) / 2 + rt1 * 16 + rr)) * 4, re[k], im[k], small, true);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);  // (one channel's values at a time)
+            });
         } else {
             ln_sfor<0, kLnCh>([&](auto chc) {
                 constexpr int ch = decltype(chc)::value;
@@ -820,7 +955,7 @@ template <bool DIAG, bool SPLIT> __device__ __forceinline__ void ln_body(const L
 }
 
 // SPLIT: time ranges, combined inside the launch (its own kernel: with both endings in one kernel the loop's register allocation suffers)
-template <bool SPLIT> __global__ __launch_bounds__(kLnThreads) void k_xe_i8_lines(LnArgs a)
+template <bool SPLIT, int NP = 1> __global__ __launch_bounds__(kLnThreads) void k_xe_i8_lines(LnArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     if (a.ts && threadIdx.x == 0) a.ts[(size_t)blockIdx.x * 8] = wall_clock64();
@@ -840,8 +975,8 @@ template <bool SPLIT> __global__ __launch_bounds__(kLnThreads) void k_xe_i8_line
         const int m = (a.dbg >> 16) & 3;
         if (m && ((m == 1) != (u0.q == 0))) return;
     }
-    if (grp < 2) ln_body<true, SPLIT>(a, lds, grp);
-    else ln_body<false, SPLIT>(a, lds, grp);
+    if (grp < 2) ln_body<true, SPLIT, NP>(a, lds, grp);
+    else ln_body<false, SPLIT, NP>(a, lds, grp);
     if (a.ts && threadIdx.x == 0) a.ts[(size_t)blockIdx.x * 8 + 1] = wall_clock64();
 }
 
@@ -854,17 +989,20 @@ bool mi355_xe_lines_ok(int N, int F, int Fout, int npol, int T, int stations_per
 {
     if (getenv("MI355_XE_NO_LINES")) return false;
     const int ng = (stations_per_group > 0 && stations_per_group < N) ? stations_per_group : N;
-    if (npol != 1 || N != 64 || F % 64 != 0 || Fout != F || T % 32 != 0 || T < 32 || T > 16384 || accumulate || ng % 8 != 0) return false;
-    const long units = (long)(nint > 0 ? nint : 1) * (F / 64) * 4;
+    // (two polarisations: lines of 32 channels, eight pair groups per line -- k_xe_i8_lines<false, 2>; MI355_XE_NO_LINES2=1: never)
+    if ((npol != 1 && npol != 2) || N != 64 || F % (64 / npol) != 0 || Fout != F || T % 32 != 0 || T < 32 || T > 16384 || accumulate || ng % 8 != 0) return false;
+    if (npol == 2 && getenv("MI355_XE_NO_LINES2")) return false;
+    const int G = npol == 2 ? 8 : 4;  // pair groups per line
+    const long units = (long)(nint > 0 ? nint : 1) * (F / (64 / npol)) * G;
     // MI355_XE_LINES_MIN_UNITS (test switch): any unit count.  Otherwise: enough units to fill the device and a multiple of 32 (the pinned map, which
     // the pacing of a line's four workgroups needs) that splits into equal shares of at most MI355_XE_LINES_MAX_ITEMS (default 64) units per workgroup
     // over a grid that is a multiple of 32 and at least 7/8 of the CUs (6 or 10 windows of config 5 would run on 192 / 160 workgroups) (measured at config 5, windows per launch 4 / 8 / 16: 180 / 350 / 637 us against 204 / 397 / 780 for the
     // 32-byte-slice kernel: the more units per workgroup, the smaller the share of the last units' matrix stores, which nothing overlaps)
-    if (getenv("MI355_XE_LINES_MIN_UNITS")) return units >= atoi(getenv("MI355_XE_LINES_MIN_UNITS")) && units % 4 == 0;
-    if (units < cus || units % 32 != 0) return false;
+    if (getenv("MI355_XE_LINES_MIN_UNITS")) return units >= atoi(getenv("MI355_XE_LINES_MIN_UNITS")) && units % G == 0;
+    if (units < cus || units % (8 * G) != 0) return false;
     const long max_items = getenv("MI355_XE_LINES_MAX_ITEMS") ? atol(getenv("MI355_XE_LINES_MAX_ITEMS")) : 64;
     for (long items = (units + cus - 1) / cus; items <= max_items; items++)
-        if (units % items == 0 && (units / items) % 32 == 0) return (units / items) * 8 >= (long)cus * 7;  // (the share mi355_xe_lines_launch will find:
+        if (units % items == 0 && (units / items) % (8 * G) == 0) return (units / items) * 8 >= (long)cus * 7;  // (the share mi355_xe_lines_launch will find:
     return false;                                                                                     //  on at least 7/8 of the CUs, or the other kernel is faster)
 }
 
@@ -888,10 +1026,12 @@ int mi355_xe_lines_split(int N, int F, int Fout, int npol, int T, int stations_p
 }
 
 int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int T, double kd, hipStream_t st, int stations_per_group, int nint, int cus,
-                          int tsplit, void *part, size_t flag_offset, unsigned *epoch)
+                          int tsplit, void *part, size_t flag_offset, unsigned *epoch, int npol)
 {
     LnArgs a;
-    a.tsplit = tsplit > 1 ? tsplit : 1;
+    a.npol = npol == 2 ? 2 : 1;
+    const int G = a.npol == 2 ? 8 : 4;
+    a.tsplit = (tsplit > 1 && a.npol == 1) ? tsplit : 1;
     a.part = (unsigned char *)part;
     a.flags = (unsigned long long *)((unsigned char *)part + flag_offset);
     a.epoch = (tsplit > 1 && epoch) ? *epoch + 1u : 1u;  // (committed only once the kernel is enqueued)
@@ -901,11 +1041,11 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
     a.out = (c32 *)out;
     a.Fout = Fout;
     a.T = T;
-    a.ncols = F / 64;
-    a.row_stride = F * 2;
+    a.ncols = F / (64 / a.npol);
+    a.row_stride = F * 2 * a.npol;
     a.ng = (stations_per_group > 0 && stations_per_group < N) ? stations_per_group : N;
     const int nw = nint > 0 ? nint : 1;
-    a.units = nw * a.ncols * 4 * a.tsplit;
+    a.units = nw * a.ncols * G * a.tsplit;
     a.steps = T / (32 * a.tsplit);
     a.flag_bank = (unsigned)(nw * a.ncols * 4);
     {
@@ -916,7 +1056,7 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
     // reference layout: [window][t][station]; group-major: [group][window][t][station in group]
     a.in_window = (size_t)T * a.ng * a.row_stride;
     a.in_group = (size_t)nw * T * a.ng * a.row_stride;
-    a.out_window = (size_t)Fout * ((size_t)N * (N + 1) / 2);
+    a.out_window = (size_t)Fout * ((size_t)N * (N + 1) / 2) * a.npol * a.npol;
     a.kd = kd;
     a.k127 = (kd == 0.007874015748031496063 && !getenv("MI355_XE_SCALE_F64")) ? 1 : 0;
     a.dbg = getenv("MI355_XE_DBG") ? atoi(getenv("MI355_XE_DBG")) : 0;
@@ -924,8 +1064,8 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
     static std::atomic<unsigned> launch_seq{0};
     a.tag = (launch_seq.fetch_add(1u) + 1u) & 0xfffffu;
     // persistent form: units / grid units per workgroup; the grid a multiple of 32 (pinned map: a workgroup keeps its XCD and group) or of 4
-    a.pinned = (a.units % 32 == 0) ? 1 : 0;
-    const int quantum = a.pinned ? 32 : 4;
+    a.pinned = (a.units % (8 * G) == 0) ? 1 : 0;
+    const int quantum = a.pinned ? 8 * G : G;
     int items = (a.units + cus - 1) / cus;
     while (items < a.units && (a.units % items != 0 || (a.units / items) % quantum != 0)) items++;
     if (a.units % items != 0 || (a.units / items) % quantum != 0) items = a.units / quantum;  // (one workgroup quantum: always divides)
@@ -946,7 +1086,7 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
                     a.pf_lines |= (unsigned)l << (8 * n);
                     n++;
                 }
-            const int touchers = (a.ncols - n) * 2;  // the diagonal groups of the other lines
+            const int touchers = (a.ncols - n) * (a.npol == 2 ? 6 : 2);  // the diagonal groups (two polarisations: the station-tile pairs) of the other lines
             a.pf_items = 32 * 64 * n;
             a.pf_per = (a.pf_items + touchers - 1) / touchers;
             a.pf_lg = n == 1 ? 0 : n == 2 ? 1 : 2;
@@ -965,6 +1105,7 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
         const int pace = getenv("MI355_XE_LINES_PACE") ? atoi(getenv("MI355_XE_LINES_PACE")) : 2;
         a.pace = (a.pinned && a.units / a.items <= cus && a.units / a.items <= 8192 && (long)a.items * a.steps < 2048 && !(a.dbg & 8)) ? pace : 0;
         if (a.tsplit > 1) a.pace = 0;  // (the tail keeps its two words where the partners' progress words land)
+        if (a.npol == 2) a.pace = 0;   // (teams of eight: not paced)
     }
     static std::atomic<unsigned long long> attr_devs{0};  // (per device: a function's attributes belong to the device that is current when they are set)
     {
@@ -974,24 +1115,26 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
         if (!(attr_devs.load(std::memory_order_relaxed) & bit)) {
             MI355_HIP(hipFuncSetAttribute((const void *)k_xe_i8_lines<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLnLds));
             MI355_HIP(hipFuncSetAttribute((const void *)k_xe_i8_lines<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLnLds));
+            MI355_HIP(hipFuncSetAttribute((const void *)k_xe_i8_lines<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLnLds));
             attr_devs.fetch_or(bit, std::memory_order_relaxed);
         }
     }
     const unsigned grid = (unsigned)(a.units / a.items);
     a.grid = (int)grid;
-    a.rot = (a.pinned && a.items > 1 && (grid / 4) % (unsigned)a.ncols == 0) ? (getenv("MI355_XE_LINES_ROT") ? atoi(getenv("MI355_XE_LINES_ROT")) : 1) : 0;
+    a.rot = (a.pinned && a.items > 1 && (grid / G) % (unsigned)a.ncols == 0) ? (getenv("MI355_XE_LINES_ROT") ? atoi(getenv("MI355_XE_LINES_ROT")) : 1) : 0;
     // MI355_XE_FAIL_LAUNCH (test switch): fail where a bad stream handle or an exhausted device would -- nothing enqueued, an error returned
     if (a.tsplit > 1 && getenv("MI355_XE_FAIL_LAUNCH")) {
         mi355_set_error("whole-line X-engine launch failed (MI355_XE_FAIL_LAUNCH)");
         return MI355_ERR_HIP;
     }
-    mi355_xe_route_set(a.tsplit > 1 ? "k_xe_i8_lines<split>" : "k_xe_i8_lines", nw, (int)grid, a.items, a.tsplit, a.tsplit > 1 ? 1 : 0, a.pf_dist, a.pace);
+    mi355_xe_route_set(a.npol == 2 ? "k_xe_i8_lines<2 pol>" : a.tsplit > 1 ? "k_xe_i8_lines<split>" : "k_xe_i8_lines", nw, (int)grid, a.items, a.tsplit, a.tsplit > 1 ? 1 : 0, a.pf_dist, a.pace);
     if (getenv("MI355_XE_TS")) {  // tuning aid: one synchronous launch with start / end stamps per workgroup
         unsigned long long *d_ts = nullptr;
         MI355_HIP(hipMalloc(&d_ts, (size_t)grid * 64));
         MI355_HIP(hipMemsetAsync(d_ts, 0, (size_t)grid * 64, st));
         a.ts = d_ts;
-        if (a.tsplit > 1) hipLaunchKernelGGL(k_xe_i8_lines<true>, dim3(grid), dim3(kLnThreads), kLnLds, st, a);
+        if (a.npol == 2) hipLaunchKernelGGL((k_xe_i8_lines<false, 2>), dim3(grid), dim3(kLnThreads), kLnLds, st, a);
+        else if (a.tsplit > 1) hipLaunchKernelGGL(k_xe_i8_lines<true>, dim3(grid), dim3(kLnThreads), kLnLds, st, a);
         else hipLaunchKernelGGL(k_xe_i8_lines<false>, dim3(grid), dim3(kLnThreads), kLnLds, st, a);
         MI355_HIP(hipGetLastError());
         if (a.tsplit > 1 && epoch) *epoch = a.epoch;
@@ -1004,7 +1147,9 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
         double end_by_grp[4] = {0, 0, 0, 0}, end_by_col[64] = {0}, last = 0;
         int n_grp[4] = {0, 0, 0, 0}, n_col[64] = {0};
         for (unsigned b = 0; b < grid; b++) {
-            const int within = a.pinned ? (int)(b >> 3) : (int)b, grp = within & 3, combo = a.pinned ? (int)((b & 7) + 8 * (within >> 2)) : (int)(b >> 2);
+            const int gbits = a.npol == 2 ? 3 : 2;
+            const int within = a.pinned ? (int)(b >> 3) : (int)b, grp = (within & ((1 << gbits) - 1)) & 3,
+                      combo = a.pinned ? (int)((b & 7) + 8 * (within >> gbits)) : (int)(b >> gbits);
             const double e = (double)(h[8 * b + 1] - t0) * 0.01;
             end_by_grp[grp] += e; n_grp[grp]++;
             end_by_col[(combo % a.ncols) & 63] += e; n_col[(combo % a.ncols) & 63]++;
@@ -1036,7 +1181,7 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
         for (int ty = 0; ty < 2; ty++) {
             double w = 0, b1 = 0, pc = 0, dur = 0; int n = 0;
             for (unsigned b = 0; b < grid; b++) {
-                const int within = a.pinned ? (int)(b >> 3) : (int)b, grp = within & 3;
+                const int within = a.pinned ? (int)(b >> 3) : (int)b, grp = within & (a.npol == 2 ? 7 : 3);
                 if ((grp >> 1) != ty) continue;
                 w += (double)h[8 * b + 2]; b1 += (double)h[8 * b + 3]; pc += (double)h[8 * b + 4];
                 dur += (double)(h[8 * b + 1] - h[8 * b]) * 0.01; n++;
@@ -1046,7 +1191,8 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
         }
         return MI355_OK;
     }
-    if (a.tsplit > 1) hipLaunchKernelGGL(k_xe_i8_lines<true>, dim3(grid), dim3(kLnThreads), kLnLds, st, a);
+    if (a.npol == 2) hipLaunchKernelGGL((k_xe_i8_lines<false, 2>), dim3(grid), dim3(kLnThreads), kLnLds, st, a);
+    else if (a.tsplit > 1) hipLaunchKernelGGL(k_xe_i8_lines<true>, dim3(grid), dim3(kLnThreads), kLnLds, st, a);
     else hipLaunchKernelGGL(k_xe_i8_lines<false>, dim3(grid), dim3(kLnThreads), kLnLds, st, a);
     MI355_HIP(hipGetLastError());
     if (a.tsplit > 1 && epoch) *epoch = a.epoch;

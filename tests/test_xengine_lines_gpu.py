@@ -341,3 +341,79 @@ def test_config5_one_and_two_windows_take_the_time_range_form(gpu):
             finally:
                 os.environ.pop("MI355_XE_NO_LINES", None)
             assert torch.equal(out, old), (nint, rep)
+
+
+# ---- two polarisations (k_xe_i8_lines<false, 2>): 64 stations x {X, Y} = 128 rows, the reference CLI's default geometry (lib/test-clxengine.cc:66)
+def _xe2(gpu, F, T):
+    return gpu.clXEngine(*GPU_ARGS, False, gpu.DTYPE_BYTE, 2, 64, gpu.CLXCORR_TRIANGULAR_ORDER, 0, F, T, [])
+
+
+@pytest.mark.parametrize("F,T", [(32, 32), (32, 96), (64, 64), (96, 160), (256, 32), (512, 64)])
+def test_two_polarisations_bit_exact(gpu, oracle, small_units, F, T):
+    """Every group type (the two diagonal groups, the six station-tile pairs), one and several K blocks, one line and many: bit exact against the oracle
+    ([chan][baseline][XX, XY, YX, YY], lib/clXEngine_impl.cc:786-808) and identical to the corner-turn + correlator path."""
+    import torch
+    N = 64
+    rng = np.random.default_rng(F + 11 * T)
+    w = rng.integers(-128, 128, size=(T, N, F, 2, 2), dtype=np.int64).astype(np.int8)
+    blk = _xe2(gpu, F, T)
+    ref = oracle.xengine_ichar(N, F, 2, T, w.reshape(-1), exact=True)
+    x = torch.from_numpy(w).cuda()
+    for rep in range(2):
+        out = torch.zeros(blk.get_output_buffer_size(), 2, device="cuda")
+        blk.xcorrelate_device(x, out)
+        torch.cuda.synchronize()
+        r = blk.last_route()
+        assert r["kernel"] == "k_xe_i8_lines<2 pol>", r
+        assert np.array_equal(out.cpu().numpy().view(np.complex64).reshape(-1), ref), rep
+    os.environ["MI355_XE_NO_LINES2"] = "1"
+    try:
+        old = torch.zeros_like(out)
+        blk.xcorrelate_device(x, old)
+        torch.cuda.synchronize()
+        assert blk.last_route()["kernel"] != "k_xe_i8_lines<2 pol>"
+    finally:
+        os.environ.pop("MI355_XE_NO_LINES2", None)
+    assert torch.equal(out, old)
+
+
+def test_two_polarisations_extremes_and_host_call(gpu, oracle, small_units):
+    """All -128 over 4096 frames (the combined accumulators of the diagonal pairs), alternating extremes; the host-pointer call takes the same route."""
+    import torch
+    N, F, T = 64, 32, 4096
+    blk = _xe2(gpu, F, T)
+    for fill in ("min", "alt"):
+        w = np.full((T, N, F, 2, 2), -128, np.int8)
+        if fill == "alt":
+            w[..., 1] = 127
+            w[::2, 1::2, :, 1] = np.array([127, -128], np.int8)
+        ref = oracle.xengine_ichar(N, F, 2, T, w.reshape(-1), exact=True)
+        out = np.empty(blk.get_output_buffer_size(), np.complex64)
+        blk.xcorrelate(w.reshape(-1), out)
+        assert blk.last_route()["kernel"] == "k_xe_i8_lines<2 pol>"
+        assert np.array_equal(out, ref), fill
+
+
+def test_two_polarisations_reference_cli_geometry(gpu):
+    """64 antennas x 2 polarisations x 1024 channels x 1024 frames, the default of the reference's timing tool (lib/test-clxengine.cc:66): 256
+    (line, pair group) units = one per compute unit, no corner-turn kernel; identical to the two-kernel path (which test_xengine_gpu.py pins on the oracle)."""
+    import torch
+    N, F, T = 64, 1024, 1024
+    g = torch.Generator(device="cuda").manual_seed(8)
+    x = torch.randint(-128, 128, (T, N, F, 2, 2), dtype=torch.int8, device="cuda", generator=g)
+    blk = _xe2(gpu, F, T)
+    out = torch.zeros(blk.get_output_buffer_size(), 2, device="cuda")
+    for rep in range(2):
+        out.zero_()
+        blk.xcorrelate_device(x, out)
+        torch.cuda.synchronize()
+    r = blk.last_route()
+    assert r["kernel"] == "k_xe_i8_lines<2 pol>" and r["workgroups"] == 256 and r["units_per_workgroup"] == 1, r
+    os.environ["MI355_XE_NO_LINES2"] = "1"
+    try:
+        old = torch.zeros_like(out)
+        blk.xcorrelate_device(x, old)
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("MI355_XE_NO_LINES2", None)
+    assert torch.equal(out, old)

@@ -10,7 +10,9 @@ pkg = e.load_package()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 N, t0, cases, lines_cases, bad = 64, time.time(), 0, 0, 0
-SW = ("MI355_XE_LINES_PACE", "MI355_XE_LINES_ROT", "MI355_XE_LINES_PF", "MI355_XE_LINES_PUB", "MI355_XE_LINES_MAX_ITEMS", "MI355_XE_LINES_MIN_UNITS")
+SW = ("MI355_XE_LINES_PACE", "MI355_XE_LINES_ROT", "MI355_XE_LINES_PF", "MI355_XE_LINES_PUB", "MI355_XE_LINES_MAX_ITEMS", "MI355_XE_LINES_MIN_UNITS",
+      "MI355_XE_LINES_SPLIT_ANY", "MI355_XE_TSPLIT", "MI355_XE_DBG", "MI355_XE_WAIT_US")
+routes = {}
 while time.time() - t0 < budget:
     F = 64 * rnd.choice([1, 2, 3, 4, 8, 8, 16, 16, 16, 32])
     T = 32 * rnd.choice([1, 2, 3, 5, 6, 8, 9, 16])
@@ -20,6 +22,17 @@ while time.time() - t0 < budget:
            "MI355_XE_LINES_PF": str(rnd.choice([0, 1, 2, 4, 4, 7])), "MI355_XE_LINES_PUB": str(rnd.choice([0, 1, 1, 1])),
            "MI355_XE_LINES_MAX_ITEMS": str(rnd.choice([2, 4, 16, 16, 64]))}
     if rnd.random() < 0.5: env["MI355_XE_LINES_MIN_UNITS"] = str(rnd.choice([4, 32, 64]))
+    # round 6: the time-range form (two or four ranges per team, combined inside the launch); now and then with every bounded wait run out at once
+    # (the last arriver of a team finishes what the others handed over) or with a short wait
+    if rnd.random() < 0.45:
+        S = rnd.choice([2, 4])
+        if T % (32 * S) == 0:
+            env.pop("MI355_XE_LINES_MIN_UNITS", None)
+            env["MI355_XE_LINES_SPLIT_ANY"] = "1"
+            env["MI355_XE_TSPLIT"] = str(S)
+            r = rnd.random()
+            if r < 0.15: env["MI355_XE_DBG"] = "512"
+            elif r < 0.3: env["MI355_XE_WAIT_US"] = str(rnd.choice([0, 1, 3]))
     for k in SW: os.environ.pop(k, None)
     os.environ.update(env)
     xe = pkg.clXEngine(1, 2, 0, 0, False, pkg.DTYPE_BYTE, 1, N, 1, 0, F, T, [])
@@ -30,6 +43,9 @@ while time.time() - t0 < budget:
     xe.xcorrelate_n_device(nint, x, a)
     if rnd.random() < 0.5: xe.xcorrelate_n_device(nint, x, a)  # (a second launch on the same handle: tags, banks)
     torch.cuda.synchronize()
+    rt = xe.last_route()["kernel"]
+    routes[rt] = routes.get(rt, 0) + 1
+    for k in ("MI355_XE_DBG", "MI355_XE_WAIT_US"): os.environ.pop(k, None)
     os.environ["MI355_XE_NO_LINES"] = "1"
     xe.xcorrelate_n_device(nint, x, b); torch.cuda.synchronize()
     os.environ.pop("MI355_XE_NO_LINES")
@@ -38,5 +54,5 @@ while time.time() - t0 < budget:
         bad += 1
         print("MISMATCH F=%d T=%d nint=%d %s" % (F, T, nint, env), flush=True)
     del xe, x, a, b
-print("xe_lines_fuzz: %d cases in %.0f s, %d mismatches" % (cases, time.time() - t0, bad))
+print("xe_lines_fuzz: %d cases in %.0f s, %d mismatches; routes of the first launch form: %s" % (cases, time.time() - t0, bad, routes))
 sys.exit(1 if bad else 0)
