@@ -612,6 +612,9 @@ template <bool DIAG, bool SPLIT, int NP> __device__ __forceinline__ void ln_body
         }
         // the products the loop carries: the pair yy of the last K block
         if constexpr (DIAG) diag_range(K1{}, X1, K0{}, C48{});
+        if constexpr (!SPLIT) {
+            if (a.ts && tid == 0 && unit == a.items - 1) a.ts[(size_t)blockIdx.x * 8 + 5] = wall_clock64();  // (tuning aid: the last unit's loop end)
+        }
         // ---- the unit's matrices: scale, scatter into [chan][baseline]
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");  // (the last products have left the pipeline before an accumulator is read)
         const LnUnit un = ln_map_unit(a, blockIdx.x + unit * grid);
@@ -852,11 +855,7 @@ template <bool DIAG, bool SPLIT, int NP> __device__ __forceinline__ void ln_body
                     __builtin_memcpy((void *)(dst + 2), &q1, 16);
                 }
             };
-            auto transposed = [&](const v4i &C) {  // C[i][j] -> C[j][i] through this wave's scratch (same wave: no barrier)
-#pragma unroll
-                for (int k = 0; k < 4; k++) tile[(4 * gg + k) * 20 + rr] = C[k];
-                return *(const v4i *)(tile + rr * 20 + 4 * gg);
-            };
+            if constexpr (DIAG) __syncthreads();  // every wave has read its last sub-stage: the ring is scratch now (the transposes below)
             ln_sfor<0, kLnU>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
                 const int f = un.col * 32 + wave * kLnU + u;
@@ -866,7 +865,17 @@ template <bool DIAG, bool SPLIT, int NP> __device__ __forceinline__ void ln_body
                         const int bt = S2 ? rt1 : rt0;
                         const v4i cxx = ln_acc_read4<ln_areg(S2, 2 * u)>(), cyy = ln_acc_read4<ln_areg(S2, 2 * u + 1)>();
                         const v4i yre = ln_acc_read4<ln_areg(2, 2 * u + S2)>(), yim = ln_acc_read4<ln_areg(3, 2 * u + S2)>();
-                        const v4i txx = transposed(cxx), tyy = transposed(cyy), tre = transposed(yre), tim = transposed(yim);
+                        // (the four transposes of a station tile and channel through four scratch tiles at once: one LDS round trip instead of four)
+                        int *const t4 = (int *)lds + wave * (4 * 320);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            t4[(4 * gg + k) * 20 + rr] = cxx[k];
+                            t4[320 + (4 * gg + k) * 20 + rr] = cyy[k];
+                            t4[640 + (4 * gg + k) * 20 + rr] = yre[k];
+                            t4[960 + (4 * gg + k) * 20 + rr] = yim[k];
+                        }
+                        const v4i txx = *(const v4i *)(t4 + rr * 20 + 4 * gg), tyy = *(const v4i *)(t4 + 320 + rr * 20 + 4 * gg),
+                                  tre = *(const v4i *)(t4 + 640 + rr * 20 + 4 * gg), tim = *(const v4i *)(t4 + 960 + rr * 20 + 4 * gg);
                         int re[4][4], im[4][4];
                         unsigned mag = 0;
 #pragma unroll
@@ -1168,6 +1177,17 @@ int mi355_xe_lines_launch(const void *in, void *out, int N, int F, int Fout, int
             for (int ty = 0; ty < 2; ty++) {
                 std::vector<double> v;
                 for (unsigned b = 0; b < grid; b++) if ((((a.pinned ? (b >> 3) : b) & 3) >> 1) == (unsigned)ty && h[8 * b + 5]) v.push_back((double)(h[8 * b + 5] - t0) * 0.01);
+                std::sort(v.begin(), v.end());
+                if (!v.empty()) fprintf(stderr, "  loop end, %s groups: %7.2f %7.2f %7.2f\n", ty ? "off-diagonal" : "diagonal", v.front(), v[v.size() / 2], v.back());
+            }
+        }
+        if (a.tsplit == 1) {  // the last unit's loop end, by group type (us after the first start: min / median / max)
+            for (int ty = 0; ty < 2; ty++) {
+                std::vector<double> v;
+                for (unsigned b = 0; b < grid; b++) {
+                    const int within = a.pinned ? (int)(b >> 3) : (int)b, grp = within & (a.npol == 2 ? 7 : 3);
+                    if ((grp < 2 ? 0 : 1) == ty && h[8 * b + 5]) v.push_back((double)(h[8 * b + 5] - t0) * 0.01);
+                }
                 std::sort(v.begin(), v.end());
                 if (!v.empty()) fprintf(stderr, "  loop end, %s groups: %7.2f %7.2f %7.2f\n", ty ? "off-diagonal" : "diagonal", v.front(), v[v.size() / 2], v.back());
             }
