@@ -35,6 +35,30 @@ while time.time() - t0 < budget:
             elif r < 0.3: env["MI355_XE_WAIT_US"] = str(rnd.choice([0, 1, 3]))
     for k in SW: os.environ.pop(k, None)
     os.environ.update(env)
+    if rnd.random() < 0.2:
+        # round 6: 64 stations x two polarisations (lines of 32 channels, eight pair groups per line) against corner turn + correlator
+        F2 = 32 * rnd.choice([1, 2, 3, 4, 8, 16, 32])
+        if T * N * F2 * 4 > 1 << 29: continue
+        for k in SW: os.environ.pop(k, None)
+        os.environ["MI355_XE_LINES_PF"] = env["MI355_XE_LINES_PF"]
+        os.environ["MI355_XE_LINES_MAX_ITEMS"] = env["MI355_XE_LINES_MAX_ITEMS"]
+        if rnd.random() < 0.8: os.environ["MI355_XE_LINES_MIN_UNITS"] = "8"
+        xe = pkg.clXEngine(1, 2, 0, 0, False, pkg.DTYPE_BYTE, 2, N, 1, 0, F2, T, [])
+        g = torch.Generator(device="cuda").manual_seed(cases)
+        x = torch.randint(-128, 128, (T, N, F2, 2, 2), dtype=torch.int8, device="cuda", generator=g)
+        a = torch.zeros(xe.get_output_buffer_size(), 2, device="cuda"); b = torch.zeros_like(a)
+        xe.xcorrelate_device(x, a); torch.cuda.synchronize()
+        rt = xe.last_route()["kernel"]
+        routes[rt] = routes.get(rt, 0) + 1
+        os.environ["MI355_XE_NO_LINES2"] = "1"
+        xe.xcorrelate_device(x, b); torch.cuda.synchronize()
+        os.environ.pop("MI355_XE_NO_LINES2")
+        cases += 1
+        if not torch.equal(a, b):
+            bad += 1
+            print("MISMATCH two polarisations F=%d T=%d %s" % (F2, T, dict(os.environ)), flush=True)
+        del xe, x, a, b
+        continue
     xe = pkg.clXEngine(1, 2, 0, 0, False, pkg.DTYPE_BYTE, 1, N, 1, 0, F, T, [])
     g = torch.Generator(device="cuda").manual_seed(cases)
     x = torch.randint(-128, 128, (nint, T, N, F, 1, 2), dtype=torch.int8, device="cuda", generator=g)
