@@ -800,17 +800,22 @@ __global__ __launch_bounds__(kDlThreads) void k_fir_dec_lds(const c32 *__restric
 // Round 6: the same staging for EVEN decimations with everything 16 bytes wide.  k_fir_dec_lds spends its time in the staging loop (8-byte loads, one
 // LDS slot computed and written per sample: ~ 3.7 ps per input sample, "reads every sample once" at a third of the read bandwidth) and in a tap loop that
 // mixes scalar tap loads with the LDS reads on one counter.  Here a thread stages sample PAIRS (global_load_dwordx4, all of a thread's loads in
-// flight before the first LDS write), pair p sits at 16-byte unit p + p / 16 (an output's window starts on a pair since D is even; lanes D samples
-// apart then meet different bank quads for every even D), the taps sit in LDS as well, padded with zeros to a multiple of eight (broadcast reads),
+// flight before the first LDS write), pair p sits at 16-byte unit p (+ p / 32 where D is a multiple of 8: dec2_pad_shift; an output's window starts on a
+// pair when D is even), the taps sit in LDS as well, padded with zeros to a multiple of eight (broadcast reads),
 // and a tap step is eight samples: four 16-byte sample reads, two (real taps) or four (complex taps) 16-byte tap reads, 16 / 32 FMAs in the
 // reference's order (lib/fir_filter.cc:222-241: one running sum over k).  Samples past the input's end are staged as zeros.
 typedef float v4f_ __attribute__((ext_vector_type(4)));
 constexpr int kD2Threads = 256;
-__host__ __device__ inline int d2_unit(int p) { return p + (p >> 4); }
+// pair p sits at 16-byte unit p + (p >> sh): which padding spreads a wave's reads over the banks depends on the lanes' stride (D / 2 units for even D, D
+// for odd D); sh = 31: none.  Chosen per decimation by the launcher (dec2_pad_shift).
+__host__ __device__ inline int d2_unit(int p, int sh) { return p + (p >> sh); }
 
-template <bool CTAPS>
+// ODD decimations: an output's window starts on the second sample of a pair for every other output; the outputs of a round of 256 are dealt so that
+// a wave's windows all start alike (waves 0, 1: even outputs, waves 2, 3: odd ones), the odd waves read five units per tap step and use them shifted by
+// one sample.  Tiles hold an even number of outputs, so a tile still starts on a pair.
+template <bool CTAPS, bool ODD>
 __global__ __launch_bounds__(kD2Threads) void k_fir_dec2(const c32 *__restrict__ in, c32 *__restrict__ out, const float *__restrict__ taps_rev, int K, int KP,
-                                                         int decim, long long n_out, int tile_out, int tap_units /* 16-byte units of taps */)
+                                                         int decim, long long n_out, int tile_out, int tap_units /* 16-byte units of taps */, int sh)
 {
     extern __shared__ __attribute__((aligned(16))) v4f_ d2_lds[];
     v4f_ *const tl = d2_lds;                 // taps: KP floats (real) / 2 KP floats (complex), zero padded
@@ -827,7 +832,7 @@ __global__ __launch_bounds__(kD2Threads) void k_fir_dec2(const c32 *__restrict__
         const int no = left < tile_out ? (int)left : tile_out;
         const long long s0 = o0 * decim;  // even
         const v4f_ *__restrict__ src = (const v4f_ *)(in + s0);
-        const int pairs = ((no - 1) * decim + KP + 1) / 2;
+        const int pairs = ((no - 1) * decim + KP + 1) / 2 + (ODD ? 1 : 0);
         const long long avail = n_in - s0;  // valid samples from s0 on
         __syncthreads();  // the previous tile's reads are done (and, the first time, nothing)
         for (int p0 = 0; p0 < pairs; p0 += 8 * kD2Threads) {
@@ -847,17 +852,28 @@ __global__ __launch_bounds__(kD2Threads) void k_fir_dec2(const c32 *__restrict__
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int p = p0 + j * kD2Threads + tid;
-                if (p < pairs) xl[d2_unit(p)] = v[j];
+                if (p < pairs) xl[d2_unit(p, sh)] = v[j];
             }
         }
         __syncthreads();
-        for (int o = tid; o < no; o += kD2Threads) {
+        for (int ob = 0; ob < no; ob += kD2Threads) {
+            const int o = ob + (ODD ? 2 * (tid & 127) + (tid >> 7) : tid);
+            if (o >= no) continue;
             const int pb = (o * decim) >> 1;
+            const bool shifted = ODD && (tid >> 7) != 0;  // (wave-uniform)
             float ax = 0.f, ay = 0.f;
             for (int k = 0; k < KP; k += 8) {
                 v4f_ sm[4];
+                if (shifted) {
+                    v4f_ un[5];
 #pragma unroll
-                for (int j = 0; j < 4; j++) sm[j] = xl[d2_unit(pb + (k >> 1) + j)];
+                    for (int j = 0; j < 5; j++) un[j] = xl[d2_unit(pb + (k >> 1) + j, sh)];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) sm[j] = (v4f_){un[j][2], un[j][3], un[j + 1][0], un[j + 1][1]};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) sm[j] = xl[d2_unit(pb + (k >> 1) + j, sh)];
+                }
                 if constexpr (CTAPS) {
                     v4f_ t[4];
 #pragma unroll
@@ -885,6 +901,11 @@ __global__ __launch_bounds__(kD2Threads) void k_fir_dec2(const c32 *__restrict__
         }
     }
 }
+
+// measured over D = 6 ... 100 (tools/r06_dec2_pad_probe.py, 65 taps): without padding the reads are conflict free or nearly so for every D that is not a
+// multiple of 8 (D = 10: 587 GS/s of input against 341 with one unit per 16, D = 15: 577 against 310); multiples of 8 need it (D = 16: 400 without,
+// 620-636 with; D = 32: 403 / 669) and one unit per 32 is the shift that is never bad there
+inline int dec2_pad_shift(int decim) { return decim % 8 == 0 ? 5 : 31; }
 
 template <bool CTAPS>
 __global__ __launch_bounds__(256) void k_fir_td_dec(const c32 *__restrict__ in, c32 *__restrict__ out,
@@ -1258,7 +1279,8 @@ int launch_filter(mi355_filter *h, size_t nout, const void *in, void *out, hipSt
     if (r_lds > 250.0) r_lds = 250.0;
     // even decimations of a 16-byte aligned input: the 16-byte-wide form k_fir_dec2 (round 6), time per output ~ 0.10 K + 1.5 D ps (65 taps 304 / 603 /
     // 637 / 653 GS/s of input at D = 10 / 16 / 32 / 64, 200 taps 404 / 467 / 505 at D = 16 / 32 / 64, 400 taps 242 / 331 / 363)
-    const bool dec2_ok = h->decim % 2 == 0 && (reinterpret_cast<uintptr_t>(in) & 15u) == 0 && h->ntaps <= 1024 && !getenv("MI355_FIR_DEC2_OFF");
+    const bool dec2_ok = (reinterpret_cast<uintptr_t>(in) & 15u) == 0 && h->ntaps <= 1024 && !getenv("MI355_FIR_DEC2_OFF") &&
+                         (h->decim % 2 == 0 || !getenv("MI355_FIR_DEC2_EVEN_ONLY"));
     if (dec2_ok) {
         r_lds = h->decim / ((h->complex_taps ? 0.00012 : 0.00010) * h->ntaps + 0.0015 * h->decim);
         if (r_lds > 700.0) r_lds = 700.0;
@@ -1344,18 +1366,22 @@ int launch_filter(mi355_filter *h, size_t nout, const void *in, void *out, hipSt
         int tile_out = span_max > KP ? (span_max - KP) / h->decim + 1 : 1;
         if (tile_out > 2048) tile_out = 2048;
         if (tile_out > kD2Threads) tile_out = tile_out / kD2Threads * kD2Threads;
-        const int pairs = ((tile_out - 1) * h->decim + KP + 1) / 2;
-        const size_t smem = (size_t)(tap_units + d2_unit(pairs) + 2) * 16;
+        if (h->decim % 2 && tile_out > 1) tile_out &= ~1;  // (odd decimations: tiles start on a sample pair)
+        const int pairs = ((tile_out - 1) * h->decim + KP + 1) / 2 + 1;
+        const int sh = getenv("MI355_FIR_DEC2_PAD") ? atoi(getenv("MI355_FIR_DEC2_PAD")) : dec2_pad_shift(h->decim);
+        const size_t smem = (size_t)(tap_units + d2_unit(pairs, sh) + 2) * 16;
         const long long ntiles = ((long long)nout + tile_out - 1) / tile_out;
         const long long grid = ntiles < (long long)cus * 8 ? ntiles : (long long)cus * 8;
-#define LAUNCH_D2(CT)                                                                                                        \
+#define LAUNCH_D2P(CT, OD)                                                                                                   \
     do {                                                                                                                     \
-        MI355_HIP(hipFuncSetAttribute((const void *)k_fir_dec2<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-        hipLaunchKernelGGL((k_fir_dec2<CT>), dim3((unsigned)grid), dim3(kD2Threads), smem, st, (const c32 *)in, (c32 *)out,   \
-                           h->d_taps_rev, h->ntaps, KP, h->decim, (long long)nout, tile_out, tap_units);                     \
+        MI355_HIP(hipFuncSetAttribute((const void *)k_fir_dec2<CT, OD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL((k_fir_dec2<CT, OD>), dim3((unsigned)grid), dim3(kD2Threads), smem, st, (const c32 *)in, (c32 *)out,   \
+                           h->d_taps_rev, h->ntaps, KP, h->decim, (long long)nout, tile_out, tap_units, sh);                 \
     } while (0)
+#define LAUNCH_D2(CT) do { if (h->decim % 2) LAUNCH_D2P(CT, true); else LAUNCH_D2P(CT, false); } while (0)
         if (h->complex_taps) LAUNCH_D2(true);
         else LAUNCH_D2(false);
+#undef LAUNCH_D2P
 #undef LAUNCH_D2
     } else if (lds_ok && !per_output) {
         // (a decimation far above the filter length skips most of the input: the per-output kernel reads only what it needs)

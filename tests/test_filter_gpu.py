@@ -303,3 +303,34 @@ def test_independent_scipy_cases(gpu, use_time):
     assert relerr(y, g["fa_y_lfilter"]) <= TOL
     gpu.clFilter(*GPU_ARGS, 1, lt, 1, 0, use_time).work(x.size, [_hist(x, 3001)], [y])
     assert relerr(y, g["fa_y_long"]) <= TOL
+
+
+@pytest.mark.parametrize("ntaps,decim,ctaps", [(65, 16, False), (65, 9, False), (77, 15, True), (200, 25, False), (33, 33, False), (129, 10, True), (1000, 21, False)])
+def test_lds_staged_decimators_agree(gpu, oracle, monkeypatch, ntaps, decim, ctaps):
+    """k_fir_dec2 (round 6: 16-byte staging and reads; even decimations, and odd ones with half of the waves reading shifted by a sample) against the oracle
+    and against k_fir_dec_lds (MI355_FIR_DEC2_OFF) on the device path, several tiles with a ragged last one."""
+    import torch
+    monkeypatch.setenv("MI355_FIR_DEC_KERNEL", "lds")
+    rng = np.random.default_rng(ntaps * 7 + decim)
+    nout = 40000 + 13
+    xh = crandn(rng, nout * decim + ntaps - 1)
+    if ctaps:
+        taps = (crandn(rng, ntaps) / np.sqrt(ntaps)).astype(np.complex64)
+        ref = oracle.fir_ccc(taps, xh, nout * decim)[::decim][:nout]
+        blk = gpu.clComplexFilter(*GPU_ARGS, decim, taps, 1, 0, use_time=True)
+    else:
+        taps = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+        ref = oracle.fir_ccf(taps, xh, nout * decim)[::decim][:nout]
+        blk = gpu.clFilter(*GPU_ARGS, decim, taps, 1, 0, True)
+    x = torch.from_numpy(xh.view(np.float32).reshape(-1, 2)).cuda()
+    y = torch.zeros(nout, 2, device="cuda")
+    blk.work_device(nout, [x], [y])
+    torch.cuda.synchronize()
+    got = y.cpu().numpy().view(np.complex64).reshape(-1)
+    assert relerr(got, ref) <= TOL
+    monkeypatch.setenv("MI355_FIR_DEC2_OFF", "1")
+    y2 = torch.zeros_like(y)
+    blk.work_device(nout, [x], [y2])
+    torch.cuda.synchronize()
+    assert relerr(y2.cpu().numpy().view(np.complex64).reshape(-1), ref) <= TOL
+    assert relerr(got, y2.cpu().numpy().view(np.complex64).reshape(-1)) <= 2e-6  # (same products, same order; the compiler may contract differently)
