@@ -1305,7 +1305,11 @@ int launch_filter(mi355_filter *h, size_t nout, const void *in, void *out, hipSt
     // one, ~ 14600 / K GS/s, below) unless one of the other two is predicted clearly ahead: at D = 8, 200 / 400 taps 107 / 60 -> 133 / 89 GS/s
     // of input LDS-staged, 33 taps 297 -> 334 per output
     const double r_inc = h->ntaps >= 96 && mf_ok ? r_all : (14600.0 / h->ntaps < 420.0 ? 14600.0 / h->ntaps : 420.0);
-    const bool early = h->decim >= 6 && h->decim <= dmax && h->ntaps >= 16 && (r_po > 1.05 * r_inc || (lds_ok && r_lds > 1.05 * r_inc));
+    // ... and decimations 3 ... 5 to k_fir_dec2 where it applies (round 6: 65 taps D = 3 / 4 / 5: 215 / 217 / 218 -> 231 / 299 / 343 GS/s of input; from
+    // 96 taps on only from D = 4: 200 taps 107 -> 140 / 160, 400 taps 60 -> 72 / 91; D = 2 stays: 207 against 207, 100 against 91)
+    const bool early2 = dec2_ok && lds_ok && h->ntaps >= 16 && h->decim <= dmax && h->decim >= (h->ntaps < 96 ? 3 : 4) && h->decim <= 5 && r_po < r_lds &&
+                        !getenv("MI355_FIR_DEC2_FROM_6");
+    const bool early = (h->decim >= 6 && h->decim <= dmax && h->ntaps >= 16 && (r_po > 1.05 * r_inc || (lds_ok && r_lds > 1.05 * r_inc))) || early2;
     const bool above = h->decim > dmax || early;
     const bool per_output = above && r_po >= (mf_ok ? r_all : 0.0) && r_po >= (lds_ok ? r_lds : 0.0) && !(h->ntaps < 16 && h->decim <= 64);
     const bool all_outputs_above_8 = h->decim > dmax && h->decim >= dl_min && r_all >= r_lds && !per_output;
