@@ -126,13 +126,25 @@ __device__ __forceinline__ float ln_scale127_small(int S)
 __device__ __forceinline__ unsigned ln_mag_bits(int v) { return (unsigned)(v + 0x1000000); }
 __device__ __forceinline__ bool ln_all_small(unsigned m) { return __builtin_amdgcn_ballot_w64((m >> 25) != 0u) == 0ull; }
 
-__device__ __forceinline__ void ln_dma16(const void *gsrc, unsigned lds_dst)
+// LEAN (the two-polarisation kernel only): m0 is written and NOT restored -- two scalar moves less per request, 32 per K block and wave; the scalar
+// unit is shared by the CU's eight waves and the loop's scalar instructions are most of its issue slots.  m0 is a reserved register to the compiler,
+// which neither tracks a write to it nor reads it in the code it generates for this file on gfx950 (LDS instructions need no m0 there; every other
+// user of m0 here is an asm statement that sets it itself): tests/test_isa_lines.py checks the built object for that.
+// The ONE-polarisation kernels keep the save and restore, the per-front timers and the guarded requests on purpose: on one box (tools/ab_lib.sh) they
+// are SLOWER without them -- 8 windows per launch 34.7 -> 37.0 us per window, two windows per call 45.6 -> 49.9 -- their diagonal groups (four
+// sub-stages per K block against six) gain most, run further ahead of their partners and the partners' re-reads miss the L2.  The two-polarisation
+// kernel, whose eight groups are alike, gains 6 % (106.2 -> 100.0 us per integration).
+template <bool LEAN> __device__ __forceinline__ void ln_dma16(const void *gsrc, unsigned lds_dst)
 {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
+    if constexpr (LEAN) {
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory");
+    } else {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(gsrc), "s"(lds_dst)
+                     : "memory");
+    }
 }
 
 
@@ -253,6 +265,11 @@ template <bool DIAG, bool SPLIT, int NP> __device__ __forceinline__ void ln_body
     // sub-stages per K block against six); two polarisations: the six station-tile pairs (32 products per wave and K block against 72)
     constexpr bool TOUCHER = NP == 2 ? !DIAG : DIAG;
     constexpr int TPL = NP == 2 ? 6 : 2;  // touchers per line
+    // Two polarisations: a straight-line loop.  Two younger sub-stages are ALWAYS in flight -- past the end of the stream the last sub-stage's rows are
+    // requested again, into the slot that has just been read for the last time -- so the wait is vmcnt(8) everywhere and the requests are
+    // unconditional (the run-time choice of the wait and the branch around every request were scalar instructions in the loop of eight waves that
+    // share one scalar unit); the drain behind another unit's matrix stores is done once, in front of the unit's K loop; no per-front timers.
+    constexpr bool STRAIGHT = NP == 2;
     constexpr int NRT = (DIAG || NP == 2) ? 2 : 3, NS = 2 * NRT;
     const unsigned lds0 = (unsigned)(size_t)lds;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -309,6 +326,9 @@ template <bool DIAG, bool SPLIT, int NP> __device__ __forceinline__ void ln_body
         const unsigned char *hb = i == 0 ? hb0 : i == 1 ? hb1 : hb2;
         iss_p0 = hb + (size_t)(32 * kb + 16 * h) * t_stride + lane_off;
         iss_dst0 = lds0 + (m & (kLnRing - 1)) * kLnSlot + ((wave >> 2) * 16 + (wave & 3) * 4) * kLnChunk;
+        if constexpr (STRAIGHT) {
+            if (a.dbg & 4) iss_p0 = a.in + (size_t)(lane & 7) * 16;  // (tuning aid "no input stream": every request the first line of four rows -- cache hits)
+        }
         // early touches: wave j, at the K block's j-th sub-stage, one instruction = up to 64 (row, slow line) items of the K block pf_dist further on.
         // (In front of the sub-stage's own requests: older than they are, so the waits that count them have seen it land -- like wave 0's poll; a
         // touch that takes long holds up a diagonal group, which has the time.)
@@ -319,7 +339,7 @@ template <bool DIAG, bool SPLIT, int NP> __device__ __forceinline__ void ln_body
                 const int which = i & ((1 << a.pf_lg) - 1), row = i >> a.pf_lg, t = row >> 6, st = row & 63;
                 const unsigned ln = (a.pf_lines >> (8 * which)) & 0xffu;
                 const unsigned char *p0 = pf_win + ((size_t)t * 64 + (size_t)st) * row_bytes + (size_t)ln * 128;
-                if (mine && kb + a.pf_dist < a.steps) ln_dma16(p0 + (size_t)(32 * (kb + a.pf_dist)) * 64 * row_bytes, lds0 + kLnTouch);
+                if (mine && kb + a.pf_dist < a.steps) ln_dma16<NP == 2>(p0 + (size_t)(32 * (kb + a.pf_dist)) * 64 * row_bytes, lds0 + kLnTouch);
                 // (time ranges: touching the K blocks nearer than the distance as well, at the range's start, measured 57.5 against 57.4 us: not done)
             }
         }
@@ -327,7 +347,8 @@ template <bool DIAG, bool SPLIT, int NP> __device__ __forceinline__ void ln_body
     // the wave's ii-th request of that sub-stage (one station's line of 8 frames).  The four requests of a sub-stage are issued one at a time
     // between the transposes: back to back, the eight waves' 32 instructions queue at the CU's address unit and every wave stands ~330 clocks
     auto issue_one = [&](int ii) {
-        if (iss_on && !(a.dbg & 4)) ln_dma16(iss_p0 + (size_t)ii * row_bytes, __builtin_amdgcn_readfirstlane(iss_dst0 + ii * kLnChunk));
+        if constexpr (STRAIGHT) ln_dma16<true>(iss_p0 + (size_t)ii * row_bytes, __builtin_amdgcn_readfirstlane(iss_dst0 + ii * kLnChunk));  // (unconditional: see front)
+        else if (iss_on && !(a.dbg & 4)) ln_dma16<false>(iss_p0 + (size_t)ii * row_bytes, __builtin_amdgcn_readfirstlane(iss_dst0 + ii * kLnChunk));
     };
 #pragma unroll
     for (int j = 0; j < 3; j++)
@@ -360,6 +381,12 @@ template <bool DIAG, bool SPLIT, int NP> __device__ __forceinline__ void ln_body
     //   front(m): wait until sub-stage m has landed, ONE barrier -- behind it every wave has also finished reading sub-stage m - 1, whose slot takes
     //             sub-stage m + 3 (requested piecemeal by the transposes that follow: issue_one) -- and the four 16-byte LDS reads of this lane
     auto front = [&](int m, int j, bool drain) {
+        if constexpr (STRAIGHT) {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __syncthreads();
+            if (m + 3 < total_sub) issue_prep(m + 3, (j + 3) % NS);
+            else iss_dst0 = lds0 + ((m + 3) & (kLnRing - 1)) * kLnSlot + ((wave >> 2) * 16 + (wave & 3) * 4) * kLnChunk;  // (the same rows once more)
+        } else {
         const int younger = total_sub - 1 - m;  // sub-stages requested after this one that may still be in flight (at most two)
         const unsigned long long c0 = a.ts ? __builtin_readcyclecounter() : 0;
         if (drain || younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -373,6 +400,7 @@ template <bool DIAG, bool SPLIT, int NP> __device__ __forceinline__ void ln_body
         }
         iss_on = m + 3 < total_sub;
         if (iss_on) issue_prep(m + 3, (j + 3) % NS);
+        }
         // ---- pacing.  Twice per K block (its first and its middle sub-stage) wave 0 publishes the half K blocks this workgroup has started and asks
         // for its partners' counts (three loads: older than the requests of sub-stage m + 3, so the vmcnt(8) of the front two sub-stages later has
         // seen them land); there, a workgroup more than `pace` half K blocks ahead of its slowest partner waits (bounded) -- the laggard's lines would
@@ -554,6 +582,9 @@ template <bool DIAG, bool SPLIT, int NP> __device__ __forceinline__ void ln_body
 #pragma unroll
             for (int ch = 0; ch < kLnCh; ch++) rs_lds[ch * 64] = 0;
         }
+        if constexpr (STRAIGHT) {
+            if (unit > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         for (int kb = 0; kb < a.steps; kb++) {
             // (the first wait of a unit that follows another one drains everything: that unit's matrix stores share the counter with the DMA and
             // complete out of order with it)
@@ -612,6 +643,9 @@ template <bool DIAG, bool SPLIT, int NP> __device__ __forceinline__ void ln_body
         }
         // the products the loop carries: the pair yy of the last K block
         if constexpr (DIAG) diag_range(K1{}, X1, K0{}, C48{});
+        if constexpr (STRAIGHT) {
+            if (unit == a.items - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the stream's trailing requests have landed: the ring may be reused)
+        }
         if constexpr (!SPLIT) {
             if (a.ts && tid == 0 && unit == a.items - 1) a.ts[(size_t)blockIdx.x * 8 + 5] = wall_clock64();  // (tuning aid: the last unit's loop end)
         }

@@ -60,11 +60,12 @@ def test_register_and_scratch_budget(device_object):
         f = {m.group(1): m.group(2) for m in re.finditer(r"\.(\w+):\s+(\S+)", ".agpr_count:" + blk)}
         kernels[f["name"]] = f
     lines = {k: v for k, v in kernels.items() if "k_xe_i8_lines" in k}
-    assert len(lines) == 2, list(kernels)
+    assert len(lines) == 3, list(kernels)  # plain, time ranges, two polarisations
     for name, f in lines.items():
         # all 128 accumulation registers + at most 128 vector registers (two waves per SIMD); a handful of spilled registers outside the K loop is
         # what the build has had since round 5 (12 / 48 bytes of scratch per lane) -- a jump means the allocator has started spilling in the loop
-        assert int(f["agpr_count"]) == 128 and int(f["vgpr_count"]) == 256, (name, f)
+        # (vgpr_count = vector + accumulation registers of a wave: at most 256 for two waves per SIMD; the two-polarisation kernel needs 244)
+        assert int(f["agpr_count"]) == 128 and 128 < int(f["vgpr_count"]) <= 256, (name, f)
         assert int(f["private_segment_fixed_size"]) <= 64 and int(f["vgpr_spill_count"]) <= 24, (name, f)
 
 
@@ -73,3 +74,19 @@ def test_the_flag_cannot_be_dropped_from_the_command_line():
     assert re.search(r"^build/xengine_lines\.o:\s*override CXXFLAGS \+= .*-amdgpu-spill-vgpr-to-agpr=0", mk, re.M), "target-specific flag must use `override`"
     out = subprocess.run(["make", "-n", "-B", "-C", CSRC, "CXXFLAGS=-O1", "build/xengine_lines.o"], capture_output=True, text=True).stdout
     assert "-amdgpu-spill-vgpr-to-agpr=0" in out, out[-500:]
+
+
+def test_only_the_lds_dma_statements_use_m0(device_object):
+    """ln_dma16 writes m0 without restoring it (two scalar moves less per request in the hot loop).  m0 is reserved to the compiler, which does not track
+    such a write: the object must therefore contain no instruction that READS m0 other than the save of the one asm statement that still restores it
+    (the progress-word poll), i.e. every mention of m0 is `s_mov_b32 m0, <sgpr>` or `s_mov_b32 <sgpr>, m0`."""
+    asm = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", device_object], check=True, capture_output=True, text=True).stdout
+    bad = []
+    for line in asm.splitlines():
+        code = line.split("//")[0]
+        if re.search(r"(?<![A-Za-z0-9_])m0(?![A-Za-z0-9_])", code):
+            parts = code.replace(",", " ").split()
+            ok = len(parts) == 3 and parts[0] == "s_mov_b32" and (parts[1] == "m0" or parts[2] == "m0")
+            if not ok:
+                bad.append(line.strip())
+    assert not bad, "\n".join(bad[:20])
