@@ -130,10 +130,9 @@ __device__ __forceinline__ bool ln_all_small(unsigned m) { return __builtin_amdg
 // unit is shared by the CU's eight waves and the loop's scalar instructions are most of its issue slots.  m0 is a reserved register to the compiler,
 // which neither tracks a write to it nor reads it in the code it generates for this file on gfx950 (LDS instructions need no m0 there; every other
 // user of m0 here is an asm statement that sets it itself): tests/test_isa_lines.py checks the built object for that.
-// The ONE-polarisation kernels keep the save and restore, the per-front timers and the guarded requests on purpose: on one box (tools/ab_lib.sh) they
-// are SLOWER without them -- 8 windows per launch 34.7 -> 37.0 us per window, two windows per call 45.6 -> 49.9 -- their diagonal groups (four
-// sub-stages per K block against six) gain most, run further ahead of their partners and the partners' re-reads miss the L2.  The two-polarisation
-// kernel, whose eight groups are alike, gains 6 % (106.2 -> 100.0 us per integration).
+// The DIAGONAL groups of the one-polarisation kernels keep the save and restore, the per-front timers and the guarded requests on purpose (see
+// STRAIGHT in ln_body): what matters there is that the four workgroups of a line walk together.  The two-polarisation kernel, whose eight groups
+// are alike, gains 6 % (106.2 -> 100.0 us per integration).
 template <bool LEAN> __device__ __forceinline__ void ln_dma16(const void *gsrc, unsigned lds_dst)
 {
     if constexpr (LEAN) {
@@ -269,7 +268,12 @@ template <bool DIAG, bool SPLIT, int NP> __device__ __forceinline__ void ln_body
     // requested again, into the slot that has just been read for the last time -- so the wait is vmcnt(8) everywhere and the requests are
     // unconditional (the run-time choice of the wait and the branch around every request were scalar instructions in the loop of eight waves that
     // share one scalar unit); the drain behind another unit's matrix stores is done once, in front of the unit's K loop; no per-front timers.
-    constexpr bool STRAIGHT = NP == 2;
+    // One polarisation: ONLY the off-diagonal groups (six sub-stages per K block: the ones that set the pace) run the straight-line loop; the diagonal
+    // groups (four) keep the guarded one on purpose.  With both lean the diagonal groups run further ahead and their partners' re-reads miss the L2
+    // (8 windows per launch 34.7 -> 37.0 us per window); with only the slower groups lean the four workgroups of a line walk closer together:
+    // 36.4 / 35.6 / 35.4 / 35.2 -> 35.1 / 34.2 / 33.6 / 34.1 us per window at 4 / 8 / 16 / 32 windows per launch (paced by 2; unpaced 40 / 38 / 37.5 / 38
+    // -> 35.9 / 34.3 / 34.3 / 34.6), one window per call 56.7 -> 55.0 (tools/ab_lib.sh, one box).
+    constexpr bool STRAIGHT = NP == 2 || !DIAG;
     constexpr int NRT = (DIAG || NP == 2) ? 2 : 3, NS = 2 * NRT;
     const unsigned lds0 = (unsigned)(size_t)lds;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -339,7 +343,7 @@ template <bool DIAG, bool SPLIT, int NP> __device__ __forceinline__ void ln_body
                 const int which = i & ((1 << a.pf_lg) - 1), row = i >> a.pf_lg, t = row >> 6, st = row & 63;
                 const unsigned ln = (a.pf_lines >> (8 * which)) & 0xffu;
                 const unsigned char *p0 = pf_win + ((size_t)t * 64 + (size_t)st) * row_bytes + (size_t)ln * 128;
-                if (mine && kb + a.pf_dist < a.steps) ln_dma16<NP == 2>(p0 + (size_t)(32 * (kb + a.pf_dist)) * 64 * row_bytes, lds0 + kLnTouch);
+                if (mine && kb + a.pf_dist < a.steps) ln_dma16<STRAIGHT>(p0 + (size_t)(32 * (kb + a.pf_dist)) * 64 * row_bytes, lds0 + kLnTouch);
                 // (time ranges: touching the K blocks nearer than the distance as well, at the range's start, measured 57.5 against 57.4 us: not done)
             }
         }
