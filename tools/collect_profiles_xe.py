@@ -26,7 +26,7 @@ f0, w0 = val_or(O + tag + "_xe_fetch.txt", K0, "FETCH_SIZE"), val_or(O + tag + "
 f1, w1 = val_or(O + tag + "_xe_fetch.txt", K1, "FETCH_SIZE"), val_or(O + tag + "_xe_write.txt", K1, "WRITE_SIZE")
 if f0 is not None:
     tot = (2 * f0 + w0) * 1024 / 1e6
-    traffic = "# config 5, one window per call: 2 x %.2f + %.2f KiB (ONE kernel, k_xe_i8_lines<true, 1>: whole-line requests, four time ranges per team, their partial sums exchanged and combined inside the launch) = %.1f MB = %.2f x the 151.3 MB algorithmic bytes at the L2's memory side (98 MB of it the exchange; round 5's 32-byte-slice kernel: 1.63 x)" % (f0, w0, tot, tot / 151.3)
+    traffic = "# config 5, one window per call: 2 x %.2f + %.2f KiB (ONE kernel, k_xe_i8_lines<true, 1>: whole-line requests, four time ranges per team, their partial sums exchanged and combined inside the launch) = %.1f MB = %.2f x the 151.3 MB algorithmic bytes at the L2's memory side (98 MB of it the exchange; round 5's 32-byte-slice kernel: 1.63 x).  NOTE: this command set launches the same kernel for other geometries too, the average mixes them -- config 5 alone, one launch size per command: profiles/%s_baseline_configs.txt (1.80 x)" % (f0, w0, tot, tot / 151.3, tag)
 elif f1 is not None:
     tot = (2 * f1 + w1) * 1024 / 1e6
     traffic = "# config 5: 2 x %.2f + %.2f KiB (ONE kernel: corner turn, correlation and the reduce-scatter of the four time ranges) = %.1f MB = %.2f x the 151.3 MB algorithmic bytes at the L2's memory side (the early touches of the slow lines count twice here, HBM reads them once: 1.50 x without them; round 3: 1.70 x, round 1: 2.78 x)" % (f1, w1, tot, tot / 151.3)
