@@ -1540,6 +1540,14 @@ static int xe_n_dev_launch(mi355_xengine *h, int nint, const void *in_dev, void 
 {
     const XeGeo &g = h->g;
     const bool grouped = stations_per_group > 0 && stations_per_group < g.N;
+    // 64 stations x two polarisations: all windows in ONE launch of the whole-line kernel, a workgroup's units back to back (a unit's matrix stores run
+    // under the next unit's first requests); no workspace
+    // (from four windows on -- 95.7 / 94.3 us per window at 4 / 8 windows per launch against 98.9 one launch per window, 102.8 at two per launch -- and for
+    // group-major input, whose windows a loop of launches cannot address)
+    if (h->data_type == MI355_DTYPE_BYTE && g.npol == 2 && (nint >= 4 || (grouped && nint > 1)) && !h->pad && (reinterpret_cast<uintptr_t>(in_dev) & 15u) == 0 &&
+        mi355_xe_lines_ok(g.N, g.F, g.Fout, 2, g.T, stations_per_group, accumulate, nint, h->ctx->num_cus))
+        return mi355_xe_lines_launch(in_dev, out_dev, g.N, g.F, g.Fout, g.T, 0.007874015748031496063, st, stations_per_group, nint, h->ctx->num_cus, 1, nullptr, 0,
+                                     nullptr, 2);
     // one launch for all windows: the fused IChar path (<= 64 rows, rows of whole 16-byte pieces, 16-byte aligned input)
     if (h->data_type == MI355_DTYPE_BYTE && !h->pad && (reinterpret_cast<uintptr_t>(in_dev) & 15u) == 0) {
         const XeFusedPlan fp = mi355_xe_fused_plan(g.N, g.F, g.Fout, g.npol, g.T, h->ctx->num_cus, nint);

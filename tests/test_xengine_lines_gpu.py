@@ -417,3 +417,27 @@ def test_two_polarisations_reference_cli_geometry(gpu):
     finally:
         os.environ.pop("MI355_XE_NO_LINES2", None)
     assert torch.equal(out, old)
+
+
+@pytest.mark.parametrize("F,T,nint,ng", [(32, 64, 3, 0), (64, 32, 8, 0), (256, 64, 4, 0), (64, 64, 2, 16)])
+def test_two_polarisations_several_windows_per_launch(gpu, oracle, small_units, F, T, nint, ng):
+    """nint windows of 64 stations x two polarisations in ONE launch (a workgroup runs its units back to back), reference layout and group-major:
+    every window bit exact against the oracle."""
+    import torch
+    N = 64
+    rng = np.random.default_rng(F + T + nint)
+    wins = rng.integers(-128, 128, size=(nint, T, N, F, 2, 2), dtype=np.int64).astype(np.int8)
+    blk = _xe2(gpu, F, T)
+    per = blk.get_output_buffer_size()
+    ref = np.concatenate([oracle.xengine_ichar(N, F, 2, T, wins[i].reshape(-1), exact=True) for i in range(nint)])
+    if ng:
+        W = N // ng
+        x = torch.from_numpy(np.ascontiguousarray(wins.reshape(nint, T, W, ng, F, 2, 2).transpose(2, 0, 1, 3, 4, 5, 6))).cuda()
+    else:
+        x = torch.from_numpy(wins).cuda()
+    out = torch.zeros(nint * per, 2, device="cuda")
+    _run(gpu, blk, nint, x, out, ng=ng)
+    r = blk.last_route()
+    one = nint >= 4 or ng  # (fewer windows in the reference layout: one launch per window is faster)
+    assert r["kernel"] == "k_xe_i8_lines<2 pol>" and r["launches"] == (1 if one else nint) and r["windows"] == (nint if one else 1), r
+    assert np.array_equal(out.cpu().numpy().view(np.complex64).reshape(-1), ref)

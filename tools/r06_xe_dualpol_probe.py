@@ -30,3 +30,16 @@ for name, env in (("whole-line kernel", {}), ("corner turn + correlator", {"MI35
     print("%-40s %s us per integration (%s)" % (name, " ".join("%.1f" % t for t in ts), xe.last_route()["kernel"]), flush=True)
 os.environ["MI355_XE_TS"] = "1"
 xe.xcorrelate_device(bufs[0], vis)
+os.environ.pop("MI355_XE_TS", None)
+per = xe.get_output_buffer_size()
+for nint in (2, 4, 8):
+    xb = [torch.randint(-127, 128, (nint, T, N, F, 2, 2), dtype=torch.int8, device="cuda", generator=g) for _ in range(2)]
+    vb = torch.zeros(nint * per, 2, device="cuda")
+    for i in range(5): xe.xcorrelate_n_device(nint, xb[i % 2], vb)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for i in range(100): xe.xcorrelate_n_device(nint, xb[i % 2], vb)
+    b.record(); torch.cuda.synchronize()
+    print("%d windows per launch: %.1f us per window (%s)" % (nint, a.elapsed_time(b) * 1e3 / 100 / nint, xe.last_route()), flush=True)
+    del xb, vb
