@@ -100,7 +100,10 @@ extern "C" int mi355_xengine_shard_create(int world, const int *device_ids, int 
     MI355_REQUIRE(npol == 1 || npol == 2, "polarization must be 1 or 2");
     MI355_REQUIRE(windows >= 1, "windows must be >= 1");
     MI355_REQUIRE(num_inputs % world == 0 && num_channels % world == 0, "the ranks must divide the inputs (antenna groups) and the channels (slabs)");
-    MI355_REQUIRE(num_inputs * npol <= 64, "the sharded X-engine reads the exchanged blocks in place: IChar, at most 64 rows (the fused path)");
+    // the exchanged blocks are read IN PLACE: the fused path (at most 64 rows) or, round 6, the whole-line kernel for 64 stations x two polarisations
+    // (slabs of whole 128-byte lines = 32 channels; enough windows per exchange to fill the device, or the correlation returns MI355_ERR_UNSUPPORTED)
+    MI355_REQUIRE(num_inputs * npol <= 64 || (num_inputs == 64 && npol == 2 && (num_channels / world) % 32 == 0),
+                  "the sharded X-engine reads the exchanged blocks in place: IChar, at most 64 rows, or 64 stations x 2 polarisations with slabs of whole 32-channel lines");
     const size_t wrow = (size_t)(num_channels / world) * npol * 2;
     MI355_REQUIRE(wrow % 16 == 0, "a rank's channel slab must be whole 16-byte pieces per (t, station) row");
     mi355_xengine_shard *h = new (std::nothrow) mi355_xengine_shard();

@@ -295,7 +295,8 @@ int mi355_xengine_gather(const mi355_xengine *h, int nframes, int frame0, const 
  * corner turn between them.  Rank r = device_ids[r] (a device may appear more than once: the ranks then share it) ingests antenna group r --
  * frames [window][t][num_inputs/world stations][chan][pol]{I,Q}, the reference's frame layout of lib/clXEngine_impl.cc:987-1061 -- and
  * produces channels [r F/W, (r+1) F/W) of the reference's [chan][baseline][pol^2] matrix (:786-808) for each of `windows` integration
- * windows per exchange.  IChar (int8 I/Q) with num_inputs * npol <= 64 rows; world must divide num_inputs and num_channels.
+ * windows per exchange.  IChar (int8 I/Q) with num_inputs * npol <= 64 rows, or 64 inputs x 2 polarisations with channel slabs of whole 32-channel
+ * lines and enough windows per exchange to fill the device (8 ranks x 1024 channels: 8); world must divide num_inputs and num_channels.
  * Per exchange: one strided device copy packs a rank's frames into per-destination blocks (mi355_pack3d_dev), `world` peer copies
  * (hipMemcpyPeerAsync: xGMI) deliver them, and mi355_xengine_xcorrelate_n_dev reads the receive buffer in place; two slots, an exchange and
  * a compute stream per rank, so exchange k+1 runs under correlation k.  (gr-clenabled_amd/shard.py is the same pipeline with one process per

@@ -106,3 +106,26 @@ def test_sharded_streaming_host_path(gpu, oracle, W, windows):
     sh.xcorrelate(xs[0], out)
     assert np.array_equal(out, refs[0])
     sh.close()
+
+
+def test_sharded_two_polarisations(gpu, oracle, monkeypatch):
+    """64 stations x two polarisations (128 rows) over two and four ranks: the receive buffer of the corner turn is read in place by the whole-line kernel
+    (k_xe_i8_lines<false, 2> with stations_per_group); MI355_XE_LINES_MIN_UNITS lets the small slabs of this test take it."""
+    monkeypatch.setenv("MI355_XE_LINES_MIN_UNITS", "8")
+    N, F, T, windows = 64, 128, 64, 2
+    rng = np.random.default_rng(21)
+    for W in (2, 4):
+        sh = gpu.clXEngineSharded([0] * W, 2, N, F, T, windows)
+        per = sh.get_output_buffer_size()
+        assert per == F * (N * (N + 1) // 2) * 4
+        x = rng.integers(-128, 128, size=(windows, T, N, F, 2, 2), dtype=np.int64).astype(np.int8)
+        ref = np.concatenate([oracle.xengine_ichar(N, F, 2, T, x[w].reshape(-1), exact=True) for w in range(windows)])
+        out = np.empty(windows * per, np.complex64)
+        sh.xcorrelate(x, out)
+        assert np.array_equal(out, ref), W
+        sh.acquire()[:] = x.reshape(-1)
+        sh.submit_acquired()
+        out2 = np.empty_like(out)
+        sh.wait(out2)
+        assert np.array_equal(out2, ref), W
+        sh.close()
