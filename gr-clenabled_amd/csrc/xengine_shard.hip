@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "common.h"
+#include "xengine_fused.h"
 
 struct mi355_xengine_shard {
     int world = 0, npol = 1, N = 0, F = 0, T = 0, windows = 1, Ng = 0, Fw = 0;
@@ -154,6 +155,20 @@ extern "C" int mi355_xengine_shard_create(int world, const int *device_ids, int 
                 (void)hipGetLastError();
             }
         }
+    // 64 stations x two polarisations: only the whole-line kernel reads the receive buffer in place, and it needs enough (window, line, pair group) units
+    // per rank to fill the device -- said here, at create, not by the first correlation
+    if (rc == MI355_OK && num_inputs * npol > 64) {
+        int need = windows;
+        while (need <= 4096 && !mi355_xe_lines_ok(num_inputs, h->Fw, h->Fw, npol, integration, h->Ng, 0, need, h->rk[0].ctx->num_cus)) need++;
+        if (need != windows) {
+            if (need <= 4096)
+                mi355_set_error("sharded X-engine, 64 inputs x 2 polarisations over %d ranks (%d channels per rank): needs at least %d windows per exchange, %d given",
+                                world, h->Fw, need, windows);
+            else
+                mi355_set_error("sharded X-engine, 64 inputs x 2 polarisations over %d ranks: %d channels per rank are not whole 32-channel lines", world, h->Fw);
+            rc = MI355_ERR_UNSUPPORTED;
+        }
+    }
     if (rc != MI355_OK) { shard_free(h); return rc; }
     *out = h;
     return MI355_OK;

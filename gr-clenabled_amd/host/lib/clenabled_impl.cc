@@ -234,7 +234,8 @@ class clXEngine_impl : public clXEngine, public MI355Base {
     mi355_xengine *d_h = nullptr;
     // several devices behind ONE block (set_shard_devices / MI355_XENGINE_DEVICES): antenna groups in, channel slabs out, the corner turn
     // between the devices inside mi355_xengine_shard_* -- the reference has one device per block (devId, lib/GRCLBase.cpp:115-134)
-    mi355_xengine_shard *d_shard = nullptr;         // one window per call: xcorrelate(char*, XComplex*), pipeline integration
+    bool d_sharded = false;                         // set_shard_devices() with two or more devices
+    mi355_xengine_shard *d_shard = nullptr;         // one window per call: xcorrelate(char*, XComplex*), pipeline integration -- created at first use
     // the STREAMING path of work_test(): d_shard_windows integration windows per exchange, gathered straight into the handle's pinned frame slots
     // (mi355_xengine_shard_acquire / submit_acquired / wait: every device uploads its antenna group over its own link, asynchronously, while the next
     // windows are gathered) -- created at the first streamed window
@@ -324,7 +325,14 @@ class clXEngine_impl : public clXEngine, public MI355Base {
         d_shard_pending_first.erase(d_shard_pending_first.begin());
         for (size_t w = 0; w < firsts.size(); w++) deliver(d_result_batch.data() + w * d_matrix_len, firsts[w]);
     }
-    bool shard_streaming() const { return d_shard && d_pipeline_integration <= 1; }
+    bool shard_streaming() const { return d_sharded && d_pipeline_integration <= 1; }
+    mi355_xengine_shard *sync_shard()  // the one-window-per-call handle (the streaming path has its own, with windows_per_exchange windows)
+    {
+        if (!d_shard)
+            chk(mi355_xengine_shard_create((int)d_shard_ids.size(), d_shard_ids.data(), d_npol, d_num_inputs, d_num_channels, d_integration, 1, &d_shard),
+                "mi355_xengine_shard_create");
+        return d_shard;
+    }
     void collect_one()
     {
         chk(mi355_xengine_wait(d_h, d_result.data()), "mi355_xengine_wait");
@@ -389,7 +397,9 @@ public:
                 try { set_shard_devices(ids); }
                 catch (const std::exception &ex) {
                     mi355_xengine_shard_destroy(d_shard);
-                    d_shard = nullptr;
+                    mi355_xengine_shard_destroy(d_shard_stream);
+                    d_shard = d_shard_stream = nullptr;
+                    d_sharded = false;
                     log_sink(nullptr, MI355_LOG_WARN, (std::string("MI355_XENGINE_DEVICES ignored for this clXEngine block: ") + ex.what()).c_str());
                 }
             }
@@ -417,13 +427,17 @@ public:
         d_shard_ids = device_ids;
         d_shard_windows = windows_per_exchange;
         if (const char *e = getenv("MI355_XENGINE_SHARD_WINDOWS")) d_shard_windows = atoi(e) > 0 ? atoi(e) : d_shard_windows;
+        d_sharded = false;
         if (device_ids.size() < 2) return;  // back to the one device of make()
-        chk(mi355_xengine_shard_create((int)device_ids.size(), device_ids.data(), d_npol, d_num_inputs, d_num_channels, d_integration, 1, &d_shard),
-            "mi355_xengine_shard_create");
+        // (the streaming handle is created here: it validates devices and geometry -- 64 inputs x 2 polarisations need enough windows per exchange)
+        chk(mi355_xengine_shard_create((int)device_ids.size(), device_ids.data(), d_npol, d_num_inputs, d_num_channels, d_integration, d_shard_windows,
+                                       &d_shard_stream), "mi355_xengine_shard_create");
+        d_result_batch.resize((size_t)d_shard_windows * d_matrix_len);
+        d_sharded = true;
         d_frames_sync.resize(d_in_bytes);
         if (d_accum.size() != d_matrix_len) d_accum.assign(d_matrix_len, XComplex());
     }
-    int shard_devices() const override { return d_shard ? mi355_xengine_shard_world(d_shard) : 1; }
+    int shard_devices() const override { return d_sharded ? (int)d_shard_ids.size() : 1; }
     bool stop() override
     {
         std::lock_guard<std::mutex> g(d_lock);
@@ -514,7 +528,7 @@ public:
                     d_batch_first.clear();
                 }
                 d_frames = d_batch_base + (size_t)d_batch_fill * d_in_bytes;
-            } else if (d_pipeline_integration > 1 || d_shard) d_frames = d_frames_sync.data();
+            } else if (d_pipeline_integration > 1 || d_sharded) d_frames = d_frames_sync.data();
             else {
                 if (mi355_xengine_pending(d_h) == 2) collect_one();  // previous result goes out before the swap (:1070-1094)
                 void *fb = nullptr;
@@ -540,7 +554,7 @@ public:
                 }
             } else if (d_pipeline_integration > 1) {
                 // device "+=" into the running matrix, read back every pipeline_integration windows (:785-796,1250-1285)
-                if (d_shard) chk(mi355_xengine_shard_xcorrelate(d_shard, d_frames, d_accum.data(), 1), "mi355_xengine_shard_xcorrelate");
+                if (d_sharded) chk(mi355_xengine_shard_xcorrelate(sync_shard(), d_frames, d_accum.data(), 1), "mi355_xengine_shard_xcorrelate");
                 else
                 chk(mi355_xengine_xcorrelate(d_h, d_frames, d_accum.data(), 1), "mi355_xengine_xcorrelate");
                 if (++d_pipe_count >= d_pipeline_integration) {
@@ -567,7 +581,7 @@ public:
     }
     void xcorrelate(char *in, XComplex *out) override
     {
-        if (d_shard) chk(mi355_xengine_shard_xcorrelate(d_shard, in, out, d_pipeline_integration > 1), "mi355_xengine_shard_xcorrelate");
+        if (d_sharded) chk(mi355_xengine_shard_xcorrelate(sync_shard(), in, out, d_pipeline_integration > 1), "mi355_xengine_shard_xcorrelate");
         else
         chk(mi355_xengine_xcorrelate(d_h, in, out, d_pipeline_integration > 1), "mi355_xengine_xcorrelate");
     }

@@ -129,3 +129,12 @@ def test_sharded_two_polarisations(gpu, oracle, monkeypatch):
         sh.wait(out2)
         assert np.array_equal(out2, ref), W
         sh.close()
+
+
+def test_sharded_two_polarisations_needs_enough_windows(gpu):
+    """Without the test switch: 64 inputs x 2 polarisations over 8 ranks of 1024 channels need 8 windows per exchange to fill a device; fewer are refused at
+    create with a message that says so (not by the first correlation)."""
+    with pytest.raises(gpu.Mi355Error, match="at least 8 windows"):
+        gpu.clXEngineSharded([0] * 8, 2, 64, 1024, 1024, 4)
+    sh = gpu.clXEngineSharded([0] * 8, 2, 64, 1024, 32, 8)
+    sh.close()
