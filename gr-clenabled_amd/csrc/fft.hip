@@ -1772,6 +1772,13 @@ extern "C" int mi355_fft_plan_text(int fft_size, char *buf, int buf_len)
     return MI355_OK;
 }
 
+const MrPlan *mi355_fft_mr_plan_of(const mi355_fft *h, int *sign)
+{
+    if (!h || !h->mr.n) return nullptr;
+    if (sign) *sign = h->sign;
+    return &h->mr;
+}
+
 extern "C" int mi355_fft_destroy(mi355_fft *h)
 {
     if (!h) return MI355_OK;

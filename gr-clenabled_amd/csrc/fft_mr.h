@@ -38,6 +38,13 @@ void mi355_fft_mr_remember(const MrPlan &plan);
 int mi355_fft_mr_launch(const MrPlan &plan, mi355_ctx *ctx, int sign, const void *in, void *out, const float *window, int nframes, int shift,
                         int real_in, hipStream_t st);
 
+// clPolyphaseChannelizer's branch filters + M-point transform in ONE kernel (k_pfb_mr, fft_mr.hip): in = the block's input (history first), taps =
+// K floats on the device, out = nsteps x M complex.  _ok: this plan / tap count / call size has the fused form (sign: the plan's direction, +1 only).
+bool mi355_fft_mr_pfb_ok(const MrPlan &plan, int sign, int K, int M, int nsteps);
+int mi355_fft_mr_pfb_launch(const MrPlan &plan, mi355_ctx *ctx, const void *in, void *out, const float *taps, int K, int M, int nsteps, hipStream_t st);
+struct mi355_fft;
+const MrPlan *mi355_fft_mr_plan_of(const mi355_fft *h, int *sign);  // (fft.hip) the handle's one-pass mixed-radix plan, nullptr if it has none
+
 // Two-pass form for longer lengths of the same kind (15361 ... 921600 points): n = n1 x n2, both 4 ... 960, every pass the mixed-radix
 // passes over sixteen columns of a matrix (fft_mr.hip).  The caller uploads a.d_tw / b.d_tw (twa / twb) and d_twn = W_n^k, k < n.
 struct MrTilePlan {

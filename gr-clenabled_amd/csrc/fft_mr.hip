@@ -36,6 +36,10 @@ struct MrArgs {
     const float *window;
     const c32 *tw;
     int n, nframes, frames, npass, in_rot, out_rot, real_in;
+    int tw_lds = 0, ntw = 0;   // k_pfb_mr: first LDS slot of the twiddle runs, their length
+    int dbg = 0;
+    int fs_shift = 0;          // k_pfb_mr: a workgroup's frames are `frames >> fs_shift` time ranges of 2^fs_shift steps each; 0 = frames in a row
+    long long range_len = 0;   // k_pfb_mr: steps between the starts of two ranges
     long long ngroups;
     MrPass pass[kMaxPass];
 };
@@ -182,8 +186,8 @@ template <int R, int SIGN> __device__ __forceinline__ void dft(c32 *v)
     }
 }
 
-// MODE 0: first pass (global -> LDS), 1: LDS -> LDS, 2: last pass (LDS -> global)
-template <int R, int SIGN, int MODE>
+// MODE 0: first pass (global -> LDS), 1: LDS -> LDS, 2: last pass (LDS -> global), 3: first pass on frames that are in LDS already (k_pfb_mr)
+template <int R, int SIGN, int MODE, bool TWL = false>
 __device__ __forceinline__ void mr_pass(const MrArgs &a, const MrPass &ps, c32 *lds, int tid, long long group)
 {
     const int TH = blockDim.x;
@@ -196,9 +200,13 @@ __device__ __forceinline__ void mr_pass(const MrArgs &a, const MrPass &ps, c32 *
     for (int i = 0; i < B; i++) {
         const int b = tid + TH * i;
         const int fr = (int)__umulhi((unsigned)b, ps.m_nb), bb = b - fr * nb;
-        if constexpr (MODE != 0) {
+        if constexpr (MODE == 1 || MODE == 2) {
             const int k = bb - (int)__umulhi((unsigned)bb, ps.m_ns) * ps.ns;
             // the butterfly's twiddle comes from L1 / L2: asked for before the LDS reads and the barrier, not after them
+            // (TWL, k_pfb_mr: the twiddle runs sit in LDS behind the frames -- a global load here would make the pass wait for every load before it,
+            // the next rows' prefetch included: the memory counter is in order)
+            if constexpr (TWL) w1[i] = b < nbt ? lds[a.tw_lds + ps.tw_off + k] : mk(1.f, 0.f);
+            else
             w1[i] = b < nbt ? a.tw[ps.tw_off + k] : mk(1.f, 0.f);
         }
         if (b < nbt) {
@@ -235,7 +243,7 @@ __device__ __forceinline__ void mr_pass(const MrArgs &a, const MrPass &ps, c32 *
         if (b < nbt) {
             const int fr = (int)__umulhi((unsigned)b, ps.m_nb), bb = b - fr * nb;
             int g = bb, k = 0;
-            if constexpr (MODE != 0) {
+            if constexpr (MODE == 1 || MODE == 2) {
                 g = (int)__umulhi((unsigned)bb, ps.m_ns);
                 k = bb - g * ps.ns;
                 // W^r from W, W^2, W^4, W^8 (at most three products per value): four stored powers instead of R - 1 -- the register
@@ -259,7 +267,8 @@ __device__ __forceinline__ void mr_pass(const MrArgs &a, const MrPass &ps, c32 *
             }
             dft<R, SIGN>(v[i]);
             if constexpr (MODE == 2) {
-                const long long frame = group * a.frames + fr;
+                // (k_pfb_mr: `group` is the step the workgroup's first range is at; frame fr = step fr mod 2^fs_shift of range fr >> fs_shift)
+                const long long frame = a.fs_shift ? group + (fr >> a.fs_shift) * a.range_len + (fr & ((1 << a.fs_shift) - 1)) : group * a.frames + fr;
                 if (frame < a.nframes) {
 #pragma unroll
                     for (int s = 0; s < R; s++) {
@@ -312,6 +321,133 @@ __global__ __launch_bounds__(1024) void k_fft_mr(const MrArgs a)
         MR_PASS(0, 0)
         for (int p = 1; p < a.npass - 1; p++) { MR_PASS(1, p) }
         MR_PASS(2, a.npass - 1)
+    }
+#undef MR_PASS
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// clPolyphaseChannelizer with a channel count that is not one of pfb.hip's power-of-two kernels (10, 20, 100, 200 ... channels), critically
+// sampled: branch filters AND the M-point transform in one pass over the input (lib/clPolyphaseChannelizer_impl.cc:150-175 filters into a
+// scratch buffer and transforms that; pfb.hip's two-kernel form of it moves every sample four times).  A workgroup walks Q time ranges;
+// thread (q, j) owns arm j of range q: the last PMAX - 1 samples of its arm stay in registers, every step loads ONE new sample (lanes along the arms:
+// a row of M consecutive samples per range), y_j[i] = sum_p h[j + M p] x_j[i - p] with fmaf, taps ascending -- the operation order of
+// k_pfb_branches_t, so the two forms agree bit for bit -- and goes to LDS as value j of frame (q, step); after FS steps the Q x FS frames are
+// transformed in place by the passes of k_fft_mr and stored.  The next FS rows are requested before the transforms and arrive behind them.
+// A range is nsteps / (workgroups x Q) steps long, so the PMAX - 1 rows of warm-up are a few per cent of what a range reads.
+struct PfbMr {
+    const c32 *in;
+    const float *taps;
+    int K, M, Q, nsteps, direct;
+    unsigned m_M, m_run;  // ceil(2^32 / M), ceil(2^32 / (FS M))
+};
+
+template <int SIGN, int PMAX, int FS>
+__global__ __launch_bounds__(512) void k_pfb_mr(const MrArgs a, const PfbMr f)
+{
+    extern __shared__ __attribute__((aligned(16))) c32 mr_lds[];
+    const int tid0 = threadIdx.x;
+    const int q = (int)__umulhi((unsigned)tid0, f.m_M), j = tid0 - q * f.M;
+    const bool arm = q < f.Q;
+    // the taps: PMAX x M floats in LDS behind the twiddle runs (tap p of arm j at p M + j: lanes along the arms, no bank conflict); a thread reads
+    // each of its taps once per iteration -- held in registers they would cost a workgroup its third wave per SIMD
+    float *tl = (float *)(mr_lds + a.tw_lds + a.ntw);
+    for (int i = tid0; i < PMAX * f.M; i += blockDim.x) tl[i] = i < f.K ? f.taps[i] : 0.f;
+    const float *th = tl + (arm ? j : 0);
+    const long long r0 = (long long)blockIdx.x * f.Q * a.range_len, s0 = r0 + (long long)q * a.range_len;
+    const f2v *xp = (const f2v *)f.in + (f.K - 1 - j);  // x_j[r] = in[r M - j + K - 1] (k_pfb_branches_t)
+    auto ld = [&](long long r) {
+        const long long o = r * f.M;
+        f2v x = {0.f, 0.f};
+        if (arm && o + (f.K - 1 - j) >= 0 && r < f.nsteps && !(a.dbg & 4)) x = __builtin_nontemporal_load(xp + o);
+        return x;
+    };
+    for (int i = tid0; i < a.ntw; i += blockDim.x) mr_lds[a.tw_lds + i] = a.tw[i];  // (the first barrier of the loop is in front of their first use)
+    f2v x[PMAX - 1 + FS], nx[FS];
+#pragma unroll
+    for (int u = 0; u < PMAX - 1 + FS; u++) x[u] = ld(s0 - (PMAX - 1) + u);  // the warm-up rows and the first FS rows
+    const int iters = (int)(a.range_len / FS);
+#pragma unroll
+    for (int s = 0; s < FS; s++) nx[s] = f2v{0.f, 0.f};
+    const int run = FS * a.n;  // values of a range per iteration: one contiguous run of the output
+#define MR_PASS(MODE, P)                                                                        \
+    switch (a.pass[P].radix) {                                                                  \
+    case 2: mr_pass<2, SIGN, MODE, true>(a, a.pass[P], mr_lds, tid, group); break;                    \
+    case 3: mr_pass<3, SIGN, MODE, true>(a, a.pass[P], mr_lds, tid, group); break;                    \
+    case 4: mr_pass<4, SIGN, MODE, true>(a, a.pass[P], mr_lds, tid, group); break;                    \
+    case 5: mr_pass<5, SIGN, MODE, true>(a, a.pass[P], mr_lds, tid, group); break;                    \
+    case 7: mr_pass<7, SIGN, MODE, true>(a, a.pass[P], mr_lds, tid, group); break;                    \
+    case 6: mr_pass<6, SIGN, MODE, true>(a, a.pass[P], mr_lds, tid, group); break;                    \
+    case 9: mr_pass<9, SIGN, MODE, true>(a, a.pass[P], mr_lds, tid, group); break;                    \
+    case 10: mr_pass<10, SIGN, MODE, true>(a, a.pass[P], mr_lds, tid, group); break;                  \
+    case 11: mr_pass<11, SIGN, MODE, true>(a, a.pass[P], mr_lds, tid, group); break;                  \
+    case 13: mr_pass<13, SIGN, MODE, true>(a, a.pass[P], mr_lds, tid, group); break;                  \
+    case 12: mr_pass<12, SIGN, MODE, true>(a, a.pass[P], mr_lds, tid, group); break;                  \
+    case 14: mr_pass<14, SIGN, MODE, true>(a, a.pass[P], mr_lds, tid, group); break;                  \
+    case 15: mr_pass<15, SIGN, MODE, true>(a, a.pass[P], mr_lds, tid, group); break;                  \
+    case 8: mr_pass<8, SIGN, MODE, true>(a, a.pass[P], mr_lds, tid, group); break;                    \
+    default: mr_pass<16, SIGN, MODE, true>(a, a.pass[P], mr_lds, tid, group); break;                  \
+    }
+    for (int it = 0; it < iters; it++) {
+        // this iteration's rows were requested at the top of the last one; the next one's go out here, in front of the arithmetic (requested at the
+        // END of an iteration, behind its stores, and taken over behind the transform -- 226 -> 260 us at 100 channels, 219 -> 248 at 20)
+        if (it > 0) {
+#pragma unroll
+            for (int s = 0; s < FS; s++) x[PMAX - 1 + s] = nx[s];
+        }
+        if (it + 1 < iters) {
+            const long long nxt = s0 + (long long)(it + 1) * FS;
+#pragma unroll
+            for (int s = 0; s < FS; s++) nx[s] = ld(nxt + s);
+        }
+        if (arm) {
+            f2v acc[FS];
+#pragma unroll
+            for (int s = 0; s < FS; s++) acc[s] = f2v{0.f, 0.f};
+            if (a.dbg & 1) {
+#pragma unroll
+                for (int s = 0; s < FS; s++) acc[s] = x[PMAX - 1 + s];
+            } else
+#pragma unroll
+            for (int p = 0; p < PMAX; p++) {  // per output: taps ascending (lib/clPolyphaseChannelizer_impl.cc:156-167); both components in one packed fma
+                const float hp = th[p * f.M];
+                const f2v hh = {hp, hp};
+#pragma unroll
+                for (int s = 0; s < FS; s++) acc[s] = __builtin_elementwise_fma(x[PMAX - 1 + s - p], hh, acc[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < FS; s++) mr_lds[slot((q * FS + s) * a.n + j)] = mk(acc[s].x, acc[s].y);
+        }
+#pragma unroll
+        for (int u = 0; u < PMAX - 1; u++) x[u] = x[u + FS];
+        __syncthreads();
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));  // (as in k_fft_mr: keeps the passes' index arithmetic out of the loop-invariant registers)
+        const long long group = r0 + (long long)it * FS;
+        if (!(a.dbg & 2)) {
+            MR_PASS(3, 0)
+            for (int p = 1; p < a.npass - 1; p++) { MR_PASS(1, p) }
+            if (f.direct) {
+                if (!(a.dbg & 8)) { MR_PASS(2, a.npass - 1) }  // runs of at least 64 bytes: the last pass stores them itself
+            } else {
+                MR_PASS(1, a.npass - 1)  // the last pass leaves its frames in LDS (g = 0: value p of frame fr at fr n + p)
+            }
+        }
+        // store: a range's FS frames are one contiguous run of FS x M values -- lanes along the run (the last pass' own order would scatter
+        // runs of `ns` values: 24 bytes at 48 channels)
+        if (!(a.dbg & 8) && !f.direct)
+            for (int idx = tid0; idx < f.Q * run; idx += blockDim.x) {
+                const int qq = (int)__umulhi((unsigned)idx, f.m_run), e = idx - qq * run;
+                const long long step0 = r0 + (long long)qq * a.range_len + (long long)it * FS;
+                if (step0 * a.n + e < (long long)a.nframes * a.n) {
+                    const c32 v = mr_lds[slot(idx)];
+                    f2v z;
+                    z.x = v.x;
+                    z.y = v.y;
+                    __builtin_nontemporal_store(z, (f2v *)a.out + step0 * a.n + e);
+                }
+            }
+        __syncthreads();  // the frames have been read: the next iteration writes them
     }
 #undef MR_PASS
 }
@@ -680,6 +816,92 @@ int mi355_fft_mr_launch(const MrPlan &plan, mi355_ctx *ctx, int sign, const void
 {
     if (nframes <= 0) return MI355_OK;
     return launch_with(plan, plan.threads, plan.frames, ctx, sign, in, out, window, nframes, shift, real_in, st);
+}
+
+// clPolyphaseChannelizer, branch filters + transform in one kernel (k_pfb_mr).  false: not this form (more than 32 taps per arm, more arms than a
+// workgroup has threads, too few steps) -- the caller runs its two kernels.
+bool mi355_fft_mr_pfb_ok(const MrPlan &plan, int sign, int K, int M, int nsteps)
+{
+    if (!plan.n || plan.n != M || sign <= 0 || plan.npass < 2 || getenv("MI355_PFB_NO_MR_FUSED")) return false;
+    const int P = (K + M - 1) / M;
+    return P <= 32 && M <= 512 && (long long)plan.per_thread * 512 >= 8LL * M && nsteps >= 1;
+}
+
+int mi355_fft_mr_pfb_launch(const MrPlan &plan, mi355_ctx *ctx, const void *in, void *out, const float *taps, int K, int M, int nsteps, hipStream_t st)
+{
+    constexpr int FS = 8, FS_SHIFT = 3;  // steps per iteration (16: 250 registers at 32 taps per arm, and no faster at 8 or 16 taps)
+    const int P = (K + M - 1) / M;
+    static const int th_env = getenv("MI355_PFB_MR_THREADS") ? atoi(getenv("MI355_PFB_MR_THREADS")) : 0;
+    auto ranges_of = [&](int th) { const long long byv = (long long)th * plan.per_thread / (FS * M); const int byt = th / M; return (int)(byv < byt ? byv : byt); };
+    int th = 512;  // (256 threads, three workgroups per CU: 268 against 226 us at 100 channels, 262 / 251 at 20, 274 / 262 at 200)
+    if (th_env == 256 || th_env == 512 || th_env == 128 || th_env == 384)
+        if (ranges_of(th_env) >= 1) th = th_env;
+    const int Q = ranges_of(th);
+    if (Q < 1) return MI355_ERR_INVALID_ARG;
+    const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+    int ntw = 0;
+    for (int p = 1; p < plan.npass; p++) ntw += plan.pass[p].ns;
+    const int tw_lds = lds_bytes_for(M, Q * FS) / 8;
+    const int pmax = P <= 8 ? 8 : P <= 16 ? 16 : 32;
+    const int lds_bytes = (tw_lds + ntw) * 8 + pmax * M * 4;
+    static const int wg_env = getenv("MI355_PFB_MR_WG_PER_CU") ? atoi(getenv("MI355_PFB_MR_WG_PER_CU")) : 0;
+    // workgroups a CU holds: 117 / 133 / 165 registers per thread at 8 / 16 / 32 taps per arm = 4 / 3 / 3 waves per SIMD
+    int per_cu = wg_env > 0 ? wg_env : (pmax == 8 ? 4 : 3) * 256 / th;
+    if (per_cu > (160 * 1024) / lds_bytes) per_cu = (160 * 1024) / lds_bytes;
+    if (per_cu < 1) per_cu = 1;
+    // ranges: one workgroup per CU first; then as many as the device runs at once, as long as a range stays 8 x the warm-up long
+    long long len = (nsteps + (long long)cus * Q - 1) / ((long long)cus * Q);
+    if (len >= 8LL * P) {
+        const long long nr = (long long)cus * per_cu * Q;
+        len = (nsteps + nr - 1) / nr;
+        if (len < 8LL * P) len = 8LL * P;
+    }
+    len = (len + FS - 1) / FS * FS;
+    const long long grid = (nsteps + len * Q - 1) / (len * Q);
+    MrArgs a;
+    a.in = nullptr;
+    a.out = (c32 *)out;
+    a.window = nullptr;
+    a.tw = (const c32 *)plan.d_tw;
+    a.n = M;
+    a.nframes = nsteps;
+    a.frames = Q * FS;
+    a.npass = plan.npass;
+    a.in_rot = a.out_rot = a.real_in = 0;
+    a.fs_shift = FS_SHIFT;
+    a.range_len = len;
+    a.tw_lds = tw_lds;
+    a.ntw = ntw;
+    a.dbg = getenv("MI355_PFB_MR_DBG") ? atoi(getenv("MI355_PFB_MR_DBG")) : 0;
+    a.ngroups = 0;
+    for (int p = 0; p < plan.npass; p++) a.pass[p] = plan.pass[p];
+    PfbMr f;
+    f.in = (const c32 *)in;
+    f.taps = taps;
+    f.K = K;
+    f.M = M;
+    f.Q = Q;
+    f.nsteps = nsteps;
+    f.m_M = magic(M);
+    f.m_run = magic(FS * M);
+    f.direct = (a.dbg & 32) ? 1 : (a.dbg & 16) ? 0 : plan.pass[plan.npass - 1].ns >= 8;
+    if (lds_bytes > 160 * 1024) return MI355_ERR_INVALID_ARG;
+    if (lds_bytes > 48 * 1024) {  // (said once per device)
+        static std::map<int, bool> lds_ok;
+        static std::mutex lds_ok_lock;
+        std::lock_guard<std::mutex> g(lds_ok_lock);
+        if (!lds_ok[ctx->device]) {
+            MI355_HIP(hipFuncSetAttribute((const void *)k_pfb_mr<1, 8, FS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            MI355_HIP(hipFuncSetAttribute((const void *)k_pfb_mr<1, 16, FS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            MI355_HIP(hipFuncSetAttribute((const void *)k_pfb_mr<1, 32, FS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            lds_ok[ctx->device] = true;
+        }
+    }
+#define PFB_MR(PM) hipLaunchKernelGGL((k_pfb_mr<1, PM, FS>), dim3((unsigned)grid), dim3(th), lds_bytes, st, a, f)
+    if (pmax == 8) PFB_MR(8); else if (pmax == 16) PFB_MR(16); else PFB_MR(32);
+#undef PFB_MR
+    MI355_HIP(hipGetLastError());
+    return MI355_OK;
 }
 
 // The rate over (threads, frames per iteration) is irregular -- 4000 points: 320 threads 163 GS/s, 384 threads 107, 512 threads 131; the

@@ -25,6 +25,7 @@
 
 #include "common.h"
 #include "fft_core.hpp"
+#include "fft_mr.h"
 
 using namespace fftc;
 
@@ -623,11 +624,17 @@ __global__ __launch_bounds__(256) void k_pfb_branches(const c32 *__restrict__ in
 // the arms: every load is a run of consecutive samples.  Same operation order per output (fma, taps ascending).
 template <int T, int PC, int S>
 __global__ __launch_bounds__(256) void k_pfb_branches_t(const c32 *__restrict__ in, c32 *__restrict__ filt, const float *__restrict__ taps, int K,
-                                                        int M, int nsteps, long long total /* blocks of T steps x M */)
+                                                        int M, int nsteps, long long total /* blocks of T steps x M */, int xcd_runs)
 {
     const int R = M / S;  // S-fold oversampling (R = M / S new samples per step): x_j[n] = in[n R - j + K - 1], y_j[i] = sum_p h[j + M p] x_j[i - S p]
     const int P = (K + M - 1) / M;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    // A thread's window reaches P - 1 rows back: the workgroups a few places earlier in time read the same rows.  Workgroups go to the XCDs round
+    // robin, so with the plain order every XCD's L2 fetches most of the input for itself; xcd_runs gives each XCD one contiguous eighth of the time
+    // axis instead (workgroup b -> place (b mod 8) * per + b / 8; the grid is a multiple of 8, the stride keeps a workgroup on its eighth).
+    const long long nblk = (total + 255) / 256, per = (nblk + 7) / 8;
+    for (long long b = blockIdx.x; b < (xcd_runs ? per * 8 : nblk); b += gridDim.x) {
+        const long long lb = xcd_runs ? (b & 7) * per + (b >> 3) : b, e = lb * 256 + threadIdx.x;
+        if (lb >= nblk || e >= total) continue;
         const long long tb = e / M;
         const int j = (int)(e - tb * M);
         const long long i0 = tb * T;
@@ -900,6 +907,23 @@ int launch_pfb(mi355_pfb *h, const void *in, void *out, hipStream_t st, int nste
 #undef OVER
         return MI355_ERR_STATE;
     }
+    // critically sampled, a transform length with a one-pass mixed-radix plan, at most 32 taps per arm: filters + transform in one kernel (fft_mr.hip)
+    if (h->dft && h->R == h->M) {
+        int sign = 0;
+        const MrPlan *mp = mi355_fft_mr_plan_of(h->dft, &sign);
+        if (mp && mi355_fft_mr_pfb_ok(*mp, sign, h->K, h->M, nsteps)) {
+            const int rc = mi355_fft_mr_pfb_launch(*mp, h->ctx, in, h->whole_map ? out : h->d_filt2, h->d_taps, h->K, h->M, nsteps, st);
+            if (rc) return rc;
+            if (!h->whole_map) {
+                const long long tot = (long long)nsteps * h->nmap, blocks = (tot + 255) / 256;
+                const long long cu8 = (long long)(h->ctx->num_cus > 0 ? h->ctx->num_cus : 256) * 8;
+                hipLaunchKernelGGL(k_pfb_map, dim3((unsigned)(blocks < cu8 ? (blocks < 1 ? 1 : blocks) : cu8)), dim3(256), 0, st, (const c32 *)h->d_filt2,
+                                   (c32 *)out, h->d_map, h->nmap, h->M, tot);
+                MI355_HIP(hipGetLastError());
+            }
+            return MI355_OK;
+        }
+    }
     int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
     long long total = (long long)nsteps * h->M;
     long long blocks = (total + 255) / 256;
@@ -907,15 +931,16 @@ int launch_pfb(mi355_pfb *h, const void *in, void *out, hipStream_t st, int nste
     const int over = h->R > 0 && h->M % h->R == 0 ? h->M / h->R : 0;  // 1: critically sampled; 2, 4: oversampled by that factor
     if ((over == 1 || over == 2 || over == 4) && !getenv("MI355_PFB_BRANCHES_PER_OUTPUT")) {
         constexpr int T = 8;
-        const long long tt = ((long long)nsteps + T - 1) / T * h->M, tb = (tt + 255) / 256;
+        const long long tt = ((long long)nsteps + T - 1) / T * h->M, tb = ((tt + 255) / 256 + 7) / 8 * 8;
         const long long g2 = tb < (long long)cus * 16 ? tb : (long long)cus * 16;
-        const dim3 gd((unsigned)(g2 < 1 ? 1 : g2));
+        const dim3 gd((unsigned)(g2 < 8 ? 8 : g2));
+        static const int xr = getenv("MI355_PFB_NO_XCD_RUNS") ? 0 : 1;
         if (over == 1)
-            hipLaunchKernelGGL((k_pfb_branches_t<T, 16, 1>), gd, dim3(256), 0, st, (const c32 *)in, (c32 *)h->d_filt, h->d_taps, h->K, h->M, nsteps, tt);
+            hipLaunchKernelGGL((k_pfb_branches_t<T, 16, 1>), gd, dim3(256), 0, st, (const c32 *)in, (c32 *)h->d_filt, h->d_taps, h->K, h->M, nsteps, tt, xr);
         else if (over == 2)
-            hipLaunchKernelGGL((k_pfb_branches_t<T, 8, 2>), gd, dim3(256), 0, st, (const c32 *)in, (c32 *)h->d_filt, h->d_taps, h->K, h->M, nsteps, tt);
+            hipLaunchKernelGGL((k_pfb_branches_t<T, 8, 2>), gd, dim3(256), 0, st, (const c32 *)in, (c32 *)h->d_filt, h->d_taps, h->K, h->M, nsteps, tt, xr);
         else
-            hipLaunchKernelGGL((k_pfb_branches_t<T, 4, 4>), gd, dim3(256), 0, st, (const c32 *)in, (c32 *)h->d_filt, h->d_taps, h->K, h->M, nsteps, tt);
+            hipLaunchKernelGGL((k_pfb_branches_t<T, 4, 4>), gd, dim3(256), 0, st, (const c32 *)in, (c32 *)h->d_filt, h->d_taps, h->K, h->M, nsteps, tt, xr);
     } else
     hipLaunchKernelGGL(k_pfb_branches, dim3((unsigned)grid), dim3(256), 0, st, (const c32 *)in, (c32 *)h->d_filt, h->d_taps, h->K,
                        h->M, h->R, total);

@@ -98,6 +98,29 @@ def test_generic_path_large_and_unusual_channel_counts(gpu, oracle, monkeypatch,
     assert relerr(_run(gpu, taps, buf, M, R, chmap, xh), ref) <= TOL
 
 
+# critically sampled, a channel count with a one-pass mixed-radix transform, at most 32 taps per arm: branch filters and transform in ONE kernel
+# (k_pfb_mr, fft_mr.hip) -- several iterations per time range, ranges that end beyond the call, last passes that store for themselves (runs of
+# at least 64 bytes: 100, 360, 500 channels) and through LDS (20, 24, 48, 96, 30), whole and partial channel maps, a call shorter than one
+# iteration; against the oracle and against the two-kernel form of the same handle (MI355_PFB_NO_MR_FUSED, read per call: same operation
+# order in the filters, the same passes in the transform -- the compiler contracts a few multiply-adds differently, hence not bit for bit)
+@pytest.mark.parametrize("M,per_arm,nmap,steps", [(100, 32, 100, 700), (20, 8, 20, 3001), (24, 9, 16, 517), (48, 32, 48, 260), (360, 5, 360, 90),
+                                                  (500, 32, 250, 41), (96, 16, 96, 1500), (30, 4, 30, 64), (100, 32, 100, 7), (12, 3, 12, 1024)])
+def test_filters_and_transform_in_one_kernel(gpu, oracle, monkeypatch, M, per_arm, nmap, steps):
+    rng = np.random.default_rng(M * 11 + per_arm + steps)
+    K = M * per_arm - (M // 3 if per_arm % 2 else 0)  # ragged last arm for the odd tap counts
+    taps = (rng.standard_normal(K) / np.sqrt(per_arm)).astype(np.float32)
+    buf = steps * M
+    xh = crandn(rng, buf - M + K)
+    chmap = list(range(M)) if nmap == M else rng.permutation(M)[:nmap].tolist()
+    ref = oracle.pfb(taps, buf, M, M, chmap, xh, f64=True)
+    y = _run(gpu, taps, buf, M, M, chmap, xh)
+    assert relerr(y, ref) <= TOL
+    monkeypatch.setenv("MI355_PFB_NO_MR_FUSED", "1")
+    y2 = _run(gpu, taps, buf, M, M, chmap, xh)
+    assert relerr(y2, ref) <= TOL
+    assert relerr(y, y2) <= 1e-6
+
+
 # 2- / 4-fold oversampled channelizers with 64 / 128 / 256 channels and <= 32 taps per arm run on the ring kernel, one launch per residue of
 # the step number (quarter-turn factors on the channels); identity and scrambled maps; step counts that leave the residues uneven; and the
 # generic path on the same input (MI355_PFB_NO_FAST_OVERSAMPLED)
