@@ -1028,12 +1028,24 @@ extern "C" int mi355_pfb_create(mi355_ctx *ctx, const float *taps, int ntaps, in
     if (hipMalloc(&h->d_tw, tw.size() * sizeof(float)) != hipSuccess) return fail(MI355_ERR_NOMEM);
     if (hipMalloc((void **)&h->d_map, (size_t)nmap * sizeof(int)) != hipSuccess) return fail(MI355_ERR_NOMEM);
     if (!h->fast && !h->fast_over && hipMalloc(&h->d_filt, (size_t)h->nsteps * M * 8) != hipSuccess) return fail(MI355_ERR_NOMEM);
-    if (!h->fast && !h->fast_over && M >= 8 && nmap >= 16 && !getenv("MI355_PFB_DIRECT_DFT")) {
+    // the M-point transform as a clFFT handle when 16 or more channels are mapped (M products per output below that) -- and, whatever the map, when
+    // the one-kernel form (k_pfb_mr: filters + transform, fft_mr.hip) takes this channelizer: 10 or 12 channels run on it as well
+    const bool few = nmap < 16 || M < 8;
+    const bool try_fused = h->R == M && M >= 6 && M <= 512 && (h->K + M - 1) / M <= 32;
+    if (!h->fast && !h->fast_over && (!few || try_fused) && !getenv("MI355_PFB_DIRECT_DFT")) {
         h->whole_map = nmap == M;
         for (int q = 0; q < nmap && h->whole_map; q++) h->whole_map = ch_map[q] == q;
         const int rc = mi355_fft_create(ctx, M, MI355_FFT_BACKWARD, nullptr, 0, MI355_DTYPE_COMPLEX, 1, 0, &h->dft);
         if (rc != MI355_OK) return fail(rc);
-        if (!h->whole_map && hipMalloc(&h->d_filt2, (size_t)h->nsteps * M * 8) != hipSuccess) return fail(MI355_ERR_NOMEM);
+        if (few) {
+            int sign = 0;
+            const MrPlan *mp = mi355_fft_mr_plan_of(h->dft, &sign);
+            if (!mp || !mi355_fft_mr_pfb_ok(*mp, sign, h->K, M, h->nsteps)) {  // not the one-kernel form after all: the direct DFT as before
+                (void)mi355_fft_destroy(h->dft);
+                h->dft = nullptr;
+            }
+        }
+        if (h->dft && !h->whole_map && hipMalloc(&h->d_filt2, (size_t)h->nsteps * M * 8) != hipSuccess) return fail(MI355_ERR_NOMEM);
     }
     if (mi355_upload(ctx, h->d_taps, t.data(), t.size() * sizeof(float)) != hipSuccess) return fail(MI355_ERR_HIP);
     if (mi355_upload(ctx, h->d_tw, tw.data(), tw.size() * sizeof(float)) != hipSuccess) return fail(MI355_ERR_HIP);
