@@ -100,11 +100,13 @@ def test_generic_path_large_and_unusual_channel_counts(gpu, oracle, monkeypatch,
 
 # critically sampled, a channel count with a one-pass mixed-radix transform, at most 32 taps per arm: branch filters and transform in ONE kernel
 # (k_pfb_mr, fft_mr.hip) -- several iterations per time range, ranges that end beyond the call, last passes that store for themselves (runs of
-# at least 64 bytes: 100, 360, 500 channels) and through LDS (20, 24, 48, 96, 30), whole and partial channel maps, a call shorter than one
+# at least 64 bytes: 100, 360, 500 channels) and through LDS (20, 24, 48, 96, 30), whole and partial channel maps (fewer than 16 channels
+# mapped too), fewer taps than channels, a call shorter than one
 # iteration; against the oracle and against the two-kernel form of the same handle (MI355_PFB_NO_MR_FUSED, read per call: same operation
 # order in the filters, the same passes in the transform -- the compiler contracts a few multiply-adds differently, hence not bit for bit)
 @pytest.mark.parametrize("M,per_arm,nmap,steps", [(100, 32, 100, 700), (20, 8, 20, 3001), (24, 9, 16, 517), (48, 32, 48, 260), (360, 5, 360, 90),
-                                                  (500, 32, 250, 41), (96, 16, 96, 1500), (30, 4, 30, 64), (100, 32, 100, 7), (12, 3, 12, 1024)])
+                                                  (500, 32, 250, 41), (96, 16, 96, 1500), (30, 4, 30, 64), (100, 32, 100, 7), (12, 3, 12, 1024),
+                                                  (504, 3, 504, 20), (6, 32, 6, 300), (14, 1, 14, 100), (10, 17, 3, 500)])
 def test_filters_and_transform_in_one_kernel(gpu, oracle, monkeypatch, M, per_arm, nmap, steps):
     rng = np.random.default_rng(M * 11 + per_arm + steps)
     K = M * per_arm - (M // 3 if per_arm % 2 else 0)  # ragged last arm for the odd tap counts
