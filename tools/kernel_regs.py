@@ -33,9 +33,10 @@ try:
                 continue
             if cur and flt in cur:
                 parts = line.split()
-                if parts and parts[0] in ops:
-                    cnt.setdefault(cur, {}).setdefault(parts[0], 0)
-                    cnt[cur][parts[0]] += 1
+                op = re.sub(r"_(e32|e64|dpp|sdwa)$", "", parts[0]) if parts else ""
+                if op in ops or (ops == ["all"] and op and not op.endswith(":")):
+                    cnt.setdefault(cur, {}).setdefault(op, 0)
+                    cnt[cur][op] += 1
         for k, v in cnt.items():
             print(k[:110], v)
 finally:
