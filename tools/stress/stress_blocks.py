@@ -91,7 +91,7 @@ def churn_xengine(seed):
 def churn_pfb_math(seed):
     rng = np.random.default_rng(seed)
     while time.time() < T_END:
-        M = int(rng.choice([4, 32, 64, 128, 20, 100, 512]))  # (the last three: branch filters + a clFFT transform per step)
+        M = int(rng.choice([4, 32, 64, 128, 20, 100, 10, 48, 360, 512]))  # (20 ... 360: filters + mixed-radix transform in one kernel; 512: two kernels)
         tpa = int(rng.choice([3, 8, 32]))
         buf = M * 128
         taps = rng.standard_normal(M * tpa).astype(np.float32)
