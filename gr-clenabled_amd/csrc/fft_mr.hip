@@ -834,8 +834,7 @@ int mi355_fft_mr_pfb_launch(const MrPlan &plan, mi355_ctx *ctx, const void *in, 
     static const int th_env = getenv("MI355_PFB_MR_THREADS") ? atoi(getenv("MI355_PFB_MR_THREADS")) : 0;
     auto ranges_of = [&](int th) { const long long byv = (long long)th * plan.per_thread / (FS * M); const int byt = th / M; return (int)(byv < byt ? byv : byt); };
     int th = 512;  // (256 threads, three workgroups per CU: 268 against 226 us at 100 channels, 262 / 251 at 20, 274 / 262 at 200)
-    if (th_env == 256 || th_env == 512 || th_env == 128 || th_env == 384)
-        if (ranges_of(th_env) >= 1) th = th_env;
+    if (th_env >= 64 && th_env <= 512 && th_env % 64 == 0 && ranges_of(th_env) >= 1) th = th_env;
     const int Q = ranges_of(th);
     if (Q < 1) return MI355_ERR_INVALID_ARG;
     const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
@@ -846,7 +845,7 @@ int mi355_fft_mr_pfb_launch(const MrPlan &plan, mi355_ctx *ctx, const void *in, 
     const int lds_bytes = (tw_lds + ntw) * 8 + pmax * M * 4;
     static const int wg_env = getenv("MI355_PFB_MR_WG_PER_CU") ? atoi(getenv("MI355_PFB_MR_WG_PER_CU")) : 0;
     // workgroups a CU holds: 117 / 133 / 165 registers per thread at 8 / 16 / 32 taps per arm = 4 / 3 / 3 waves per SIMD
-    int per_cu = wg_env > 0 ? wg_env : (pmax == 8 ? 4 : 3) * 256 / th;
+    int per_cu = wg_env > 0 ? wg_env : (pmax == 8 ? 16 : 12) / (th / 64);
     if (per_cu > (160 * 1024) / lds_bytes) per_cu = (160 * 1024) / lds_bytes;
     if (per_cu < 1) per_cu = 1;
     // ranges: one workgroup per CU first; then as many as the device runs at once, as long as a range stays 8 x the warm-up long
