@@ -1081,7 +1081,14 @@ extern "C" int mi355_pfb_work_dev_n(mi355_pfb *h, int nbuf, const void *in, void
     // (2- / 4-fold oversampled on the ring kernel: buf_items is a whole number of M-item frames, so a buffer holds a whole number of
     // step residues and nbuf buffers are one longer stream)
     const bool over_one_stream = h->fast_over && ((long long)h->buf_items * nbuf + h->K) * 8 < (4ll << 30) - (64 << 10);  // (32-bit row offsets)
-    if (!h->fast && !over_one_stream) {  // the generic two-kernel path keeps a one-buffer scratch: one buffer at a time
+    // filters + transform in one kernel (k_pfb_mr) writing the output itself: no scratch, nbuf buffers are one longer stream
+    bool mr_one_stream = false;
+    if (!h->fast && !over_one_stream && h->dft && h->whole_map && h->R == h->M) {
+        int sign = 0;
+        const MrPlan *mp = mi355_fft_mr_plan_of(h->dft, &sign);
+        mr_one_stream = mp && mi355_fft_mr_pfb_ok(*mp, sign, h->K, h->M, h->nsteps * nbuf);
+    }
+    if (!h->fast && !over_one_stream && !mr_one_stream) {  // the generic two-kernel path keeps a one-buffer scratch: one buffer at a time
         for (int b = 0; b < nbuf; b++) {
             const int rc = launch_pfb(h, (const char *)in + (size_t)b * h->buf_items * 8, (char *)out + (size_t)b * h->nmap * h->nsteps * 8, st,
                                       h->nsteps, h->buf_items);

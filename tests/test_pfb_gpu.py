@@ -170,7 +170,8 @@ def test_baseline_config4_shape_and_streaming(gpu, oracle):
     assert p.argmax() == 5 and p[5] > 1e3 * np.delete(p, 5).max()
 
 
-@pytest.mark.parametrize("M,tpa,ident", [(64, 32, True), (64, 8, False), (128, 16, True), (256, 8, True), (256, 32, True), (32, 16, True), (12, 5, False)])
+@pytest.mark.parametrize("M,tpa,ident", [(64, 32, True), (64, 8, False), (128, 16, True), (256, 8, True), (256, 32, True), (32, 16, True), (12, 5, False),
+                                         (100, 32, True), (20, 8, True), (48, 16, True), (360, 3, True)])  # (the last four: k_pfb_mr, k buffers = one stream)
 def test_batched_call_equals_single_calls(gpu, oracle, M, tpa, ident, monkeypatch):
     """work_device(nbuf=k) -- general_work() offered k output multiples -- returns exactly the samples of k single calls, and the
     small-call schedule (k_pfbq: one workgroup per 16-step group) exactly those of the ring kernel (MI355_PFB_SMALL=0)."""
