@@ -123,6 +123,28 @@ def test_filters_and_transform_in_one_kernel(gpu, oracle, monkeypatch, M, per_ar
     assert relerr(y, y2) <= 1e-6
 
 
+@pytest.mark.parametrize("M,per_arm,steps", [(100, 32, 333), (20, 8, 1001), (48, 16, 77), (360, 5, 19), (10, 32, 4099)])
+def test_one_kernel_form_stays_inside_its_buffers(gpu, oracle, M, per_arm, steps):
+    """Input and output of k_pfb_mr sit inside larger allocations: NaNs around the input (a read outside that reached an output would show), a sentinel
+    around the output (ranges that end beyond the call, the unconditional part of the store loops)."""
+    import torch
+    rng = np.random.default_rng(M + steps)
+    taps = (rng.standard_normal(M * per_arm) / np.sqrt(per_arm)).astype(np.float32)
+    buf = steps * M
+    blk = gpu.clPolyphaseChannelizer(*GPU_ARGS, taps, buf, M, M, list(range(M)))
+    nin, nout, pad = blk.ninput(), blk.noutput(), 4096
+    big = torch.full((nin + 2 * pad, 2), float("nan"), device="cuda")
+    xh = crandn(rng, nin)
+    big[pad:pad + nin] = torch.from_numpy(xh.view(np.float32).reshape(-1, 2)).cuda()
+    ybig = torch.full((nout + 2 * pad, 2), 7.0, device="cuda")
+    blk.work_device([big[pad:pad + nin]], [ybig[pad:pad + nout]])
+    torch.cuda.synchronize()
+    assert torch.all(ybig[:pad] == 7.0) and torch.all(ybig[pad + nout:] == 7.0)
+    y = ybig[pad:pad + nout].cpu().numpy().view(np.complex64).reshape(-1)
+    assert np.all(np.isfinite(y.view(np.float32)))
+    assert relerr(y, oracle.pfb(taps, buf, M, M, list(range(M)), xh, f64=True)) <= TOL
+
+
 # 2- / 4-fold oversampled channelizers with 64 / 128 / 256 channels and <= 32 taps per arm run on the ring kernel, one launch per residue of
 # the step number (quarter-turn factors on the channels); identity and scrambled maps; step counts that leave the residues uneven; and the
 # generic path on the same input (MI355_PFB_NO_FAST_OVERSAMPLED)
