@@ -36,6 +36,8 @@ struct MrArgs {
     const float *window;
     const c32 *tw;
     int n, nframes, frames, npass, in_rot, out_rot, real_in;
+    int copy_out = 0;          // k_fft_mr: the last pass leaves its frames in LDS and the workgroup stores them as one contiguous run (last-pass runs < 256 B)
+    unsigned m_n = 0;          // ceil(2^32 / n)
     int tw_lds = 0, ntw = 0;   // k_pfb_mr: first LDS slot of the twiddle runs, their length
     int dbg = 0;
     int fs_shift = 0;          // k_pfb_mr: a workgroup's frames are `frames >> fs_shift` time ranges of 2^fs_shift steps each; 0 = frames in a row
@@ -320,7 +322,28 @@ __global__ __launch_bounds__(1024) void k_fft_mr(const MrArgs a)
         asm volatile("" : "+v"(tid));
         MR_PASS(0, 0)
         for (int p = 1; p < a.npass - 1; p++) { MR_PASS(1, p) }
-        MR_PASS(2, a.npass - 1)
+        if (a.copy_out) {
+            // The last pass stores runs of `ns` values (n = 48 = 3 x 16: three values, 24 bytes, some twenty lines per store instruction): below 256
+            // bytes it leaves the frames in LDS instead (value p of frame fr at fr n + p) and the workgroup's frames -- neighbours in memory -- go out
+            // as one contiguous run, lanes along it; the forward shift is a rotation of the read index.
+            MR_PASS(1, a.npass - 1)
+            const int tot = a.frames * a.n;
+            for (int idx = tid0; idx < tot; idx += blockDim.x) {
+                const int fr = (int)__umulhi((unsigned)idx, a.m_n);
+                int p = idx - fr * a.n + a.out_rot;  // out[q] = X[(q + ceil(n/2)) mod n]
+                if (p >= a.n) p -= a.n;
+                if (group * a.frames + fr < a.nframes) {
+                    const c32 v = mr_lds[slot(fr * a.n + p)];
+                    f2v z;
+                    z.x = v.x;
+                    z.y = v.y;
+                    __builtin_nontemporal_store(z, (f2v *)a.out + (size_t)group * a.frames * a.n + idx);
+                }
+            }
+            __syncthreads();  // the frames have been read: the next group's first pass writes them
+        } else {
+            MR_PASS(2, a.npass - 1)
+        }
     }
 #undef MR_PASS
 }
@@ -780,6 +803,10 @@ int launch_with(const MrPlan &plan, int threads, int frames, mi355_ctx *ctx, int
     a.real_in = real_in;
     a.ngroups = ((long long)nframes + frames - 1) / frames;
     for (int p = 0; p < plan.npass; p++) a.pass[p] = plan.pass[p];
+    static const bool no_copy_out = getenv("MI355_FFT_MR_NO_COPY_OUT") != nullptr;
+    static const int copy_ns = getenv("MI355_FFT_MR_COPY_OUT_NS") ? atoi(getenv("MI355_FFT_MR_COPY_OUT_NS")) : 32;  // (runs under 256 bytes; 120 points 455 -> 290 us per 2^26 samples, 1000 points and up: the last pass own stores are as fast or faster)
+    a.copy_out = plan.pass[plan.npass - 1].ns < copy_ns && !no_copy_out;
+    a.m_n = magic(plan.n);
     const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
     const int lds_bytes = lds_bytes_for(plan.n, frames);
     int per_cu = (160 * 1024) / lds_bytes;
