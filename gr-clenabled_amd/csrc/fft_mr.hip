@@ -36,6 +36,7 @@ struct MrArgs {
     const float *window;
     const c32 *tw;
     int n, nframes, frames, npass, in_rot, out_rot, real_in;
+    int copy_in = 0;           // k_fft_mr: the workgroup's frames are loaded as one contiguous run into LDS (first-pass runs n / radix < 128 B)
     int copy_out = 0;          // k_fft_mr: the last pass leaves its frames in LDS and the workgroup stores them as one contiguous run (last-pass runs < 256 B)
     unsigned m_n = 0;          // ceil(2^32 / n)
     int tw_lds = 0, ntw = 0;   // k_pfb_mr: first LDS slot of the twiddle runs, their length
@@ -320,7 +321,32 @@ __global__ __launch_bounds__(1024) void k_fft_mr(const MrArgs a)
         // radix of the three switches at once -- it costs hundreds of registers (256 + 190 spilled before this line was here)
         int tid = tid0;
         asm volatile("" : "+v"(tid));
-        MR_PASS(0, 0)
+        if (a.copy_in) {
+            // The first pass reads runs of n / radix values (20 = 5 x 4 points: four values, 32 bytes): under 128 bytes the workgroup's frames come in as
+            // one contiguous run instead, lanes along it, windowed by the position in memory and rotated by the reverse shift on the way into LDS.
+            const int tot = a.frames * a.n;
+            for (int idx = tid0; idx < tot; idx += blockDim.x) {
+                const int fr = (int)__umulhi((unsigned)idx, a.m_n), q = idx - fr * a.n;
+                int i = q - a.in_rot;  // the first pass' value i is the sample at (i + in_rot) mod n
+                if (i < 0) i += a.n;
+                c32 x = mk(0.f, 0.f);
+                if (group * a.frames + fr < a.nframes) {
+                    const size_t at = (size_t)group * a.frames * a.n + idx;
+                    if (a.real_in) x = mk(((const float *)a.in)[at], 0.f);
+                    else {
+                        const f2v t = __builtin_nontemporal_load((const f2v *)a.in + at);
+                        x = mk(t.x, t.y);
+                    }
+                    const float w = a.window[q];
+                    x = mk(x.x * w, x.y * w);
+                }
+                mr_lds[slot(fr * a.n + i)] = x;
+            }
+            __syncthreads();
+            MR_PASS(3, 0)
+        } else {
+            MR_PASS(0, 0)
+        }
         for (int p = 1; p < a.npass - 1; p++) { MR_PASS(1, p) }
         if (a.copy_out) {
             // The last pass stores runs of `ns` values (n = 48 = 3 x 16: three values, 24 bytes, some twenty lines per store instruction): below 256
@@ -807,6 +833,8 @@ int launch_with(const MrPlan &plan, int threads, int frames, mi355_ctx *ctx, int
     static const int copy_ns = getenv("MI355_FFT_MR_COPY_OUT_NS") ? atoi(getenv("MI355_FFT_MR_COPY_OUT_NS")) : 32;  // (runs under 256 bytes; 120 points 455 -> 290 us per 2^26 samples, 1000 points and up: the last pass own stores are as fast or faster)
     a.copy_out = plan.pass[plan.npass - 1].ns < copy_ns && !no_copy_out;
     a.m_n = magic(plan.n);
+    static const int copy_nb = getenv("MI355_FFT_MR_COPY_IN_NB") ? atoi(getenv("MI355_FFT_MR_COPY_IN_NB")) : 16;
+    a.copy_in = plan.pass[0].nb < copy_nb && !no_copy_out;
     const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
     const int lds_bytes = lds_bytes_for(plan.n, frames);
     int per_cu = (160 * 1024) / lds_bytes;
