@@ -227,7 +227,7 @@ template <int M> struct GeoArm {
 };
 
 template <int M, int PMAX, bool IDENT, int OS = 1>
-__global__ __launch_bounds__(M, 2) void k_pfbw(const c32 *__restrict__ in, c32 *__restrict__ out, const float *__restrict__ taps_pad,
+__global__ __launch_bounds__(M, (M >= 512 ? 1 : 2)) void k_pfbw(const c32 *__restrict__ in, c32 *__restrict__ out, const float *__restrict__ taps_pad,
                                                  const c32 *__restrict__ tw_inv, const int *__restrict__ ch_map, int nmap, int K,
                                                  long long n_in, int nsteps, int groups_per_wave, int par)
 {
@@ -749,7 +749,7 @@ int launch_wave(mi355_pfb *h, const void *in, void *out, hipStream_t st, int nst
     const int cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
     // fewer 16-step groups than two per CU: one workgroup per group, its steps split over four sets of M threads (k_pfbq)
     const int small_on = getenv("MI355_PFB_SMALL") ? atoi(getenv("MI355_PFB_SMALL")) : 1;  // (read per call: a tuning / test switch)
-    if constexpr (!(M == 256 && PMAX > 16)) {  // (1024 threads x 32 taps per arm would spill: that shape keeps the ring kernel)
+    if constexpr (!(M == 256 && PMAX > 16) && M <= 256) {  // (1024 threads x 32 taps per arm would spill: that shape keeps the ring kernel; 512 channels too)
         if (small_on && ngroups <= 2 * cus) {
             const long long n_in = (long long)buf_items - h->R + h->K;
             if (h->ident)
@@ -763,7 +763,8 @@ int launch_wave(mi355_pfb *h, const void *in, void *out, hipStream_t st, int nst
         }
     }
     // waves per CU of the ring kernel; interleaved A/B at 64 x 32 over 2^26 samples: 4 -> 227 us, 8 -> 218, 16 -> 214, 32 -> 218
-    const int wpc = getenv("MI355_PFB_WAVES_PER_CU") ? atoi(getenv("MI355_PFB_WAVES_PER_CU")) : 16;
+    // (512 channels: one 8-wave workgroup per CU and a single round: 8 -> 133 us, 16 -> 142, 32 -> 157 per 2^25 items)
+    const int wpc = getenv("MI355_PFB_WAVES_PER_CU") ? atoi(getenv("MI355_PFB_WAVES_PER_CU")) : (M >= 512 ? 8 : 16);
     long long wgs = (long long)cus * (wpc > 0 ? wpc : 16) / (M / 64);
     if (wgs > ngroups) wgs = ngroups;
     const int per = (int)((ngroups + wgs - 1) / wgs);
@@ -785,7 +786,8 @@ int launch_wave_over(mi355_pfb *h, const void *in, void *out, hipStream_t st, in
 {
     const int S = h->M / h->R, cus = h->ctx->num_cus > 0 ? h->ctx->num_cus : 256;
     const long long n_in = (long long)nsteps * h->R - h->R + h->K;
-    const int wpc = getenv("MI355_PFB_WAVES_PER_CU") ? atoi(getenv("MI355_PFB_WAVES_PER_CU")) : 16;
+    // (512 channels: one 8-wave workgroup per CU and a single round: 8 -> 133 us, 16 -> 142, 32 -> 157 per 2^25 items)
+    const int wpc = getenv("MI355_PFB_WAVES_PER_CU") ? atoi(getenv("MI355_PFB_WAVES_PER_CU")) : (M >= 512 ? 8 : 16);
     for (int par = 0; par < S; par++) {
         const int nsub = (nsteps - par + S - 1) / S;
         if (nsub <= 0) continue;
@@ -842,7 +844,8 @@ int launch_fast(mi355_pfb *h, const void *in, void *out, hipStream_t st, int nst
         const long long n_in = (long long)buf_items - h->R + h->K;
         if (wave && n_in * 8 < (4ll << 30) - (64 << 10)) return launch_streams<M, PMAX>(h, in, out, st, nsteps, buf_items);
     }
-    if constexpr ((M == 64 || M == 128 || M == 256) && PMAX <= 32) {
+    if constexpr (M == 512 && PMAX > 32) return MI355_ERR_STATE;  // (create sends that shape down the two-kernel path)
+    if constexpr ((M == 64 || M == 128 || M == 256 || M == 512) && PMAX <= 32) {
         static const bool wave = getenv("MI355_PFB_WAVE") ? atoi(getenv("MI355_PFB_WAVE")) != 0 : true;
         const long long n_in = (long long)buf_items - h->R + h->K;
         // 32-bit byte offsets: the input as it is read (n_in * 8) and the OUTPUT including the rows the last group's unconditional, range-checked stores
@@ -851,6 +854,8 @@ int launch_fast(mi355_pfb *h, const void *in, void *out, hipStream_t st, int nst
         if (wave && n_in * 8 < (4ll << 30) - (64 << 10) && ((long long)nsteps + 32) * M * 8 < (4ll << 30))
             return launch_wave<M, PMAX>(h, in, out, st, nsteps, buf_items);
     }
+    if constexpr (M == 512) return MI355_ERR_STATE;  // 512 channels exist on the ring kernel only (create and work_dev_n keep its calls inside the 32-bit offsets)
+    else {
     constexpr int T = 4096 / M;
     int ngroups = (nsteps + T - 1) / T;
     // many short grid-stride workgroups (measured at 8 and 16 channels: 2 per CU 250 GS/s, 8 per CU 280, 32 per CU 302)
@@ -864,6 +869,7 @@ int launch_fast(mi355_pfb *h, const void *in, void *out, hipStream_t st, int nst
                            (const c32 *)h->d_tw, h->d_map, h->nmap, h->K, n_in, nsteps, ngroups);
     MI355_HIP(hipGetLastError());
     return MI355_OK;
+    }
 }
 
 template <int M>
@@ -890,6 +896,7 @@ int launch_pfb(mi355_pfb *h, const void *in, void *out, hipStream_t st, int nste
         case 64: return launch_fast_m<64>(h, in, out, st, nsteps, buf_items);
         case 128: return launch_fast_m<128>(h, in, out, st, nsteps, buf_items);
         case 256: return launch_fast_m<256>(h, in, out, st, nsteps, buf_items);
+        case 512: return launch_fast_m<512>(h, in, out, st, nsteps, buf_items);
         }
         return MI355_ERR_STATE;
     }
@@ -1000,6 +1007,11 @@ extern "C" int mi355_pfb_create(mi355_ctx *ctx, const float *taps, int ntaps, in
     const int M = h->M;
     const int per_arm = (ntaps + M - 1) / M;
     h->fast = (M >= 2 && M <= 256 && (M & (M - 1)) == 0 && h->R == M && per_arm <= 64);
+    // 512 channels, at most 32 taps per arm: the ring kernel with one 512-thread workgroup per CU (256 registers per thread); it has no staged
+    // fallback, so a buffer must fit the ring kernel's 32-bit offsets (launch_fast)
+    if (M == 512 && h->R == M && per_arm <= 32 && !getenv("MI355_PFB_NO_RING_512") &&
+        ((long long)buf_items - h->R + ntaps) * 8 < (4ll << 30) - (64 << 10) && ((long long)h->nsteps + 32) * M * 8 < (4ll << 30))
+        h->fast = true;
     h->pmax = per_arm <= 8 ? 8 : per_arm <= 16 ? 16 : per_arm <= 32 ? 32 : 64;
     {
         const long long n_in1 = (long long)buf_items - h->R + ntaps;
@@ -1090,6 +1102,15 @@ extern "C" int mi355_pfb_work_dev_n(mi355_pfb *h, int nbuf, const void *in, void
     }
     if (!h->fast && !over_one_stream && !mr_one_stream) {  // the generic two-kernel path keeps a one-buffer scratch: one buffer at a time
         for (int b = 0; b < nbuf; b++) {
+            const int rc = launch_pfb(h, (const char *)in + (size_t)b * h->buf_items * 8, (char *)out + (size_t)b * h->nmap * h->nsteps * 8, st,
+                                      h->nsteps, h->buf_items);
+            if (rc) return rc;
+        }
+        return MI355_OK;
+    }
+    if (h->M == 512 && h->fast && nbuf > 1 &&
+        !(((long long)h->buf_items * nbuf - h->R + h->K) * 8 < (4ll << 30) - (64 << 10) && ((long long)h->nsteps * nbuf + 32) * h->M * 8 < (4ll << 30))) {
+        for (int b = 0; b < nbuf; b++) {  // (the ring kernel's 32-bit offsets: one buffer at a time; same samples either way)
             const int rc = launch_pfb(h, (const char *)in + (size_t)b * h->buf_items * 8, (char *)out + (size_t)b * h->nmap * h->nsteps * 8, st,
                                       h->nsteps, h->buf_items);
             if (rc) return rc;

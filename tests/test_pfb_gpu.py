@@ -38,7 +38,7 @@ def test_independent_scipy_cases(gpu):
         assert relerr(y, g[c + "_y"]) <= TOL, c
 
 
-@pytest.mark.parametrize("M", [2, 4, 8, 16, 32, 64, 128, 256])
+@pytest.mark.parametrize("M", [2, 4, 8, 16, 32, 64, 128, 256, 512])  # (512: the ring kernel up to 32 taps per arm, two kernels above)
 @pytest.mark.parametrize("per_arm", [1, 5, 8, 13, 32, 33, 64])
 def test_fast_path_all_channel_counts(gpu, oracle, M, per_arm):
     rng = np.random.default_rng(M * 100 + per_arm)
@@ -193,7 +193,8 @@ def test_baseline_config4_shape_and_streaming(gpu, oracle):
 
 
 @pytest.mark.parametrize("M,tpa,ident", [(64, 32, True), (64, 8, False), (128, 16, True), (256, 8, True), (256, 32, True), (32, 16, True), (12, 5, False),
-                                         (100, 32, True), (20, 8, True), (48, 16, True), (360, 3, True)])  # (the last four: k_pfb_mr, k buffers = one stream)
+                                         (100, 32, True), (20, 8, True), (48, 16, True), (360, 3, True),  # (these four: k_pfb_mr, k buffers = one stream)
+                                         (512, 32, True), (512, 8, False)])
 def test_batched_call_equals_single_calls(gpu, oracle, M, tpa, ident, monkeypatch):
     """work_device(nbuf=k) -- general_work() offered k output multiples -- returns exactly the samples of k single calls, and the
     small-call schedule (k_pfbq: one workgroup per 16-step group) exactly those of the ring kernel (MI355_PFB_SMALL=0)."""
