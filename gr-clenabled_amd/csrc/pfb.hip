@@ -19,6 +19,7 @@
 // Everything else (oversampled R != M, M not a power of two such as the reference
 // flowgraph's M=3, very long arms) takes the generic two-kernel path.
 #include <cmath>
+#include <mutex>
 #include <cstdlib>
 #include <type_traits>
 #include <vector>
@@ -674,6 +675,105 @@ __global__ __launch_bounds__(256) void k_pfb_branches_t(const c32 *__restrict__ 
     }
 }
 
+// The branch filters of a critically sampled channelizer as a streaming kernel (the first of the two kernels wherever neither a ring kernel nor the
+// one-kernel form k_pfb_mr takes the shape: more than 512 channels, more than 32 taps per arm, ...).  Thread (range q, arm j): the arm's last PMAX - 1
+// samples stay in registers, ONE load per step (lanes along the arms: a row of consecutive samples), eight steps of packed fmas, taps ascending from +0
+// (lib/clPolyphaseChannelizer_impl.cc:156-167; the operation order of k_pfb_branches_t, bit for bit), eight stores of consecutive lanes.  No barrier in
+// the loop; the taps of the workgroup's arms sit in LDS.  k_pfb_branches_t spends six loads, their 64-bit addresses and 32 tap loads per output: 245 us
+// per 2^25 outputs at 32 taps per arm against this kernel's time in DESIGN_EXPERIMENTS R6.12.
+struct FirRing {
+    const c32 *in;
+    c32 *filt;
+    const float *taps;
+    int K, M, A, Q, nsteps, arm_blocks;  // A arms per workgroup (M, or 256 when M > 256), Q = 256 / A time ranges per workgroup
+    unsigned m_A;
+    long long range_len;
+};
+
+template <int PH, int PERIOD, class F>
+__device__ __forceinline__ void fir_phases(F &&body, int it, int iters)
+{
+    if constexpr (PH < PERIOD) {
+        if (it + PH < iters) {
+            body(std::integral_constant<int, PH>{}, it + PH);
+            fir_phases<PH + 1, PERIOD>(body, it, iters);
+        }
+    }
+}
+
+template <int PMAX>
+__global__ __launch_bounds__(256) void k_pfb_fir(const FirRing f)
+{
+    constexpr int FS = 8;
+    // the window (PMAX - 1 + FS rows) lives in a ring of RS = PMAX + FS registers; in phase PH row u of the window is slot (PH FS + u) mod RS, the next
+    // iteration's rows take the slots of the FS rows this iteration retires (and the spare): no register of the window ever moves.  The loop is
+    // unrolled over the RS / FS phases (moving the window instead cost twice its registers: 214 at 32 taps per arm)
+    constexpr int RS = PMAX + FS, PERIOD = RS / FS;
+    static_assert(RS % FS == 0, "ring period");
+    extern __shared__ float fir_taps[];  // [PMAX][A]
+    const int t = threadIdx.x;
+    const int q = (int)__umulhi((unsigned)t, f.m_A), j0 = t - q * f.A;
+    const int ab = blockIdx.x % f.arm_blocks;
+    const long long rb = blockIdx.x / f.arm_blocks;
+    const int j = ab * 256 + j0;
+    const bool arm = q < f.Q && j < f.M;
+    for (int i = t; i < PMAX * f.A; i += 256) {
+        const int p = i / f.A, jj = ab * 256 + (i - p * f.A);
+        const long long k = (long long)jj + (long long)f.M * p;
+        fir_taps[i] = (jj < f.M && k < f.K) ? f.taps[k] : 0.f;
+    }
+    __syncthreads();
+    const float *th = fir_taps + (arm ? j0 : 0);
+    const long long s0 = (rb * f.Q + q) * f.range_len;
+    const f2v *xp = (const f2v *)f.in + (f.K - 1 - j);  // x_j[r] = in[r M - j + K - 1]
+    auto ld = [&](long long r) {
+        const long long o = r * f.M;
+        f2v x = {0.f, 0.f};
+        if (arm && o + (f.K - 1 - j) >= 0 && r < f.nsteps) x = __builtin_nontemporal_load(xp + o);
+        return x;
+    };
+    f2v ring[RS], nx[FS];
+#pragma unroll
+    for (int u = 0; u < PMAX - 1 + FS; u++) ring[u] = ld(s0 - (PMAX - 1) + u);
+    ring[RS - 1] = f2v{0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < FS; s++) nx[s] = f2v{0.f, 0.f};
+    const int iters = (int)(f.range_len / FS);
+    auto iteration = [&](auto phase_tag, int it) {
+        constexpr int PH = decltype(phase_tag)::value;
+        const long long cur = s0 + (long long)it * FS;
+        if (it + 1 < iters) {  // the next iteration's rows: requested in front of the arithmetic
+#pragma unroll
+            for (int s = 0; s < FS; s++) nx[s] = ld(cur + FS + s);
+        }
+        f2v acc[FS];
+#pragma unroll
+        for (int s = 0; s < FS; s++) acc[s] = f2v{0.f, 0.f};
+        const float *thv = th;
+        asm volatile("" : "+v"(thv));  // the taps are read from LDS every iteration, not kept in 2 x PMAX registers
+#pragma unroll
+        for (int p0 = 0; p0 < PMAX; p0 += 8) {  // per output: taps ascending from +0; eight taps' reads at a time
+#pragma unroll
+            for (int p = p0; p < p0 + 8; p++) {
+                const float hp = thv[p * f.A];
+                const f2v hh = {hp, hp};
+#pragma unroll
+                for (int s = 0; s < FS; s++) acc[s] = __builtin_elementwise_fma(ring[(PH * FS + PMAX - 1 + s - p) % RS], hh, acc[s]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (arm) {
+#pragma unroll
+            for (int s = 0; s < FS; s++)
+                if (cur + s < f.nsteps) __builtin_nontemporal_store(acc[s], (f2v *)f.filt + (cur + s) * f.M + j);
+        }
+        // rows 0 .. FS-1 of the window retire; the new rows are rows PMAX-1 .. PMAX-2+FS of the next phase = the spare slot and the slots of rows 0 .. FS-2
+#pragma unroll
+        for (int s = 0; s < FS; s++) ring[(PH * FS + RS - 1 + s) % RS] = nx[s];
+    };
+    for (int it = 0; it < iters; it += PERIOD) fir_phases<0, PERIOD>(iteration, it, iters);
+}
+
 __global__ __launch_bounds__(256) void k_pfb_dft_map(const c32 *__restrict__ filt, c32 *__restrict__ out,
                                                      const c32 *__restrict__ twM,  // exp(+2 pi i t / M), t < M
                                                      const int *__restrict__ ch_map, int nmap, int M, long long total)
@@ -936,6 +1036,35 @@ int launch_pfb(mi355_pfb *h, const void *in, void *out, hipStream_t st, int nste
     long long blocks = (total + 255) / 256;
     long long grid = blocks < (long long)cus * 8 ? blocks : (long long)cus * 8;
     const int over = h->R > 0 && h->M % h->R == 0 ? h->M / h->R : 0;  // 1: critically sampled; 2, 4: oversampled by that factor
+    const int P_arm = (h->K + h->M - 1) / h->M;
+    if (over == 1 && (P_arm <= 8 || (P_arm > 16 && P_arm <= 32)) && !getenv("MI355_PFB_BRANCHES_PER_OUTPUT") && !getenv("MI355_PFB_NO_FIR_RING")) {  // (64 taps per arm: 309 + 53 registers, slower than k_pfb_branches_t; 9 ... 16: no faster)
+        FirRing f;
+        f.in = (const c32 *)in;
+        f.filt = (c32 *)h->d_filt;
+        f.taps = h->d_taps;
+        f.K = h->K;
+        f.M = h->M;
+        f.A = h->M <= 256 ? h->M : 256;
+        f.Q = 256 / f.A;
+        f.nsteps = nsteps;
+        f.arm_blocks = (h->M + 255) / 256;
+        f.m_A = (unsigned)((0x100000000ull + (unsigned)f.A - 1) / (unsigned)f.A);
+        if (f.A == 1) { f.m_A = 0; f.Q = 0; }  // (one channel never gets here: M >= 2 on this path; kept defined)
+        const int pm = P_arm <= 8 ? 8 : 32;  // (a 16-tap instance takes 254 registers -- it spills at 168 -- and is no faster than the 32-tap one on zero taps)
+        // time ranges: about 12 waves per CU, but at least 8 x the warm-up long
+        const long long want = (long long)cus * 12 / 4;  // workgroups
+        long long nr = want / f.arm_blocks * f.Q;
+        if (nr < 1) nr = 1;
+        long long len = (nsteps + nr - 1) / nr;
+        if (len < 8LL * P_arm) len = 8LL * P_arm;
+        len = (len + 7) / 8 * 8;
+        f.range_len = len;
+        const long long nrb = (nsteps + len * f.Q - 1) / (len * f.Q);  // range blocks
+        const dim3 gd((unsigned)(nrb * f.arm_blocks));
+        const size_t lds = (size_t)pm * f.A * 4;
+        if (pm == 8) hipLaunchKernelGGL((k_pfb_fir<8>), gd, dim3(256), lds, st, f);
+        else hipLaunchKernelGGL((k_pfb_fir<32>), gd, dim3(256), lds, st, f);
+    } else
     if ((over == 1 || over == 2 || over == 4) && !getenv("MI355_PFB_BRANCHES_PER_OUTPUT")) {
         constexpr int T = 8;
         const long long tt = ((long long)nsteps + T - 1) / T * h->M, tb = ((tt + 255) / 256 + 7) / 8 * 8;

@@ -145,6 +145,23 @@ def test_one_kernel_form_stays_inside_its_buffers(gpu, oracle, M, per_arm, steps
     assert relerr(y, oracle.pfb(taps, buf, M, M, list(range(M)), xh, f64=True)) <= TOL
 
 
+# the two-kernel path (more than 512 channels, ...): the streaming branch-filter kernel k_pfb_fir (register ring rotated by phases, <= 8 and 17 ... 32
+# taps per arm) against the register-tiled k_pfb_branches_t (MI355_PFB_NO_FIR_RING, read per call) -- the same operation order, so bit for bit -- and
+# against the oracle; arm blocks with a ragged last block, ranges that end beyond the call, fewer arms than a workgroup has threads, a prime count
+@pytest.mark.parametrize("M,per_arm,steps", [(1024, 32, 300), (1000, 7, 333), (600, 25, 100), (2048, 4, 50), (7, 5, 3000), (768, 17, 9), (1024, 1, 40)])
+def test_streaming_branch_filters_equal_the_tiled_ones(gpu, oracle, monkeypatch, M, per_arm, steps):
+    rng = np.random.default_rng(M + per_arm)
+    K = M * per_arm - (M // 3 if per_arm % 2 and per_arm > 1 else 0)
+    taps = (rng.standard_normal(K) / np.sqrt(per_arm)).astype(np.float32)
+    buf = steps * M
+    xh = crandn(rng, buf - M + K)
+    chmap = list(range(M))
+    y = _run(gpu, taps, buf, M, M, chmap, xh)
+    assert relerr(y, oracle.pfb(taps, buf, M, M, chmap, xh, f64=True)) <= TOL
+    monkeypatch.setenv("MI355_PFB_NO_FIR_RING", "1")
+    assert np.array_equal(y, _run(gpu, taps, buf, M, M, chmap, xh))
+
+
 # 2- / 4-fold oversampled channelizers with 64 / 128 / 256 channels and <= 32 taps per arm run on the ring kernel, one launch per residue of
 # the step number (quarter-turn factors on the channels); identity and scrambled maps; step counts that leave the residues uneven; and the
 # generic path on the same input (MI355_PFB_NO_FAST_OVERSAMPLED)
