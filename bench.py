@@ -581,6 +581,14 @@ def extra_blocks(pkg, o_taps, dev, steps, warmup, world, rank, out=None):
     yo = c[:pfbc.noutput()]
     out["clPolyphaseChannelizer_100x32_stream"] = rate(lambda: pfbc.work_device([xi], [yo]), bufc, 16)
     del pfbc
+    # 512 channels x 32 taps per arm: the ring kernel with one 512-thread workgroup per CU (round 6; two kernels before)
+    tp512 = np.resize(taps2048, 512 * 32).astype(np.float32)
+    buf5 = ((n // 2) // 512) * 512
+    pfb5 = pkg.clPolyphaseChannelizer(*args, tp512, buf5, 512, 512, list(range(512)))
+    xi = a[:pfb5.ninput()]
+    yo = c[:pfb5.noutput()]
+    out["clPolyphaseChannelizer_512x32_stream"] = rate(lambda: pfb5.work_device([xi], [yo]), buf5, 16)
+    del pfb5
     fd = pkg.clFilter(*args, 16, taps65, 1, 0, True)
     nd = (n - 64) // 16
     out["clFilter_fir_65taps_decim16"] = rate(lambda: fd.work_device(nd, [a], [c]), nd * 16, 8 + 0.5)
